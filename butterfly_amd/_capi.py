@@ -1,0 +1,135 @@
+"""ctypes declarations of the C-ABI in include/bfhip.h and the loader of
+libbfhip.so.  Loading fails loudly: there is no CPU fallback for the engine."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libbfhip.so")
+
+BFHIP_C128, BFHIP_F64, BFHIP_F32 = 0, 1, 2
+FLAG_PROFILE = 1
+
+ERROR_NAMES = {0: "BF_ERROR_NONE", 1: "BF_ERROR_INVALID_ARGUMENTS", 2: "BF_ERROR_RUNTIME_ERROR",
+               3: "BF_ERROR_NOT_IMPLEMENTED", 4: "BF_ERROR_MEMORY_ERROR", 5: "BF_ERROR_OUT_OF_RANGE",
+               6: "BF_ERROR_FILE_ERROR", 7: "BF_ERROR_TYPE_ERROR", 8: "BF_ERROR_INCOMPATIBLE_SHAPES"}
+
+
+class BfhipOptions(C.Structure):
+    _fields_ = [("structSize", C.c_uint32), ("device", C.c_int32), ("flags", C.c_uint32),
+                ("maxRhs", C.c_uint32), ("demoteToF32", C.c_uint32), ("reserved0", C.c_uint32),
+                ("seed", C.c_uint64), ("rowBlockBegin", C.c_uint64), ("rowBlockEnd", C.c_uint64)]
+
+
+class BfhipDesc(C.Structure):
+    _fields_ = [("structSize", C.c_uint32), ("dtype", C.c_uint32), ("numNodes", C.c_uint64),
+                ("root", C.c_uint64), ("kind", C.c_void_p), ("rows", C.c_void_p), ("cols", C.c_void_p),
+                ("childBegin", C.c_void_p), ("childNode", C.c_void_p), ("childRow0", C.c_void_p),
+                ("childCol0", C.c_void_p), ("leafData", C.c_void_p), ("leafRowStride", C.c_void_p),
+                ("topRowBlock", C.c_void_p), ("blockKind", C.c_void_p)]
+
+
+class BfhipStats(C.Structure):
+    _fields_ = [("structSize", C.c_uint32), ("dtype", C.c_uint32)] + [
+        (n, C.c_uint64) for n in ("numRows", "numCols", "numStages", "numLeaves", "numItems", "numPieces",
+                                  "leafElems", "leafBytes", "vecElemsRead", "vecElemsWritten",
+                                  "arenaBytes", "tempElems", "metaBytes")]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_}
+
+
+class DescArrays:
+    """Keeps the numpy arrays behind a BfhipDesc alive."""
+
+    def __init__(self, desc, root=None, leaf_values=None):
+        a = desc.arrays()
+        self.arrays = a
+        self.keep = []
+        d = BfhipDesc()
+        d.structSize = C.sizeof(BfhipDesc)
+        d.dtype = desc.dtype
+        d.numNodes = desc.num_nodes
+        d.root = desc.root if root is None else root
+        for f in ("kind", "rows", "cols", "childBegin", "childNode", "childRow0", "childCol0", "blockKind"):
+            setattr(d, f, a[f].ctypes.data)
+        if leaf_values is not None:
+            ptrs = np.zeros(desc.num_nodes, dtype=np.uint64)
+            for node, v in leaf_values.items():
+                v = np.ascontiguousarray(v)
+                self.keep.append(v)
+                ptrs[node] = v.ctypes.data
+            self.keep.append(ptrs)
+            d.leafData = ptrs.ctypes.data
+        if desc.top_row_block is not None and (root is None or root == desc.root):
+            trb = np.asarray(desc.top_row_block, dtype=np.uint64)
+            self.keep.append(trb)
+            d.topRowBlock = trb.ctypes.data
+        self.struct = d
+
+    def byref(self):
+        return C.byref(self.struct)
+
+
+class BfhipError(RuntimeError):
+    def __init__(self, code, msg=""):
+        self.code = code
+        super().__init__(f"{ERROR_NAMES.get(code, code)}: {msg}")
+
+
+_lib = None
+
+
+def load():
+    """Load libbfhip.so (built by `make -C butterfly_amd/csrc` / __graft_entry__.build)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(there is no CPU fallback for the butterfly-apply engine)")
+    lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    vp = C.c_void_p
+    lib.bfhipCompile.argtypes = [vp, C.POINTER(BfhipOptions), C.POINTER(vp)]
+    lib.bfhipCompile.restype = C.c_int
+    lib.bfhipCompileDesc.argtypes = [C.POINTER(BfhipDesc), C.POINTER(BfhipOptions), C.POINTER(vp)]
+    lib.bfhipCompileDesc.restype = C.c_int
+    lib.bfhipApply.argtypes = [vp, vp, C.c_size_t, C.c_size_t, vp, C.c_size_t]
+    lib.bfhipApply.restype = C.c_int
+    lib.bfhipApplyDevice.argtypes = [vp, vp, C.c_size_t, vp, vp]
+    lib.bfhipApplyDevice.restype = C.c_int
+    lib.bfhipGetStats.argtypes = [vp, C.POINTER(BfhipStats)]
+    lib.bfhipGetStats.restype = C.c_int
+    lib.bfhipGetNumRows.argtypes = [vp]
+    lib.bfhipGetNumRows.restype = C.c_size_t
+    lib.bfhipGetNumCols.argtypes = [vp]
+    lib.bfhipGetNumCols.restype = C.c_size_t
+    lib.bfhipNumBytes.argtypes = [vp]
+    lib.bfhipNumBytes.restype = C.c_size_t
+    lib.bfhipGetStageProfile.argtypes = [vp, vp, vp, vp, C.c_int]
+    lib.bfhipGetStageProfile.restype = C.c_int
+    lib.bfhipFree.argtypes = [C.POINTER(vp)]
+    lib.bfhipFree.restype = None
+    lib.bfhipMatNew.argtypes = [vp, C.c_int]
+    lib.bfhipMatNew.restype = vp
+    lib.bfhipMatMulFunc.argtypes = [vp, vp]
+    lib.bfhipMatMulFunc.restype = vp
+    lib.bfhipErrorString.argtypes = [C.c_int]
+    lib.bfhipErrorString.restype = C.c_char_p
+    lib.bfhipLastErrorMessage.argtypes = []
+    lib.bfhipLastErrorMessage.restype = C.c_char_p
+    lib.bfhipSyntheticValue.argtypes = [C.c_uint64, C.c_uint64, C.c_int]
+    lib.bfhipSyntheticValue.restype = C.c_double
+    lib.bfhipSyntheticLeafBases.argtypes = [C.POINTER(BfhipDesc), vp]
+    lib.bfhipSyntheticLeafBases.restype = C.c_int
+    _lib = lib
+    return lib
+
+
+def check(code):
+    if code != 0:
+        msg = load().bfhipLastErrorMessage().decode()
+        raise BfhipError(code, msg)

@@ -1,0 +1,192 @@
+/* bfhip.h -- C-ABI of the MI355X butterfly-apply engine (libbfhip.so).
+ *
+ * One hot path of sampotter/butterfly is replaced: applying an already-built
+ * factorization, i.e. `bfMatMul(A, X)` / `bfMatMulVec(A, x)` where A is a
+ * `BfMatProduct` / `BfMatBlock{Dense,Diag,Coo}` hierarchy over dense leaves
+ * (reference src/mat.c:183-189 dispatching to src/mat_product.c:211-280,
+ * src/mat_block_dense.c:512-638, src/mat_block_diag.c:370-456,
+ * src/mat_block_coo.c:382-474, src/mat_dense_complex.c:1024-1051,
+ * src/mat_dense_real.c:1373-1407, src/mat_identity.c:149-181).
+ *
+ * Usage mirrors what a cgo/ctypes/C caller of the reference would bind:
+ *
+ *   BfhipOperator *op;
+ *   bfhipCompile(A, NULL, &op);          // walk the BfMat graph once, upload
+ *   BfMat *A_hip = bfhipMatNew(op);      // drop-in BfMat: bfMatMul(A_hip, X)
+ *   ... or bfhipApply(op, X, ldx, nrhs, Y, ldy) on raw host buffers,
+ *   ... or bfhipApplyDevice(op, dX, nrhs, dY, stream) on resident vectors.
+ *   bfhipFree(&op);
+ *
+ * Every function returns 0 (BF_ERROR_NONE) or a reference `enum BfError`
+ * value (include/bf/error.h:3-16); nothing in this library aborts.  All
+ * pointers are plain C; no torch / HIP types appear in signatures (streams
+ * are passed as `void *` = hipStream_t).
+ *
+ * Thread-safety: as the reference (single host thread per operator).
+ */
+#ifndef BFHIP_H
+#define BFHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct BfhipOperator BfhipOperator;
+
+/* element type of leaves and vectors */
+enum {
+  BFHIP_C128 = 0,  /* double _Complex: fac_helm2 operands (BfMatDenseComplex) */
+  BFHIP_F64 = 1,   /* double: fac_streamer operands (BfMatDenseReal)          */
+  BFHIP_F32 = 2    /* float: build extension -- real leaves demoted on upload */
+};
+
+/* node kinds of the flat expression descriptor */
+enum {
+  BFHIP_NODE_DENSE = 0,     /* leaf: rows x cols row-major values          */
+  BFHIP_NODE_IDENTITY = 1,  /* leaf: square identity (mat_identity.c:149)   */
+  BFHIP_NODE_BLOCK = 2,     /* sum of children placed at (row0, col0)      */
+  BFHIP_NODE_PRODUCT = 3    /* F0 * F1 * ... * F_{L-1}, applied right-to-left */
+};
+
+enum {
+  BFHIP_FLAG_NONE = 0,
+  BFHIP_FLAG_PROFILE = 1u << 0   /* record hipEvents around every stage launch */
+};
+
+typedef struct BfhipOptions {
+  uint32_t structSize;      /* = sizeof(BfhipOptions) */
+  int32_t device;           /* HIP ordinal; -1 = current device */
+  uint32_t flags;           /* BFHIP_FLAG_* */
+  uint32_t maxRhs;          /* intermediates preallocated for this many RHS (0 -> 1); grows on demand */
+  uint32_t demoteToF32;     /* 1: store/compute BFHIP_F64 operands in fp32 (config 5 extension) */
+  uint32_t reserved0;
+  uint64_t seed;            /* value seed for synthetic (data == NULL) leaves */
+  /* row sharding: keep only block rows
+   * [rowBlockBegin, rowBlockEnd) of a BLOCK root; rowBlockEnd == 0 -> all.
+   * The operator then maps the full x to the concatenation of those rows. */
+  uint64_t rowBlockBegin;
+  uint64_t rowBlockEnd;
+} BfhipOptions;
+
+/* Flat description of an operand: the same expression tree as a BfMat graph,
+ * as arrays.  Used (a) internally by bfhipCompile after walking a BfMat graph
+ * and (b) directly by callers that synthesize structure-exact operands
+ * without ever materializing host values (leafData[i] == NULL: values are
+ * generated on the device from `seed`, see bfhipSyntheticValue). */
+typedef struct BfhipDesc {
+  uint32_t structSize;      /* = sizeof(BfhipDesc) */
+  uint32_t dtype;           /* BFHIP_C128 or BFHIP_F64 */
+  uint64_t numNodes;
+  uint64_t root;
+  const uint8_t *kind;          /* [numNodes] BFHIP_NODE_* */
+  const uint64_t *rows;         /* [numNodes] element rows */
+  const uint64_t *cols;         /* [numNodes] element cols */
+  const uint64_t *childBegin;   /* [numNodes+1] CSR into child arrays */
+  const uint64_t *childNode;    /* [numChildren] */
+  const uint64_t *childRow0;    /* [numChildren] row offset inside parent (BLOCK) */
+  const uint64_t *childCol0;    /* [numChildren] col offset inside parent (BLOCK) */
+  const void *const *leafData;  /* [numNodes] or NULL; row-major host values */
+  const uint64_t *leafRowStride;/* [numNodes] or NULL (-> cols), in elements */
+  const uint64_t *topRowBlock;  /* [numChildren of root] or NULL: block-row id of each root child (for sharding) */
+  const uint8_t *blockKind;     /* [numNodes] or NULL: reference BfType of BLOCK nodes (15 coo, 16 dense, 17 diag); informative only */
+} BfhipDesc;
+
+typedef struct BfhipStats {
+  uint32_t structSize;
+  uint32_t dtype;
+  uint64_t numRows, numCols;
+  uint64_t numStages;
+  uint64_t numLeaves;        /* dense leaves kept (after sharding) */
+  uint64_t numItems;         /* kernel work items over all stages */
+  uint64_t numPieces;
+  uint64_t leafElems;        /* sum over leaves of m*n */
+  uint64_t leafBytes;        /* leafElems * sizeof(element) = algorithmic operand bytes */
+  uint64_t vecElemsRead;     /* sum over stages of input elements read once per distinct segment */
+  uint64_t vecElemsWritten;  /* sum over stages of output elements */
+  uint64_t arenaBytes;       /* device bytes actually held for leaves (incl. padding) */
+  uint64_t tempElems;        /* intermediate-vector elements per RHS */
+  uint64_t metaBytes;        /* device bytes of index metadata */
+} BfhipStats;
+
+/* ---- compile ------------------------------------------------------------- */
+
+/* Walk a reference object graph (read-only; nothing of A is retained) and
+ * build the device operator.  `bfMat` is a `BfMat const *` of the reference
+ * (layouts: bfhip_abi.h).  Replaces the recursive dispatch the reference does
+ * on every bfMatMul call (src/mat.c:183 and callees listed above).
+ * Errors: TYPE_ERROR (unknown node type / mixed real+complex),
+ * NOT_IMPLEMENTED (transposed or conjugated leaf, mat_dense_complex.c:27-35),
+ * INVALID_ARGUMENTS (NULL vtable, non-monotone offsets, shape mismatch),
+ * MEMORY_ERROR (host or device OOM), RUNTIME_ERROR (HIP failure). */
+int bfhipCompile(const void *bfMat, const BfhipOptions *opts, BfhipOperator **out);
+
+/* Same, from a flat descriptor. */
+int bfhipCompileDesc(const BfhipDesc *desc, const BfhipOptions *opts, BfhipOperator **out);
+
+/* ---- apply --------------------------------------------------------------- */
+
+/* Y[numRows x nrhs] = A * X[numCols x nrhs]; host buffers, row-major with
+ * leading dimensions ldx/ldy in elements (the layout of BfMatDenseComplex
+ * with colStride == 1, mat_dense_complex.h:69-81).  Synchronous. */
+int bfhipApply(BfhipOperator *op, const void *X, size_t ldx, size_t nrhs, void *Y, size_t ldy);
+
+/* Same on device-resident, densely packed (ld == nrhs) vectors; enqueued on
+ * `stream` (hipStream_t, NULL = default stream) and asynchronous. */
+int bfhipApplyDevice(BfhipOperator *op, const void *dX, size_t nrhs, void *dY, void *stream);
+
+/* ---- introspection ------------------------------------------------------- */
+int bfhipGetStats(const BfhipOperator *op, BfhipStats *stats);
+size_t bfhipGetNumRows(const BfhipOperator *op);
+size_t bfhipGetNumCols(const BfhipOperator *op);
+/* same meaning as bfMatNumBytes on the original graph: leaf payload bytes
+ * (mat_block_coo.c:238-258, mat_dense_complex.c:452-455). */
+size_t bfhipNumBytes(const BfhipOperator *op);
+
+/* With BFHIP_FLAG_PROFILE: per-stage accumulated kernel time (ms) and launch
+ * count since the last reset, measured with hipEvents on the apply stream.
+ * `ms`/`launches`/`bytes` are [numStages] arrays (any may be NULL); `bytes`
+ * receives the algorithmic bytes one launch of that stage moves for the nrhs
+ * of the last apply.  Synchronizes the stream. */
+int bfhipGetStageProfile(BfhipOperator *op, double *ms, uint64_t *launches, uint64_t *bytes, int reset);
+
+/* ---- lifetime ------------------------------------------------------------ */
+void bfhipFree(BfhipOperator **op);
+
+/* ---- reference-vtable shim ----------------------------------------------- */
+
+/* A `BfMat *` whose vtable implements Mul, MulVec, GetNumRows, GetNumCols,
+ * GetType (-> BF_TYPE_MAT_FUNC), NumBytes and Delete on top of `op`, so that
+ * unmodified reference code (bfSolveGMRES src/linalg.c:125,155; the example
+ * drivers) can call bfMatMul on it.  Results are allocated through the
+ * RHS's own vtable (`EmptyLike`, slot 8) so that the reference's bfMatDelete
+ * frees them (mat_dense_complex.c:2164-2187).  Delete releases the shim and,
+ * if `ownsOperator`, the operator. */
+void *bfhipMatNew(BfhipOperator *op, int ownsOperator);
+
+/* `MatMulFunc` for the reference's own callback operator
+ * (include/bf/mat_func.h:5): bfMatFuncInit(f, m, n, bfhipMatMulFunc, op). */
+void *bfhipMatMulFunc(const void *rhsBfMat, void *op);
+
+/* ---- errors -------------------------------------------------------------- */
+const char *bfhipErrorString(int code);
+/* message of the most recent failure on this thread ("" if none) */
+const char *bfhipLastErrorMessage(void);
+
+/* Value of element `idx` of the synthetic value stream for `seed`: uniform in
+ * [-1, 1).  Identical on host and device (exact IEEE operations), so a CPU
+ * restatement can rebuild the very operand the device synthesized.  A leaf
+ * with node id L and m x n row-major elements uses
+ *   idx = leafBase(L) + i*n + j  (re) and the same idx with stream bit set (im),
+ * scaled by sqrt(3/(2n)) (complex) or sqrt(3/n) (real). */
+double bfhipSyntheticValue(uint64_t seed, uint64_t idx, int imag);   /* = bfhip_synth_value, include/bfhip_synth.h */
+/* virtual base index of leaf `node` (prefix sum of rows*cols over dense nodes
+ * in node order), for a given descriptor */
+int bfhipSyntheticLeafBases(const BfhipDesc *desc, uint64_t *bases);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BFHIP_H */

@@ -1,0 +1,138 @@
+"""ORACLE (test infrastructure, not product code).
+
+Numpy restatement of the *value* side of the reference's Helmholtz butterfly
+builder, used only to manufacture real operands and known answers for parity
+tests (the engine itself never builds factorizations):
+
+  kernel matrix (single layer, (i/4) H0(k r), 0 on r == 0)   reference src/helm2.c:93-125
+  proxy-circle sampling                                       src/circle.c:12-35
+  re-expansion matrix Z_equiv \\ Z_orig                        src/helm2.c:321-365
+  truncated-SVD least squares (rtol = max(m,n) eps)           src/mat_dense_complex.c:1767-1849
+  seeded complex normal RHS (xoshiro256+ / Box-Muller)        src/rand.c:19-76,
+                                                              src/splitmix64.c, src/xoshiro256plus.c
+
+H0 is evaluated with scipy's j0/y0 (the reference uses libm's, src/bessel.c:284-296);
+the two agree to a few ulp, far below the butterfly's own 1e-10 truncation.
+
+PARITY STATUS: see oracle/bfref.h ("parity unpinned" by reference goldens; pinned
+by dense-kernel known answers and the survey's ||y||^2 checksums).
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+from scipy.special import j0, y0
+
+EPS_MACH = 2.220446049250313e-16
+TWO_PI = 6.283185307179586
+
+
+def sample_circle(cx, cy, r, count):
+    """bfCircle2SamplePoints, src/circle.c:12-35."""
+    scale = TWO_PI / float(count)
+    theta = scale * np.arange(count)
+    return np.stack([r * np.cos(theta) + cx, r * np.sin(theta) + cy], axis=1)
+
+
+def resolve_points(spec, tree_points):
+    if spec[0] == "node":
+        return tree_points[spec[1]:spec[2]]
+    if spec[0] == "circle":
+        return sample_circle(spec[1], spec[2], spec[3], spec[4])
+    raise ValueError(spec)
+
+
+def kernel_matrix(k, src, tgt):
+    """get_S_kernel_matrix, src/helm2.c:93-125: rows = targets, cols = sources."""
+    r = np.hypot(tgt[:, None, 0] - src[None, :, 0], tgt[:, None, 1] - src[None, :, 1])
+    z = np.zeros(r.shape, dtype=np.complex128)
+    nz = r != 0
+    kr = k * r[nz]
+    z[nz] = 0.25j * (j0(kr) + 1j * y0(kr))
+    return z
+
+
+def lstsq_truncated(lhs, rhs):
+    """bfMatDenseComplexDenseComplexLstSq, src/mat_dense_complex.c:1767-1849."""
+    m, n = lhs.shape
+    u, s, vh = np.linalg.svd(lhs, full_matrices=False)
+    tol = max(m, n) * EPS_MACH * s[0] + EPS_MACH
+    below = np.nonzero(s < tol)[0]
+    kk = int(below[0]) if len(below) else len(s)
+    tmp = u[:, :kk].conj().T @ rhs
+    tmp /= s[:kk, None]
+    return vh[:kk].conj().T @ tmp
+
+
+def reexpansion_matrix(k, src_orig, src_equiv, tgt):
+    """bfHelm2GetReexpansionMatrix, src/helm2.c:321-365."""
+    z_orig = kernel_matrix(k, src_orig, tgt)
+    z_equiv = kernel_matrix(k, src_equiv, tgt)
+    return lstsq_truncated(z_equiv, z_orig)
+
+
+def leaf_values(desc, k, tree_points):
+    """Evaluate every dense leaf's recipe -> {node: complex128 array}."""
+    out = {}
+    for node, rc in desc.recipe.items():
+        if rc[0] == "kernel":
+            z = kernel_matrix(k, resolve_points(rc[1], tree_points), resolve_points(rc[2], tree_points))
+        elif rc[0] == "reexp":
+            z = reexpansion_matrix(k, resolve_points(rc[1], tree_points), resolve_points(rc[2], tree_points),
+                                   resolve_points(rc[3], tree_points))
+        else:
+            raise ValueError(rc)
+        assert z.shape == (desc.rows[node], desc.cols[node]), (z.shape, desc.rows[node], desc.cols[node], rc[0])
+        out[node] = np.ascontiguousarray(z)
+    return out
+
+
+# --------------------------------------------------------------------------
+# the reference's PRNG, to reproduce bfMatDenseComplexNewRandn after bfSeed(0)
+# --------------------------------------------------------------------------
+_M64 = (1 << 64) - 1
+
+
+class Xoshiro256Plus:
+    def __init__(self, seed: int):
+        # bfSeed, src/rand.c:19-33: splitmix64(seed) -> 4 state words
+        x = seed & _M64
+        s = []
+        for _ in range(4):
+            x = (x + 0x9E3779B97F4A7C15) & _M64
+            z = x
+            z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & _M64
+            z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & _M64
+            s.append(z ^ (z >> 31))
+        self.s = s
+
+    def next(self) -> int:
+        s = self.s
+        result = (s[0] + s[3]) & _M64
+        t = (s[1] << 17) & _M64
+        s[2] ^= s[0]
+        s[3] ^= s[1]
+        s[1] ^= s[2]
+        s[0] ^= s[3]
+        s[2] ^= t
+        s[3] = ((s[3] << 45) | (s[3] >> 19)) & _M64
+        return result
+
+    def uniform(self, n):
+        # bfRealUniform1, src/rand.c:43-47
+        return np.array([(self.next() >> 11) * (2.0 ** -53) for _ in range(n)])
+
+
+def complex_randn(n, seed=0):
+    """bfComplexRandn(n) after bfSeed(seed): Box-Muller over interleaved re/im
+    (src/rand.c:53-76)."""
+    g = Xoshiro256Plus(seed)
+    m = 2 * n
+    x = g.uniform(2 * (m // 2))
+    u0, u1 = x[0::2].copy(), x[1::2].copy()
+    mag = np.sqrt(-2 * np.log(u0))
+    theta = TWO_PI * u1
+    x[0::2] = mag * np.cos(theta)
+    x[1::2] = mag * np.sin(theta)
+    return x[0::2] + 1j * x[1::2]
