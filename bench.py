@@ -1,0 +1,277 @@
+#!/usr/bin/env python3
+"""bench.py -- butterfly matvecs/sec + achieved HBM GB/s on MI355X.
+
+Workload (BASELINE.json `metric`): 2D Helmholtz single-layer operator on N
+equispaced points of the unit circle, k = N/16 (16 points per wavelength),
+fac_helm2-style multilevel butterfly (HODBF), complex128, one right-hand side.
+The operand is *structure-exact, value-synthetic* (SURVEY.md section 8(d)): every
+block shape is what the reference's builder would produce (checked against the
+survey's probe statistics in tests/test_structure.py); values are a seeded
+counter-based stream generated directly in HBM.  Apply cost does not depend on
+the values.
+
+A "step" is one full apply y = A x with x, y resident in HBM.  With N GPUs the
+top-level row blocks are dealt to ranks (strong scaling: the operator is fixed);
+each step then ends with one RCCL all-gather of y over xGMI.
+
+Prints ONE JSON line on rank 0 (contract in the round prompt): metric, value,
+roofline{...} for the stage kernel from hipEvents inside the library, and
+cpu_baseline{...} = the CPU oracle (oracle/bfref.c, a port of the reference's
+bfMatMul) timed on a bounded sample of the same operand on this box.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable copy)
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def assign_row_blocks(weights, world):
+    """LPT bin packing of top-level row blocks by leaf bytes."""
+    order = np.argsort(-np.asarray(weights))
+    loads = [0] * world
+    owner = [0] * len(weights)
+    for rb in order:
+        r = int(np.argmin(loads))
+        owner[rb] = r
+        loads[r] += weights[rb]
+    return owner, loads
+
+
+def row_block_weights(desc):
+    """leaf elements under each top-level block row"""
+    kind = np.asarray(desc.kind)
+    rows = np.asarray(desc.rows, dtype=np.int64)
+    cols = np.asarray(desc.cols, dtype=np.int64)
+    own = rows * cols * (kind == 0)
+    # subtree sums by DFS from each root child
+    nrb = len(desc.meta["top_rows"])
+    w = [0] * nrb
+    for (c, _, _), rb in zip(desc.children[desc.root], desc.top_row_block):
+        tot = 0
+        stack = [c]
+        while stack:
+            v = stack.pop()
+            tot += int(own[v])
+            stack.extend(ch for ch, _, _ in desc.children[v])
+        w[rb] += tot
+    return w
+
+
+def cpu_baseline(desc, seed, total_leaf_elems, weights, budget_bytes, nrhs, x, y_gpu_full, row_offsets):
+    """Oracle (port of the reference bfMatMul) on a bounded sample: the top-level
+    block rows, smallest first, that fit in `budget_bytes` of leaf data."""
+    from butterfly_amd import helm2_structure as hs
+    from oracle import bfref
+    blas = bfref.try_use_openblas()
+    order = np.argsort(weights)
+    chosen, acc = [], 0
+    for rb in order:
+        if weights[rb] == 0:
+            continue
+        if acc + weights[rb] * 16 > budget_bytes and chosen:
+            break
+        chosen.append(int(rb))
+        acc += weights[rb] * 16
+    chosen.sort()
+    root, nrows = hs.shard_desc(desc, chosen)
+    t0 = time.time()
+    A = bfref.from_desc(desc, None, seed=seed, root=root)
+    t_build = time.time() - t0
+    xs = x if nrhs > 1 else x[:, None]
+    best = None
+    reps = 0
+    t_start = time.time()
+    y = None
+    while reps < 5 and (reps < 2 or time.time() - t_start < 20):
+        bfref.reset_counters()
+        t0 = time.perf_counter()
+        y = bfref.mat_mul(A, xs)
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+        reps += 1
+    cnt = bfref.counters()
+    # parity of the device result on the sampled rows (full-size operand)
+    ref_rows = np.concatenate([np.arange(row_offsets[rb], row_offsets[rb + 1]) for rb in chosen])
+    yg = y_gpu_full[ref_rows]
+    err = float(np.linalg.norm(yg - y.reshape(yg.shape)) / np.linalg.norm(y))
+    sample_elems = sum(weights[rb] for rb in chosen)
+    frac = sample_elems / total_leaf_elems
+    full_equiv = nrhs / (best / frac)
+    return dict(value=full_equiv, unit="matvec/s", cores=1, kind="port",
+                sample=(f"top-level block rows {chosen} of {len(weights)} ({sample_elems * 16 / 1e9:.2f} GB of "
+                        f"{total_leaf_elems * 16 / 1e9:.2f} GB leaf data, {frac * 100:.1f}%), best of {reps} in "
+                        f"{best * 1e3:.1f} ms, scaled by leaf bytes; blas={os.path.basename(blas) if blas else 'builtin-c'}; "
+                        f"{cnt['gemmCalls']} leaf gemm calls, {cnt['mallocs']} mallocs per apply; graph build {t_build:.1f}s"),
+                sample_seconds=best, parity_rel_l2=err)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--n", type=int, default=262144)
+    ap.add_argument("--k", type=float, default=None, help="wavenumber (default N/16)")
+    ap.add_argument("--nrhs", type=int, default=1)
+    ap.add_argument("--seed", type=int, default=1234)
+    ap.add_argument("--cpu-budget-gb", type=float, default=4.0, help="leaf bytes of the cpu_baseline sample")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from butterfly_amd import _capi, helm2_structure as hs
+    from butterfly_amd.operator import HipOperator
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl")
+    if world != args.gpus and rank == 0:
+        log(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    n = args.n
+    k = args.k if args.k is not None else n / 16.0
+    t0 = time.time()
+    desc, qroot, perm = hs.helm2_multilevel_structure(hs.circle_points(n), k)
+    t_struct = time.time() - t0
+    weights = row_block_weights(desc)
+    total_leaf = int(sum(weights))
+    top_rows = desc.meta["top_rows"]
+    row_offsets = np.concatenate([[0], np.cumsum(top_rows)]).astype(np.int64)
+    owner, loads = assign_row_blocks(weights, world)
+    mine = [rb for rb in range(len(weights)) if owner[rb] == rank]
+    if rank == 0:
+        log(f"structure: N={n} k={k:g} nodes={desc.num_nodes} leafGB={total_leaf * 16 / 1e9:.2f} "
+            f"products={desc.meta['stats']['products']} [{t_struct:.1f}s]; rank loads GB="
+            f"{[round(l * 16 / 1e9, 2) for l in loads]}")
+
+    t0 = time.time()
+    if world == 1:
+        root, local_rows = desc.root, n
+    else:
+        root, local_rows = hs.shard_desc(desc, mine)
+    op = HipOperator.from_desc(desc, None, root=root, device=local_rank, flags=_capi.FLAG_PROFILE,
+                               seed=args.seed, max_rhs=args.nrhs)
+    torch.cuda.synchronize()
+    t_compile = time.time() - t0
+    st = op.stats()
+    if rank == 0:
+        log(f"compile+synthesize: {t_compile:.1f}s stages={st['numStages']} items={st['numItems']} pieces={st['numPieces']} "
+            f"arenaGB={st['arenaBytes'] / 1e9:.2f} metaMB={st['metaBytes'] / 1e6:.1f} tempElems={st['tempElems']}")
+
+    # x: seeded complex normal, identical on every rank (replicated input)
+    rng = np.random.default_rng(args.seed)
+    shape = (n,) if args.nrhs == 1 else (n, args.nrhs)
+    x_host = (rng.standard_normal(shape) + 1j * rng.standard_normal(shape)) / np.sqrt(2)
+    x = torch.from_numpy(x_host).to(dev)
+    y_local = torch.empty((local_rows,) + shape[1:], dtype=torch.complex128, device=dev)
+
+    if world > 1:
+        max_rows = max(sum(top_rows[rb] for rb in range(len(weights)) if owner[rb] == r) for r in range(world))
+        pad = torch.zeros((max_rows,) + shape[1:], dtype=torch.complex128, device=dev)
+        gathered = torch.empty((world * max_rows,) + shape[1:], dtype=torch.complex128, device=dev)
+        # index map: global row -> position in `gathered`
+        idx = np.empty(n, dtype=np.int64)
+        for r in range(world):
+            pos = r * max_rows
+            for rb in range(len(weights)):
+                if owner[rb] == r:
+                    m = top_rows[rb]
+                    idx[row_offsets[rb]:row_offsets[rb] + m] = np.arange(pos, pos + m)
+                    pos += m
+        idx_t = torch.from_numpy(idx).to(dev)
+
+    def step():
+        op.apply_device(x, y_local)
+        if world > 1:
+            pad[:local_rows] = y_local
+            dist.all_gather_into_tensor(gathered, pad)
+            return gathered.index_select(0, idx_t)
+        return y_local
+
+    for _ in range(args.warmup):
+        y_full = step()
+    torch.cuda.synchronize()
+    op.stage_profile(reset=True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        y_full = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    ms, launches, sbytes = op.stage_profile()
+    if rank == 0:
+        kern_ms = float(ms.sum())
+        n_launch = int(launches.sum())
+        bytes_per_apply = int(sbytes.sum())
+        avg_launch_ms = kern_ms / max(n_launch, 1)
+        achieved = (bytes_per_apply * (n_launch / len(ms))) / 1e9 / (kern_ms / 1e3) if kern_ms > 0 else 0.0
+        for s in range(len(ms)):
+            log(f"  stage {s}: {ms[s] / max(launches[s], 1):8.3f} ms/launch  {sbytes[s] / 1e9:8.3f} GB  "
+                f"{(sbytes[s] / 1e9) / (ms[s] / max(launches[s], 1) / 1e3) if ms[s] > 0 else 0:8.1f} GB/s")
+        out = {
+            "metric": "butterfly matvecs/sec (2D Helmholtz HODBF apply)",
+            "value": args.steps * args.nrhs / elapsed,
+            "unit": "matvec/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "c128",
+            "data": "synthetic (structure-exact fac_helm2 layout, seeded values generated in HBM)",
+            "config": {"workload": f"fac_helm2 multilevel butterfly, unit circle, N={n}, k={k:g} (16 ppw), nrhs={args.nrhs}",
+                       "n": n, "k": k, "nrhs": args.nrhs, "leaf_bytes": total_leaf * 16,
+                       "stages": st["numStages"], "sharding": "top-level row blocks, LPT by leaf bytes" if world > 1 else "none"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "bfStageKernelC128", "launches_per_apply": len(ms),
+                         "avg_launch_ms": avg_launch_ms, "algorithmic_bytes_per_apply": bytes_per_apply,
+                         "kernel_ms_per_apply": kern_ms / max(launches.max(), 1)},
+            "hbm_gbs_whole_step": (total_leaf * 16 / 1e9) / (elapsed / args.steps),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                y_host = y_full.cpu().numpy()
+                out["cpu_baseline"] = cpu_baseline(desc, args.seed, total_leaf, weights, args.cpu_budget_gb * 1e9,
+                                                   args.nrhs, x_host, y_host, row_offsets)
+            except Exception as e:  # the baseline must never take the measurement down
+                out["cpu_baseline"] = {"value": None, "unit": "matvec/s", "cores": 1, "kind": "port", "sample": f"failed: {e!r}"}
+        print(json.dumps(out), flush=True)
+    op.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -12,6 +12,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libbfhip.so")
 
 BFHIP_C128, BFHIP_F64, BFHIP_F32 = 0, 1, 2
 FLAG_PROFILE = 1
+FLAG_PLAN_ONLY = 2
 
 ERROR_NAMES = {0: "BF_ERROR_NONE", 1: "BF_ERROR_INVALID_ARGUMENTS", 2: "BF_ERROR_RUNTIME_ERROR",
                3: "BF_ERROR_NOT_IMPLEMENTED", 4: "BF_ERROR_MEMORY_ERROR", 5: "BF_ERROR_OUT_OF_RANGE",
@@ -40,6 +41,26 @@ class BfhipStats(C.Structure):
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}
+
+
+class BfhipPlanInfo(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in ("structSize", "dtype", "elemSize", "epl", "xcap", "reserved")] + [
+        (n, C.c_uint64) for n in ("numRows", "numCols", "numStages", "arenaElems", "tempElems")]
+
+
+class BfhipStageView(C.Structure):
+    _fields_ = [("structSize", C.c_uint32), ("reserved", C.c_uint32), ("numItems", C.c_uint64),
+                ("numPieces", C.c_uint64), ("numReduce", C.c_uint64), ("items", C.c_void_p), ("pieces", C.c_void_p)]
+
+
+class BfhipReduceView(C.Structure):
+    _fields_ = [("structSize", C.c_uint32), ("destIsY", C.c_uint32), ("destOff", C.c_uint64),
+                ("numRows", C.c_uint64), ("numIntervals", C.c_uint64), ("numSrc", C.c_uint64),
+                ("rowInterval", C.c_void_p), ("ivBegin", C.c_void_p), ("srcBias", C.c_void_p)]
+
+
+ITEM_DTYPE = np.dtype([("pieceBegin", "<u4"), ("numPieces", "<u4"), ("outOff", "<u4"), ("mrFlags", "<u4")])
+PIECE_DTYPE = np.dtype([("dataOff", "<u8"), ("inOff", "<u4"), ("ncols", "<u4"), ("flags", "<u4"), ("pad", "<u4")])
 
 
 class DescArrays:
@@ -111,6 +132,14 @@ def load():
     lib.bfhipNumBytes.restype = C.c_size_t
     lib.bfhipGetStageProfile.argtypes = [vp, vp, vp, vp, C.c_int]
     lib.bfhipGetStageProfile.restype = C.c_int
+    lib.bfhipPlanGetInfo.argtypes = [vp, C.POINTER(BfhipPlanInfo)]
+    lib.bfhipPlanGetInfo.restype = C.c_int
+    lib.bfhipPlanGetStage.argtypes = [vp, C.c_uint64, C.POINTER(BfhipStageView)]
+    lib.bfhipPlanGetStage.restype = C.c_int
+    lib.bfhipPlanGetReduce.argtypes = [vp, C.c_uint64, C.c_uint64, C.POINTER(BfhipReduceView)]
+    lib.bfhipPlanGetReduce.restype = C.c_int
+    lib.bfhipPlanPackArena.argtypes = [vp, vp]
+    lib.bfhipPlanPackArena.restype = C.c_int
     lib.bfhipFree.argtypes = [C.POINTER(vp)]
     lib.bfhipFree.restype = None
     lib.bfhipMatNew.argtypes = [vp, C.c_int]

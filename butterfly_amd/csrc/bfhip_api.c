@@ -1,0 +1,630 @@
+/* bfhip_api.c -- the C-ABI of include/bfhip.h: operator lifetime, compile
+ * (IR -> plan -> HBM), apply, profiling, and the BfMat vtable shim that makes
+ * the device operator a drop-in behind the reference's bfMatMul / bfMatMulVec
+ * (reference src/mat.c:183-189; precedent for a foreign operator behind the
+ * vtable: BfMatFunc, include/bf/mat_func.h:5-28, src/mat_func.c:59-82).
+ */
+#define _GNU_SOURCE
+#include "bfhip_internal.h"
+#include "../../include/bfhip_abi.h"
+#include "../../include/bfhip_synth.h"
+
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ---- errors ----------------------------------------------------------------- */
+static __thread char lastError[512];
+
+int bfhipFail(int code, char const *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(lastError, sizeof lastError, fmt, ap);
+  va_end(ap);
+  return code;
+}
+char const *bfhipLastErrorMessage(void) { return lastError; }
+char const *bfhipErrorString(int code) {
+  static char const *const names[] = {"BF_ERROR_NONE", "BF_ERROR_INVALID_ARGUMENTS", "BF_ERROR_RUNTIME_ERROR",
+                                      "BF_ERROR_NOT_IMPLEMENTED", "BF_ERROR_MEMORY_ERROR", "BF_ERROR_OUT_OF_RANGE",
+                                      "BF_ERROR_FILE_ERROR", "BF_ERROR_TYPE_ERROR", "BF_ERROR_INCOMPATIBLE_SHAPES"};
+  return (code >= 0 && code <= 8) ? names[code] : "BF_ERROR_UNKNOWN";
+}
+
+double bfhipSyntheticValue(uint64_t seed, uint64_t idx, int imag) { return bfhip_synth_value(seed, idx, imag); }
+
+int bfhipSyntheticLeafBases(BfhipDesc const *desc, uint64_t *bases) {
+  if (!desc || !bases) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "NULL argument");
+  uint64_t acc = 0;
+  for (uint64_t i = 0; i < desc->numNodes; ++i) {
+    bases[i] = acc;
+    if (desc->kind[i] == BFHIP_NODE_DENSE) acc += desc->rows[i] * desc->cols[i];
+  }
+  return 0;
+}
+
+/* ---- operator --------------------------------------------------------------- */
+struct BfhipOperator {
+  BfPlan plan;
+  uint32_t srcDtype;          /* dtype of the operand as given (C128 / F64) */
+  int device;
+  uint32_t flags;
+  void *dArena;               /* leaf data */
+  void *dTemp;                /* vector arena: intermediates + partial slots, tempElems * maxRhs */
+  uint32_t tempRhs;
+  uint64_t metaBytes;
+  uint64_t leafBytesAlgorithmic;
+  /* staging for the host-pointer apply */
+  void *dX, *dY;
+  uint32_t xyRhs;
+  /* profiling */
+  void **evStart, **evStop;   /* [numStages] */
+  double *stageMs;
+  uint64_t *stageLaunches;
+  uint32_t lastNrhs;
+  int evPending;
+  /* BFHIP_FLAG_PLAN_ONLY: the IR is kept (borrowed leaf pointers!) for bfhipPlanPackArena */
+  BfIr *ir;
+  uint64_t seed;
+};
+
+static void freeDevicePlan(BfhipOperator *op) {
+  for (uint64_t s = 0; s < op->plan.numStages && op->plan.stages; ++s) {
+    BfStage *st = &op->plan.stages[s];
+    bfdevFree(st->dItems); st->dItems = NULL;
+    bfdevFree(st->dPieces); st->dPieces = NULL;
+    for (uint64_t r = 0; r < st->numReduce; ++r) {
+      bfdevFree(st->reduce[r].dRowInterval); bfdevFree(st->reduce[r].dIvBegin); bfdevFree(st->reduce[r].dSrcBias);
+      st->reduce[r].dRowInterval = st->reduce[r].dIvBegin = st->reduce[r].dSrcBias = NULL;
+    }
+  }
+}
+
+void bfhipFree(BfhipOperator **pop) {
+  if (!pop || !*pop) return;
+  BfhipOperator *op = *pop;
+  int prev = -1;
+  if (!(op->flags & BFHIP_FLAG_PLAN_ONLY)) {
+    bfdevGetDevice(&prev);
+    bfdevSetDevice(op->device);
+  }
+  if (op->evStart) for (uint64_t s = 0; s < op->plan.numStages; ++s) { bfdevEventDestroy(op->evStart[s]); bfdevEventDestroy(op->evStop[s]); }
+  free(op->evStart); free(op->evStop); free(op->stageMs); free(op->stageLaunches);
+  freeDevicePlan(op);
+  bfdevFree(op->dArena);
+  bfdevFree(op->dTemp);
+  bfdevFree(op->dX);
+  bfdevFree(op->dY);
+  bfPlanFree(&op->plan);
+  if (op->ir) { bfIrFree(op->ir); free(op->ir); }
+  int const touchedDevice = !(op->flags & BFHIP_FLAG_PLAN_ONLY);
+  free(op);
+  *pop = NULL;
+  if (touchedDevice && prev >= 0) bfdevSetDevice(prev);
+}
+
+static int uploadArray(void **d, void const *h, size_t bytes, uint64_t *meta) {
+  int rc = bfdevMalloc(d, bytes);
+  if (rc) return rc;
+  *meta += bytes;
+  return bfdevMemcpyH2D(*d, h, bytes);
+}
+
+/* write one piece (mr x ncols sub-block of a leaf, column-major, rows padded
+ * to mrPad) at dst */
+static void packPiece(BfPlan const *pl, BfIr const *ir, BfDevPiece const *pc, BfPieceSrc const *src,
+                      uint32_t mr, uint32_t mrPad, unsigned char *dst, uint64_t seed) {
+  uint64_t node = src->node;
+  void const *data = ir->leafData[node];
+  int const cplx = pl->dtype == BFHIP_C128;
+  uint64_t ldr = ir->leafRowStride[node], ldc = ir->leafColStride[node];
+  double const *A = (double const *)data;
+  double scale = 0;
+  uint64_t vbase = ir->synthBase[node], n = ir->cols[node];
+  if (!data) scale = cplx ? sqrt(3.0 / (2.0 * (double)n)) : sqrt(3.0 / (double)n);
+  for (uint32_t c = 0; c < pc->ncols; ++c) {
+    for (uint32_t r = 0; r < mrPad; ++r) {
+      double re = 0, im = 0;
+      if (r < mr) {
+        uint64_t i = src->row0 + r, j = src->col0 + c;
+        if (data) {
+          if (cplx) { double const *e = A + 2 * (i * ldr + j * ldc); re = e[0]; im = e[1]; }
+          else re = A[i * ldr + j * ldc];
+        } else {
+          re = bfhip_synth_value(seed, vbase + i * n + j, 0) * scale;
+          if (cplx) im = bfhip_synth_value(seed, vbase + i * n + j, 1) * scale;
+        }
+      }
+      uint64_t e = (uint64_t)c * mrPad + r;
+      if (cplx) { ((double *)dst)[2 * e] = re; ((double *)dst)[2 * e + 1] = im; }
+      else if (pl->dtype == BFHIP_F64) ((double *)dst)[e] = re;
+      else ((float *)dst)[e] = (float)re;
+    }
+  }
+}
+
+/* pack leaves into the arena, stage by stage, in arena order.  hostDst != NULL:
+ * write everything (synthetic leaves included) to host memory; else upload
+ * host-valued leaves through a staging buffer and synthesize the rest on the
+ * device. */
+static int packLeaves(BfhipOperator const *op, BfIr const *ir, uint64_t seed, void *hostDst) {
+  BfPlan const *pl = &op->plan;
+  size_t const es = pl->elemSize;
+  int const cplx = pl->dtype == BFHIP_C128;
+  size_t const chunkBytes = (size_t)64 << 20;
+  unsigned char *stage = NULL;
+  BfSynthPiece *synth = NULL;
+  uint64_t numSynth = 0, capSynth = 0;
+  int rc = 0;
+  uint64_t chunkBase = 0;    /* arena element offset of stage[0] */
+  size_t fill = 0;           /* bytes used in stage */
+  for (uint64_t s = 0; s < pl->numStages && !rc; ++s) {
+    BfStage const *st = &pl->stages[s];
+    for (uint64_t i = 0; i < st->numItems && !rc; ++i) {
+      BfDevItem const *it = &st->items[i];
+      uint32_t mr = it->mrFlags & 0xffffu;
+      uint32_t mrPad = (mr + pl->epl - 1) / pl->epl * pl->epl;
+      for (uint32_t k = 0; k < it->numPieces && !rc; ++k) {
+        BfDevPiece const *pc = &st->pieces[it->pieceBegin + k];
+        BfPieceSrc const *src = &st->pieceSrc[it->pieceBegin + k];
+        if (pc->flags & BF_PIECE_IDENTITY) continue;
+        uint64_t node = src->node;
+        size_t bytes = (size_t)mrPad * pc->ncols * es;
+        if (hostDst) {
+          packPiece(pl, ir, pc, src, mr, mrPad, (unsigned char *)hostDst + pc->dataOff * es, seed);
+          continue;
+        }
+        if (!ir->leafData[node]) {
+          if (numSynth == capSynth) {
+            capSynth = capSynth ? capSynth * 2 : 4096;
+            BfSynthPiece *p = realloc(synth, capSynth * sizeof *synth);
+            if (!p) { rc = bfhipFail(BFABI_ERROR_MEMORY_ERROR, "host OOM (synth pieces)"); break; }
+            synth = p;
+          }
+          BfSynthPiece *sp = &synth[numSynth++];
+          sp->dataOff = pc->dataOff;
+          sp->vbase = ir->synthBase[node];
+          sp->leafCols = (uint32_t)ir->cols[node];
+          sp->row0 = src->row0; sp->col0 = src->col0;
+          sp->mr = mr; sp->mrPad = mrPad; sp->ncols = pc->ncols;
+          sp->scale = cplx ? sqrt(3.0 / (2.0 * (double)ir->cols[node])) : sqrt(3.0 / (double)ir->cols[node]);
+          continue;
+        }
+        if (!stage) {
+          stage = malloc(chunkBytes);
+          if (!stage) { rc = bfhipFail(BFABI_ERROR_MEMORY_ERROR, "host OOM (staging)"); break; }
+          chunkBase = pc->dataOff; fill = 0;
+        }
+        /* pieces are consecutive in the arena except across synthetic ones */
+        if (fill && (pc->dataOff != chunkBase + fill / es || fill + bytes > chunkBytes)) {
+          rc = bfdevMemcpyH2D((char *)op->dArena + chunkBase * es, stage, fill);
+          fill = 0;
+          if (rc) break;
+        }
+        if (!fill) chunkBase = pc->dataOff;
+        if (bytes > chunkBytes) { rc = bfhipFail(BFABI_ERROR_RUNTIME_ERROR, "piece larger than staging chunk"); break; }
+        packPiece(pl, ir, pc, src, mr, mrPad, stage + fill, seed);
+        fill += bytes;
+      }
+    }
+  }
+  if (!rc && fill) rc = bfdevMemcpyH2D((char *)op->dArena + chunkBase * es, stage, fill);
+  free(stage);
+  if (!rc && numSynth) rc = bfdevSynthFill(op->dArena, pl->dtype, synth, numSynth, seed);
+  free(synth);
+  return rc;
+}
+
+static int ensureTemp(BfhipOperator *op, uint32_t nrhs) {
+  if (op->dTemp && op->tempRhs >= nrhs) return 0;
+  bfdevFree(op->dTemp);
+  op->dTemp = NULL;
+  op->tempRhs = 0;
+  int rc = bfdevMalloc(&op->dTemp, (size_t)op->plan.tempElems * nrhs * op->plan.elemSize);
+  if (rc) return rc;
+  op->tempRhs = nrhs;
+  return 0;
+}
+
+static int compileIr(BfIr *ir, BfhipOptions const *opts, BfhipOperator **out) {
+  BfhipOptions o;
+  memset(&o, 0, sizeof o);
+  o.device = -1;
+  if (opts) {
+    if (opts->structSize < sizeof(BfhipOptions)) { bfIrFree(ir); return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "BfhipOptions.structSize too small"); }
+    o = *opts;
+  }
+  BfhipOperator *op = calloc(1, sizeof *op);
+  if (!op) { bfIrFree(ir); return bfhipFail(BFABI_ERROR_MEMORY_ERROR, "host OOM"); }
+  int rc = 0;
+  int prevDev = -1;
+  int const planOnly = (o.flags & BFHIP_FLAG_PLAN_ONLY) != 0;
+  op->flags = o.flags;
+  op->seed = o.seed;
+  if (!planOnly) {
+    bfdevGetDevice(&prevDev);
+    if ((rc = bfdevSetDevice(o.device))) goto done;
+    if ((rc = bfdevGetDevice(&op->device))) goto done;
+  }
+  op->srcDtype = ir->dtype;
+  BfPlanOptions po;
+  memset(&po, 0, sizeof po);
+  po.storeDtype = ir->dtype;
+  if (o.demoteToF32) {
+    if (ir->dtype != BFHIP_F64) { rc = bfhipFail(BFABI_ERROR_TYPE_ERROR, "demoteToF32 applies to real operands only"); goto done; }
+    po.storeDtype = BFHIP_F32;
+  }
+  po.rowBlockBegin = o.rowBlockBegin;
+  po.rowBlockEnd = o.rowBlockEnd;
+  if ((rc = bfPlanBuild(ir, &po, &op->plan))) goto done;
+  op->leafBytesAlgorithmic = op->plan.leafElems * op->plan.elemSize;
+  if (planOnly) {
+    /* keep the IR (with its borrowed leaf pointers) for bfhipPlanPackArena */
+    op->ir = malloc(sizeof *op->ir);
+    if (!op->ir) { rc = bfhipFail(BFABI_ERROR_MEMORY_ERROR, "host OOM"); goto done; }
+    *op->ir = *ir;
+    memset(ir, 0, sizeof *ir);
+    *out = op;
+    return 0;
+  }
+
+  if ((rc = bfdevMalloc(&op->dArena, (size_t)op->plan.arenaElems * op->plan.elemSize))) goto done;
+  for (uint64_t s = 0; s < op->plan.numStages && !rc; ++s) {
+    BfStage *st = &op->plan.stages[s];
+    rc = uploadArray(&st->dItems, st->items, st->numItems * sizeof(BfDevItem), &op->metaBytes);
+    if (!rc) rc = uploadArray(&st->dPieces, st->pieces, st->numPieces * sizeof(BfDevPiece), &op->metaBytes);
+    for (uint64_t r = 0; r < st->numReduce && !rc; ++r) {
+      BfReduce *rd = &st->reduce[r];
+      rc = uploadArray(&rd->dRowInterval, rd->rowInterval, rd->numRows * 4, &op->metaBytes);
+      if (!rc) rc = uploadArray(&rd->dIvBegin, rd->ivBegin, (rd->numIntervals + 1) * 4, &op->metaBytes);
+      if (!rc) rc = uploadArray(&rd->dSrcBias, rd->srcBias, rd->numSrc * 8, &op->metaBytes);
+    }
+  }
+  if (rc) goto done;
+  if ((rc = packLeaves(op, ir, o.seed, NULL))) goto done;
+  /* host mirrors of the bulky per-piece arrays are no longer needed */
+  for (uint64_t s = 0; s < op->plan.numStages; ++s) {
+    BfStage *st = &op->plan.stages[s];
+    free(st->pieceSrc); st->pieceSrc = NULL;
+    free(st->pieces); st->pieces = NULL;
+    free(st->items); st->items = NULL;
+    for (uint64_t r = 0; r < st->numReduce; ++r) {
+      free(st->reduce[r].rowInterval); st->reduce[r].rowInterval = NULL;
+      free(st->reduce[r].ivBegin); st->reduce[r].ivBegin = NULL;
+      free(st->reduce[r].srcBias); st->reduce[r].srcBias = NULL;
+    }
+  }
+  if ((rc = ensureTemp(op, o.maxRhs ? o.maxRhs : 1))) goto done;
+  if (op->flags & BFHIP_FLAG_PROFILE) {
+    uint64_t S = op->plan.numStages;
+    op->evStart = calloc(S, sizeof(void *));
+    op->evStop = calloc(S, sizeof(void *));
+    op->stageMs = calloc(S, sizeof(double));
+    op->stageLaunches = calloc(S, sizeof(uint64_t));
+    if (!op->evStart || !op->evStop || !op->stageMs || !op->stageLaunches) { rc = bfhipFail(BFABI_ERROR_MEMORY_ERROR, "host OOM"); goto done; }
+    for (uint64_t s = 0; s < S && !rc; ++s) {
+      rc = bfdevEventCreate(&op->evStart[s]);
+      if (!rc) rc = bfdevEventCreate(&op->evStop[s]);
+    }
+  }
+done:
+  bfIrFree(ir);
+  if (rc) { bfhipFree(&op); if (prevDev >= 0) bfdevSetDevice(prevDev); return rc; }
+  if (prevDev >= 0 && o.device >= 0) bfdevSetDevice(prevDev);
+  *out = op;
+  return 0;
+}
+
+int bfhipCompile(void const *bfMat, BfhipOptions const *opts, BfhipOperator **out) {
+  if (!bfMat || !out) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "NULL argument");
+  *out = NULL;
+  BfIr ir;
+  int rc = bfIrFromBfMat(bfMat, &ir);
+  if (rc) return rc;
+  return compileIr(&ir, opts, out);
+}
+
+int bfhipCompileDesc(BfhipDesc const *desc, BfhipOptions const *opts, BfhipOperator **out) {
+  if (!desc || !out) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "NULL argument");
+  *out = NULL;
+  BfIr ir;
+  int rc = bfIrFromDesc(desc, &ir);
+  if (rc) return rc;
+  return compileIr(&ir, opts, out);
+}
+
+/* ---- profiling helpers ------------------------------------------------------ */
+static int harvestEvents(BfhipOperator *op) {
+  if (!op->evPending) return 0;
+  for (uint64_t s = 0; s < op->plan.numStages; ++s) {
+    float ms = 0;
+    int rc = bfdevEventElapsed(op->evStart[s], op->evStop[s], &ms);
+    if (rc) return rc;
+    op->stageMs[s] += ms;
+    op->stageLaunches[s] += 1;
+  }
+  op->evPending = 0;
+  return 0;
+}
+
+static uint64_t stageBytes(BfhipOperator const *op, uint64_t s, uint32_t nrhs) {
+  BfStage const *st = &op->plan.stages[s];
+  return st->leafElems * op->plan.elemSize + (st->vecIn + st->vecOut) * (uint64_t)nrhs * op->plan.elemSize;
+}
+
+int bfhipGetStageProfile(BfhipOperator *op, double *ms, uint64_t *launches, uint64_t *bytes, int reset) {
+  if (!op) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "NULL operator");
+  if (!(op->flags & BFHIP_FLAG_PROFILE)) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "operator was not compiled with BFHIP_FLAG_PROFILE");
+  int rc = harvestEvents(op);
+  if (rc) return rc;
+  for (uint64_t s = 0; s < op->plan.numStages; ++s) {
+    if (ms) ms[s] = op->stageMs[s];
+    if (launches) launches[s] = op->stageLaunches[s];
+    if (bytes) bytes[s] = stageBytes(op, s, op->lastNrhs ? op->lastNrhs : 1);
+    if (reset) { op->stageMs[s] = 0; op->stageLaunches[s] = 0; }
+  }
+  return 0;
+}
+
+/* ---- apply ------------------------------------------------------------------ */
+int bfhipApplyDevice(BfhipOperator *op, void const *dX, size_t nrhs, void *dY, void *stream) {
+  if (!op || !dX || !dY) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "NULL argument");
+  if (nrhs == 0 || nrhs > 0xffffu) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "nrhs out of range");
+  if (op->flags & BFHIP_FLAG_PLAN_ONLY) return bfhipFail(BFABI_ERROR_RUNTIME_ERROR, "operator was compiled with BFHIP_FLAG_PLAN_ONLY: no device operator exists");
+  int rc;
+  int prev = -1;
+  bfdevGetDevice(&prev);
+  if (prev != op->device && (rc = bfdevSetDevice(op->device))) return rc;
+  if (op->tempRhs < nrhs) {
+    /* growing the vector arena is not stream-ordered: drain first */
+    if ((rc = bfdevSync(stream))) return rc;
+    if ((rc = ensureTemp(op, (uint32_t)nrhs))) return rc;
+  }
+  int const prof = (op->flags & BFHIP_FLAG_PROFILE) != 0;
+  if (prof && (rc = harvestEvents(op))) return rc;
+  for (uint64_t s = 0; s < op->plan.numStages; ++s) {
+    BfStage *st = &op->plan.stages[s];
+    BfLaunchArgs a;
+    a.arena = op->dArena; a.items = st->dItems; a.pieces = st->dPieces; a.numItems = st->numItems;
+    a.x = dX; a.y = dY; a.temp = op->dTemp; a.nrhs = (uint32_t)nrhs; a.dtype = op->plan.dtype; a.maxRows = st->maxRows;
+    if (prof && (rc = bfdevEventRecord(op->evStart[s], stream))) return rc;
+    if ((rc = bfdevLaunchStage(&a, stream))) return rc;
+    if (prof && (rc = bfdevEventRecord(op->evStop[s], stream))) return rc;
+    for (uint64_t r = 0; r < st->numReduce; ++r) {
+      BfReduce *rd = &st->reduce[r];
+      BfReduceArgs ra;
+      ra.rowInterval = rd->dRowInterval; ra.ivBegin = rd->dIvBegin; ra.srcBias = rd->dSrcBias;
+      ra.numRows = rd->numRows; ra.temp = op->dTemp; ra.nrhs = (uint32_t)nrhs; ra.dtype = op->plan.dtype;
+      ra.dest = rd->destSpace == BF_SPACE_Y ? dY : (void *)((char *)op->dTemp + rd->destOff * nrhs * op->plan.elemSize);
+      if ((rc = bfdevLaunchReduce(&ra, stream))) return rc;
+    }
+  }
+  if (prof) { op->evPending = 1; op->lastNrhs = (uint32_t)nrhs; }
+  if (prev >= 0 && prev != op->device) bfdevSetDevice(prev);
+  return 0;
+}
+
+int bfhipApply(BfhipOperator *op, void const *X, size_t ldx, size_t nrhs, void *Y, size_t ldy) {
+  if (!op || !X || !Y) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "NULL argument");
+  if (nrhs == 0 || ldx < nrhs || ldy < nrhs) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "bad nrhs / leading dimension");
+  if (op->flags & BFHIP_FLAG_PLAN_ONLY) return bfhipFail(BFABI_ERROR_RUNTIME_ERROR, "operator was compiled with BFHIP_FLAG_PLAN_ONLY: no device operator exists");
+  int rc;
+  int prev = -1;
+  bfdevGetDevice(&prev);
+  if ((rc = bfdevSetDevice(op->device))) return rc;
+  size_t es = op->plan.elemSize;
+  size_t hostEs = op->srcDtype == BFHIP_C128 ? 16 : 8;      /* host side is always double precision */
+  uint64_t n = op->plan.numCols, m = op->plan.numRows;
+  if (op->xyRhs < nrhs) {
+    bfdevFree(op->dX); bfdevFree(op->dY); op->dX = op->dY = NULL; op->xyRhs = 0;
+    if ((rc = bfdevMalloc(&op->dX, n * nrhs * es))) return rc;
+    if ((rc = bfdevMalloc(&op->dY, m * nrhs * es))) return rc;
+    op->xyRhs = (uint32_t)nrhs;
+  }
+  /* pack to ld == nrhs (and demote if the operator computes in fp32) */
+  void *hx = NULL, *hy = NULL;
+  int needPackX = ldx != nrhs || es != hostEs, needPackY = ldy != nrhs || es != hostEs;
+  if (needPackX) {
+    hx = malloc(n && nrhs ? n * nrhs * es : 1);
+    if (!hx) return bfhipFail(BFABI_ERROR_MEMORY_ERROR, "host OOM");
+    if (es == hostEs) for (uint64_t i = 0; i < n; ++i) memcpy((char *)hx + i * nrhs * es, (char const *)X + i * ldx * es, nrhs * es);
+    else for (uint64_t i = 0; i < n; ++i) for (size_t q = 0; q < nrhs; ++q) ((float *)hx)[i * nrhs + q] = (float)((double const *)X)[i * ldx + q];
+  }
+  rc = bfdevMemcpyH2D(op->dX, needPackX ? hx : X, n * nrhs * es);
+  free(hx);
+  if (rc) return rc;
+  if ((rc = bfhipApplyDevice(op, op->dX, nrhs, op->dY, NULL))) return rc;
+  if ((rc = bfdevSync(NULL))) return rc;
+  if (needPackY) {
+    hy = malloc(m && nrhs ? m * nrhs * es : 1);
+    if (!hy) return bfhipFail(BFABI_ERROR_MEMORY_ERROR, "host OOM");
+    rc = bfdevMemcpyD2H(hy, op->dY, m * nrhs * es);
+    if (!rc) {
+      if (es == hostEs) for (uint64_t i = 0; i < m; ++i) memcpy((char *)Y + i * ldy * es, (char *)hy + i * nrhs * es, nrhs * es);
+      else for (uint64_t i = 0; i < m; ++i) for (size_t q = 0; q < nrhs; ++q) ((double *)Y)[i * ldy + q] = ((float *)hy)[i * nrhs + q];
+    }
+    free(hy);
+  } else {
+    rc = bfdevMemcpyD2H(Y, op->dY, m * nrhs * es);
+  }
+  if (prev >= 0 && prev != op->device) bfdevSetDevice(prev);
+  return rc;
+}
+
+/* ---- introspection ---------------------------------------------------------- */
+size_t bfhipGetNumRows(BfhipOperator const *op) { return op ? op->plan.numRows : 0; }
+size_t bfhipGetNumCols(BfhipOperator const *op) { return op ? op->plan.numCols : 0; }
+size_t bfhipNumBytes(BfhipOperator const *op) { return op ? op->plan.leafElems * (op->srcDtype == BFHIP_C128 ? 16 : 8) : 0; }
+
+int bfhipGetStats(BfhipOperator const *op, BfhipStats *st) {
+  if (!op || !st || st->structSize < sizeof(BfhipStats)) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "bad stats struct");
+  BfPlan const *pl = &op->plan;
+  st->dtype = pl->dtype;
+  st->numRows = pl->numRows; st->numCols = pl->numCols; st->numStages = pl->numStages;
+  st->numLeaves = pl->numLeaves;
+  st->numItems = 0; st->numPieces = 0; st->vecElemsRead = 0; st->vecElemsWritten = 0;
+  for (uint64_t s = 0; s < pl->numStages; ++s) {
+    st->numItems += pl->stages[s].numItems;
+    st->numPieces += pl->stages[s].numPieces;
+    st->vecElemsRead += pl->stages[s].vecIn;
+    st->vecElemsWritten += pl->stages[s].vecOut;
+  }
+  st->leafElems = pl->leafElems;
+  st->leafBytes = pl->leafElems * pl->elemSize;
+  st->arenaBytes = pl->arenaElems * pl->elemSize;
+  st->tempElems = pl->tempElems;
+  st->metaBytes = op->metaBytes;
+  return 0;
+}
+
+/* ---- plan inspection (BFHIP_FLAG_PLAN_ONLY) --------------------------------- */
+static int needPlanOnly(BfhipOperator const *op) {
+  if (!op) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "NULL operator");
+  if (!(op->flags & BFHIP_FLAG_PLAN_ONLY)) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "plan inspection needs BFHIP_FLAG_PLAN_ONLY");
+  return 0;
+}
+int bfhipPlanGetInfo(BfhipOperator const *op, BfhipPlanInfo *info) {
+  int rc = needPlanOnly(op);
+  if (rc) return rc;
+  if (!info || info->structSize < sizeof *info) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "bad info struct");
+  BfPlan const *pl = &op->plan;
+  info->dtype = pl->dtype; info->elemSize = pl->elemSize; info->epl = pl->epl; info->xcap = pl->xcap;
+  info->numRows = pl->numRows; info->numCols = pl->numCols; info->numStages = pl->numStages;
+  info->arenaElems = pl->arenaElems; info->tempElems = pl->tempElems;
+  return 0;
+}
+int bfhipPlanGetStage(BfhipOperator const *op, uint64_t stage, BfhipStageView *v) {
+  int rc = needPlanOnly(op);
+  if (rc) return rc;
+  if (!v || v->structSize < sizeof *v || stage >= op->plan.numStages) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "bad stage view request");
+  BfStage const *st = &op->plan.stages[stage];
+  v->numItems = st->numItems; v->numPieces = st->numPieces; v->numReduce = st->numReduce;
+  v->items = st->items; v->pieces = st->pieces;
+  return 0;
+}
+int bfhipPlanGetReduce(BfhipOperator const *op, uint64_t stage, uint64_t index, BfhipReduceView *v) {
+  int rc = needPlanOnly(op);
+  if (rc) return rc;
+  if (!v || v->structSize < sizeof *v || stage >= op->plan.numStages || index >= op->plan.stages[stage].numReduce)
+    return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "bad reduce view request");
+  BfReduce const *rd = &op->plan.stages[stage].reduce[index];
+  v->destIsY = rd->destSpace == BF_SPACE_Y; v->destOff = rd->destOff; v->numRows = rd->numRows;
+  v->numIntervals = rd->numIntervals; v->numSrc = rd->numSrc;
+  v->rowInterval = rd->rowInterval; v->ivBegin = rd->ivBegin; v->srcBias = rd->srcBias;
+  return 0;
+}
+int bfhipPlanPackArena(BfhipOperator const *op, void *dst) {
+  int rc = needPlanOnly(op);
+  if (rc) return rc;
+  if (!dst) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "NULL destination");
+  return packLeaves(op, op->ir, op->seed, dst);
+}
+
+/* =============================================================================
+ * BfMat vtable shim
+ * ============================================================================= */
+typedef struct BfhipMat {
+  BfAbiMat super;             /* must be first: this IS a BfMat */
+  BfhipOperator *op;
+  int ownsOperator;
+} BfhipMat;
+
+static size_t shimGetNumRows(BfAbiMat const *m) { return bfhipGetNumRows(((BfhipMat const *)m)->op); }
+static size_t shimGetNumCols(BfAbiMat const *m) { return bfhipGetNumCols(((BfhipMat const *)m)->op); }
+static int shimGetType(BfAbiMat const *m) { (void)m; return BFABI_TYPE_MAT_FUNC; }
+static size_t shimNumBytes(BfAbiMat const *m) { return bfhipNumBytes(((BfhipMat const *)m)->op); }
+static void shimDelete(BfAbiMat **m) {
+  if (!m || !*m) return;
+  BfhipMat *s = (BfhipMat *)*m;
+  if (s->ownsOperator) bfhipFree(&s->op);
+  free(s);
+  *m = NULL;
+}
+
+/* Y = A X for a reference dense RHS; the result is allocated through the
+ * RHS's own EmptyLike slot so the reference owns and frees it
+ * (bfMatBlockCooMul does the same with ZerosLike, mat_block_coo.c:401). */
+void *bfhipMatMulFunc(void const *rhsV, void *opV) {
+  BfhipOperator *op = opV;
+  BfAbiMat const *rhs = rhsV;
+  if (!op || !rhs || !rhs->vtbl) { bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "NULL operand"); return NULL; }
+  BfAbiGetTypeFn getType = (BfAbiGetTypeFn)rhs->vtbl->slot[BFABI_SLOT_GetType];
+  if (!getType || getType(rhs) != BFABI_TYPE_MAT_DENSE_COMPLEX || op->srcDtype != BFHIP_C128) {
+    /* same restriction as bfMatDenseComplexMul's switch (mat_dense_complex.c:1036-1047) */
+    bfhipFail(BFABI_ERROR_NOT_IMPLEMENTED, "Mul needs a complex operator and a BfMatDenseComplex right-hand side");
+    return NULL;
+  }
+  if (rhs->props & (BFABI_MAT_PROPS_TRANS | BFABI_MAT_PROPS_CONJ)) { bfhipFail(BFABI_ERROR_NOT_IMPLEMENTED, "transposed right-hand side"); return NULL; }
+  BfAbiMatDenseComplex const *x = (BfAbiMatDenseComplex const *)rhs;
+  if (rhs->numRows != op->plan.numCols) { bfhipFail(BFABI_ERROR_INCOMPATIBLE_SHAPES, "operator has %llu columns, right-hand side %llu rows", (unsigned long long)op->plan.numCols, (unsigned long long)rhs->numRows); return NULL; }
+  if (x->colStride != 1) { bfhipFail(BFABI_ERROR_NOT_IMPLEMENTED, "right-hand side with colStride != 1"); return NULL; }
+  BfAbiLikeFn emptyLike = (BfAbiLikeFn)rhs->vtbl->slot[BFABI_SLOT_EmptyLike];
+  if (!emptyLike) { bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "right-hand side has no EmptyLike"); return NULL; }
+  BfAbiMat *res = emptyLike(rhs, op->plan.numRows, rhs->numCols);
+  if (!res) { bfhipFail(BFABI_ERROR_MEMORY_ERROR, "EmptyLike failed"); return NULL; }
+  BfAbiMatDenseComplex *y = (BfAbiMatDenseComplex *)res;
+  int rc = bfhipApply(op, x->data, x->rowStride, rhs->numCols, y->data, y->rowStride);
+  if (rc) {
+    BfAbiDeleteFn del = (BfAbiDeleteFn)res->vtbl->slot[BFABI_SLOT_Delete];
+    if (del) del(&res);
+    return NULL;
+  }
+  return res;
+}
+
+static BfAbiMat *shimMul(BfAbiMat const *lhs, BfAbiMat const *rhs) {
+  return bfhipMatMulFunc(rhs, ((BfhipMat const *)lhs)->op);
+}
+
+/* y = A x for a reference BfVecReal (real operators only: the block types
+ * reject complex vectors, mat_block_coo.c:438-444).  The result is a Copy of
+ * the argument when sizes agree, so it carries the reference's own vtable. */
+static BfAbiVec *shimMulVec(BfAbiMat const *lhs, BfAbiVec const *vec) {
+  BfhipOperator *op = ((BfhipMat const *)lhs)->op;
+  if (!vec || !vec->vtbl) { bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "NULL vector"); return NULL; }
+  BfAbiVecGetTypeFn getType = (BfAbiVecGetTypeFn)vec->vtbl->slot[BFABI_VSLOT_GetType];
+  if (!getType || getType(vec) != BFABI_TYPE_VEC_REAL || op->srcDtype != BFHIP_F64) {
+    bfhipFail(BFABI_ERROR_NOT_IMPLEMENTED, "MulVec needs a real operator and a BfVecReal");
+    return NULL;
+  }
+  if (vec->size != op->plan.numCols) { bfhipFail(BFABI_ERROR_NOT_IMPLEMENTED, "vector size mismatch"); return NULL; }
+  if (op->plan.numRows != op->plan.numCols) { bfhipFail(BFABI_ERROR_NOT_IMPLEMENTED, "MulVec shim needs a square operator (result is a Copy of the argument)"); return NULL; }
+  BfAbiVecReal const *x = (BfAbiVecReal const *)vec;
+  BfAbiVecCopyFn copy = (BfAbiVecCopyFn)vec->vtbl->slot[BFABI_VSLOT_Copy];
+  if (!copy) { bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "vector has no Copy"); return NULL; }
+  BfAbiVec *res = copy(vec);
+  if (!res) { bfhipFail(BFABI_ERROR_MEMORY_ERROR, "vector Copy failed"); return NULL; }
+  BfAbiVecReal *y = (BfAbiVecReal *)res;
+  int rc = bfhipApply(op, x->data, x->stride, 1, y->data, y->stride);
+  if (rc) {
+    BfAbiVecDeleteFn del = (BfAbiVecDeleteFn)res->vtbl->slot[BFABI_VSLOT_Delete];
+    if (del) del(&res);
+    return NULL;
+  }
+  return res;
+}
+
+static BfAbiMatVtable ShimVtable = {.slot = {
+  [BFABI_SLOT_Delete] = (void *)shimDelete,
+  [BFABI_SLOT_GetType] = (void *)shimGetType,
+  [BFABI_SLOT_NumBytes] = (void *)shimNumBytes,
+  [BFABI_SLOT_GetNumRows] = (void *)shimGetNumRows,
+  [BFABI_SLOT_GetNumCols] = (void *)shimGetNumCols,
+  [BFABI_SLOT_Mul] = (void *)shimMul,
+  [BFABI_SLOT_MulVec] = (void *)shimMulVec,
+}};
+
+void *bfhipMatNew(BfhipOperator *op, int ownsOperator) {
+  if (!op) { bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "NULL operator"); return NULL; }
+  BfhipMat *m = calloc(1, sizeof *m);
+  if (!m) { bfhipFail(BFABI_ERROR_MEMORY_ERROR, "host OOM"); return NULL; }
+  m->super.vtbl = &ShimVtable;
+  m->super.props = BFABI_MAT_PROPS_NONE;
+  m->super.numRows = op->plan.numRows;
+  m->super.numCols = op->plan.numCols;
+  m->op = op;
+  m->ownsOperator = ownsOperator;
+  return m;
+}

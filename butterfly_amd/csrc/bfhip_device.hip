@@ -1,0 +1,369 @@
+// bfhip_device.hip -- gfx950 (MI355X, CDNA4) device layer of the butterfly
+// apply engine: the stage kernel (variable-size batched small GEMV over a
+// CSR-of-blocks level), the deterministic reduce kernel, the on-device
+// operand synthesizer, and thin wrappers over the HIP runtime so that the C
+// host never includes HIP headers.
+//
+// Stage kernel (what replaces one level of the reference's recursion, i.e.
+// every cblas_zgemm / cblas_dgemv call of that level -- reference
+// src/mat_dense_complex.c:1754, src/mat_dense_real.c:1358 -- plus the
+// AddInplace / SetRowRange scatter passes around them,
+// src/mat_block_coo.c:404-418, src/mat_block_diag.c:387-399):
+//
+//   * one 64-lane wavefront per work item = <= 64 row slots of one output row
+//     group, looping over the item's pieces (the blocks of that block row);
+//   * a piece is stored column-major (rows x cols), so with lanes owning rows
+//     a wave load of 16 B/lane is one contiguous <= 1 KiB segment: HBM-bound
+//     streaming with no cross-lane reduction in the inner loop;
+//   * when the item has fewer than 64 row slots, g = 64 / slots column groups
+//     share the wave (lane = group * slots + slot), so narrow blocks (rank
+//     16..20 inner factors) still issue near-full-width loads; groups are
+//     combined once per item through LDS;
+//   * the piece's input sub-vector is gathered into LDS once and read back
+//     with broadcast ds_reads (all lanes of a group read the same address);
+//   * every output row has exactly one owner: plain stores, no atomics, and a
+//     fixed summation order (results are run-to-run reproducible).
+//
+// Roofline: nrhs = 1 does 8 flops per 16 bytes of leaf data (0.5 flop/B), far
+// below the ~10 flop/B ridge of MI355X FP64: the kernel is HBM-bound and is
+// judged on leaf bytes / time against 8 TB/s (MI355X_MICROARCH.md).
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "bfhip_internal.h"
+#include "../../include/bfhip_abi.h"
+#include "../../include/bfhip_synth.h"
+
+#define BF_WAVES_PER_WG 4
+#define BF_XCAP 256            /* must equal BfPlan.xcap */
+#define BF_WAVE_LDS_BYTES (BF_XCAP * 16)
+
+static int hipFail(hipError_t e, char const *what) {
+  if (e == hipSuccess) return 0;
+  int code = (e == hipErrorOutOfMemory) ? BFABI_ERROR_MEMORY_ERROR : BFABI_ERROR_RUNTIME_ERROR;
+  return bfhipFail(code, "%s: %s", what, hipGetErrorString(e));
+}
+
+// ---------------------------------------------------------------------------
+// element traits
+// ---------------------------------------------------------------------------
+template <int DT> struct Traits;
+template <> struct Traits<BFHIP_C128> { using S = double; static constexpr int EPL = 1; static constexpr bool CPLX = true; };
+template <> struct Traits<BFHIP_F64> { using S = double; static constexpr int EPL = 2; static constexpr bool CPLX = false; };
+template <> struct Traits<BFHIP_F32> { using S = float; static constexpr int EPL = 4; static constexpr bool CPLX = false; };
+
+struct StageParams {
+  void const *arena;
+  BfDevItem const *items;
+  BfDevPiece const *pieces;
+  uint32_t numItems;
+  uint32_t nrhs;
+  void const *x;
+  void *y;
+  void *temp;
+};
+
+__device__ __forceinline__ void waveSync() {
+  // LDS traffic of one wave is issued in order; this only stops the compiler
+  // from moving LDS accesses across the hand-off between lanes.
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// ---------------------------------------------------------------------------
+// complex128 stage kernel
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(BF_WAVES_PER_WG * 64) void bfStageKernelC128(StageParams p) {
+  __shared__ __attribute__((aligned(16))) double2 lds[BF_WAVES_PER_WG][BF_XCAP];
+  int const wave = threadIdx.x >> 6;
+  int const lane = threadIdx.x & 63;
+  uint32_t item = __builtin_amdgcn_readfirstlane(blockIdx.x * BF_WAVES_PER_WG + wave);
+  if (item >= p.numItems) return;
+  BfDevItem const it = p.items[item];
+  uint32_t const mr = it.mrFlags & 0xffffu;
+  uint32_t const g = 64u / mr;
+  uint32_t const G = g * mr;
+  bool const active = (uint32_t)lane < G;
+  uint32_t const lc = active ? (uint32_t)lane : G - 1;   // clamped lane: inactive lanes recompute the last slot
+  uint32_t const c = lc / mr;
+  uint32_t const r = lc - c * mr;
+  double2 *xs = lds[wave];
+  double2 const *arena = (double2 const *)p.arena;
+  uint32_t const nrhs = p.nrhs;
+  double2 *out = (it.mrFlags & BF_ITEM_OUT_Y) ? (double2 *)p.y : (double2 *)p.temp;
+
+  for (uint32_t q = 0; q < nrhs; ++q) {
+    double accr = 0.0, acci = 0.0;
+    for (uint32_t pi = 0; pi < it.numPieces; ++pi) {
+      BfDevPiece const pc = p.pieces[it.pieceBegin + pi];
+      double2 const *xin = (pc.flags & BF_PIECE_IN_X) ? (double2 const *)p.x : (double2 const *)p.temp;
+      xin += (uint64_t)pc.inOff * nrhs + q;
+      uint32_t const n = pc.ncols;
+      if (pc.flags & BF_PIECE_IDENTITY) {
+        if (c == 0 && active) {
+          double2 v = xin[(uint64_t)r * nrhs];
+          accr += v.x; acci += v.y;
+        }
+        continue;
+      }
+      // gather the input sub-vector into LDS
+      waveSync();   // previous piece's reads are done before overwriting
+      for (uint32_t j = lane; j < n; j += 64) xs[j] = xin[(uint64_t)j * nrhs];
+      waveSync();
+      double2 const *ap = arena + pc.dataOff + lc;
+      uint32_t const nfull = n / g;
+      uint32_t j = c;
+      uint32_t s = 0;
+#pragma unroll 4
+      for (; s < nfull; ++s) {
+        double2 a = ap[(uint64_t)s * G];
+        double2 xv = xs[j];
+        accr = fma(a.x, xv.x, accr); accr = fma(-a.y, xv.y, accr);
+        acci = fma(a.x, xv.y, acci); acci = fma(a.y, xv.x, acci);
+        j += g;
+      }
+      uint32_t const rem = n - nfull * g;
+      if (active && c < rem) {
+        double2 a = ap[(uint64_t)nfull * G];
+        double2 xv = xs[j];
+        accr = fma(a.x, xv.x, accr); accr = fma(-a.y, xv.y, accr);
+        acci = fma(a.x, xv.y, acci); acci = fma(a.y, xv.x, acci);
+      }
+    }
+    // combine the g column groups (fixed order) and store
+    waveSync();
+    xs[lane] = make_double2(accr, acci);
+    waveSync();
+    if ((uint32_t)lane < mr) {
+      double sr = 0.0, si = 0.0;
+      for (uint32_t cc = 0; cc < g; ++cc) { double2 v = xs[cc * mr + lane]; sr += v.x; si += v.y; }
+      out[((uint64_t)it.outOff + lane) * nrhs + q] = make_double2(sr, si);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// real stage kernel (f64: 2 rows per lane, f32: 4 rows per lane)
+// ---------------------------------------------------------------------------
+template <int DT>
+__global__ __launch_bounds__(BF_WAVES_PER_WG * 64) void bfStageKernelReal(StageParams p) {
+  using S = typename Traits<DT>::S;
+  constexpr int EPL = Traits<DT>::EPL;
+  struct __attribute__((aligned(16))) V { S v[EPL]; };
+  __shared__ __attribute__((aligned(16))) unsigned char ldsRaw[BF_WAVES_PER_WG][BF_WAVE_LDS_BYTES];
+  int const wave = threadIdx.x >> 6;
+  int const lane = threadIdx.x & 63;
+  uint32_t item = __builtin_amdgcn_readfirstlane(blockIdx.x * BF_WAVES_PER_WG + wave);
+  if (item >= p.numItems) return;
+  BfDevItem const it = p.items[item];
+  uint32_t const mr = it.mrFlags & 0xffffu;
+  uint32_t const ms = (mr + EPL - 1) / EPL;        // row slots
+  uint32_t const mrPad = ms * EPL;
+  uint32_t const g = 64u / ms;
+  uint32_t const G = g * ms;
+  bool const active = (uint32_t)lane < G;
+  uint32_t const lc = active ? (uint32_t)lane : G - 1;
+  uint32_t const c = lc / ms;
+  uint32_t const rs = lc - c * ms;
+  S *xs = (S *)ldsRaw[wave];
+  V const *arena = (V const *)p.arena;
+  uint32_t const nrhs = p.nrhs;
+  S *out = (it.mrFlags & BF_ITEM_OUT_Y) ? (S *)p.y : (S *)p.temp;
+
+  for (uint32_t q = 0; q < nrhs; ++q) {
+    S acc[EPL];
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) acc[e] = 0;
+    for (uint32_t pi = 0; pi < it.numPieces; ++pi) {
+      BfDevPiece const pc = p.pieces[it.pieceBegin + pi];
+      S const *xin = (pc.flags & BF_PIECE_IN_X) ? (S const *)p.x : (S const *)p.temp;
+      xin += (uint64_t)pc.inOff * nrhs + q;
+      uint32_t const n = pc.ncols;
+      if (pc.flags & BF_PIECE_IDENTITY) {
+        if (c == 0 && active) {
+#pragma unroll
+          for (int e = 0; e < EPL; ++e) {
+            uint32_t row = rs * EPL + e;
+            if (row < mr) acc[e] += xin[(uint64_t)row * nrhs];
+          }
+        }
+        continue;
+      }
+      waveSync();
+      for (uint32_t j = lane; j < n; j += 64) xs[j] = xin[(uint64_t)j * nrhs];
+      waveSync();
+      // dataOff is in elements; a lane load is EPL elements
+      V const *ap = arena + pc.dataOff / EPL + lc;
+      uint32_t const nfull = n / g;
+      uint32_t j = c;
+      uint32_t s = 0;
+#pragma unroll 4
+      for (; s < nfull; ++s) {
+        V a = ap[(uint64_t)s * G];
+        S xv = xs[j];
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) acc[e] = fma(a.v[e], xv, acc[e]);
+        j += g;
+      }
+      uint32_t const rem = n - nfull * g;
+      if (active && c < rem) {
+        V a = ap[(uint64_t)nfull * G];
+        S xv = xs[j];
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) acc[e] = fma(a.v[e], xv, acc[e]);
+      }
+    }
+    waveSync();
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) xs[lane * EPL + e] = acc[e];   // index = c*mrPad + row for active lanes
+    waveSync();
+    for (uint32_t row = lane; row < mr; row += 64) {
+      S sum = 0;
+      for (uint32_t cc = 0; cc < g; ++cc) sum += xs[cc * mrPad + row];
+      out[((uint64_t)it.outOff + row) * nrhs + q] = sum;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// deterministic reduce: dest[row] = sum over the row's interval sources, in
+// list order, of temp[srcBias + row]
+// ---------------------------------------------------------------------------
+template <typename T, int NC>   // NC = scalar components per element
+__global__ __launch_bounds__(256) void bfReduceKernel(uint32_t const *rowInterval, uint32_t const *ivBegin, int64_t const *srcBias,
+                                                      uint64_t numRows, T const *temp, T *dest, uint32_t nrhs) {
+  uint64_t idx = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  uint64_t total = numRows * nrhs;
+  if (idx >= total) return;
+  uint64_t row = idx / nrhs;
+  uint32_t q = (uint32_t)(idx - row * nrhs);
+  uint32_t iv = rowInterval[row];
+  uint32_t b = ivBegin[iv], e = ivBegin[iv + 1];
+  T acc[NC];
+#pragma unroll
+  for (int k = 0; k < NC; ++k) acc[k] = 0;
+  for (uint32_t s = b; s < e; ++s) {
+    T const *src = temp + ((uint64_t)(srcBias[s] + (int64_t)row) * nrhs + q) * NC;
+#pragma unroll
+    for (int k = 0; k < NC; ++k) acc[k] += src[k];
+  }
+#pragma unroll
+  for (int k = 0; k < NC; ++k) dest[idx * NC + k] = acc[k];
+}
+
+// ---------------------------------------------------------------------------
+// synthetic operand fill: one workgroup per piece
+// ---------------------------------------------------------------------------
+template <int DT>
+__global__ __launch_bounds__(256) void bfSynthKernel(void *arenaV, BfSynthPiece const *pieces, uint64_t seed) {
+  using S = typename Traits<DT>::S;
+  constexpr bool CPLX = Traits<DT>::CPLX;
+  BfSynthPiece const pc = pieces[blockIdx.x];
+  uint64_t total = (uint64_t)pc.mrPad * pc.ncols;
+  S *dst = (S *)arenaV + pc.dataOff * (CPLX ? 2 : 1);
+  for (uint64_t e = threadIdx.x; e < total; e += 256) {
+    uint32_t col = (uint32_t)(e / pc.mrPad);
+    uint32_t r = (uint32_t)(e - (uint64_t)col * pc.mrPad);
+    S re = 0, im = 0;
+    if (r < pc.mr) {
+      uint64_t idx = pc.vbase + (uint64_t)(pc.row0 + r) * pc.leafCols + (pc.col0 + col);
+      re = (S)(bfhip_synth_value(seed, idx, 0) * pc.scale);
+      if (CPLX) im = (S)(bfhip_synth_value(seed, idx, 1) * pc.scale);
+    }
+    if (CPLX) { dst[2 * e] = re; dst[2 * e + 1] = im; }
+    else dst[e] = re;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// host-callable wrappers
+// ---------------------------------------------------------------------------
+extern "C" {
+
+int bfdevSetDevice(int device) {
+  if (device < 0) return 0;
+  return hipFail(hipSetDevice(device), "hipSetDevice");
+}
+int bfdevGetDevice(int *device) { return hipFail(hipGetDevice(device), "hipGetDevice"); }
+int bfdevMalloc(void **p, size_t bytes) {
+  *p = NULL;
+  if (!bytes) bytes = 16;
+  return hipFail(hipMalloc(p, bytes), "hipMalloc");
+}
+void bfdevFree(void *p) { if (p) (void)hipFree(p); }
+int bfdevMemcpyH2D(void *dst, void const *src, size_t bytes) { return bytes ? hipFail(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice), "hipMemcpy H2D") : 0; }
+int bfdevMemcpyD2H(void *dst, void const *src, size_t bytes) { return bytes ? hipFail(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost), "hipMemcpy D2H") : 0; }
+int bfdevMemset(void *dst, int value, size_t bytes) { return bytes ? hipFail(hipMemset(dst, value, bytes), "hipMemset") : 0; }
+int bfdevSync(void *stream) { return hipFail(hipStreamSynchronize((hipStream_t)stream), "hipStreamSynchronize"); }
+int bfdevHostAllocPinned(void **p, size_t bytes) { return hipFail(hipHostMalloc(p, bytes, hipHostMallocDefault), "hipHostMalloc"); }
+void bfdevHostFreePinned(void *p) { if (p) (void)hipHostFree(p); }
+
+int bfdevSynthFill(void *arena, uint32_t dtype, BfSynthPiece const *hostPieces, uint64_t count, uint64_t seed) {
+  if (!count) return 0;
+  BfSynthPiece *d = NULL;
+  int rc = hipFail(hipMalloc((void **)&d, count * sizeof(BfSynthPiece)), "hipMalloc(synth pieces)");
+  if (rc) return rc;
+  rc = hipFail(hipMemcpy(d, hostPieces, count * sizeof(BfSynthPiece), hipMemcpyHostToDevice), "hipMemcpy(synth pieces)");
+  if (!rc) {
+    // grid.x is limited to 2^31-1; chunk to be safe
+    uint64_t done = 0;
+    while (done < count && !rc) {
+      uint32_t n = (uint32_t)((count - done) > (1u << 30) ? (1u << 30) : (count - done));
+      if (dtype == BFHIP_C128) hipLaunchKernelGGL(bfSynthKernel<BFHIP_C128>, dim3(n), dim3(256), 0, 0, arena, d + done, seed);
+      else if (dtype == BFHIP_F64) hipLaunchKernelGGL(bfSynthKernel<BFHIP_F64>, dim3(n), dim3(256), 0, 0, arena, d + done, seed);
+      else hipLaunchKernelGGL(bfSynthKernel<BFHIP_F32>, dim3(n), dim3(256), 0, 0, arena, d + done, seed);
+      rc = hipFail(hipGetLastError(), "synth fill launch");
+      done += n;
+    }
+    if (!rc) rc = hipFail(hipDeviceSynchronize(), "synth fill");
+  }
+  (void)hipFree(d);
+  return rc;
+}
+
+int bfdevLaunchStage(BfLaunchArgs const *a, void *stream) {
+  if (!a->numItems) return 0;
+  StageParams p;
+  p.arena = a->arena;
+  p.items = (BfDevItem const *)a->items;
+  p.pieces = (BfDevPiece const *)a->pieces;
+  p.numItems = (uint32_t)a->numItems;
+  p.nrhs = a->nrhs;
+  p.x = a->x;
+  p.y = a->y;
+  p.temp = a->temp;
+  uint32_t grid = (uint32_t)((a->numItems + BF_WAVES_PER_WG - 1) / BF_WAVES_PER_WG);
+  hipStream_t s = (hipStream_t)stream;
+  if (a->dtype == BFHIP_C128) hipLaunchKernelGGL(bfStageKernelC128, dim3(grid), dim3(BF_WAVES_PER_WG * 64), 0, s, p);
+  else if (a->dtype == BFHIP_F64) hipLaunchKernelGGL(bfStageKernelReal<BFHIP_F64>, dim3(grid), dim3(BF_WAVES_PER_WG * 64), 0, s, p);
+  else if (a->dtype == BFHIP_F32) hipLaunchKernelGGL(bfStageKernelReal<BFHIP_F32>, dim3(grid), dim3(BF_WAVES_PER_WG * 64), 0, s, p);
+  else return bfhipFail(BFABI_ERROR_TYPE_ERROR, "unknown dtype %u", a->dtype);
+  return hipFail(hipGetLastError(), "stage launch");
+}
+
+int bfdevLaunchReduce(BfReduceArgs const *a, void *stream) {
+  uint64_t total = a->numRows * a->nrhs;
+  if (!total) return 0;
+  uint32_t grid = (uint32_t)((total + 255) / 256);
+  hipStream_t s = (hipStream_t)stream;
+  uint32_t const *ri = (uint32_t const *)a->rowInterval, *ib = (uint32_t const *)a->ivBegin;
+  int64_t const *sb = (int64_t const *)a->srcBias;
+  if (a->dtype == BFHIP_C128) hipLaunchKernelGGL((bfReduceKernel<double, 2>), dim3(grid), dim3(256), 0, s, ri, ib, sb, a->numRows, (double const *)a->temp, (double *)a->dest, a->nrhs);
+  else if (a->dtype == BFHIP_F64) hipLaunchKernelGGL((bfReduceKernel<double, 1>), dim3(grid), dim3(256), 0, s, ri, ib, sb, a->numRows, (double const *)a->temp, (double *)a->dest, a->nrhs);
+  else hipLaunchKernelGGL((bfReduceKernel<float, 1>), dim3(grid), dim3(256), 0, s, ri, ib, sb, a->numRows, (float const *)a->temp, (float *)a->dest, a->nrhs);
+  return hipFail(hipGetLastError(), "reduce launch");
+}
+
+int bfdevEventCreate(void **ev) { return hipFail(hipEventCreate((hipEvent_t *)ev), "hipEventCreate"); }
+void bfdevEventDestroy(void *ev) { if (ev) (void)hipEventDestroy((hipEvent_t)ev); }
+int bfdevEventRecord(void *ev, void *stream) { return hipFail(hipEventRecord((hipEvent_t)ev, (hipStream_t)stream), "hipEventRecord"); }
+int bfdevEventElapsed(void *start, void *stop, float *ms) {
+  hipError_t e = hipEventSynchronize((hipEvent_t)stop);
+  if (e != hipSuccess) return hipFail(e, "hipEventSynchronize");
+  return hipFail(hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop), "hipEventElapsedTime");
+}
+
+}  // extern "C"

@@ -1,0 +1,192 @@
+/* bfhip_internal.h -- shared between the C host (ir / plan / api) and the HIP
+ * device layer (bfhip_device.hip).  The host side is plain C11; it reaches HIP
+ * only through the `bfdev*` functions declared at the bottom (the "thin
+ * C-ABI" between host C and device code). */
+#ifndef BFHIP_INTERNAL_H
+#define BFHIP_INTERNAL_H
+
+#include <stddef.h>
+#include <stdint.h>
+#include "../../include/bfhip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------------
+ * error plumbing
+ * ---------------------------------------------------------------------- */
+int bfhipFail(int code, char const *fmt, ...);   /* records message, returns code */
+
+/* ------------------------------------------------------------------------
+ * IR: owned copy of a BfhipDesc (or of a walked BfMat graph)
+ * ---------------------------------------------------------------------- */
+typedef struct BfIr {
+  uint32_t dtype;
+  uint64_t numNodes, numChildren, root;
+  uint8_t *kind;
+  uint64_t *rows, *cols;
+  uint64_t *childBegin;        /* numNodes+1 */
+  uint64_t *childNode, *childRow0, *childCol0;
+  void const **leafData;       /* borrowed host pointers (valid during compile only) */
+  uint64_t *leafRowStride;
+  uint64_t *leafColStride;     /* element stride between columns (BfMat graphs may have colStride != 1) */
+  uint64_t *synthBase;         /* per node: base index in the synthetic stream */
+  uint64_t *topRowBlock;       /* per child of root, or NULL */
+  uint32_t *depth;             /* stages needed by the subtree */
+  /* growable capacity (walker) */
+  uint64_t capNodes, capChildren;
+} BfIr;
+
+void bfIrFree(BfIr *ir);
+int bfIrFromDesc(BfhipDesc const *desc, BfIr *ir);
+int bfIrFromBfMat(void const *bfMat, BfIr *ir);
+int bfIrFinalize(BfIr *ir);   /* validation, depth, synthetic bases */
+
+/* ------------------------------------------------------------------------
+ * Plan: the flattened per-stage layout (host mirror of what lives in HBM)
+ * ---------------------------------------------------------------------- */
+
+/* Where a vector segment lives.  All intermediates and partial-result slots
+ * are sub-ranges of one device "vector arena" (element offsets, per RHS);
+ * X and Y are the caller's buffers. */
+enum { BF_SPACE_TEMP = 0, BF_SPACE_X = 1, BF_SPACE_Y = 2 };
+
+/* device records (layouts shared with the kernels) */
+typedef struct BfDevItem {
+  uint32_t pieceBegin;
+  uint32_t numPieces;
+  uint32_t outOff;     /* element offset of row 0 of this item in its output space */
+  uint32_t mrFlags;    /* bits 0..15: rows; bit 16: output space is Y (else vector arena) */
+} BfDevItem;
+
+typedef struct BfDevPiece {
+  uint64_t dataOff;    /* element offset into the leaf arena (column-major mr_pad x ncols) */
+  uint32_t inOff;      /* element offset of column 0 in the input space */
+  uint32_t ncols;
+  uint32_t flags;      /* bit 0: input space is X (else vector arena); bit 1: identity piece */
+  uint32_t pad;
+} BfDevPiece;
+
+#define BF_ITEM_OUT_Y (1u << 16)
+#define BF_PIECE_IN_X 1u
+#define BF_PIECE_IDENTITY 2u
+
+/* host-only: where each piece's values come from (for packing / synthesis) */
+typedef struct BfPieceSrc {
+  uint64_t node;       /* IR leaf */
+  uint32_t row0, col0; /* sub-block origin inside the leaf */
+} BfPieceSrc;
+
+/* deterministic reduction of overlapping row groups (final accumulate into
+ * Y, or any buffer several differently-shaped contributions land in) */
+typedef struct BfReduce {
+  uint32_t destSpace;       /* BF_SPACE_Y or BF_SPACE_TEMP */
+  uint64_t destOff;         /* element offset in dest space */
+  uint64_t numRows;
+  uint64_t numIntervals;
+  uint32_t *rowInterval;    /* [numRows] interval id of each row */
+  uint32_t *ivBegin;        /* [numIntervals+1] CSR into srcBias */
+  int64_t *srcBias;         /* per source: (slot offset in arena) - (first row of the group) */
+  uint64_t numSrc;
+  /* device copies */
+  void *dRowInterval, *dIvBegin, *dSrcBias;
+} BfReduce;
+
+typedef struct BfStage {
+  uint64_t numItems, numPieces;
+  BfDevItem *items;
+  BfDevPiece *pieces;
+  BfPieceSrc *pieceSrc;
+  uint32_t maxRows;          /* largest item row count */
+  uint64_t leafElems;        /* algorithmic: sum m*n over this stage's leaves */
+  uint64_t vecIn, vecOut;    /* algorithmic vector elements read / written */
+  uint64_t numReduce;
+  BfReduce *reduce;
+  /* device copies */
+  void *dItems, *dPieces;
+} BfStage;
+
+typedef struct BfPlan {
+  uint32_t dtype;            /* storage/compute type: BFHIP_C128 / F64 / F32 */
+  uint32_t elemSize;         /* bytes per element */
+  uint32_t epl;              /* elements per 16-byte lane load */
+  uint32_t maxItemRows;      /* 64 * epl */
+  uint32_t xcap;             /* max columns per piece (LDS staging capacity) */
+  uint64_t numRows, numCols;
+  uint64_t numStages;
+  BfStage *stages;
+  uint64_t arenaElems;       /* leaf arena size in elements */
+  uint64_t tempElems;        /* vector arena elements per RHS */
+  uint64_t numLeaves, leafElems;
+} BfPlan;
+
+typedef struct BfPlanOptions {
+  uint32_t storeDtype;
+  uint32_t itemRows;         /* rows per item cap (<= 64*epl); 0 -> default */
+  uint32_t xcap;
+  uint64_t rowBlockBegin, rowBlockEnd;
+} BfPlanOptions;
+
+int bfPlanBuild(BfIr const *ir, BfPlanOptions const *po, BfPlan *plan);
+void bfPlanFree(BfPlan *plan);
+
+/* ------------------------------------------------------------------------
+ * Device layer (implemented in bfhip_device.hip)
+ * ---------------------------------------------------------------------- */
+int bfdevSetDevice(int device);                 /* -1: keep current; returns BfError */
+int bfdevGetDevice(int *device);
+int bfdevMalloc(void **p, size_t bytes);
+void bfdevFree(void *p);
+int bfdevMemcpyH2D(void *dst, void const *src, size_t bytes);
+int bfdevMemcpyD2H(void *dst, void const *src, size_t bytes);
+int bfdevMemset(void *dst, int value, size_t bytes);
+int bfdevSync(void *stream);
+int bfdevHostAllocPinned(void **p, size_t bytes);
+void bfdevHostFreePinned(void *p);
+
+/* fill pieces [p0, p1) of a stage with the synthetic stream, directly in HBM */
+typedef struct BfSynthPiece {
+  uint64_t dataOff;     /* element offset in arena */
+  uint64_t vbase;       /* synthetic index of leaf element (0,0) */
+  uint32_t leafCols;    /* leaf row length n (row-major virtual index = i*n + j) */
+  uint32_t row0, col0;
+  uint32_t mr, mrPad, ncols;
+  double scale;
+} BfSynthPiece;
+int bfdevSynthFill(void *arena, uint32_t dtype, BfSynthPiece const *hostPieces, uint64_t count, uint64_t seed);
+
+typedef struct BfLaunchArgs {
+  void const *arena;
+  void const *items;
+  void const *pieces;
+  uint64_t numItems;
+  void const *x;
+  void *y;
+  void *temp;
+  uint32_t nrhs;
+  uint32_t dtype;
+  uint32_t maxRows;
+} BfLaunchArgs;
+int bfdevLaunchStage(BfLaunchArgs const *a, void *stream);
+
+typedef struct BfReduceArgs {
+  void const *rowInterval, *ivBegin, *srcBias;
+  uint64_t numRows;
+  void const *temp;
+  void *dest;            /* already offset to destOff*nrhs */
+  uint32_t nrhs;
+  uint32_t dtype;
+} BfReduceArgs;
+int bfdevLaunchReduce(BfReduceArgs const *a, void *stream);
+
+/* events for BFHIP_FLAG_PROFILE */
+int bfdevEventCreate(void **ev);
+void bfdevEventDestroy(void *ev);
+int bfdevEventRecord(void *ev, void *stream);
+int bfdevEventElapsed(void *start, void *stop, float *ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

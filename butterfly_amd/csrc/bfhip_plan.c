@@ -1,0 +1,535 @@
+/* bfhip_plan.c -- the "compile" step: expression IR -> per-stage
+ * CSR-of-blocks layout resident in HBM.
+ *
+ * What the reference does on every bfMatMul call -- recurse through
+ * Product / BlockDense / BlockDiag / BlockCoo, allocating a view per row
+ * range and a fresh result per leaf -- is done here
+ * once, ahead of time:
+ *
+ * 1. Scheduling (ALAP).  Every leaf product becomes a task
+ *    (stage, leaf, input segment, output segment).  A Block contributes its
+ *    children in the stage its result is due; a Product F0*...*F_{L-1} gives
+ *    F0 the due stage and each later factor an earlier one, through one
+ *    intermediate vector per factor boundary (mat_product.c:225-238 keeps the
+ *    same intermediates, heap-allocated per call).  With as-late-as-possible
+ *    placement all contributions to one vector land in the same stage, so
+ *    stages are the only synchronization (kernel boundaries).
+ *
+ * 2. Row groups.  Tasks of a stage that write exactly the same rows of the
+ *    same vector (the <= 4 blocks of a BlockCoo block row,
+ *    fac_helm2.c:277-318; a BlockDiag block on its own) form a group; a group
+ *    is cut into items of <= 64 row slots, one wavefront each, and the item
+ *    accumulates all its blocks in registers -- the reference's AddInplace
+ *    pass (mat_block_coo.c:413) disappears and each output row has one owner.
+ *
+ * 3. Overlapping groups.  Where differently shaped groups hit the same rows
+ *    (the final accumulation into y: evaluation factors of many products at
+ *    different tree depths plus dense near-field leaves,
+ *    mat_block_dense.c:541-563) each group writes a private slot and one
+ *    deterministic reduce pass sums the slots per row in a fixed order.
+ *
+ * 4. Packing.  Each (item, block) "piece" is stored column-major (rows x
+ *    cols, rows padded to the 16-byte lane granule) and pieces are laid out in
+ *    the order the kernel consumes them, so a wavefront streams its bytes
+ *    linearly with 16-byte-per-lane coalesced loads.
+ */
+#include "bfhip_internal.h"
+#include "../../include/bfhip_abi.h"
+
+#include <stdlib.h>
+#include <string.h>
+
+typedef struct Task {
+  uint32_t stage;
+  uint32_t outBuf, inBuf;
+  uint64_t leaf;
+  uint64_t outOff, inOff;
+  uint64_t rows, cols;
+  uint64_t seq;        /* emission order: fixes the summation order */
+} Task;
+
+typedef struct Buf {
+  uint64_t len;
+  uint64_t arenaOff;   /* element offset in the vector arena (temps only) */
+  int32_t stage;       /* stage in which it is written (-1: X) */
+} Buf;
+
+typedef struct Builder {
+  BfIr const *ir;
+  Task *tasks; uint64_t numTasks, capTasks;
+  Buf *bufs; uint64_t numBufs, capBufs;
+  int err;
+} Builder;
+
+static int pushTask(Builder *b, Task const *t) {
+  if (b->numTasks == b->capTasks) {
+    uint64_t cap = b->capTasks ? b->capTasks * 2 : 4096;
+    Task *p = realloc(b->tasks, cap * sizeof(Task));
+    if (!p) return bfhipFail(BFABI_ERROR_MEMORY_ERROR, "host OOM (tasks)");
+    b->tasks = p; b->capTasks = cap;
+  }
+  b->tasks[b->numTasks] = *t;
+  b->tasks[b->numTasks].seq = b->numTasks;
+  ++b->numTasks;
+  return 0;
+}
+static int newBuf(Builder *b, uint64_t len, int32_t stage, uint32_t *id) {
+  if (b->numBufs == b->capBufs) {
+    uint64_t cap = b->capBufs ? b->capBufs * 2 : 256;
+    Buf *p = realloc(b->bufs, cap * sizeof(Buf));
+    if (!p) return bfhipFail(BFABI_ERROR_MEMORY_ERROR, "host OOM (buffers)");
+    b->bufs = p; b->capBufs = cap;
+  }
+  if (b->numBufs >= 0xffffffffu) return bfhipFail(BFABI_ERROR_RUNTIME_ERROR, "too many intermediate vectors");
+  b->bufs[b->numBufs].len = len;
+  b->bufs[b->numBufs].arenaOff = 0;
+  b->bufs[b->numBufs].stage = stage;
+  *id = (uint32_t)b->numBufs++;
+  return 0;
+}
+
+static int emit(Builder *b, uint64_t node, uint32_t inBuf, uint64_t inOff, uint32_t outBuf, uint64_t outOff, int32_t stageEnd) {
+  BfIr const *ir = b->ir;
+  int rc;
+  switch (ir->kind[node]) {
+  case BFHIP_NODE_DENSE:
+  case BFHIP_NODE_IDENTITY: {
+    Task t;
+    memset(&t, 0, sizeof t);
+    t.stage = (uint32_t)stageEnd; t.leaf = node;
+    t.inBuf = inBuf; t.inOff = inOff; t.outBuf = outBuf; t.outOff = outOff;
+    t.rows = ir->rows[node]; t.cols = ir->cols[node];
+    return pushTask(b, &t);
+  }
+  case BFHIP_NODE_BLOCK:
+    for (uint64_t c = ir->childBegin[node]; c < ir->childBegin[node + 1]; ++c)
+      if ((rc = emit(b, ir->childNode[c], inBuf, inOff + ir->childCol0[c], outBuf, outOff + ir->childRow0[c], stageEnd))) return rc;
+    return 0;
+  case BFHIP_NODE_PRODUCT: {
+    uint64_t cb = ir->childBegin[node], ce = ir->childBegin[node + 1];
+    uint32_t curOut = outBuf; uint64_t curOutOff = outOff;
+    int32_t se = stageEnd;
+    for (uint64_t c = cb; c < ce; ++c) {
+      uint64_t f = ir->childNode[c];
+      uint32_t in = inBuf; uint64_t inO = inOff;
+      int32_t seNext = se - (int32_t)ir->depth[f];
+      if (c + 1 < ce) {
+        if ((rc = newBuf(b, ir->cols[f], seNext, &in))) return rc;
+        inO = 0;
+      }
+      if ((rc = emit(b, f, in, inO, curOut, curOutOff, se))) return rc;
+      se = seNext; curOut = in; curOutOff = 0;
+    }
+    return 0;
+  }
+  }
+  return bfhipFail(BFABI_ERROR_TYPE_ERROR, "unknown node kind");
+}
+
+/* sort tasks by (stage, outBuf, outOff, rows, seq) */
+static int cmpTask(void const *pa, void const *pb) {
+  Task const *a = pa, *b = pb;
+  if (a->stage != b->stage) return a->stage < b->stage ? -1 : 1;
+  if (a->outBuf != b->outBuf) return a->outBuf < b->outBuf ? -1 : 1;
+  if (a->outOff != b->outOff) return a->outOff < b->outOff ? -1 : 1;
+  if (a->rows != b->rows) return a->rows < b->rows ? -1 : 1;
+  return a->seq < b->seq ? -1 : (a->seq > b->seq);
+}
+
+typedef struct Group {
+  uint64_t taskBegin, taskEnd;   /* range in the sorted task array */
+  uint64_t outOff, rows;
+  uint32_t outBuf;
+  uint64_t slotOff;              /* vector-arena offset of its private slot, if reduced */
+  int reduced;
+} Group;
+
+typedef struct ItemTmp {
+  uint64_t cost;
+  uint64_t group;
+  uint32_t rowBegin, rows;       /* chunk inside the group */
+} ItemTmp;
+
+static int cmpItemCost(void const *pa, void const *pb) {
+  ItemTmp const *a = pa, *b = pb;
+  if (a->cost != b->cost) return a->cost > b->cost ? -1 : 1;      /* big first */
+  if (a->group != b->group) return a->group < b->group ? -1 : 1;
+  return a->rowBegin < b->rowBegin ? -1 : (a->rowBegin > b->rowBegin);
+}
+static int cmpU64(void const *pa, void const *pb) {
+  uint64_t a = *(uint64_t const *)pa, b = *(uint64_t const *)pb;
+  return a < b ? -1 : a > b;
+}
+static uint64_t roundUp(uint64_t v, uint64_t m) { return (v + m - 1) / m * m; }
+
+void bfPlanFree(BfPlan *plan) {
+  if (!plan) return;
+  for (uint64_t s = 0; s < plan->numStages && plan->stages; ++s) {
+    BfStage *st = &plan->stages[s];
+    free(st->items); free(st->pieces); free(st->pieceSrc);
+    for (uint64_t r = 0; r < st->numReduce; ++r) {
+      free(st->reduce[r].rowInterval); free(st->reduce[r].ivBegin); free(st->reduce[r].srcBias);
+    }
+    free(st->reduce);
+  }
+  free(plan->stages);
+  memset(plan, 0, sizeof *plan);
+}
+
+/* vector-arena allocator: 4-element alignment keeps every segment 16-byte
+ * aligned for all element types */
+static uint64_t arenaAlloc(uint64_t *top, uint64_t len) {
+  uint64_t off = roundUp(*top, 4);
+  *top = off + len;
+  return off;
+}
+
+int bfPlanBuild(BfIr const *ir, BfPlanOptions const *po, BfPlan *plan) {
+  memset(plan, 0, sizeof *plan);
+  Builder b;
+  memset(&b, 0, sizeof b);
+  b.ir = ir;
+  int rc = 0;
+
+  plan->dtype = po->storeDtype;
+  plan->elemSize = plan->dtype == BFHIP_C128 ? 16 : (plan->dtype == BFHIP_F64 ? 8 : 4);
+  plan->epl = 16 / plan->elemSize;
+  plan->maxItemRows = 64 * plan->epl;
+  uint32_t itemRows = po->itemRows ? po->itemRows : plan->maxItemRows;
+  if (itemRows > plan->maxItemRows) itemRows = plan->maxItemRows;
+  itemRows = (uint32_t)roundUp(itemRows, plan->epl);
+  plan->xcap = po->xcap ? po->xcap : 256;
+
+  uint32_t bx, by;
+  uint64_t root = ir->root;
+  int32_t S = (int32_t)ir->depth[root];
+  uint64_t numRows = ir->rows[root];
+
+  /* ---- 1. schedule ------------------------------------------------------ */
+  if ((rc = newBuf(&b, ir->cols[root], -1, &bx))) goto fail;     /* buffer 0 = X */
+  if (po->rowBlockEnd > 0) {
+    /* row sharding: keep block rows [begin, end) of a BLOCK root */
+    if (ir->kind[root] != BFHIP_NODE_BLOCK || !ir->topRowBlock) { rc = bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "row sharding needs a block-matrix root"); goto fail; }
+    uint64_t cb = ir->childBegin[root], ce = ir->childBegin[root + 1];
+    uint64_t nb = 0;
+    for (uint64_t c = cb; c < ce; ++c) if (ir->topRowBlock[c - cb] + 1 > nb) nb = ir->topRowBlock[c - cb] + 1;
+    if (po->rowBlockEnd > nb && nb) { /* allow end beyond the last non-empty row */ }
+    uint64_t *lo = malloc((nb + 1) * 8), *hi = calloc(nb + 1, 8), *base = calloc(nb + 1, 8);
+    if (!lo || !hi || !base) { free(lo); free(hi); free(base); rc = bfhipFail(BFABI_ERROR_MEMORY_ERROR, "host OOM"); goto fail; }
+    for (uint64_t i = 0; i <= nb; ++i) lo[i] = UINT64_MAX;
+    for (uint64_t c = cb; c < ce; ++c) {
+      uint64_t rb = ir->topRowBlock[c - cb], ch = ir->childNode[c];
+      if (ir->childRow0[c] < lo[rb]) lo[rb] = ir->childRow0[c];
+      if (ir->childRow0[c] + ir->rows[ch] > hi[rb]) hi[rb] = ir->childRow0[c] + ir->rows[ch];
+    }
+    uint64_t acc = 0;
+    for (uint64_t i = 0; i < nb; ++i) {
+      base[i] = acc;
+      if (i >= po->rowBlockBegin && i < po->rowBlockEnd && lo[i] != UINT64_MAX) acc += hi[i] - lo[i];
+    }
+    numRows = acc;
+    /* depth of the kept part */
+    uint32_t dep = 1;
+    for (uint64_t c = cb; c < ce; ++c) {
+      uint64_t rb = ir->topRowBlock[c - cb];
+      if (rb >= po->rowBlockBegin && rb < po->rowBlockEnd && ir->depth[ir->childNode[c]] > dep) dep = ir->depth[ir->childNode[c]];
+    }
+    S = (int32_t)dep;
+    if ((rc = newBuf(&b, numRows, S - 1, &by))) { free(lo); free(hi); free(base); goto fail; }
+    for (uint64_t c = cb; c < ce && !rc; ++c) {
+      uint64_t rb = ir->topRowBlock[c - cb];
+      if (rb < po->rowBlockBegin || rb >= po->rowBlockEnd) continue;
+      rc = emit(&b, ir->childNode[c], bx, ir->childCol0[c], by, ir->childRow0[c] - lo[rb] + base[rb], S - 1);
+    }
+    free(lo); free(hi); free(base);
+    if (rc) goto fail;
+  } else {
+    if ((rc = newBuf(&b, numRows, S - 1, &by))) goto fail;        /* buffer 1 = Y */
+    if ((rc = emit(&b, root, bx, 0, by, 0, S - 1))) goto fail;
+  }
+  plan->numRows = numRows;
+  plan->numCols = ir->cols[root];
+  plan->numStages = (uint64_t)S;
+  plan->stages = calloc((size_t)S, sizeof(BfStage));
+  if (!plan->stages) { rc = bfhipFail(BFABI_ERROR_MEMORY_ERROR, "host OOM"); goto fail; }
+
+  /* invariant: every buffer is written in exactly one stage */
+  for (uint64_t t = 0; t < b.numTasks; ++t) {
+    Task const *tk = &b.tasks[t];
+    if (b.bufs[tk->outBuf].stage != (int32_t)tk->stage || (int32_t)tk->stage >= S ||
+        b.bufs[tk->inBuf].stage >= (int32_t)tk->stage) {
+      rc = bfhipFail(BFABI_ERROR_RUNTIME_ERROR, "internal: stage schedule inconsistent");
+      goto fail;
+    }
+  }
+
+  /* vector arena: intermediates first */
+  uint64_t top = 0;
+  for (uint64_t i = 2; i < b.numBufs; ++i) b.bufs[i].arenaOff = arenaAlloc(&top, b.bufs[i].len);
+
+  qsort(b.tasks, b.numTasks, sizeof(Task), cmpTask);
+
+  /* ---- 2..4 per stage --------------------------------------------------- */
+  uint64_t arenaTop = 0;       /* leaf arena, elements */
+  uint64_t tBegin = 0;
+  uint8_t *bufRead = calloc(b.numBufs, 1);
+  if (!bufRead) { rc = bfhipFail(BFABI_ERROR_MEMORY_ERROR, "host OOM"); goto fail; }
+  for (int32_t s = 0; s < S; ++s) {
+    BfStage *st = &plan->stages[s];
+    uint64_t tEnd = tBegin;
+    while (tEnd < b.numTasks && b.tasks[tEnd].stage == (uint32_t)s) ++tEnd;
+
+    /* groups */
+    uint64_t numGroups = 0, capGroups = 1024;
+    Group *groups = malloc(capGroups * sizeof(Group));
+    if (!groups) { rc = bfhipFail(BFABI_ERROR_MEMORY_ERROR, "host OOM"); free(bufRead); goto fail; }
+    for (uint64_t t = tBegin; t < tEnd;) {
+      uint64_t u = t + 1;
+      while (u < tEnd && b.tasks[u].outBuf == b.tasks[t].outBuf && b.tasks[u].outOff == b.tasks[t].outOff && b.tasks[u].rows == b.tasks[t].rows) ++u;
+      if (numGroups == capGroups) {
+        capGroups *= 2;
+        Group *p = realloc(groups, capGroups * sizeof(Group));
+        if (!p) { free(groups); free(bufRead); rc = bfhipFail(BFABI_ERROR_MEMORY_ERROR, "host OOM"); goto fail; }
+        groups = p;
+      }
+      Group *g = &groups[numGroups++];
+      g->taskBegin = t; g->taskEnd = u; g->outBuf = b.tasks[t].outBuf; g->outOff = b.tasks[t].outOff; g->rows = b.tasks[t].rows;
+      g->slotOff = 0; g->reduced = 0;
+      t = u;
+    }
+
+    /* which output vectors of this stage need a reduce pass, and the gaps of
+     * those that do not.  Groups are sorted by (outBuf, outOff). */
+    uint64_t numZeroItems = 0;
+    uint64_t capRed = 4;
+    st->reduce = calloc(capRed, sizeof(BfReduce));
+    /* zero-fill chunks for direct buffers are appended as group-less items */
+    typedef struct Gap { uint32_t buf; uint64_t off, len; } Gap;
+    uint64_t numGaps = 0, capGaps = 16;
+    Gap *gaps = malloc(capGaps * sizeof(Gap));
+    if (!st->reduce || !gaps) { free(groups); free(gaps); free(bufRead); rc = bfhipFail(BFABI_ERROR_MEMORY_ERROR, "host OOM"); goto fail; }
+#define PUSH_GAP(B, O, L) do { if ((L) > 0) { if (numGaps == capGaps) { capGaps *= 2; Gap *p_ = realloc(gaps, capGaps * sizeof(Gap)); if (!p_) { rc = bfhipFail(BFABI_ERROR_MEMORY_ERROR, "host OOM"); goto stage_fail; } gaps = p_; } gaps[numGaps].buf = (B); gaps[numGaps].off = (O); gaps[numGaps].len = (L); ++numGaps; } } while (0)
+
+    /* buffers written in this stage with no tasks at all must still be zeroed */
+    for (uint64_t bi = 1; bi < b.numBufs; ++bi) {
+      if (b.bufs[bi].stage != s) continue;
+      /* find its groups (binary search would do; stages have few buffers relative to groups, but
+       * products can have many: do a linear pass over groups once per stage instead) */
+      (void)bi;
+    }
+    {
+      /* walk groups buffer by buffer */
+      uint64_t gi = 0;
+      /* mark buffers seen */
+      uint8_t *seen = calloc(b.numBufs, 1);
+      if (!seen) { rc = bfhipFail(BFABI_ERROR_MEMORY_ERROR, "host OOM"); goto stage_fail; }
+      while (gi < numGroups) {
+        uint64_t gj = gi;
+        uint32_t ob = groups[gi].outBuf;
+        int overlap = 0;
+        uint64_t prevEnd = 0;
+        while (gj < numGroups && groups[gj].outBuf == ob) {
+          if (gj > gi && groups[gj].outOff < prevEnd) overlap = 1;
+          uint64_t e = groups[gj].outOff + groups[gj].rows;
+          if (e > prevEnd) prevEnd = e;
+          ++gj;
+        }
+        seen[ob] = 1;
+        uint64_t blen = b.bufs[ob].len;
+        if (!overlap) {
+          uint64_t pos = 0;
+          for (uint64_t g = gi; g < gj; ++g) {
+            PUSH_GAP(ob, pos, groups[g].outOff - pos);
+            pos = groups[g].outOff + groups[g].rows;
+          }
+          PUSH_GAP(ob, pos, blen - pos);
+        } else {
+          /* private slots + reduce */
+          if (st->numReduce == capRed) {
+            capRed *= 2;
+            BfReduce *p = realloc(st->reduce, capRed * sizeof(BfReduce));
+            if (!p) { free(seen); rc = bfhipFail(BFABI_ERROR_MEMORY_ERROR, "host OOM"); goto stage_fail; }
+            memset(p + st->numReduce, 0, (capRed - st->numReduce) * sizeof(BfReduce));
+            st->reduce = p;
+          }
+          BfReduce *rd = &st->reduce[st->numReduce++];
+          memset(rd, 0, sizeof *rd);
+          rd->destSpace = ob == by ? BF_SPACE_Y : BF_SPACE_TEMP;
+          rd->destOff = ob == by ? 0 : b.bufs[ob].arenaOff;
+          rd->numRows = blen;
+          uint64_t ng = gj - gi;
+          uint64_t *bp = malloc((2 * ng + 2) * 8);
+          if (!bp) { free(seen); rc = bfhipFail(BFABI_ERROR_MEMORY_ERROR, "host OOM"); goto stage_fail; }
+          uint64_t nbp = 0;
+          bp[nbp++] = 0; bp[nbp++] = blen;
+          for (uint64_t g = gi; g < gj; ++g) {
+            groups[g].reduced = 1;
+            groups[g].slotOff = arenaAlloc(&top, groups[g].rows);
+            bp[nbp++] = groups[g].outOff; bp[nbp++] = groups[g].outOff + groups[g].rows;
+          }
+          qsort(bp, nbp, 8, cmpU64);
+          uint64_t w = 1;
+          for (uint64_t i = 1; i < nbp; ++i) if (bp[i] != bp[w - 1]) bp[w++] = bp[i];
+          nbp = w;
+          uint64_t niv = nbp - 1;
+          if (niv >= 0xffffffffu) { free(bp); free(seen); rc = bfhipFail(BFABI_ERROR_RUNTIME_ERROR, "too many reduce intervals"); goto stage_fail; }
+          rd->numIntervals = niv;
+          rd->rowInterval = malloc((blen ? blen : 1) * 4);
+          rd->ivBegin = calloc(niv + 2, 4);
+          if (!rd->rowInterval || !rd->ivBegin) { free(bp); free(seen); rc = bfhipFail(BFABI_ERROR_MEMORY_ERROR, "host OOM"); goto stage_fail; }
+          for (uint64_t i = 0; i < niv; ++i)
+            for (uint64_t r = bp[i]; r < bp[i + 1]; ++r) rd->rowInterval[r] = (uint32_t)i;
+          /* count sources per interval */
+          uint64_t nsrc = 0;
+          for (uint64_t g = gi; g < gj; ++g) {
+            uint64_t lo = 0, hi = nbp;   /* first bp >= outOff */
+            while (lo < hi) { uint64_t mid = (lo + hi) / 2; if (bp[mid] < groups[g].outOff) lo = mid + 1; else hi = mid; }
+            uint64_t endRow = groups[g].outOff + groups[g].rows;
+            for (uint64_t i = lo; i < niv && bp[i] < endRow; ++i) { ++rd->ivBegin[i + 1]; ++nsrc; }
+          }
+          for (uint64_t i = 0; i < niv; ++i) rd->ivBegin[i + 1] += rd->ivBegin[i];
+          rd->numSrc = nsrc;
+          rd->srcBias = malloc((nsrc ? nsrc : 1) * 8);
+          uint32_t *fill = calloc(niv + 1, 4);
+          if (!rd->srcBias || !fill) { free(fill); free(bp); free(seen); rc = bfhipFail(BFABI_ERROR_MEMORY_ERROR, "host OOM"); goto stage_fail; }
+          /* deterministic order: groups in (outOff, rows, emission) order */
+          for (uint64_t g = gi; g < gj; ++g) {
+            uint64_t lo = 0, hi = nbp;
+            while (lo < hi) { uint64_t mid = (lo + hi) / 2; if (bp[mid] < groups[g].outOff) lo = mid + 1; else hi = mid; }
+            uint64_t endRow = groups[g].outOff + groups[g].rows;
+            for (uint64_t i = lo; i < niv && bp[i] < endRow; ++i)
+              rd->srcBias[rd->ivBegin[i] + fill[i]++] = (int64_t)groups[g].slotOff - (int64_t)groups[g].outOff;
+          }
+          free(fill);
+          free(bp);
+        }
+        gi = gj;
+      }
+      /* buffers due this stage that received nothing: all zeros */
+      for (uint64_t bi = 1; bi < b.numBufs; ++bi)
+        if (b.bufs[bi].stage == s && !seen[bi]) PUSH_GAP((uint32_t)bi, 0, b.bufs[bi].len);
+      free(seen);
+    }
+
+    /* items */
+    uint64_t numItems = 0;
+    for (uint64_t g = 0; g < numGroups; ++g) numItems += (groups[g].rows + itemRows - 1) / itemRows;
+    for (uint64_t z = 0; z < numGaps; ++z) numZeroItems += (gaps[z].len + plan->maxItemRows - 1) / plan->maxItemRows;
+    ItemTmp *tmp = malloc((numItems + numZeroItems + 1) * sizeof(ItemTmp));
+    if (!tmp) { rc = bfhipFail(BFABI_ERROR_MEMORY_ERROR, "host OOM"); goto stage_fail; }
+    uint64_t ni = 0;
+    uint64_t numPieces = 0;
+    for (uint64_t g = 0; g < numGroups; ++g) {
+      uint64_t m = groups[g].rows;
+      uint64_t nch = (m + itemRows - 1) / itemRows;
+      uint64_t chunk = roundUp((m + nch - 1) / nch, plan->epl);
+      uint64_t colsSum = 0, piecesPerChunk = 0;
+      for (uint64_t t = groups[g].taskBegin; t < groups[g].taskEnd; ++t) {
+        Task const *tk = &b.tasks[t];
+        if (ir->kind[tk->leaf] == BFHIP_NODE_IDENTITY) { piecesPerChunk += 1; colsSum += 1; }
+        else { piecesPerChunk += (tk->cols + plan->xcap - 1) / plan->xcap; colsSum += tk->cols; }
+      }
+      for (uint64_t r0 = 0; r0 < m; r0 += chunk) {
+        uint64_t rows = m - r0 < chunk ? m - r0 : chunk;
+        tmp[ni].group = g; tmp[ni].rowBegin = (uint32_t)r0; tmp[ni].rows = (uint32_t)rows;
+        tmp[ni].cost = rows * colsSum;
+        ++ni;
+        numPieces += piecesPerChunk;
+      }
+    }
+    numItems = ni;
+    qsort(tmp, numItems, sizeof(ItemTmp), cmpItemCost);
+    uint64_t totalItems = numItems + numZeroItems;
+    if (totalItems >= 0xffffffffu || numPieces >= 0xffffffffu) { free(tmp); rc = bfhipFail(BFABI_ERROR_RUNTIME_ERROR, "stage too large for 32-bit indices"); goto stage_fail; }
+    st->items = malloc((totalItems ? totalItems : 1) * sizeof(BfDevItem));
+    st->pieces = malloc((numPieces ? numPieces : 1) * sizeof(BfDevPiece));
+    st->pieceSrc = malloc((numPieces ? numPieces : 1) * sizeof(BfPieceSrc));
+    if (!st->items || !st->pieces || !st->pieceSrc) { free(tmp); rc = bfhipFail(BFABI_ERROR_MEMORY_ERROR, "host OOM"); goto stage_fail; }
+    uint64_t np = 0;
+    for (uint64_t i = 0; i < numItems; ++i) {
+      Group const *g = &groups[tmp[i].group];
+      BfDevItem *it = &st->items[i];
+      uint32_t mr = tmp[i].rows, r0 = tmp[i].rowBegin;
+      uint32_t mrPad = (uint32_t)roundUp(mr, plan->epl);
+      it->pieceBegin = (uint32_t)np;
+      uint64_t outOff;
+      uint32_t flags = 0;
+      if (g->reduced) outOff = g->slotOff + r0;
+      else if (g->outBuf == by) { outOff = g->outOff + r0; flags = BF_ITEM_OUT_Y; }
+      else outOff = b.bufs[g->outBuf].arenaOff + g->outOff + r0;
+      if (outOff >= 0xffffffffu) { free(tmp); rc = bfhipFail(BFABI_ERROR_RUNTIME_ERROR, "vector arena exceeds 32-bit offsets"); goto stage_fail; }
+      it->outOff = (uint32_t)outOff;
+      it->mrFlags = mr | flags;
+      if (mr > st->maxRows) st->maxRows = mr;
+      for (uint64_t t = g->taskBegin; t < g->taskEnd; ++t) {
+        Task const *tk = &b.tasks[t];
+        uint64_t inBase = tk->inBuf == bx ? tk->inOff : b.bufs[tk->inBuf].arenaOff + tk->inOff;
+        uint32_t inFlag = tk->inBuf == bx ? BF_PIECE_IN_X : 0;
+        if (!bufRead[tk->inBuf]) { bufRead[tk->inBuf] = 1; st->vecIn += b.bufs[tk->inBuf].len; }
+        if (ir->kind[tk->leaf] == BFHIP_NODE_IDENTITY) {
+          BfDevPiece *pc = &st->pieces[np];
+          pc->dataOff = 0; pc->inOff = (uint32_t)(inBase + r0); pc->ncols = mr; pc->flags = inFlag | BF_PIECE_IDENTITY; pc->pad = 0;
+          st->pieceSrc[np].node = tk->leaf; st->pieceSrc[np].row0 = r0; st->pieceSrc[np].col0 = 0;
+          ++np;
+          continue;
+        }
+        for (uint64_t c0 = 0; c0 < tk->cols; c0 += plan->xcap) {
+          uint64_t nc = tk->cols - c0 < plan->xcap ? tk->cols - c0 : plan->xcap;
+          BfDevPiece *pc = &st->pieces[np];
+          if (inBase + c0 >= 0xffffffffu) { free(tmp); rc = bfhipFail(BFABI_ERROR_RUNTIME_ERROR, "vector arena exceeds 32-bit offsets"); goto stage_fail; }
+          pc->dataOff = arenaTop; pc->inOff = (uint32_t)(inBase + c0); pc->ncols = (uint32_t)nc; pc->flags = inFlag; pc->pad = 0;
+          st->pieceSrc[np].node = tk->leaf; st->pieceSrc[np].row0 = r0; st->pieceSrc[np].col0 = (uint32_t)c0;
+          arenaTop += (uint64_t)mrPad * nc;
+          ++np;
+        }
+        if (r0 == 0) { /* count each leaf once */ }
+      }
+      it->numPieces = (uint32_t)(np - it->pieceBegin);
+    }
+    /* zero-fill items */
+    uint64_t ii = numItems;
+    for (uint64_t z = 0; z < numGaps; ++z) {
+      for (uint64_t r0 = 0; r0 < gaps[z].len; r0 += plan->maxItemRows) {
+        uint64_t rows = gaps[z].len - r0 < plan->maxItemRows ? gaps[z].len - r0 : plan->maxItemRows;
+        BfDevItem *it = &st->items[ii++];
+        it->pieceBegin = (uint32_t)np; it->numPieces = 0;
+        uint64_t outOff = gaps[z].buf == by ? gaps[z].off + r0 : b.bufs[gaps[z].buf].arenaOff + gaps[z].off + r0;
+        if (outOff >= 0xffffffffu) { free(tmp); rc = bfhipFail(BFABI_ERROR_RUNTIME_ERROR, "vector arena exceeds 32-bit offsets"); goto stage_fail; }
+        it->outOff = (uint32_t)outOff;
+        it->mrFlags = (uint32_t)rows | (gaps[z].buf == by ? BF_ITEM_OUT_Y : 0);
+        if (rows > st->maxRows) st->maxRows = (uint32_t)rows;
+      }
+    }
+    st->numItems = totalItems;
+    st->numPieces = np;
+    /* algorithmic counts */
+    for (uint64_t t = tBegin; t < tEnd; ++t)
+      if (ir->kind[b.tasks[t].leaf] == BFHIP_NODE_DENSE) { st->leafElems += b.tasks[t].rows * b.tasks[t].cols; ++plan->numLeaves; }
+    for (uint64_t bi = 1; bi < b.numBufs; ++bi) if (b.bufs[bi].stage == s) st->vecOut += b.bufs[bi].len;
+    plan->leafElems += st->leafElems;
+    memset(bufRead, 0, b.numBufs);
+    free(tmp);
+    free(groups);
+    free(gaps);
+    tBegin = tEnd;
+    continue;
+  stage_fail:
+    free(groups);
+    free(gaps);
+    free(bufRead);
+    goto fail;
+#undef PUSH_GAP
+  }
+  free(bufRead);
+  plan->arenaElems = arenaTop;
+  plan->tempElems = roundUp(top, 4);
+  free(b.tasks);
+  free(b.bufs);
+  return 0;
+
+fail:
+  free(b.tasks);
+  free(b.bufs);
+  bfPlanFree(plan);
+  return rc ? rc : BFABI_ERROR_RUNTIME_ERROR;
+}

@@ -1,0 +1,150 @@
+"""Host-side mirror of the engine's C-ABI (include/bfhip.h) for Python callers.
+
+`HipOperator` owns a `BfhipOperator*`.  It is created either from a reference
+`BfMat*` (the drop-in path: `bfhipCompile`) or from a flat structure
+descriptor (`bfhipCompileDesc`, used for structure-exact synthetic operands
+whose values are generated directly in HBM).  `apply` mirrors `bfMatMul`
+(reference src/mat.c:183): Y = A X with X an N x nrhs row-major array.
+
+torch is used for device memory and streams only.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _capi
+from ._capi import BFHIP_C128, BFHIP_F32, BFHIP_F64, BfhipOptions, BfhipStats, DescArrays, check
+
+
+def _options(device=-1, flags=0, max_rhs=1, demote_to_f32=False, seed=0, row_blocks=None):
+    o = BfhipOptions()
+    o.structSize = C.sizeof(BfhipOptions)
+    o.device = device
+    o.flags = flags
+    o.maxRhs = max_rhs
+    o.demoteToF32 = 1 if demote_to_f32 else 0
+    o.seed = seed
+    if row_blocks is not None:
+        o.rowBlockBegin, o.rowBlockEnd = row_blocks
+    return o
+
+
+class HipOperator:
+    def __init__(self, handle, keep=()):
+        self._h = C.c_void_p(handle)
+        self._keep = list(keep)
+        self._lib = _capi.load()
+
+    # ---- construction ------------------------------------------------------
+    @classmethod
+    def from_bfmat(cls, bfmat_ptr, **opts):
+        """Compile a reference BfMat object graph (bfhipCompile)."""
+        lib = _capi.load()
+        h = C.c_void_p()
+        o = _options(**opts)
+        check(lib.bfhipCompile(C.c_void_p(bfmat_ptr), C.byref(o), C.byref(h)))
+        return cls(h.value)
+
+    @classmethod
+    def from_desc(cls, desc, leaf_values=None, root=None, **opts):
+        """Compile a flat descriptor (bfhipCompileDesc); leaves without values are
+        synthesized on the device from `seed`."""
+        lib = _capi.load()
+        da = DescArrays(desc, root=root, leaf_values=leaf_values)
+        h = C.c_void_p()
+        o = _options(**opts)
+        check(lib.bfhipCompileDesc(da.byref(), C.byref(o), C.byref(h)))
+        keep = [da] if (o.flags & _capi.FLAG_PLAN_ONLY) else []
+        return cls(h.value, keep=keep)
+
+    def close(self):
+        if self._h:
+            self._lib.bfhipFree(C.byref(self._h))
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- introspection -----------------------------------------------------
+    @property
+    def handle(self):
+        return self._h
+
+    @property
+    def shape(self):
+        return int(self._lib.bfhipGetNumRows(self._h)), int(self._lib.bfhipGetNumCols(self._h))
+
+    def num_bytes(self):
+        return int(self._lib.bfhipNumBytes(self._h))
+
+    def stats(self):
+        st = BfhipStats()
+        st.structSize = C.sizeof(BfhipStats)
+        check(self._lib.bfhipGetStats(self._h, C.byref(st)))
+        return st.as_dict()
+
+    @property
+    def dtype(self):
+        return self.stats()["dtype"]
+
+    def np_dtype(self):
+        return {BFHIP_C128: np.complex128, BFHIP_F64: np.float64, BFHIP_F32: np.float32}[self.dtype]
+
+    # ---- apply -------------------------------------------------------------
+    def apply_host(self, x: np.ndarray) -> np.ndarray:
+        """bfhipApply on host arrays (H2D, all stages, D2H)."""
+        m, n = self.shape
+        src_dtype = np.complex128 if self.dtype == BFHIP_C128 else np.float64
+        x2 = np.ascontiguousarray(x, dtype=src_dtype)
+        one_d = x2.ndim == 1
+        if one_d:
+            x2 = x2[:, None]
+        if x2.shape[0] != n:
+            raise ValueError(f"operator has {n} columns, x has {x2.shape[0]} rows")
+        nrhs = x2.shape[1]
+        y = np.empty((m, nrhs), dtype=src_dtype)
+        check(self._lib.bfhipApply(self._h, x2.ctypes.data, nrhs, nrhs, y.ctypes.data, nrhs))
+        return y[:, 0] if one_d else y
+
+    def apply_device(self, x, y=None, stream=None):
+        """bfhipApplyDevice on torch tensors resident on the operator's GPU.
+        x: [numCols] or [numCols, nrhs], contiguous; returns y (async on the
+        current torch stream unless `stream` is given)."""
+        import torch
+        m, n = self.shape
+        tdt = {BFHIP_C128: torch.complex128, BFHIP_F64: torch.float64, BFHIP_F32: torch.float32}[self.dtype]
+        if x.dtype != tdt or not x.is_cuda or not x.is_contiguous():
+            raise ValueError(f"x must be a contiguous CUDA tensor of dtype {tdt}")
+        nrhs = 1 if x.dim() == 1 else x.shape[1]
+        if x.shape[0] != n:
+            raise ValueError(f"operator has {n} columns, x has {x.shape[0]} rows")
+        if y is None:
+            y = torch.empty((m,) if x.dim() == 1 else (m, nrhs), dtype=tdt, device=x.device)
+        s = stream if stream is not None else torch.cuda.current_stream(x.device)
+        check(self._lib.bfhipApplyDevice(self._h, C.c_void_p(x.data_ptr()), nrhs, C.c_void_p(y.data_ptr()),
+                                         C.c_void_p(s.cuda_stream)))
+        return y
+
+    def stage_profile(self, reset=False):
+        """(ms, launches, bytes) per stage, from hipEvents (needs FLAG_PROFILE)."""
+        S = self.stats()["numStages"]
+        ms = np.zeros(S, dtype=np.float64)
+        launches = np.zeros(S, dtype=np.uint64)
+        nbytes = np.zeros(S, dtype=np.uint64)
+        check(self._lib.bfhipGetStageProfile(self._h, ms.ctypes.data, launches.ctypes.data, nbytes.ctypes.data,
+                                             1 if reset else 0))
+        return ms, launches, nbytes
+
+    # ---- reference-vtable shim ---------------------------------------------
+    def as_bfmat(self):
+        """A BfMat* whose Mul/MulVec run on the device (bfhipMatNew).  The shim
+        does not own the operator; keep this object alive while it is used."""
+        p = self._lib.bfhipMatNew(self._h, 0)
+        if not p:
+            raise _capi.BfhipError(1, self._lib.bfhipLastErrorMessage().decode())
+        return p

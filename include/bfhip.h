@@ -53,7 +53,9 @@ enum {
 
 enum {
   BFHIP_FLAG_NONE = 0,
-  BFHIP_FLAG_PROFILE = 1u << 0   /* record hipEvents around every stage launch */
+  BFHIP_FLAG_PROFILE = 1u << 0,  /* record hipEvents around every stage launch */
+  BFHIP_FLAG_PLAN_ONLY = 1u << 1 /* build the host-side plan only: no device is touched, apply is refused;
+                                    for inspecting the flattened layout (bfhipPlan* below) */
 };
 
 typedef struct BfhipOptions {
@@ -151,6 +153,37 @@ size_t bfhipNumBytes(const BfhipOperator *op);
  * receives the algorithmic bytes one launch of that stage moves for the nrhs
  * of the last apply.  Synchronizes the stream. */
 int bfhipGetStageProfile(BfhipOperator *op, double *ms, uint64_t *launches, uint64_t *bytes, int reset);
+
+/* ---- plan inspection (no device needed) ---------------------------------- */
+/* The flattened per-stage layout, as the kernels see it.  Valid only for an
+ * operator compiled with BFHIP_FLAG_PLAN_ONLY (the host mirrors are dropped
+ * after upload otherwise); pointers stay owned by the operator.  Record
+ * layouts: BfDevItem = {u32 pieceBegin, numPieces, outOff, mrFlags},
+ * BfDevPiece = {u64 dataOff; u32 inOff, ncols, flags, pad}. */
+typedef struct BfhipPlanInfo {
+  uint32_t structSize, dtype, elemSize, epl, xcap, reserved;
+  uint64_t numRows, numCols, numStages, arenaElems, tempElems;
+} BfhipPlanInfo;
+typedef struct BfhipStageView {
+  uint32_t structSize, reserved;
+  uint64_t numItems, numPieces, numReduce;
+  const void *items;      /* BfDevItem[numItems]  (16 bytes each) */
+  const void *pieces;     /* BfDevPiece[numPieces] (24 bytes each) */
+} BfhipStageView;
+typedef struct BfhipReduceView {
+  uint32_t structSize, destIsY;
+  uint64_t destOff, numRows, numIntervals, numSrc;
+  const uint32_t *rowInterval;   /* [numRows] */
+  const uint32_t *ivBegin;       /* [numIntervals+1] */
+  const int64_t *srcBias;        /* [numSrc] */
+} BfhipReduceView;
+int bfhipPlanGetInfo(const BfhipOperator *op, BfhipPlanInfo *info);
+int bfhipPlanGetStage(const BfhipOperator *op, uint64_t stage, BfhipStageView *view);
+int bfhipPlanGetReduce(const BfhipOperator *op, uint64_t stage, uint64_t index, BfhipReduceView *view);
+/* Write the packed leaf arena (arenaElems elements) to host memory; the
+ * descriptor's / graph's leaf values must still be alive.  Synthetic leaves
+ * are generated with the host copy of the value stream. */
+int bfhipPlanPackArena(const BfhipOperator *op, void *dst);
 
 /* ---- lifetime ------------------------------------------------------------ */
 void bfhipFree(BfhipOperator **op);

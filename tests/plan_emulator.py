@@ -1,0 +1,85 @@
+"""Test infrastructure: a numpy interpreter of the engine's flattened plan.
+
+It executes exactly what the HIP kernels are specified to do (per item:
+sum over pieces of  A_piece @ x_segment, then the reduce passes), reading the
+plan through the inspection C-ABI (BFHIP_FLAG_PLAN_ONLY; no GPU needed).  It
+lets the CPU test-suite check the host logic -- scheduling, row groups,
+packing, reduce intervals -- against the oracle without a device.  It is NOT a
+fallback for the engine and lives only under tests/."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from butterfly_amd import _capi
+
+BF_ITEM_OUT_Y = 1 << 16
+BF_PIECE_IN_X = 1
+BF_PIECE_IDENTITY = 2
+
+
+def _view(ptr, count, dtype):
+    if count == 0:
+        return np.zeros(0, dtype=dtype)
+    buf = (C.c_char * (count * dtype.itemsize)).from_address(ptr)
+    return np.frombuffer(buf, dtype=dtype)
+
+
+def run_plan(op, x):
+    """op: butterfly_amd.operator.HipOperator compiled with FLAG_PLAN_ONLY."""
+    lib = _capi.load()
+    info = _capi.BfhipPlanInfo()
+    info.structSize = C.sizeof(info)
+    _capi.check(lib.bfhipPlanGetInfo(op.handle, C.byref(info)))
+    dt = {0: np.complex128, 1: np.float64, 2: np.float32}[info.dtype]
+    epl = info.epl
+    arena = np.zeros(int(info.arenaElems), dtype=dt)
+    _capi.check(lib.bfhipPlanPackArena(op.handle, arena.ctypes.data))
+    x = np.asarray(x, dtype=dt)
+    one_d = x.ndim == 1
+    if one_d:
+        x = x[:, None]
+    nrhs = x.shape[1]
+    y = np.full((int(info.numRows), nrhs), np.nan, dtype=dt)
+    temp = np.full((int(info.tempElems), nrhs), np.nan, dtype=dt)
+    for s in range(int(info.numStages)):
+        sv = _capi.BfhipStageView()
+        sv.structSize = C.sizeof(sv)
+        _capi.check(lib.bfhipPlanGetStage(op.handle, s, C.byref(sv)))
+        items = _view(sv.items, int(sv.numItems), _capi.ITEM_DTYPE)
+        pieces = _view(sv.pieces, int(sv.numPieces), _capi.PIECE_DTYPE)
+        for it in items:
+            mr = int(it["mrFlags"]) & 0xFFFF
+            mr_pad = (mr + epl - 1) // epl * epl
+            acc = np.zeros((mr, nrhs), dtype=dt)
+            for pc in pieces[int(it["pieceBegin"]):int(it["pieceBegin"]) + int(it["numPieces"])]:
+                src = x if (int(pc["flags"]) & BF_PIECE_IN_X) else temp
+                io, n = int(pc["inOff"]), int(pc["ncols"])
+                if int(pc["flags"]) & BF_PIECE_IDENTITY:
+                    acc += src[io:io + mr]
+                    continue
+                assert n <= info.xcap
+                d0 = int(pc["dataOff"])
+                a = arena[d0:d0 + mr_pad * n].reshape(n, mr_pad).T[:mr]
+                acc += a @ src[io:io + n]
+            dst = y if (int(it["mrFlags"]) & BF_ITEM_OUT_Y) else temp
+            oo = int(it["outOff"])
+            dst[oo:oo + mr] = acc
+        for r in range(int(sv.numReduce)):
+            rv = _capi.BfhipReduceView()
+            rv.structSize = C.sizeof(rv)
+            _capi.check(lib.bfhipPlanGetReduce(op.handle, s, r, C.byref(rv)))
+            row_iv = _view(rv.rowInterval, int(rv.numRows), np.dtype("<u4"))
+            iv_begin = _view(rv.ivBegin, int(rv.numIntervals) + 1, np.dtype("<u4"))
+            bias = _view(rv.srcBias, int(rv.numSrc), np.dtype("<i8"))
+            dest = y if rv.destIsY else temp[int(rv.destOff):]
+            rows = np.arange(int(rv.numRows))
+            out = np.zeros((int(rv.numRows), nrhs), dtype=dt)
+            cnt = iv_begin[row_iv + 1] - iv_begin[row_iv]
+            for k in range(int(cnt.max()) if len(cnt) else 0):
+                sel = cnt > k
+                src_rows = bias[iv_begin[row_iv[sel]] + k] + rows[sel]
+                out[sel] += temp[src_rows]
+            dest[:int(rv.numRows)] = out
+    return y[:, 0] if one_d else y
