@@ -39,38 +39,6 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def assign_row_blocks(weights, world):
-    """LPT bin packing of top-level row blocks by leaf bytes."""
-    order = np.argsort(-np.asarray(weights))
-    loads = [0] * world
-    owner = [0] * len(weights)
-    for rb in order:
-        r = int(np.argmin(loads))
-        owner[rb] = r
-        loads[r] += weights[rb]
-    return owner, loads
-
-
-def row_block_weights(desc):
-    """leaf elements under each top-level block row"""
-    kind = np.asarray(desc.kind)
-    rows = np.asarray(desc.rows, dtype=np.int64)
-    cols = np.asarray(desc.cols, dtype=np.int64)
-    own = rows * cols * (kind == 0)
-    # subtree sums by DFS from each root child
-    nrb = len(desc.meta["top_rows"])
-    w = [0] * nrb
-    for (c, _, _), rb in zip(desc.children[desc.root], desc.top_row_block):
-        tot = 0
-        stack = [c]
-        while stack:
-            v = stack.pop()
-            tot += int(own[v])
-            stack.extend(ch for ch, _, _ in desc.children[v])
-        w[rb] += tot
-    return w
-
-
 def cpu_baseline(desc, seed, total_leaf_elems, weights, budget_bytes, nrhs, x, y_gpu_full, row_offsets):
     """Oracle (port of the reference bfMatMul) on a bounded sample: the top-level
     block rows, smallest first, that fit in `budget_bytes` of leaf data."""
@@ -135,6 +103,7 @@ def main():
     import torch
     import torch.distributed as dist
     from butterfly_amd import _capi, helm2_structure as hs
+    from butterfly_amd.dist import ShardLayout, ShardedApply, assign_row_blocks, row_block_weights
     from butterfly_amd.operator import HipOperator
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -183,33 +152,12 @@ def main():
     shape = (n,) if args.nrhs == 1 else (n, args.nrhs)
     x_host = (rng.standard_normal(shape) + 1j * rng.standard_normal(shape)) / np.sqrt(2)
     x = torch.from_numpy(x_host).to(dev)
-    y_local = torch.empty((local_rows,) + shape[1:], dtype=torch.complex128, device=dev)
-
-    if world > 1:
-        max_rows = max(sum(top_rows[rb] for rb in range(len(weights)) if owner[rb] == r) for r in range(world))
-        pad = torch.zeros((max_rows,) + shape[1:], dtype=torch.complex128, device=dev)
-        gathered = torch.empty((world * max_rows,) + shape[1:], dtype=torch.complex128, device=dev)
-        # index map: global row -> position in `gathered`
-        idx = np.empty(n, dtype=np.int64)
-        for r in range(world):
-            pos = r * max_rows
-            for rb in range(len(weights)):
-                if owner[rb] == r:
-                    m = top_rows[rb]
-                    idx[row_offsets[rb]:row_offsets[rb] + m] = np.arange(pos, pos + m)
-                    pos += m
-        idx_t = torch.from_numpy(idx).to(dev)
-
-    def step():
-        op.apply_device(x, y_local)
-        if world > 1:
-            pad[:local_rows] = y_local
-            dist.all_gather_into_tensor(gathered, pad)
-            return gathered.index_select(0, idx_t)
-        return y_local
+    layout = ShardLayout(top_rows, owner, world)
+    assert layout.rows_of[rank] == local_rows
+    step = ShardedApply(layout, rank, lambda xin, out: op.apply_device(xin, out), dev, torch.complex128, nrhs=args.nrhs)
 
     for _ in range(args.warmup):
-        y_full = step()
+        y_full = step(x)
     torch.cuda.synchronize()
     op.stage_profile(reset=True)
     if world > 1:
@@ -217,7 +165,7 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        y_full = step()
+        y_full = step(x)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()

@@ -1,0 +1,87 @@
+"""Test infrastructure: random expression graphs (Dense / Identity / Block /
+Product, arbitrarily nested, ragged sizes) in the flat descriptor form, plus a
+numpy densifier used as an independent known answer.  Mirrors the zoo of the
+reference's real (fac_streamer) operands: Identity leaves inside factors,
+blocks nested in products nested in blocks."""
+import numpy as np
+
+from butterfly_amd.helm2_structure import (BF_TYPE_BLOCK_COO, BF_TYPE_BLOCK_DENSE, BF_TYPE_BLOCK_DIAG, Desc,
+                                           NODE_BLOCK, NODE_DENSE, NODE_IDENTITY, NODE_PRODUCT)
+
+
+def _split(rng, total, parts):
+    """`parts` positive integers summing to `total`."""
+    parts = max(1, min(parts, total))
+    cuts = np.sort(rng.choice(np.arange(1, total), size=parts - 1, replace=False)) if parts > 1 else np.array([], dtype=int)
+    edges = np.concatenate([[0], cuts, [total]])
+    return [int(b - a) for a, b in zip(edges[:-1], edges[1:])]
+
+
+def _gen(rng, d, vals, m, n, depth, cplx):
+    """A node computing an m x n operator."""
+    choice = rng.random()
+    if depth == 0 or m < 4 or n < 4 or choice < 0.25:
+        if m == n and rng.random() < 0.2:
+            return d.add(NODE_IDENTITY, m, n)
+        node = d.add(NODE_DENSE, m, n)
+        v = rng.standard_normal((m, n)) / np.sqrt(n)
+        if cplx:
+            v = v + 1j * rng.standard_normal((m, n)) / np.sqrt(n)
+        vals[node] = v
+        return node
+    if choice < 0.5:   # product through random inner dims
+        nf = int(rng.integers(2, 4))
+        dims = [m] + [int(rng.integers(2, max(3, min(m, n) + 8))) for _ in range(nf - 1)] + [n]
+        fs = [_gen(rng, d, vals, dims[i], dims[i + 1], depth - 1, cplx) for i in range(nf)]
+        return d.add(NODE_PRODUCT, m, n, [(f, 0, 0) for f in fs])
+    rs = _split(rng, m, int(rng.integers(1, 4)))
+    cs = _split(rng, n, int(rng.integers(1, 4)))
+    ro = np.concatenate([[0], np.cumsum(rs)])
+    co = np.concatenate([[0], np.cumsum(cs)])
+    if choice < 0.65 and len(rs) == len(cs):   # block diagonal
+        ch = [(_gen(rng, d, vals, rs[i], cs[i], depth - 1, cplx), int(ro[i]), int(co[i])) for i in range(len(rs))]
+        return d.add(NODE_BLOCK, m, n, ch, BF_TYPE_BLOCK_DIAG)
+    if choice < 0.85:                          # sparse of blocks, possibly with empty block rows
+        ch = []
+        for i in range(len(rs)):
+            for j in range(len(cs)):
+                if rng.random() < 0.6:
+                    ch.append((_gen(rng, d, vals, rs[i], cs[j], depth - 1, cplx), int(ro[i]), int(co[j])))
+        return d.add(NODE_BLOCK, m, n, ch, BF_TYPE_BLOCK_COO)
+    ch = [(_gen(rng, d, vals, rs[i], cs[j], depth - 1, cplx), int(ro[i]), int(co[j]))
+          for i in range(len(rs)) for j in range(len(cs))]
+    return d.add(NODE_BLOCK, m, n, ch, BF_TYPE_BLOCK_DENSE)
+
+
+def random_operand(rng, depth=3, size_hint=80, cplx=False, m=None, n=None):
+    d = Desc(dtype=0 if cplx else 1)
+    vals = {}
+    m = m or int(rng.integers(size_hint // 2, size_hint * 2))
+    n = n or int(rng.integers(size_hint // 2, size_hint * 2))
+    d.root = _gen(rng, d, vals, m, n, depth, cplx)
+    return d, vals
+
+
+def random_real_operand(rng, depth=3, size_hint=80):
+    return random_operand(rng, depth, size_hint, cplx=False)
+
+
+def densify(d, vals, node):
+    k = d.kind[node]
+    m, n = d.rows[node], d.cols[node]
+    if k == NODE_DENSE:
+        return np.asarray(vals[node])
+    if k == NODE_IDENTITY:
+        return np.eye(m)
+    if k == NODE_PRODUCT:
+        out = None
+        for c, _, _ in d.children[node]:
+            a = densify(d, vals, c)
+            out = a if out is None else out @ a
+        return out
+    dt = np.complex128 if d.dtype == 0 else np.float64
+    out = np.zeros((m, n), dtype=dt)
+    for c, r0, c0 in d.children[node]:
+        a = densify(d, vals, c)
+        out[r0:r0 + a.shape[0], c0:c0 + a.shape[1]] += a
+    return out

@@ -1,0 +1,201 @@
+"""Host logic of the engine, without a GPU: the flattened plan (scheduling,
+row groups, packing, reduce intervals) is read back through the inspection
+C-ABI and interpreted in numpy (tests/plan_emulator.py), then compared with
+the CPU oracle on the same operand."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from butterfly_amd import _capi, helm2_structure as hs
+from butterfly_amd.operator import HipOperator
+from oracle import bfref, helm2_build as hb
+from fixtures import load_fixture
+import plan_emulator
+import randgraph
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+PLAN = dict(flags=_capi.FLAG_PLAN_ONLY)
+
+
+def rel(a, b):
+    return float(np.linalg.norm(np.ravel(a) - np.ravel(b)) / np.linalg.norm(np.ravel(b)))
+
+
+@pytest.mark.parametrize("n,k", [(1024, 100), (2048, 128)])
+def test_helm2_plan_matches_oracle(helm2_cases, n, k):
+    desc, tp, vals = helm2_cases(n, k)
+    A = bfref.from_desc(desc, vals)
+    x = hb.complex_randn(n, 0)
+    y_ref = bfref.mat_mul(A, x)
+    op = HipOperator.from_desc(desc, vals, **PLAN)
+    assert rel(plan_emulator.run_plan(op, x), y_ref) < 1e-13
+    st = op.stats()
+    assert st["leafElems"] == desc.leaf_elems() and st["leafBytes"] == A.num_bytes() == op.num_bytes()
+    assert st["arenaBytes"] == st["leafBytes"]          # complex128: no padding
+    # the drop-in route: walk the BfMat graph instead of the descriptor
+    op2 = HipOperator.from_bfmat(A.ptr.value, **PLAN)
+    assert op2.stats()["numStages"] == st["numStages"]
+    assert rel(plan_emulator.run_plan(op2, x), y_ref) < 1e-13
+    # multi-RHS
+    rng = np.random.default_rng(0)
+    xm = rng.standard_normal((n, 3)) + 1j * rng.standard_normal((n, 3))
+    assert rel(plan_emulator.run_plan(op, xm), bfref.mat_mul(A, xm)) < 1e-13
+
+
+def test_synthetic_values_identical_host_and_oracle():
+    desc, root, perm = hs.helm2_multilevel_structure(hs.circle_points(2048), 128)
+    x = hb.complex_randn(2048, 3)
+    y_ref = bfref.mat_mul(bfref.from_desc(desc, None, seed=99), x)
+    op = HipOperator.from_desc(desc, None, seed=99, **PLAN)
+    assert rel(plan_emulator.run_plan(op, x), y_ref) < 1e-13
+    op_other = HipOperator.from_desc(desc, None, seed=100, **PLAN)
+    assert rel(plan_emulator.run_plan(op_other, x), y_ref) > 0.1
+
+
+def test_golden_one_block_plan():
+    desc, vals, ex = load_fixture(os.path.join(GOLD, "helm2_one_block_n2048_k128.npz"))
+    op = HipOperator.from_desc(desc, vals, **PLAN)
+    y = plan_emulator.run_plan(op, ex["x"])
+    assert op.stats()["numStages"] == 3
+    assert rel(y, ex["y_oracle"]) < 1e-13 and rel(y, ex["y_dense"]) < 1e-11
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_nested_real_graphs(seed):
+    """Arbitrary nesting of all container types, Identity leaves, ragged
+    sizes, empty block rows (zero fill): real operands through bfMatMulVec."""
+    rng = np.random.default_rng(1000 + seed)
+    desc, vals = randgraph.random_real_operand(rng, depth=int(rng.integers(1, 5)), size_hint=int(rng.integers(8, 200)))
+    n = desc.cols[desc.root]
+    x = rng.standard_normal(n)
+    want = randgraph.densify(desc, vals, desc.root) @ x
+    A = bfref.from_desc(desc, vals)
+    assert rel(bfref.mat_mul_vec(A, x) + 1, want + 1) < 1e-12
+    for demote in (False, True):
+        op = HipOperator.from_desc(desc, vals, demote_to_f32=demote, **PLAN)
+        y = plan_emulator.run_plan(op, x)
+        assert rel(y + 1, want + 1) < (2e-5 if demote else 1e-12)
+    op3 = HipOperator.from_bfmat(A.ptr.value, **PLAN)
+    assert rel(plan_emulator.run_plan(op3, x) + 1, want + 1) < 1e-12
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_nested_complex_graphs(seed):
+    rng = np.random.default_rng(2000 + seed)
+    desc, vals = randgraph.random_operand(rng, depth=3, size_hint=int(rng.integers(20, 400)), cplx=True)
+    n = desc.cols[desc.root]
+    x = rng.standard_normal((n, 2)) + 1j * rng.standard_normal((n, 2))
+    want = randgraph.densify(desc, vals, desc.root) @ x
+    op = HipOperator.from_desc(desc, vals, **PLAN)
+    assert rel(plan_emulator.run_plan(op, x) + 1, want + 1) < 1e-12
+
+
+def test_wide_and_tall_leaves_are_split():
+    """cols > xcap (256) are cut into column pieces, rows > 64 into items."""
+    rng = np.random.default_rng(7)
+    d = hs.Desc(dtype=0)
+    vals = {}
+    a = d.add(hs.NODE_DENSE, 150, 700); vals[a] = rng.standard_normal((150, 700)) + 1j * rng.standard_normal((150, 700))
+    b = d.add(hs.NODE_DENSE, 700, 3); vals[b] = rng.standard_normal((700, 3)) + 1j * rng.standard_normal((700, 3))
+    d.root = d.add(hs.NODE_PRODUCT, 150, 3, [(a, 0, 0), (b, 0, 0)])
+    x = rng.standard_normal(3) + 1j * rng.standard_normal(3)
+    op = HipOperator.from_desc(d, vals, **PLAN)
+    st = op.stats()
+    assert st["numStages"] == 2
+    assert st["numItems"] == 3 + 11          # ceil(150/64) + ceil(700/64)
+    assert st["numPieces"] == 3 * 3 + 11     # 700 cols -> 3 column pieces per item
+    assert rel(plan_emulator.run_plan(op, x), vals[a] @ (vals[b] @ x)) < 1e-13
+
+
+def test_row_sharding_union_equals_full(helm2_cases):
+    n, k = 2048, 128
+    desc, tp, vals = helm2_cases(n, k)
+    x = hb.complex_randn(n, 0)
+    y_ref = bfref.mat_mul(bfref.from_desc(desc, vals), x)
+    nrb = len(desc.meta["top_rows"])
+    offs = np.concatenate([[0], np.cumsum(desc.meta["top_rows"])])
+    # C-ABI sharding option: contiguous block-row ranges
+    parts = []
+    for b, e in ((0, 5), (5, nrb)):
+        op = HipOperator.from_desc(desc, vals, row_blocks=(b, e), **PLAN)
+        assert op.shape == (int(offs[e] - offs[b]), n)
+        parts.append(plan_emulator.run_plan(op, x))
+    assert rel(np.concatenate(parts), y_ref) < 1e-13
+    # descriptor-level sharding: arbitrary subsets
+    mine = [0, 3, 7, 11]
+    root, m = hs.shard_desc(desc, mine)
+    op = HipOperator.from_desc(desc, vals, root=root, **PLAN)
+    want = np.concatenate([y_ref[offs[rb]:offs[rb + 1]] for rb in mine])
+    assert rel(plan_emulator.run_plan(op, x), want) < 1e-13
+
+
+# ---- error behaviour (mirrors the reference's BfError codes) ---------------
+def _compile_bfmat(ptr):
+    lib = _capi.load()
+    h = C.c_void_p()
+    o = _capi.BfhipOptions()
+    o.structSize = C.sizeof(o)
+    o.device = -1
+    o.flags = _capi.FLAG_PLAN_ONLY
+    rc = lib.bfhipCompile(C.c_void_p(ptr), C.byref(o), C.byref(h))
+    if h:
+        lib.bfhipFree(C.byref(h))
+    return rc, lib.bfhipLastErrorMessage().decode()
+
+
+def test_transposed_leaf_is_refused():
+    from butterfly_amd._capi import ERROR_NAMES
+    a = bfref.dense_complex(np.ones((4, 4), dtype=complex))
+    # set BF_MAT_PROPS_TRANS on the leaf (props is the int at offset 8 of BfMat)
+    C.c_int.from_address(a.ptr.value + 8).value |= 2
+    rc, msg = _compile_bfmat(a.ptr.value)
+    assert ERROR_NAMES[rc] == "BF_ERROR_NOT_IMPLEMENTED" and "transposed" in msg
+    C.c_int.from_address(a.ptr.value + 8).value &= ~2
+
+
+def test_mixed_real_and_complex_is_a_type_error():
+    from butterfly_amd._capi import ERROR_NAMES
+    g = bfref.block_diag([bfref.dense_complex(np.ones((2, 2), dtype=complex)), bfref.dense_real(np.ones((2, 2)))])
+    rc, msg = _compile_bfmat(g.ptr.value)
+    assert ERROR_NAMES[rc] == "BF_ERROR_TYPE_ERROR"
+
+
+def test_non_chaining_product_is_refused():
+    from butterfly_amd._capi import ERROR_NAMES
+    p = bfref.product([bfref.dense_complex(np.ones((3, 4), dtype=complex)), bfref.dense_complex(np.ones((5, 2), dtype=complex))])
+    rc, msg = _compile_bfmat(p.ptr.value)
+    assert ERROR_NAMES[rc] == "BF_ERROR_INCOMPATIBLE_SHAPES"
+
+
+def test_null_and_bad_arguments():
+    lib = _capi.load()
+    h = C.c_void_p()
+    assert lib.bfhipCompile(None, None, C.byref(h)) == 1
+    d = _capi.BfhipDesc()
+    d.structSize = 4
+    assert lib.bfhipCompileDesc(C.byref(d), None, C.byref(h)) == 1
+    assert lib.bfhipGetNumRows(None) == 0
+    lib.bfhipFree(C.byref(h))          # freeing NULL is a no-op
+
+
+def test_plan_only_operator_refuses_apply():
+    desc, vals, ex = load_fixture(os.path.join(GOLD, "helm2_one_block_n2048_k128.npz"))
+    op = HipOperator.from_desc(desc, vals, **PLAN)
+    with pytest.raises(_capi.BfhipError) as e:
+        op.apply_host(ex["x"])
+    assert e.value.code == 2
+
+
+def test_unsupported_node_type_is_a_type_error():
+    """A BfMat whose GetType answers something outside the factorization zoo."""
+    from butterfly_amd._capi import ERROR_NAMES
+    a = bfref.identity(4)
+    # the shim object itself reports BF_TYPE_MAT_FUNC (6): nesting it is refused
+    op = HipOperator.from_bfmat(a.ptr.value, **PLAN)
+    shim = op.as_bfmat()
+    rc, msg = _compile_bfmat(shim)
+    assert ERROR_NAMES[rc] == "BF_ERROR_TYPE_ERROR"
+    p = C.c_void_p(shim)
+    bfref.load().bfMatDelete(C.byref(p))
