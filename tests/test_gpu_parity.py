@@ -103,3 +103,169 @@ def test_device_apply_torch(helm2_cases):
     torch.cuda.synchronize()
     assert torch.equal(yd, yd2)
     op.close()
+
+
+# ---------------------------------------------------------------------------
+# committed golden fixtures (tests/golden/, generator: make_golden.py)
+# ---------------------------------------------------------------------------
+def _gold(name):
+    import os
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name)
+
+
+def test_golden_one_block_on_gpu():
+    from butterfly_amd.operator import HipOperator
+    from fixtures import load_fixture
+    desc, vals, ex = load_fixture(_gold("helm2_one_block_n2048_k128.npz"))
+    op = HipOperator.from_desc(desc, vals)
+    y = op.apply_host(ex["x"])
+    assert rel(y, ex["y_oracle"]) <= TOL
+    assert rel(y, ex["y_dense"]) <= 1e-11
+    op.close()
+
+
+def test_golden_multilevel_vectors_on_gpu(helm2_cases):
+    from butterfly_amd.operator import HipOperator
+    z = np.load(_gold("helm2_multilevel_n2048_k128_vectors.npz"))
+    desc, tp, vals = helm2_cases(int(z["n"]), float(z["k"]))
+    op = HipOperator.from_desc(desc, vals)
+    y = op.apply_host(z["x"])
+    assert rel(y, z["y_oracle"]) <= TOL
+    assert rel(y, z["y_dense"]) <= 1e-10
+    op.close()
+
+
+def test_golden_real_nested_on_gpu_f64_and_f32():
+    """Real (fac_streamer-like) operand through MulVec semantics; fp32 is the
+    build's extension (reference has no single precision, include/bf/def.h:31-35):
+    tolerance 2e-5 relative, fp64 1e-12."""
+    from butterfly_amd.operator import HipOperator
+    from fixtures import load_fixture
+    desc, vals, ex = load_fixture(_gold("real_nested_small.npz"))
+    op = HipOperator.from_desc(desc, vals)
+    assert rel(op.apply_host(ex["x"]), ex["y_oracle"]) <= TOL
+    op.close()
+    op32 = HipOperator.from_desc(desc, vals, demote_to_f32=True)
+    assert rel(op32.apply_host(ex["x"]), ex["y_oracle"]) <= 2e-5
+    op32.close()
+
+
+# ---------------------------------------------------------------------------
+# operand zoo: nesting, Identity leaves, ragged sizes, empty block rows
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("seed", range(8))
+def test_random_nested_real_graphs_on_gpu(seed):
+    import randgraph
+    from butterfly_amd.operator import HipOperator
+    from oracle import bfref
+    rng = np.random.default_rng(1000 + seed)
+    desc, vals = randgraph.random_real_operand(rng, depth=int(rng.integers(1, 5)), size_hint=int(rng.integers(8, 200)))
+    x = rng.standard_normal(desc.cols[desc.root])
+    A = bfref.from_desc(desc, vals)
+    want = bfref.mat_mul_vec(A, x)
+    op = HipOperator.from_bfmat(A.ptr.value)
+    assert rel(op.apply_host(x) + 1, want + 1) <= TOL
+    op.close()
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_random_nested_complex_graphs_on_gpu_multi_rhs(seed):
+    import randgraph
+    from butterfly_amd.operator import HipOperator
+    rng = np.random.default_rng(2000 + seed)
+    desc, vals = randgraph.random_operand(rng, depth=3, size_hint=int(rng.integers(20, 400)), cplx=True)
+    n = desc.cols[desc.root]
+    x = rng.standard_normal((n, 5)) + 1j * rng.standard_normal((n, 5))
+    want = randgraph.densify(desc, vals, desc.root) @ x
+    op = HipOperator.from_desc(desc, vals)
+    assert rel(op.apply_host(x) + 1, want + 1) <= TOL
+    op.close()
+
+
+def test_mulvec_shim_real_operator():
+    """bfMatMulVec(A_hip, v) for a square real operator through the vtable shim."""
+    import randgraph
+    from butterfly_amd.operator import HipOperator
+    from oracle import bfref
+    rng = np.random.default_rng(77)
+    desc, vals = randgraph.random_operand(rng, depth=3, size_hint=120, cplx=False, m=150, n=150)
+    A = bfref.from_desc(desc, vals)
+    x = rng.standard_normal(150)
+    want = bfref.mat_mul_vec(A, x)
+    op = HipOperator.from_bfmat(A.ptr.value)
+    a_hip = C.c_void_p(op.as_bfmat())
+    got = bfref.mat_mul_vec(type("H", (), {"ptr": a_hip, "shape": (150, 150)})(), x)
+    assert rel(got, want) <= TOL
+    bfref.load().bfMatDelete(C.byref(a_hip))
+    op.close()
+
+
+def test_wide_tall_leaves_and_zero_fill_on_gpu():
+    from butterfly_amd import helm2_structure as hs
+    from butterfly_amd.operator import HipOperator
+    rng = np.random.default_rng(7)
+    d = hs.Desc(dtype=0)
+    vals = {}
+    a = d.add(hs.NODE_DENSE, 150, 700); vals[a] = rng.standard_normal((150, 700)) + 1j * rng.standard_normal((150, 700))
+    b = d.add(hs.NODE_DENSE, 700, 3); vals[b] = rng.standard_normal((700, 3)) + 1j * rng.standard_normal((700, 3))
+    p = d.add(hs.NODE_PRODUCT, 150, 3, [(a, 0, 0), (b, 0, 0)])
+    # place the product in the middle of a larger, otherwise empty block matrix: rows 0..99 and 250..299 must come out zero
+    d.root = d.add(hs.NODE_BLOCK, 300, 10, [(p, 100, 4)], hs.BF_TYPE_BLOCK_COO)
+    x = rng.standard_normal((10, 2)) + 1j * rng.standard_normal((10, 2))
+    want = np.zeros((300, 2), dtype=complex)
+    want[100:250] = vals[a] @ (vals[b] @ x[4:7])
+    op = HipOperator.from_desc(d, vals)
+    y = op.apply_host(x)
+    assert np.all(y[:100] == 0) and np.all(y[250:] == 0)
+    assert rel(y[100:250], want[100:250]) <= TOL
+    op.close()
+
+
+def test_row_sharded_operators_on_gpu(helm2_cases):
+    from butterfly_amd import helm2_structure as hs
+    from butterfly_amd.operator import HipOperator
+    from oracle import bfref, helm2_build as hb
+    n, k = 4096, 100
+    desc, tp, vals = helm2_cases(n, k)
+    x = hb.complex_randn(n, 0)
+    y_ref = bfref.mat_mul(bfref.from_desc(desc, vals), x)
+    nrb = len(desc.meta["top_rows"])
+    parts = []
+    for b, e in ((0, 4), (4, 9), (9, nrb)):
+        op = HipOperator.from_desc(desc, vals, row_blocks=(b, e))
+        parts.append(op.apply_host(x))
+        op.close()
+    assert rel(np.concatenate(parts), y_ref) <= TOL
+
+
+def test_apply_argument_errors():
+    from butterfly_amd import _capi
+    from butterfly_amd.operator import HipOperator
+    from fixtures import load_fixture
+    desc, vals, ex = load_fixture(_gold("helm2_one_block_n2048_k128.npz"))
+    op = HipOperator.from_desc(desc, vals)
+    lib = _capi.load()
+    x = np.ascontiguousarray(ex["x"])
+    y = np.empty(op.shape[0], dtype=complex)
+    assert lib.bfhipApply(op.handle, x.ctypes.data, 1, 0, y.ctypes.data, 1) == 1      # nrhs = 0
+    assert lib.bfhipApply(op.handle, None, 1, 1, y.ctypes.data, 1) == 1              # NULL X
+    assert lib.bfhipApply(op.handle, x.ctypes.data, 1, 2, y.ctypes.data, 2) == 1     # ldx < nrhs
+    with pytest.raises(ValueError):
+        op.apply_host(np.zeros(3, dtype=complex))
+    op.close()
+
+
+def test_stage_profile_reports_every_stage(helm2_cases):
+    import torch
+    from butterfly_amd import _capi
+    from butterfly_amd.operator import HipOperator
+    desc, tp, vals = helm2_cases(4096, 100)
+    op = HipOperator.from_desc(desc, vals, flags=_capi.FLAG_PROFILE)
+    x = torch.randn(4096, dtype=torch.complex128, device="cuda")
+    for _ in range(3):
+        op.apply_device(x)
+    ms, launches, nbytes = op.stage_profile()
+    st = op.stats()
+    assert len(ms) == st["numStages"] and all(launches == 3) and all(ms > 0)
+    assert int(nbytes.sum()) == st["leafBytes"] + 16 * (st["vecElemsRead"] + st["vecElemsWritten"])
+    op.close()
