@@ -53,6 +53,7 @@ struct BfhipOperator {
   uint32_t flags;
   void *dArena;               /* leaf data */
   void *dTemp;                /* vector arena: intermediates + partial slots, tempElems * maxRhs */
+  void *dZero;                /* 4 KiB of zeros */
   uint32_t tempRhs;
   uint64_t metaBytes;
   uint64_t leafBytesAlgorithmic;
@@ -95,6 +96,7 @@ void bfhipFree(BfhipOperator **pop) {
   freeDevicePlan(op);
   bfdevFree(op->dArena);
   bfdevFree(op->dTemp);
+  bfdevFree(op->dZero);
   bfdevFree(op->dX);
   bfdevFree(op->dY);
   bfPlanFree(&op->plan);
@@ -297,6 +299,8 @@ static int compileIr(BfIr *ir, BfhipOptions const *opts, BfhipOperator **out) {
     }
   }
   if ((rc = ensureTemp(op, o.maxRhs ? o.maxRhs : 1))) goto done;
+  if ((rc = bfdevMalloc(&op->dZero, 4096))) goto done;
+  if ((rc = bfdevMemset(op->dZero, 0, 4096))) goto done;
   if (op->flags & BFHIP_FLAG_PROFILE) {
     uint64_t S = op->plan.numStages;
     op->evStart = calloc(S, sizeof(void *));
@@ -388,7 +392,7 @@ int bfhipApplyDevice(BfhipOperator *op, void const *dX, size_t nrhs, void *dY, v
     BfStage *st = &op->plan.stages[s];
     BfLaunchArgs a;
     a.arena = op->dArena; a.items = st->dItems; a.pieces = st->dPieces; a.numItems = st->numItems;
-    a.x = dX; a.y = dY; a.temp = op->dTemp; a.nrhs = (uint32_t)nrhs; a.dtype = op->plan.dtype; a.maxRows = st->maxRows;
+    a.x = dX; a.y = dY; a.temp = op->dTemp; a.zero = op->dZero; a.nrhs = (uint32_t)nrhs; a.dtype = op->plan.dtype; a.maxRows = st->maxRows;
     if (prof && (rc = bfdevEventRecord(op->evStart[s], stream))) return rc;
     if ((rc = bfdevLaunchStage(&a, stream))) return rc;
     if (prof && (rc = bfdevEventRecord(op->evStop[s], stream))) return rc;

@@ -164,6 +164,7 @@ typedef struct BfLaunchArgs {
   void const *x;
   void *y;
   void *temp;
+  void const *zero;      /* device buffer of >= 64 zero bytes */
   uint32_t nrhs;
   uint32_t dtype;
   uint32_t maxRows;

@@ -421,8 +421,10 @@ int bfPlanBuild(BfIr const *ir, BfPlanOptions const *po, BfPlan *plan) {
     uint64_t numPieces = 0;
     for (uint64_t g = 0; g < numGroups; ++g) {
       uint64_t m = groups[g].rows;
-      uint64_t nch = (m + itemRows - 1) / itemRows;
-      uint64_t chunk = roundUp((m + nch - 1) / nch, plan->epl);
+      /* full items of itemRows rows plus one remainder item: multiples of 16
+       * rows keep the MFMA (multi-RHS) kernel's 16-row slabs full, and a short
+       * remainder still fills the GEMV kernel's lanes through column groups */
+      uint64_t chunk = itemRows;
       uint64_t colsSum = 0, piecesPerChunk = 0;
       for (uint64_t t = groups[g].taskBegin; t < groups[g].taskEnd; ++t) {
         Task const *tk = &b.tasks[t];
