@@ -89,34 +89,50 @@ def cpu_baseline(desc, seed, total_leaf_elems, weights, budget_bytes, nrhs, x, y
 
 
 def main():
+    # Exactly one line may reach stdout (the JSON).  Native libraries (RCCL prints a
+    # version banner at communicator creation) write to fd 1 directly, so fd 1 is
+    # pointed at stderr for the whole run and the JSON goes to the saved descriptor.
+    sys.stdout.flush()
+    real_stdout = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--n", type=int, default=262144)
-    ap.add_argument("--k", type=float, default=None, help="wavenumber (default N/16)")
+    ap.add_argument("--npoints", "--n", dest="n", type=int, default=262144,
+                    help="(use --npoints under torch.distributed.run: its parser treats a bare --n as ambiguous)")
+    ap.add_argument("--wavenumber", "--k", dest="k", type=float, default=None, help="wavenumber (default N/16)")
     ap.add_argument("--nrhs", type=int, default=1)
     ap.add_argument("--seed", type=int, default=1234)
     ap.add_argument("--cpu-budget-gb", type=float, default=4.0, help="leaf bytes of the cpu_baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-collective", action="store_true",
+                    help="rehearsal: initialise RCCL and run the step's collective even with one rank")
+    ap.add_argument("--shard", choices=["auto", "rows", "blocks"], default="auto",
+                    help="multi-GPU: top-level block rows + all-gather, or (row, col) blocks + all-reduce")
     args = ap.parse_args()
 
     import torch
     import torch.distributed as dist
     from butterfly_amd import _capi, helm2_structure as hs
-    from butterfly_amd.dist import ShardLayout, ShardedApply, assign_row_blocks, row_block_weights
+    from butterfly_amd.dist import (ShardLayout, ShardedApply, assign_row_blocks, block_weights, choose_mode,
+                                    row_block_weights)
     from butterfly_amd.operator import HipOperator
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl")
-    if world != args.gpus and rank == 0:
-        log(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    use_pg = world > 1 or args.force_collective
+    if use_pg:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+        dist.init_process_group("nccl", device_id=dev)
+    if world != args.gpus and rank == 0:
+        log(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE")
 
     n = args.n
     k = args.k if args.k is not None else n / 16.0
@@ -127,18 +143,27 @@ def main():
     total_leaf = int(sum(weights))
     top_rows = desc.meta["top_rows"]
     row_offsets = np.concatenate([[0], np.cumsum(top_rows)]).astype(np.int64)
-    owner, loads = assign_row_blocks(weights, world)
-    mine = [rb for rb in range(len(weights)) if owner[rb] == rank]
+    mode = choose_mode(desc, world, args.shard)
+    if mode == "rows":
+        owner, loads = assign_row_blocks(weights, world)
+        mine = [rb for rb in range(len(weights)) if owner[rb] == rank]
+    else:
+        bw = block_weights(desc)
+        bowner, loads = assign_row_blocks(bw, world)
+        mine = [i for i in range(len(bw)) if bowner[i] == rank]
+        owner = [0] * len(weights)
     if rank == 0:
         log(f"structure: N={n} k={k:g} nodes={desc.num_nodes} leafGB={total_leaf * 16 / 1e9:.2f} "
-            f"products={desc.meta['stats']['products']} [{t_struct:.1f}s]; rank loads GB="
+            f"products={desc.meta['stats']['products']} [{t_struct:.1f}s]; shard mode={mode}; rank loads GB="
             f"{[round(l * 16 / 1e9, 2) for l in loads]}")
 
     t0 = time.time()
     if world == 1:
         root, local_rows = desc.root, n
-    else:
+    elif mode == "rows":
         root, local_rows = hs.shard_desc(desc, mine)
+    else:
+        root, local_rows = hs.shard_desc_blocks(desc, mine), n
     op = HipOperator.from_desc(desc, None, root=root, device=local_rank, flags=_capi.FLAG_PROFILE,
                                seed=args.seed, max_rhs=args.nrhs)
     torch.cuda.synchronize()
@@ -154,24 +179,25 @@ def main():
     x_host = (rng.standard_normal(shape) + 1j * rng.standard_normal(shape)) / np.sqrt(2)
     x = torch.from_numpy(x_host).to(dev)
     layout = ShardLayout(top_rows, owner, world)
-    assert layout.rows_of[rank] == local_rows
-    step = ShardedApply(layout, rank, lambda xin, out: op.apply_device(xin, out), dev, torch.complex128, nrhs=args.nrhs)
+    assert mode == "blocks" or layout.rows_of[rank] == local_rows
+    step = ShardedApply(layout, rank, lambda xin, out: op.apply_device(xin, out), dev, torch.complex128, nrhs=args.nrhs,
+                        mode=mode, force_collective=args.force_collective)
 
     for _ in range(args.warmup):
         y_full = step(x)
     torch.cuda.synchronize()
     op.stage_profile(reset=True)
-    if world > 1:
+    if use_pg:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         y_full = step(x)
     torch.cuda.synchronize()
-    if world > 1:
+    if use_pg:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_pg:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -216,7 +242,8 @@ def main():
             "data": "synthetic (structure-exact fac_helm2 layout, seeded values generated in HBM)",
             "config": {"workload": f"fac_helm2 multilevel butterfly, unit circle, N={n}, k={k:g} (16 ppw), nrhs={args.nrhs}",
                        "n": n, "k": k, "nrhs": args.nrhs, "leaf_bytes": total_leaf * 16,
-                       "stages": st["numStages"], "sharding": "top-level row blocks, LPT by leaf bytes" if world > 1 else "none"},
+                       "stages": st["numStages"], "sharding": ("none" if world == 1 else "top-level row blocks (LPT by leaf bytes) + one all-gather" if mode == "rows"
+                                    else "top-level (row, col) blocks (LPT by leaf bytes) + one all-reduce")},
             "roofline": roofline,
             "hbm_gbs_whole_step": (total_leaf * 16 / 1e9) / (elapsed / args.steps),
         }
@@ -227,9 +254,10 @@ def main():
                                                    args.nrhs, x_host, y_host, row_offsets)
             except Exception as e:  # the baseline must never take the measurement down
                 out["cpu_baseline"] = {"value": None, "unit": "matvec/s", "cores": 1, "kind": "port", "sample": f"failed: {e!r}"}
-        print(json.dumps(out), flush=True)
+        real_stdout.write(json.dumps(out) + "\n")
+        real_stdout.flush()
     op.close()
-    if world > 1:
+    if use_pg:
         dist.destroy_process_group()
 
 

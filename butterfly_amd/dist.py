@@ -12,7 +12,14 @@ owns, keeps a replica of x, and a step is
 
 No reduction is needed: outputs are disjoint.  Block rows are dealt to ranks
 by longest-processing-time-first on leaf bytes (12 non-empty row blocks on a
-circle => 8 ranks cannot do better than 2/12 of the work on the busiest one).
+circle => 8 ranks cannot do better than 2/12 of the work on the busiest one:
+6.17x at N = 262144).
+
+Where that bound bites (8 ranks), the finer "blocks" mode deals the 144
+top-level (row, col) blocks instead (LPT again: 7.98x ideal at N = 262144);
+every rank then produces a full-length partial y and the step ends with ONE
+all-reduce (sum) of y instead of the all-gather.  `choose_mode` picks rows
+unless blocks is better balanced by more than 2 %.
 """
 from __future__ import annotations
 
@@ -48,6 +55,32 @@ def assign_row_blocks(weights, world):
     return owner, loads
 
 
+def block_weights(desc):
+    """Leaf elements under each top-level (row, col) block, in child order."""
+    kind = np.asarray(desc.kind)
+    own = np.asarray(desc.rows, dtype=np.int64) * np.asarray(desc.cols, dtype=np.int64) * (kind == hs.NODE_DENSE)
+    w = []
+    for (c, _, _) in desc.children[desc.root]:
+        tot, stack = 0, [c]
+        while stack:
+            v = stack.pop()
+            tot += int(own[v])
+            stack.extend(ch for ch, _, _ in desc.children[v])
+        w.append(tot)
+    return w
+
+
+def choose_mode(desc, world, requested="auto"):
+    """'rows' (all-gather) or 'blocks' (all-reduce) for this operand and world size."""
+    if requested in ("rows", "blocks"):
+        return requested
+    if world == 1:
+        return "rows"
+    _, lr = assign_row_blocks(row_block_weights(desc), world)
+    _, lb = assign_row_blocks(block_weights(desc), world)
+    return "rows" if max(lr) <= 1.02 * max(lb) else "blocks"
+
+
 class ShardLayout:
     """Who owns which rows, and where each global row lands in the gathered
     (rank-major, padded) buffer."""
@@ -76,10 +109,16 @@ class ShardedApply:
     torch.distributed group.  `local_apply(x, out)` runs this rank's rows
     (HipOperator.apply_device on a GPU; tests inject a CPU stand-in)."""
 
-    def __init__(self, layout: ShardLayout, rank, local_apply, device, dtype, nrhs=1, group=None):
+    def __init__(self, layout: ShardLayout, rank, local_apply, device, dtype, nrhs=1, group=None, mode="rows",
+                 force_collective=False):
         import torch
-        self.layout, self.rank, self.local_apply, self.group = layout, rank, local_apply, group
+        self.layout, self.rank, self.local_apply, self.group, self.mode = layout, rank, local_apply, group, mode
+        self.force_collective = force_collective   # run the collective even on one rank (rehearsal)
         tail = () if nrhs == 1 else (nrhs,)
+        if mode == "blocks":
+            self.local_rows = layout.n
+            self.y_local = torch.empty((layout.n,) + tail, dtype=dtype, device=device)
+            return
         self.local_rows = layout.rows_of[rank]
         self.y_local = torch.empty((self.local_rows,) + tail, dtype=dtype, device=device)
         self.pad = torch.zeros((layout.max_rows,) + tail, dtype=dtype, device=device)
@@ -88,9 +127,18 @@ class ShardedApply:
 
     def __call__(self, x):
         import torch.distributed as dist
+        import torch
         self.local_apply(x, self.y_local)
-        if self.layout.world == 1:
+        if self.layout.world == 1 and not self.force_collective:
+            return self.y_local
+        if self.mode == "blocks":
+            # partial results add up: one all-reduce (RCCL) replaces the all-gather
+            buf = torch.view_as_real(self.y_local) if self.y_local.is_complex() else self.y_local
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
             return self.y_local
         self.pad[:self.local_rows] = self.y_local
-        dist.all_gather_into_tensor(self.gathered, self.pad, group=self.group)
+        # collectives run on the real view (re, im pairs): every backend moves doubles
+        src = torch.view_as_real(self.pad) if self.pad.is_complex() else self.pad
+        dst = torch.view_as_real(self.gathered) if self.gathered.is_complex() else self.gathered
+        dist.all_gather_into_tensor(dst, src, group=self.group)
         return self.gathered.index_select(0, self.index)

@@ -470,3 +470,13 @@ def shard_desc(desc: Desc, row_blocks):
             ch.append((c, r0 - int(orig_off[rb]) + base[rb], c0))
     new_root = desc.add(NODE_BLOCK, acc, desc.cols[desc.root], ch, BF_TYPE_BLOCK_DENSE)
     return new_root, acc
+
+
+def shard_desc_blocks(desc: Desc, child_indices):
+    """Restrict a multilevel descriptor to a subset of its top-level (row, col)
+    blocks, kept at their original offsets: the result maps the full x to a
+    full-length *partial* y (rows without blocks are zero); partial results of
+    all ranks add up to y (one all-reduce).  Returns the new root id."""
+    keep = set(child_indices)
+    ch = [c for i, c in enumerate(desc.children[desc.root]) if i in keep]
+    return desc.add(NODE_BLOCK, desc.rows[desc.root], desc.cols[desc.root], ch, BF_TYPE_BLOCK_DENSE)

@@ -23,22 +23,28 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, n, k, nrhs, out_dir):
+def _worker(rank, world, port, n, k, nrhs, out_dir, mode):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from butterfly_amd import _capi, helm2_structure as hs
-    from butterfly_amd.dist import ShardLayout, ShardedApply, assign_row_blocks, row_block_weights
+    from butterfly_amd.dist import ShardLayout, ShardedApply, assign_row_blocks, block_weights, row_block_weights
     from butterfly_amd.operator import HipOperator
     import plan_emulator
     desc, root, perm = hs.helm2_multilevel_structure(hs.circle_points(n), k)
-    weights = row_block_weights(desc)
-    owner, loads = assign_row_blocks(weights, world)
-    layout = ShardLayout(desc.meta["top_rows"], owner, world)
-    shard_root, rows = hs.shard_desc(desc, layout.blocks_of[rank])
-    assert rows == layout.rows_of[rank]
+    if mode == "rows":
+        weights = row_block_weights(desc)
+        owner, loads = assign_row_blocks(weights, world)
+        layout = ShardLayout(desc.meta["top_rows"], owner, world)
+        shard_root, rows = hs.shard_desc(desc, layout.blocks_of[rank])
+        assert rows == layout.rows_of[rank]
+    else:
+        bw = block_weights(desc)
+        bowner, loads = assign_row_blocks(bw, world)
+        layout = ShardLayout(desc.meta["top_rows"], [0] * len(desc.meta["top_rows"]), world)
+        shard_root = hs.shard_desc_blocks(desc, [i for i in range(len(bw)) if bowner[i] == rank])
     op = HipOperator.from_desc(desc, None, root=shard_root, seed=11, flags=_capi.FLAG_PLAN_ONLY)
 
     def local_apply(x, out):
@@ -47,10 +53,10 @@ def _worker(rank, world, port, n, k, nrhs, out_dir):
     rng = np.random.default_rng(5)
     shape = (n,) if nrhs == 1 else (n, nrhs)
     x = torch.from_numpy(rng.standard_normal(shape) + 1j * rng.standard_normal(shape))
-    step = ShardedApply(layout, rank, local_apply, torch.device("cpu"), torch.complex128, nrhs=nrhs)
+    step = ShardedApply(layout, rank, local_apply, torch.device("cpu"), torch.complex128, nrhs=nrhs, mode=mode)
     y = step(x)
     # every rank ends with the full, row-ordered result
-    np.save(os.path.join(out_dir, f"y{rank}.npy"), y.numpy())
+    np.save(os.path.join(out_dir, f"y{rank}.npy"), y.numpy().copy())
     if rank == 0:
         np.save(os.path.join(out_dir, "x.npy"), x.numpy())
         np.save(os.path.join(out_dir, "loads.npy"), np.asarray(loads))
@@ -58,12 +64,12 @@ def _worker(rank, world, port, n, k, nrhs, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("nrhs", [1, 2])
-def test_two_rank_sharded_apply_matches_full_oracle(tmp_path, nrhs):
+@pytest.mark.parametrize("nrhs,mode", [(1, "rows"), (2, "rows"), (1, "blocks"), (2, "blocks")])
+def test_two_rank_sharded_apply_matches_full_oracle(tmp_path, nrhs, mode):
     from butterfly_amd import helm2_structure as hs
     from oracle import bfref
     n, k, world = 2048, 128, 2
-    mp.spawn(_worker, args=(world, _free_port(), n, k, nrhs, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), n, k, nrhs, str(tmp_path), mode), nprocs=world, join=True)
     x = np.load(tmp_path / "x.npy")
     desc, root, perm = hs.helm2_multilevel_structure(hs.circle_points(n), k)
     y_ref = bfref.mat_mul(bfref.from_desc(desc, None, seed=11), x)
@@ -73,6 +79,18 @@ def test_two_rank_sharded_apply_matches_full_oracle(tmp_path, nrhs):
         assert np.linalg.norm(y - y_ref) / np.linalg.norm(y_ref) < 1e-13
     loads = np.load(tmp_path / "loads.npy")
     assert loads.min() > 0.8 * loads.max()       # LPT keeps two ranks balanced
+
+
+def test_mode_choice_follows_balance():
+    """12 equal row blocks: 2 and 4 ranks are perfectly balanced by rows (all-gather);
+    8 ranks are not (2/12 on the busiest) and fall back to (row, col) blocks + all-reduce."""
+    from butterfly_amd import helm2_structure as hs
+    from butterfly_amd.dist import choose_mode
+    desc, root, perm = hs.helm2_multilevel_structure(hs.circle_points(4096), 256)
+    assert choose_mode(desc, 1) == "rows"
+    assert choose_mode(desc, 2) == "rows" and choose_mode(desc, 4) == "rows"
+    assert choose_mode(desc, 8) == "blocks"
+    assert choose_mode(desc, 8, "rows") == "rows"
 
 
 def test_lpt_assignment_and_layout():
