@@ -106,6 +106,7 @@ def main():
     ap.add_argument("--seed", type=int, default=1234)
     ap.add_argument("--cpu-budget-gb", type=float, default=4.0, help="leaf bytes of the cpu_baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--pcie", action="store_true", help="also time the host-buffer path (H2D + apply + D2H)")
     ap.add_argument("--force-collective", action="store_true",
                     help="rehearsal: initialise RCCL and run the step's collective even with one rank")
     ap.add_argument("--shard", choices=["auto", "rows", "blocks"], default="auto",
@@ -227,6 +228,24 @@ def main():
                         "kernel": "bfStageKernelC128", "launches_per_apply": len(ms),
                         "avg_launch_ms": avg_launch_ms, "algorithmic_bytes_per_apply": bytes_per_apply,
                         "kernel_ms_per_apply": kern_ms / max(launches.max(), 1)}
+        # HBM traffic per launch from the committed PMC profile of this very command (rocprofv3 --pmc
+        # FETCH_SIZE / WRITE_SIZE in separate passes, gfx950 x2 FETCH correction); PMC counters cannot be
+        # read from inside the process, so other configurations report null.
+        prof = os.path.join(ROOT, "profiles", "r1_bench_n262144_pmc_hbm.json")
+        if world == 1 and n == 262144 and abs(k - 16384) < 1e-9 and args.nrhs == 1 and os.path.exists(prof):
+            try:
+                pm = json.load(open(prof))["bfStageKernelC128_per_launch"]
+                roofline["traffic"] = pm["hbm_bytes"]
+                roofline["traffic_source"] = "profiles/r1_bench_n262144_pmc_hbm.json (bytes per launch; algorithmic %.4g)" % pm["algorithmic_bytes"]
+            except Exception:
+                pass
+        if args.pcie:
+            # host-buffer path (bfhipApply): H2D of x, all stages, D2H of y -- never the headline value
+            t1 = time.perf_counter()
+            reps = 5
+            for _ in range(reps):
+                op.apply_host(x_host)
+            pcie_ms = (time.perf_counter() - t1) / reps * 1e3
         out = {
             "metric": "butterfly matvecs/sec (2D Helmholtz HODBF apply)",
             "value": args.steps * args.nrhs / elapsed,
@@ -247,6 +266,9 @@ def main():
             "roofline": roofline,
             "hbm_gbs_whole_step": (total_leaf * 16 / 1e9) / (elapsed / args.steps),
         }
+        if args.pcie:
+            out["pcie_inclusive"] = {"ms_per_apply": pcie_ms, "matvec_per_s": args.nrhs / (pcie_ms / 1e3),
+                                     "note": "bfhipApply on pageable host buffers: H2D x + apply + D2H y"}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 y_host = y_full.cpu().numpy()

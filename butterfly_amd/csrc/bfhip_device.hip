@@ -66,6 +66,34 @@ struct StageParams {
   void const *zero;   // >= 1 KiB of zeros (X fragments of out-of-range columns)
 };
 
+// Leaf data is read exactly once per apply: stream it with the non-temporal
+// policy so it does not displace the (re-read) vectors from L2 / Infinity Cache.
+#ifndef BF_STREAM_NT
+#define BF_STREAM_NT 1
+#endif
+typedef double bf_d2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ double2 bfLoadStream(double2 const *p) {
+#if BF_STREAM_NT
+  bf_d2 v = __builtin_nontemporal_load((bf_d2 const *)p);
+  return make_double2(v.x, v.y);
+#else
+  return *p;
+#endif
+}
+
+typedef unsigned int bf_u4 __attribute__((ext_vector_type(4)));
+template <typename V> __device__ __forceinline__ V bfLoadStreamV(V const *p) {
+  static_assert(sizeof(V) == 16, "one 16-byte lane load");
+#if BF_STREAM_NT
+  bf_u4 raw = __builtin_nontemporal_load((bf_u4 const *)p);
+  V v;
+  __builtin_memcpy(&v, &raw, 16);
+  return v;
+#else
+  return *p;
+#endif
+}
+
 __device__ __forceinline__ void waveSync() {
   // LDS traffic of one wave is issued in order; this only stops the compiler
   // from moving LDS accesses across the hand-off between lanes.
@@ -120,7 +148,7 @@ __global__ __launch_bounds__(BF_WAVES_PER_WG * 64) void bfStageKernelC128(StageP
       uint32_t s = 0;
 #pragma unroll 4
       for (; s < nfull; ++s) {
-        double2 a = ap[(uint64_t)s * G];
+        double2 a = bfLoadStream(ap + (uint64_t)s * G);
         double2 xv = xs[j];
         accr = fma(a.x, xv.x, accr); accr = fma(-a.y, xv.y, accr);
         acci = fma(a.x, xv.y, acci); acci = fma(a.y, xv.x, acci);
@@ -128,7 +156,7 @@ __global__ __launch_bounds__(BF_WAVES_PER_WG * 64) void bfStageKernelC128(StageP
       }
       uint32_t const rem = n - nfull * g;
       if (active && c < rem) {
-        double2 a = ap[(uint64_t)nfull * G];
+        double2 a = bfLoadStream(ap + (uint64_t)nfull * G);
         double2 xv = xs[j];
         accr = fma(a.x, xv.x, accr); accr = fma(-a.y, xv.y, accr);
         acci = fma(a.x, xv.y, acci); acci = fma(a.y, xv.x, acci);
@@ -206,7 +234,7 @@ __device__ __forceinline__ void bfMfmaPass(StageParams const &p, BfDevItem const
       uint32_t const c0 = min(lk, nlast);
       double2 const *a0 = ap + (uint64_t)c0 * mr, *x0 = xin + (uint64_t)c0 * nrhs;
 #pragma unroll
-      for (int m = 0; m < MS; ++m) aCur[m] = a0[arow[m]];
+      for (int m = 0; m < MS; ++m) aCur[m] = bfLoadStream(a0 + arow[m]);
 #pragma unroll
       for (int t = 0; t < NT; ++t) bCur[t] = x0[qoff[t]];
     }
@@ -216,7 +244,7 @@ __device__ __forceinline__ void bfMfmaPass(StageParams const &p, BfDevItem const
       double2 const *a1 = ap + (uint64_t)cn * mr, *x1 = xin + (uint64_t)cn * nrhs;
       double2 aNxt[MS], bNxt[NT];
 #pragma unroll
-      for (int m = 0; m < MS; ++m) aNxt[m] = a1[arow[m]];
+      for (int m = 0; m < MS; ++m) aNxt[m] = bfLoadStream(a1 + arow[m]);
 #pragma unroll
       for (int t = 0; t < NT; ++t) bNxt[t] = x1[qoff[t]];
       // keep the requests above the MFMAs of this step ...
@@ -360,7 +388,7 @@ __global__ __launch_bounds__(BF_WAVES_PER_WG * 64) void bfStageKernelReal(StageP
       uint32_t s = 0;
 #pragma unroll 4
       for (; s < nfull; ++s) {
-        V a = ap[(uint64_t)s * G];
+        V a = bfLoadStreamV(ap + (uint64_t)s * G);
         S xv = xs[j];
 #pragma unroll
         for (int e = 0; e < EPL; ++e) acc[e] = fma(a.v[e], xv, acc[e]);
@@ -368,7 +396,7 @@ __global__ __launch_bounds__(BF_WAVES_PER_WG * 64) void bfStageKernelReal(StageP
       }
       uint32_t const rem = n - nfull * g;
       if (active && c < rem) {
-        V a = ap[(uint64_t)nfull * G];
+        V a = bfLoadStreamV(ap + (uint64_t)nfull * G);
         S xv = xs[j];
 #pragma unroll
         for (int e = 0; e < EPL; ++e) acc[e] = fma(a.v[e], xv, acc[e]);
