@@ -122,6 +122,12 @@ def load():
     lib.bfhipApply.restype = C.c_int
     lib.bfhipApplyDevice.argtypes = [vp, vp, C.c_size_t, vp, vp]
     lib.bfhipApplyDevice.restype = C.c_int
+    lib.bfhipSolveGMRES.argtypes = [vp, vp, C.c_size_t, C.c_size_t, vp, C.c_size_t, C.c_double, C.c_size_t,
+                                    C.POINTER(C.c_size_t), C.POINTER(C.c_double), vp, C.c_size_t]
+    lib.bfhipSolveGMRES.restype = C.c_int
+    lib.bfhipSolveGMRESDevice.argtypes = [vp, vp, C.c_size_t, vp, C.c_double, C.c_size_t, C.POINTER(C.c_size_t),
+                                          C.POINTER(C.c_double), vp, vp]
+    lib.bfhipSolveGMRESDevice.restype = C.c_int
     lib.bfhipGetStats.argtypes = [vp, C.POINTER(BfhipStats)]
     lib.bfhipGetStats.restype = C.c_int
     lib.bfhipGetNumRows.argtypes = [vp]

@@ -464,6 +464,131 @@ __global__ __launch_bounds__(256) void bfSynthKernel(void *arenaV, BfSynthPiece 
   }
 }
 
+
+// ---------------------------------------------------------------------------
+// device-resident GMRES building blocks (reference caller of the apply path:
+// bfSolveGMRES, src/linalg.c:47-317: residual :127-131, column norms :139,
+// modified Gram-Schmidt :174-184, normalisation :197-198, solution :245-285)
+// ---------------------------------------------------------------------------
+#define BF_GM_THREADS 256
+
+__device__ __forceinline__ double2 bfBlockReduce2(double2 v, double2 *sh) {
+  // fixed-order tree over the 256 threads of the block
+  sh[threadIdx.x] = v;
+  __syncthreads();
+  for (int s = BF_GM_THREADS / 2; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) { sh[threadIdx.x].x += sh[threadIdx.x + s].x; sh[threadIdx.x].y += sh[threadIdx.x + s].y; }
+    __syncthreads();
+  }
+  double2 r = sh[0];
+  __syncthreads();
+  return r;
+}
+
+__device__ __forceinline__ void bfRowRange(uint64_t n, uint32_t nb, uint64_t &r0, uint64_t &r1) {
+  uint64_t per = (n + nb - 1) / nb;
+  r0 = (uint64_t)blockIdx.x * per;
+  r1 = r0 + per < n ? r0 + per : n;
+  if (r0 > n) r0 = n;
+}
+
+// W = B - AX0 (AX0 may be null); partialOut[q*nb + bx] = sum |W|^2 over the block's rows
+__global__ __launch_bounds__(BF_GM_THREADS) void bfGmresResidualKernel(double2 const *B, double2 const *AX0, double2 *W,
+                                                                      double2 *partialOut, uint64_t n, uint32_t nrhs, uint32_t nb) {
+  __shared__ double2 sh[BF_GM_THREADS];
+  uint32_t const q = blockIdx.y;
+  uint64_t r0, r1;
+  bfRowRange(n, nb, r0, r1);
+  double acc = 0.0;
+  for (uint64_t r = r0 + threadIdx.x; r < r1; r += BF_GM_THREADS) {
+    double2 v = B[r * nrhs + q];
+    if (AX0) { double2 y = AX0[r * nrhs + q]; v.x -= y.x; v.y -= y.y; }
+    W[r * nrhs + q] = v;
+    acc += v.x * v.x + v.y * v.y;
+  }
+  double2 t = bfBlockReduce2(make_double2(acc, 0.0), sh);
+  if (threadIdx.x == 0) partialOut[(uint64_t)q * nb + blockIdx.x] = t;
+}
+
+__global__ __launch_bounds__(BF_GM_THREADS) void bfGmresDotKernel(double2 const *Vi, double2 const *W, double2 *partialOut,
+                                                                 uint64_t n, uint32_t nrhs, uint32_t nb) {
+  __shared__ double2 sh[BF_GM_THREADS];
+  uint32_t const q = blockIdx.y;
+  uint64_t r0, r1;
+  bfRowRange(n, nb, r0, r1);
+  double ar = 0.0, ai = 0.0;
+  for (uint64_t r = r0 + threadIdx.x; r < r1; r += BF_GM_THREADS) {
+    double2 v = Vi[r * nrhs + q], w = W[r * nrhs + q];
+    ar += v.x * w.x + v.y * w.y;      // conj(v) * w
+    ai += v.x * w.y - v.y * w.x;
+  }
+  double2 t = bfBlockReduce2(make_double2(ar, ai), sh);
+  if (threadIdx.x == 0) partialOut[(uint64_t)q * nb + blockIdx.x] = t;
+}
+
+__device__ __forceinline__ double2 bfSumPartials(double2 const *partial, uint32_t q, uint32_t nb, double2 *sh) {
+  double2 a = make_double2(0.0, 0.0);
+  for (uint32_t b = threadIdx.x; b < nb; b += BF_GM_THREADS) { double2 v = partial[(uint64_t)q * nb + b]; a.x += v.x; a.y += v.y; }
+  return bfBlockReduce2(a, sh);
+}
+
+__global__ __launch_bounds__(BF_GM_THREADS) void bfGmresMgsKernel(double2 const *Vi, double2 const *Vnext, double2 *W,
+                                                                 double2 const *partialIn, double2 *partialOut, double2 *hOut,
+                                                                 uint64_t n, uint32_t nrhs, uint32_t nb) {
+  __shared__ double2 sh[BF_GM_THREADS];
+  uint32_t const q = blockIdx.y;
+  double2 const h = bfSumPartials(partialIn, q, nb, sh);
+  if (blockIdx.x == 0 && threadIdx.x == 0) hOut[q] = h;
+  uint64_t r0, r1;
+  bfRowRange(n, nb, r0, r1);
+  double ar = 0.0, ai = 0.0;
+  for (uint64_t r = r0 + threadIdx.x; r < r1; r += BF_GM_THREADS) {
+    double2 v = Vi[r * nrhs + q], w = W[r * nrhs + q];
+    w.x -= h.x * v.x - h.y * v.y;
+    w.y -= h.x * v.y + h.y * v.x;
+    W[r * nrhs + q] = w;
+    if (Vnext) {
+      double2 u = Vnext[r * nrhs + q];
+      ar += u.x * w.x + u.y * w.y;
+      ai += u.x * w.y - u.y * w.x;
+    } else {
+      ar += w.x * w.x + w.y * w.y;
+    }
+  }
+  double2 t = bfBlockReduce2(make_double2(ar, ai), sh);
+  if (threadIdx.x == 0) partialOut[(uint64_t)q * nb + blockIdx.x] = t;
+}
+
+__global__ __launch_bounds__(BF_GM_THREADS) void bfGmresFinishKernel(double2 const *W, double2 const *partialIn, double2 *Vout,
+                                                                    double2 *hOut, uint64_t n, uint32_t nrhs, uint32_t nb) {
+  __shared__ double2 sh[BF_GM_THREADS];
+  uint32_t const q = blockIdx.y;
+  double2 const s = bfSumPartials(partialIn, q, nb, sh);
+  double const nrm = sqrt(s.x);
+  if (blockIdx.x == 0 && threadIdx.x == 0) hOut[q] = make_double2(nrm, 0.0);
+  uint64_t r0, r1;
+  bfRowRange(n, nb, r0, r1);
+  for (uint64_t r = r0 + threadIdx.x; r < r1; r += BF_GM_THREADS) {
+    double2 w = W[r * nrhs + q];
+    Vout[r * nrhs + q] = make_double2(w.x / nrm, w.y / nrm);
+  }
+}
+
+__global__ __launch_bounds__(BF_GM_THREADS) void bfGmresUpdateKernel(double2 const *X0, double2 const *V, double2 const *y, uint32_t j,
+                                                                    double2 *X, uint64_t n, uint32_t nrhs) {
+  uint64_t e = (uint64_t)blockIdx.x * BF_GM_THREADS + threadIdx.x;
+  uint64_t total = n * nrhs;
+  if (e >= total) return;
+  uint32_t q = (uint32_t)(e % nrhs);
+  double2 x = X0 ? X0[e] : make_double2(0.0, 0.0);
+  for (uint32_t i = 0; i < j; ++i) {
+    double2 v = V[(uint64_t)i * total + e], c = y[(uint64_t)i * nrhs + q];
+    x.x += v.x * c.x - v.y * c.y;
+    x.y += v.x * c.y + v.y * c.x;
+  }
+  X[e] = x;
+}
+
 // ---------------------------------------------------------------------------
 // host-callable wrappers
 // ---------------------------------------------------------------------------
@@ -544,6 +669,32 @@ int bfdevLaunchReduce(BfReduceArgs const *a, void *stream) {
   else hipLaunchKernelGGL((bfReduceKernel<float, 1>), dim3(grid), dim3(256), 0, s, ri, ib, sb, a->numRows, (float const *)a->temp, (float *)a->dest, a->nrhs);
   return hipFail(hipGetLastError(), "reduce launch");
 }
+
+int bfdevGmresResidual(void const *B, void const *AX0, void *W, void *partialOut, uint64_t n, uint32_t nrhs, uint32_t nb, void *stream) {
+  hipLaunchKernelGGL(bfGmresResidualKernel, dim3(nb, nrhs), dim3(BF_GM_THREADS), 0, (hipStream_t)stream, (double2 const *)B, (double2 const *)AX0, (double2 *)W, (double2 *)partialOut, n, nrhs, nb);
+  return hipFail(hipGetLastError(), "gmres residual launch");
+}
+int bfdevGmresDot(void const *Vi, void const *W, void *partialOut, uint64_t n, uint32_t nrhs, uint32_t nb, void *stream) {
+  hipLaunchKernelGGL(bfGmresDotKernel, dim3(nb, nrhs), dim3(BF_GM_THREADS), 0, (hipStream_t)stream, (double2 const *)Vi, (double2 const *)W, (double2 *)partialOut, n, nrhs, nb);
+  return hipFail(hipGetLastError(), "gmres dot launch");
+}
+int bfdevGmresMgsStep(void const *Vi, void const *Vnext, void *W, void const *partialIn, void *partialOut, void *hOut,
+                      uint64_t n, uint32_t nrhs, uint32_t nb, void *stream) {
+  hipLaunchKernelGGL(bfGmresMgsKernel, dim3(nb, nrhs), dim3(BF_GM_THREADS), 0, (hipStream_t)stream, (double2 const *)Vi, (double2 const *)Vnext, (double2 *)W, (double2 const *)partialIn, (double2 *)partialOut, (double2 *)hOut, n, nrhs, nb);
+  return hipFail(hipGetLastError(), "gmres mgs launch");
+}
+int bfdevGmresFinish(void const *W, void const *partialIn, void *Vout, void *hOut, uint64_t n, uint32_t nrhs, uint32_t nb, void *stream) {
+  hipLaunchKernelGGL(bfGmresFinishKernel, dim3(nb, nrhs), dim3(BF_GM_THREADS), 0, (hipStream_t)stream, (double2 const *)W, (double2 const *)partialIn, (double2 *)Vout, (double2 *)hOut, n, nrhs, nb);
+  return hipFail(hipGetLastError(), "gmres finish launch");
+}
+int bfdevGmresUpdate(void const *X0, void const *V, void const *y, uint32_t j, void *X, uint64_t n, uint32_t nrhs, void *stream) {
+  uint64_t total = n * nrhs;
+  hipLaunchKernelGGL(bfGmresUpdateKernel, dim3((uint32_t)((total + BF_GM_THREADS - 1) / BF_GM_THREADS)), dim3(BF_GM_THREADS), 0, (hipStream_t)stream, (double2 const *)X0, (double2 const *)V, (double2 const *)y, j, (double2 *)X, n, nrhs);
+  return hipFail(hipGetLastError(), "gmres update launch");
+}
+int bfdevMemcpyD2HAsync(void *dst, void const *src, size_t bytes, void *stream) { return bytes ? hipFail(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream), "hipMemcpyAsync D2H") : 0; }
+int bfdevMemcpyH2DAsync(void *dst, void const *src, size_t bytes, void *stream) { return bytes ? hipFail(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, (hipStream_t)stream), "hipMemcpyAsync H2D") : 0; }
+int bfdevMemcpyD2DAsync(void *dst, void const *src, size_t bytes, void *stream) { return bytes ? hipFail(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream), "hipMemcpyAsync D2D") : 0; }
 
 int bfdevEventCreate(void **ev) { return hipFail(hipEventCreate((hipEvent_t *)ev), "hipEventCreate"); }
 void bfdevEventDestroy(void *ev) { if (ev) (void)hipEventDestroy((hipEvent_t)ev); }

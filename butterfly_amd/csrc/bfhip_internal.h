@@ -181,6 +181,23 @@ typedef struct BfReduceArgs {
 } BfReduceArgs;
 int bfdevLaunchReduce(BfReduceArgs const *a, void *stream);
 
+/* device-resident GMRES building blocks (complex128; bfhip_gmres.c drives them).
+ * Vectors are n x nrhs row-major; reductions are per RHS column, two-stage and
+ * in fixed order (per-block partials, then a tree over the partials), so a
+ * solve is bit-reproducible.  `nb` = number of row blocks = partials per RHS. */
+int bfdevGmresResidual(void const *B, void const *AX0, void *W, void *partialOut, uint64_t n, uint32_t nrhs, uint32_t nb, void *stream);
+int bfdevGmresDot(void const *Vi, void const *W, void *partialOut, uint64_t n, uint32_t nrhs, uint32_t nb, void *stream);
+/* h = sum(partialIn); hOut[q] = h; W -= h * Vi; then partialOut = conj(Vnext).W (Vnext != NULL) or |W|^2 */
+int bfdevGmresMgsStep(void const *Vi, void const *Vnext, void *W, void const *partialIn, void *partialOut, void *hOut,
+                      uint64_t n, uint32_t nrhs, uint32_t nb, void *stream);
+/* nrm = sqrt(sum(partialIn)); hOut[q] = nrm; Vout = W / nrm */
+int bfdevGmresFinish(void const *W, void const *partialIn, void *Vout, void *hOut, uint64_t n, uint32_t nrhs, uint32_t nb, void *stream);
+/* X = X0 + sum_{i<j} V_i * y[i] ; V = (j) vectors of n*nrhs, y = [j][nrhs] */
+int bfdevGmresUpdate(void const *X0, void const *V, void const *y, uint32_t j, void *X, uint64_t n, uint32_t nrhs, void *stream);
+int bfdevMemcpyD2HAsync(void *dst, void const *src, size_t bytes, void *stream);
+int bfdevMemcpyH2DAsync(void *dst, void const *src, size_t bytes, void *stream);
+int bfdevMemcpyD2DAsync(void *dst, void const *src, size_t bytes, void *stream);
+
 /* events for BFHIP_FLAG_PROFILE */
 int bfdevEventCreate(void **ev);
 void bfdevEventDestroy(void *ev);

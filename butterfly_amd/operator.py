@@ -130,6 +130,40 @@ class HipOperator:
                                          C.c_void_p(s.cuda_stream)))
         return y
 
+    # ---- GMRES ---------------------------------------------------------------
+    def solve_gmres(self, b: np.ndarray, x0=None, tol=1e-12, max_num_iter=100):
+        """bfhipSolveGMRES on host arrays; returns (x, num_iter, residual), as the
+        reference's bfSolveGMRES(A, B, X0, tol, maxNumIter, &numIter, NULL)."""
+        n = self.shape[0]
+        b2 = np.ascontiguousarray(b, dtype=np.complex128)
+        one_d = b2.ndim == 1
+        if one_d:
+            b2 = b2[:, None]
+        nrhs = b2.shape[1]
+        x = np.empty((n, nrhs), dtype=np.complex128)
+        x0p = None
+        if x0 is not None:
+            x02 = np.ascontiguousarray(x0, dtype=np.complex128).reshape(n, nrhs)
+            x0p = x02.ctypes.data
+        it = C.c_size_t(0)
+        res = C.c_double(0)
+        check(self._lib.bfhipSolveGMRES(self._h, b2.ctypes.data, nrhs, nrhs, x0p, nrhs, tol, max_num_iter,
+                                        C.byref(it), C.byref(res), x.ctypes.data, nrhs))
+        return (x[:, 0] if one_d else x), int(it.value), float(res.value)
+
+    def solve_gmres_device(self, b, x0=None, tol=1e-12, max_num_iter=100):
+        """Device-resident form on torch tensors; returns (x, num_iter, residual)."""
+        import torch
+        nrhs = 1 if b.dim() == 1 else b.shape[1]
+        x = torch.empty_like(b)
+        it = C.c_size_t(0)
+        res = C.c_double(0)
+        s = torch.cuda.current_stream(b.device)
+        check(self._lib.bfhipSolveGMRESDevice(self._h, C.c_void_p(b.data_ptr()), nrhs,
+                                              C.c_void_p(x0.data_ptr()) if x0 is not None else None, tol, max_num_iter,
+                                              C.byref(it), C.byref(res), C.c_void_p(x.data_ptr()), C.c_void_p(s.cuda_stream)))
+        return x, int(it.value), float(res.value)
+
     def stage_profile(self, reset=False):
         """(ms, launches, bytes) per stage, from hipEvents (needs FLAG_PROFILE)."""
         S = self.stats()["numStages"]

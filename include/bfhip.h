@@ -139,6 +139,26 @@ int bfhipApply(BfhipOperator *op, const void *X, size_t ldx, size_t nrhs, void *
  * `stream` (hipStream_t, NULL = default stream) and asynchronous. */
 int bfhipApplyDevice(BfhipOperator *op, const void *dX, size_t nrhs, void *dY, void *stream);
 
+/* ---- GMRES (the production caller of the apply path) --------------------- */
+
+/* Solve A X = B with the operator as A, mirroring the reference's
+ * bfSolveGMRES(A, B, X0, tol, maxNumIter, &numIter, M = NULL)
+ * (src/linalg.c:47-317): unrestarted GMRES, modified Gram-Schmidt, Givens
+ * rotations, convergence when max_p |s_{j+1,p}| / max_p ||r_p|| < tol.  The
+ * Krylov basis, the work vector, x0 and b stay on the device; only the new
+ * Hessenberg column crosses PCIe per iteration.  X0 may be NULL (zeros).
+ * `numIter` receives the reference's iteration count (the number of basis
+ * vectors the solution is built from), `residual` the last relative residual;
+ * either may be NULL.  Complex square operators only; a left preconditioner
+ * (the reference's M) is NOT_IMPLEMENTED.  Host-pointer form: B, X0, X are
+ * row-major n x nrhs with leading dimensions in elements. */
+int bfhipSolveGMRES(BfhipOperator *op, const void *B, size_t ldb, size_t nrhs, const void *X0, size_t ldx0,
+                    double tol, size_t maxNumIter, size_t *numIter, double *residual, void *X, size_t ldx);
+/* Device-resident form (densely packed n x nrhs buffers on the operator's
+ * GPU, which must be the current device); synchronous on return. */
+int bfhipSolveGMRESDevice(BfhipOperator *op, const void *dB, size_t nrhs, const void *dX0, double tol,
+                          size_t maxNumIter, size_t *numIter, double *residual, void *dX, void *stream);
+
 /* ---- introspection ------------------------------------------------------- */
 int bfhipGetStats(const BfhipOperator *op, BfhipStats *stats);
 size_t bfhipGetNumRows(const BfhipOperator *op);

@@ -1,0 +1,85 @@
+"""GMRES: the production caller of the apply path (reference src/linalg.c:47-317).
+CPU: the numpy restatement (oracle/linalg_ref.py) driven by the oracle's
+bfMatMul solves a second-kind system to the dense answer.  GPU: the
+device-resident solver follows the restatement iteration for iteration."""
+import numpy as np
+import pytest
+
+from oracle import bfref, linalg_ref
+import bie
+
+
+def rel(a, b):
+    return float(np.linalg.norm(np.ravel(a) - np.ravel(b)) / np.linalg.norm(np.ravel(b)))
+
+
+@pytest.fixture(scope="module")
+def system():
+    n, k = 2048, 128
+    desc, root, vals, dense = bie.second_kind_case(n, k)
+    A = bfref.from_desc(desc, vals, root=root)
+    rng = np.random.default_rng(12)
+    b = rng.standard_normal((n, 2)) + 1j * rng.standard_normal((n, 2))
+    return desc, root, vals, dense, A, b
+
+
+def test_oracle_gmres_solves_second_kind_system(system):
+    desc, root, vals, dense, A, b = system
+    assert rel(bfref.mat_mul(A, b), dense @ b) < 1e-10          # I + alpha S through Identity leaves
+    x, it, hist = linalg_ref.solve_gmres(lambda v: bfref.mat_mul(A, v), b[:, 0], tol=1e-10, max_num_iter=80)
+    assert it < 80 and hist[-1] < 1e-10
+    assert rel(x, np.linalg.solve(dense, b[:, 0])) < 1e-8
+    # two right-hand sides at once, and the not-converged path (all maxNumIter vectors are used)
+    x2, it2, hist2 = linalg_ref.solve_gmres(lambda v: bfref.mat_mul(A, v), b, tol=1e-10, max_num_iter=80)
+    assert rel(x2, np.linalg.solve(dense, b)) < 1e-8
+    x3, it3, hist3 = linalg_ref.solve_gmres(lambda v: bfref.mat_mul(A, v), b[:, 0], tol=1e-30, max_num_iter=5)
+    assert it3 == 5 and len(hist3) == 5
+
+
+def test_plan_of_decorated_operator_matches_oracle(system):
+    from butterfly_amd import _capi
+    from butterfly_amd.operator import HipOperator
+    import plan_emulator
+    desc, root, vals, dense, A, b = system
+    op = HipOperator.from_desc(desc, vals, root=root, flags=_capi.FLAG_PLAN_ONLY)
+    assert rel(plan_emulator.run_plan(op, b), bfref.mat_mul(A, b)) < 1e-13
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nrhs", [1, 2])
+def test_device_gmres_follows_the_restatement(system, nrhs):
+    from butterfly_amd.operator import HipOperator
+    desc, root, vals, dense, A, b = system
+    bb = b[:, 0] if nrhs == 1 else b
+    op = HipOperator.from_desc(desc, vals, root=root, max_rhs=nrhs)
+    x_ref, it_ref, hist = linalg_ref.solve_gmres(lambda v: bfref.mat_mul(A, v), bb, tol=1e-10, max_num_iter=80)
+    x, it, res = op.solve_gmres(bb, tol=1e-10, max_num_iter=80)
+    assert it == it_ref
+    assert abs(res - hist[-1]) <= 1e-6 * hist[-1] + 1e-16
+    assert rel(x, x_ref) < 1e-9
+    assert rel(x, np.linalg.solve(dense, bb)) < 1e-8
+    # warm start and an iteration cap: the not-converged path uses all maxNumIter vectors
+    x0 = 0.5 * x_ref
+    xr, itr, _ = linalg_ref.solve_gmres(lambda v: bfref.mat_mul(A, v), bb, X0=x0, tol=1e-30, max_num_iter=6)
+    xg, itg, _ = op.solve_gmres(bb, x0=x0, tol=1e-30, max_num_iter=6)
+    assert itg == itr == 6
+    assert rel(xg, xr) < 1e-9
+    op.close()
+
+
+@pytest.mark.gpu
+def test_device_gmres_on_resident_tensors(system):
+    import torch
+    from butterfly_amd.operator import HipOperator
+    desc, root, vals, dense, A, b = system
+    op = HipOperator.from_desc(desc, vals, root=root)
+    bd = torch.from_numpy(np.ascontiguousarray(b[:, 0])).cuda()
+    x, it, res = op.solve_gmres_device(bd, tol=1e-10, max_num_iter=80)
+    assert res < 1e-10
+    assert rel(x.cpu().numpy(), np.linalg.solve(dense, b[:, 0])) < 1e-8
+    # errors mirror the reference's argument checks (linalg.c:81-92)
+    from butterfly_amd import _capi
+    with pytest.raises(_capi.BfhipError) as e:
+        op.solve_gmres(b[:, 0], max_num_iter=0)
+    assert e.value.code == 1
+    op.close()
