@@ -106,6 +106,9 @@ def main():
     ap.add_argument("--seed", type=int, default=1234)
     ap.add_argument("--cpu-budget-gb", type=float, default=4.0, help="leaf bytes of the cpu_baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dtype", choices=["c128", "f64", "f32"], default="c128",
+                    help="c128: the fac_helm2 operand (headline).  f64 / f32: the SAME block layout with real values, a proxy "
+                         "for the real BfMatDenseReal path (BASELINE.json configs[4]); fp32 is the build's extension")
     ap.add_argument("--pcie", action="store_true", help="also time the host-buffer path (H2D + apply + D2H)")
     ap.add_argument("--force-collective", action="store_true",
                     help="rehearsal: initialise RCCL and run the step's collective even with one rank")
@@ -140,6 +143,11 @@ def main():
     t0 = time.time()
     desc, qroot, perm = hs.helm2_multilevel_structure(hs.circle_points(n), k)
     t_struct = time.time() - t0
+    real = args.dtype != "c128"
+    if real:
+        desc.dtype = 1          # BFHIP_F64 leaves; --dtype f32 demotes them on upload
+    esz = {"c128": 16, "f64": 8, "f32": 4}[args.dtype]
+    tdtype = {"c128": torch.complex128, "f64": torch.float64, "f32": torch.float32}[args.dtype]
     weights = row_block_weights(desc)
     total_leaf = int(sum(weights))
     top_rows = desc.meta["top_rows"]
@@ -166,7 +174,7 @@ def main():
     else:
         root, local_rows = hs.shard_desc_blocks(desc, mine), n
     op = HipOperator.from_desc(desc, None, root=root, device=local_rank, flags=_capi.FLAG_PROFILE,
-                               seed=args.seed, max_rhs=args.nrhs)
+                               seed=args.seed, max_rhs=args.nrhs, demote_to_f32=(args.dtype == "f32"))
     torch.cuda.synchronize()
     t_compile = time.time() - t0
     st = op.stats()
@@ -177,11 +185,14 @@ def main():
     # x: seeded complex normal, identical on every rank (replicated input)
     rng = np.random.default_rng(args.seed)
     shape = (n,) if args.nrhs == 1 else (n, args.nrhs)
-    x_host = (rng.standard_normal(shape) + 1j * rng.standard_normal(shape)) / np.sqrt(2)
-    x = torch.from_numpy(x_host).to(dev)
+    if real:
+        x_host = rng.standard_normal(shape)
+    else:
+        x_host = (rng.standard_normal(shape) + 1j * rng.standard_normal(shape)) / np.sqrt(2)
+    x = torch.from_numpy(x_host).to(dev).to(tdtype)
     layout = ShardLayout(top_rows, owner, world)
     assert mode == "blocks" or layout.rows_of[rank] == local_rows
-    step = ShardedApply(layout, rank, lambda xin, out: op.apply_device(xin, out), dev, torch.complex128, nrhs=args.nrhs,
+    step = ShardedApply(layout, rank, lambda xin, out: op.apply_device(xin, out), dev, tdtype, nrhs=args.nrhs,
                         mode=mode, force_collective=args.force_collective)
 
     for _ in range(args.warmup):
@@ -213,7 +224,7 @@ def main():
         for s in range(len(ms)):
             log(f"  stage {s}: {ms[s] / max(launches[s], 1):8.3f} ms/launch  {sbytes[s] / 1e9:8.3f} GB  "
                 f"{(sbytes[s] / 1e9) / (ms[s] / max(launches[s], 1) / 1e3) if ms[s] > 0 else 0:8.1f} GB/s")
-        if args.nrhs >= 3:
+        if args.nrhs >= 3 and not real:
             # block of right-hand sides: 8*nrhs flops per leaf element (32 flop/B at nrhs=64) -> FP64-MFMA bound
             flops_per_apply = 8.0 * args.nrhs * st["leafElems"]
             tf = flops_per_apply * (n_launch / len(ms)) / 1e12 / (kern_ms / 1e3) if kern_ms > 0 else 0.0
@@ -225,18 +236,19 @@ def main():
         else:
             roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                        "kernel": "bfStageKernelC128", "launches_per_apply": len(ms),
+                        "kernel": "bfStageKernelC128" if not real else f"bfStageKernelReal<{args.dtype}>", "launches_per_apply": len(ms),
                         "avg_launch_ms": avg_launch_ms, "algorithmic_bytes_per_apply": bytes_per_apply,
                         "kernel_ms_per_apply": kern_ms / max(launches.max(), 1)}
         # HBM traffic per launch from the committed PMC profile of this very command (rocprofv3 --pmc
         # FETCH_SIZE / WRITE_SIZE in separate passes, gfx950 x2 FETCH correction); PMC counters cannot be
         # read from inside the process, so other configurations report null.
-        prof = os.path.join(ROOT, "profiles", "r1_bench_n262144_pmc_hbm.json")
-        if world == 1 and n == 262144 and abs(k - 16384) < 1e-9 and args.nrhs == 1 and os.path.exists(prof):
+        prof = os.path.join(ROOT, "profiles", "r1_pmc_summary.json")
+        if world == 1 and n == 262144 and abs(k - 16384) < 1e-9 and args.nrhs in (1, 64) and not real and os.path.exists(prof):
             try:
-                pm = json.load(open(prof))["bfStageKernelC128_per_launch"]
+                key = "bfStageKernelC128_per_launch" if args.nrhs == 1 else "bfStageKernelC128Mfma_per_launch"
+                pm = json.load(open(prof))[key]
                 roofline["traffic"] = pm["hbm_bytes"]
-                roofline["traffic_source"] = "profiles/r1_bench_n262144_pmc_hbm.json (bytes per launch; algorithmic %.4g)" % pm["algorithmic_bytes"]
+                roofline["traffic_source"] = f"profiles/r1_pmc_summary.json [{key}]: HBM bytes per launch of this command under rocprofv3 --pmc"
             except Exception:
                 pass
         if args.pcie:
@@ -257,19 +269,20 @@ def main():
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
-            "dtype": "c128",
+            "dtype": args.dtype,
             "data": "synthetic (structure-exact fac_helm2 layout, seeded values generated in HBM)",
-            "config": {"workload": f"fac_helm2 multilevel butterfly, unit circle, N={n}, k={k:g} (16 ppw), nrhs={args.nrhs}",
-                       "n": n, "k": k, "nrhs": args.nrhs, "leaf_bytes": total_leaf * 16,
+            "config": {"workload": f"fac_helm2 multilevel butterfly, unit circle, N={n}, k={k:g} (16 ppw), nrhs={args.nrhs}"
+                                   + ("" if not real else f" [real-valued {args.dtype} proxy on the same block layout]"),
+                       "n": n, "k": k, "nrhs": args.nrhs, "leaf_bytes": total_leaf * esz,
                        "stages": st["numStages"], "sharding": ("none" if world == 1 else "top-level row blocks (LPT by leaf bytes) + one all-gather" if mode == "rows"
                                     else "top-level (row, col) blocks (LPT by leaf bytes) + one all-reduce")},
             "roofline": roofline,
-            "hbm_gbs_whole_step": (total_leaf * 16 / 1e9) / (elapsed / args.steps),
+            "hbm_gbs_whole_step": (total_leaf * esz / 1e9) / (elapsed / args.steps),
         }
         if args.pcie:
             out["pcie_inclusive"] = {"ms_per_apply": pcie_ms, "matvec_per_s": args.nrhs / (pcie_ms / 1e3),
                                      "note": "bfhipApply on pageable host buffers: H2D x + apply + D2H y"}
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not real:
             try:
                 y_host = y_full.cpu().numpy()
                 out["cpu_baseline"] = cpu_baseline(desc, args.seed, total_leaf, weights, args.cpu_budget_gb * 1e9,

@@ -1,0 +1,27 @@
+#!/bin/bash
+# Collects the rocprofv3 evidence committed under profiles/ (run on the GPU box via gpurun).
+#   usage: tools/profile_round.sh <round-tag>      e.g. r1
+# Each PMC set is its own pass with --kernel-trace only (no --stats / sys-trace with --pmc).
+set -u
+TAG=${1:-r1}
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$R/gpurun_out/prof_$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+run() { # name, rocprof args..., -- bench args
+  local name=$1; shift
+  local rp=(); while [ "$1" != "--" ]; do rp+=("$1"); shift; done; shift
+  rocprofv3 "${rp[@]}" --output-format csv -d $OUT/$name -- python3 $R/bench.py "$@" --no-cpu-baseline > $OUT/$name.json 2> $OUT/$name.log
+  echo "$name exit=$?"
+}
+# headline: N=262144, nrhs=1
+run stats_r1   --kernel-trace --stats -- --steps 10 --warmup 2
+run fetch_r1   --kernel-trace --pmc FETCH_SIZE -- --steps 3 --warmup 1
+run write_r1   --kernel-trace --pmc WRITE_SIZE -- --steps 3 --warmup 1
+run lds_r1     --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES GRBM_GUI_ACTIVE -- --steps 3 --warmup 1
+# 64 right-hand sides (MFMA kernel)
+run stats_r64  --kernel-trace --stats -- --nrhs 64 --steps 3 --warmup 1
+run mfma_r64   --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -- --nrhs 64 --steps 2 --warmup 1
+run fetch_r64  --kernel-trace --pmc FETCH_SIZE -- --nrhs 64 --steps 2 --warmup 1
+run write_r64  --kernel-trace --pmc WRITE_SIZE -- --nrhs 64 --steps 2 --warmup 1
+ls $OUT

@@ -1,0 +1,66 @@
+#!/usr/bin/env python3
+"""Condense gpurun_out/prof_<tag>/ (tools/profile_round.sh) into the small files committed under profiles/."""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r1"
+src = f"gpurun_out/prof_{tag}"
+os.makedirs("profiles", exist_ok=True)
+
+
+def counters(name):
+    files = glob.glob(f"{src}/{name}/*/*_counter_collection.csv")
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    if not files:
+        return {}
+    for r in csv.DictReader(open(files[0])):
+        kn = r["Kernel_Name"].split("(")[0]
+        agg[kn][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return {k: {c: {"dispatches": len(v), "sum": sum(v), "mean": sum(v) / len(v)} for c, v in d.items()} for k, d in agg.items()}
+
+
+out = {"tag": tag, "note": "FETCH_SIZE/WRITE_SIZE in KiB; on gfx950 FETCH_SIZE counts half the bytes of a 16-B/lane streaming read "
+       "(MI355X_MICROARCH.md, HBM): fetch bytes = FETCH_SIZE*1024*2; WRITE_SIZE exact.  SQ_* are summed over SEs/XCDs as rocprofv3 reports them."}
+for name in ("stats_r1", "stats_r64"):
+    for f in glob.glob(f"{src}/{name}/*/*_kernel_stats.csv"):
+        shutil.copy(f, f"profiles/{tag}_{name}_kernel_stats.csv")
+    if os.path.exists(f"{src}/{name}.json"):
+        shutil.copy(f"{src}/{name}.json", f"profiles/{tag}_{name}_bench_under_rocprof.json")
+for name in ("fetch_r1", "write_r1", "lds_r1", "mfma_r64", "fetch_r64", "write_r64"):
+    out[name] = counters(name)
+
+
+def per_launch(fetch, write, kern):
+    try:
+        f = out[fetch][kern]["FETCH_SIZE"]["mean"] * 1024 * 2
+        w = out[write][kern]["WRITE_SIZE"]["mean"] * 1024
+        return {"fetch_bytes_corrected": f, "write_bytes": w, "hbm_bytes": f + w}
+    except KeyError:
+        return None
+
+
+out["bfStageKernelC128_per_launch"] = per_launch("fetch_r1", "write_r1", "bfStageKernelC128")
+out["bfStageKernelC128Mfma_per_launch"] = per_launch("fetch_r64", "write_r64", "bfStageKernelC128Mfma")
+for nm, key in (("stats_r1", "bfStageKernelC128_per_launch"), ("stats_r64", "bfStageKernelC128Mfma_per_launch")):
+    p = f"{src}/{nm}.json"
+    if os.path.exists(p) and out.get(key):
+        b = json.load(open(p))
+        rl = b["roofline"]
+        if "algorithmic_bytes_per_apply" in rl:
+            out[key]["algorithmic_bytes"] = rl["algorithmic_bytes_per_apply"] / rl["launches_per_apply"]
+            out[key]["ratio"] = out[key]["hbm_bytes"] / out[key]["algorithmic_bytes"]
+try:
+    m = out["mfma_r64"]["bfStageKernelC128Mfma"]
+    busy, gui = m["SQ_VALU_MFMA_BUSY_CYCLES"]["sum"], m["GRBM_GUI_ACTIVE"]["sum"]
+    out["mfma_util_percent"] = {"formula": "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE(max over XCDs ~ sum/8) * 1024 SIMDs) * 100",
+                                "value": busy / (gui / 8 * 1024) * 100,
+                                "mfma_f64_ops_x512_flops": m["SQ_INSTS_VALU_MFMA_MOPS_F64"]["sum"] * 512}
+except KeyError:
+    pass
+json.dump(out, open(f"profiles/{tag}_pmc_summary.json", "w"), indent=1)
+print(json.dumps({k: out[k] for k in out if k.endswith("per_launch") or k.startswith("mfma_util")}, indent=1))
