@@ -13,6 +13,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libbfhip.so")
 BFHIP_C128, BFHIP_F64, BFHIP_F32 = 0, 1, 2
 FLAG_PROFILE = 1
 FLAG_PLAN_ONLY = 2
+FLAG_ADJOINT = 4
 
 ERROR_NAMES = {0: "BF_ERROR_NONE", 1: "BF_ERROR_INVALID_ARGUMENTS", 2: "BF_ERROR_RUNTIME_ERROR",
                3: "BF_ERROR_NOT_IMPLEMENTED", 4: "BF_ERROR_MEMORY_ERROR", 5: "BF_ERROR_OUT_OF_RANGE",
@@ -45,7 +46,7 @@ class BfhipStats(C.Structure):
 
 class BfhipPlanInfo(C.Structure):
     _fields_ = [(n, C.c_uint32) for n in ("structSize", "dtype", "elemSize", "epl", "xcap", "reserved")] + [
-        (n, C.c_uint64) for n in ("numRows", "numCols", "numStages", "arenaElems", "tempElems")]
+        (n, C.c_uint64) for n in ("numRows", "numCols", "numStages", "arenaElems", "tempElems", "numStagesT", "tempElemsT")]
 
 
 class BfhipStageView(C.Structure):
@@ -60,7 +61,7 @@ class BfhipReduceView(C.Structure):
 
 
 ITEM_DTYPE = np.dtype([("pieceBegin", "<u4"), ("numPieces", "<u4"), ("outOff", "<u4"), ("mrFlags", "<u4")])
-PIECE_DTYPE = np.dtype([("dataOff", "<u8"), ("inOff", "<u4"), ("ncols", "<u4"), ("flags", "<u4"), ("pad", "<u4")])
+PIECE_DTYPE = np.dtype([("dataOff", "<u8"), ("inOff", "<u4"), ("ncols", "<u4"), ("flags", "<u4"), ("ld", "<u4")])
 
 
 class DescArrays:
@@ -122,6 +123,10 @@ def load():
     lib.bfhipApply.restype = C.c_int
     lib.bfhipApplyDevice.argtypes = [vp, vp, C.c_size_t, vp, vp]
     lib.bfhipApplyDevice.restype = C.c_int
+    lib.bfhipApplyTranspose.argtypes = [vp, vp, C.c_size_t, C.c_size_t, vp, C.c_size_t]
+    lib.bfhipApplyTranspose.restype = C.c_int
+    lib.bfhipApplyTransposeDevice.argtypes = [vp, vp, C.c_size_t, vp, vp]
+    lib.bfhipApplyTransposeDevice.restype = C.c_int
     lib.bfhipSolveGMRES.argtypes = [vp, vp, C.c_size_t, C.c_size_t, vp, C.c_size_t, C.c_double, C.c_size_t,
                                     C.POINTER(C.c_size_t), C.POINTER(C.c_double), vp, C.c_size_t]
     lib.bfhipSolveGMRES.restype = C.c_int

@@ -48,6 +48,8 @@ int bfhipSyntheticLeafBases(BfhipDesc const *desc, uint64_t *bases) {
 /* ---- operator --------------------------------------------------------------- */
 struct BfhipOperator {
   BfPlan plan;
+  BfPlan tplan;               /* plan of A^T over the same leaf arena (BFHIP_FLAG_ADJOINT) */
+  int hasTplan;
   uint32_t srcDtype;          /* dtype of the operand as given (C128 / F64) */
   int device;
   uint32_t flags;
@@ -71,9 +73,9 @@ struct BfhipOperator {
   uint64_t seed;
 };
 
-static void freeDevicePlan(BfhipOperator *op) {
-  for (uint64_t s = 0; s < op->plan.numStages && op->plan.stages; ++s) {
-    BfStage *st = &op->plan.stages[s];
+static void freeDevicePlanOf(BfPlan *plan) {
+  for (uint64_t s = 0; s < plan->numStages && plan->stages; ++s) {
+    BfStage *st = &plan->stages[s];
     bfdevFree(st->dItems); st->dItems = NULL;
     bfdevFree(st->dPieces); st->dPieces = NULL;
     for (uint64_t r = 0; r < st->numReduce; ++r) {
@@ -81,6 +83,10 @@ static void freeDevicePlan(BfhipOperator *op) {
       st->reduce[r].dRowInterval = st->reduce[r].dIvBegin = st->reduce[r].dSrcBias = NULL;
     }
   }
+}
+static void freeDevicePlan(BfhipOperator *op) {
+  freeDevicePlanOf(&op->plan);
+  freeDevicePlanOf(&op->tplan);
 }
 
 void bfhipFree(BfhipOperator **pop) {
@@ -100,6 +106,7 @@ void bfhipFree(BfhipOperator **pop) {
   bfdevFree(op->dX);
   bfdevFree(op->dY);
   bfPlanFree(&op->plan);
+  bfPlanFree(&op->tplan);
   if (op->ir) { bfIrFree(op->ir); free(op->ir); }
   int const touchedDevice = !(op->flags & BFHIP_FLAG_PLAN_ONLY);
   free(op);
@@ -219,12 +226,43 @@ static int packLeaves(BfhipOperator const *op, BfIr const *ir, uint64_t seed, vo
   return rc;
 }
 
+static int uploadPlanMeta(BfhipOperator *op, BfPlan *plan) {
+  int rc = 0;
+  for (uint64_t s = 0; s < plan->numStages && !rc; ++s) {
+    BfStage *st = &plan->stages[s];
+    rc = uploadArray(&st->dItems, st->items, st->numItems * sizeof(BfDevItem), &op->metaBytes);
+    if (!rc) rc = uploadArray(&st->dPieces, st->pieces, st->numPieces * sizeof(BfDevPiece), &op->metaBytes);
+    for (uint64_t r = 0; r < st->numReduce && !rc; ++r) {
+      BfReduce *rd = &st->reduce[r];
+      rc = uploadArray(&rd->dRowInterval, rd->rowInterval, rd->numRows * 4, &op->metaBytes);
+      if (!rc) rc = uploadArray(&rd->dIvBegin, rd->ivBegin, (rd->numIntervals + 1) * 4, &op->metaBytes);
+      if (!rc) rc = uploadArray(&rd->dSrcBias, rd->srcBias, rd->numSrc * 8, &op->metaBytes);
+    }
+  }
+  return rc;
+}
+
+static void dropPlanMirrors(BfPlan *plan) {
+  for (uint64_t s = 0; s < plan->numStages && plan->stages; ++s) {
+    BfStage *st = &plan->stages[s];
+    free(st->pieceSrc); st->pieceSrc = NULL;
+    free(st->pieces); st->pieces = NULL;
+    free(st->items); st->items = NULL;
+    for (uint64_t r = 0; r < st->numReduce; ++r) {
+      free(st->reduce[r].rowInterval); st->reduce[r].rowInterval = NULL;
+      free(st->reduce[r].ivBegin); st->reduce[r].ivBegin = NULL;
+      free(st->reduce[r].srcBias); st->reduce[r].srcBias = NULL;
+    }
+  }
+}
+
 static int ensureTemp(BfhipOperator *op, uint32_t nrhs) {
   if (op->dTemp && op->tempRhs >= nrhs) return 0;
   bfdevFree(op->dTemp);
   op->dTemp = NULL;
   op->tempRhs = 0;
-  int rc = bfdevMalloc(&op->dTemp, (size_t)op->plan.tempElems * nrhs * op->plan.elemSize);
+  uint64_t te = op->plan.tempElems > op->tplan.tempElems ? op->plan.tempElems : op->tplan.tempElems;
+  int rc = bfdevMalloc(&op->dTemp, (size_t)te * nrhs * op->plan.elemSize);
   if (rc) return rc;
   op->tempRhs = nrhs;
   return 0;
@@ -262,6 +300,18 @@ static int compileIr(BfIr *ir, BfhipOptions const *opts, BfhipOperator **out) {
   po.rowBlockEnd = o.rowBlockEnd;
   if ((rc = bfPlanBuild(ir, &po, &op->plan))) goto done;
   op->leafBytesAlgorithmic = op->plan.leafElems * op->plan.elemSize;
+  if (o.flags & BFHIP_FLAG_ADJOINT) {
+    BfFwdPiece *fwd = NULL;
+    uint64_t nf = 0;
+    if ((rc = bfPlanFwdPieces(&op->plan, &fwd, &nf))) goto done;
+    BfPlanOptions pt = po;
+    pt.fwdPieces = fwd;
+    pt.numFwdPieces = nf;
+    rc = bfPlanBuild(ir, &pt, &op->tplan);
+    free(fwd);
+    if (rc) goto done;
+    op->hasTplan = 1;
+  }
   if (planOnly) {
     /* keep the IR (with its borrowed leaf pointers) for bfhipPlanPackArena */
     op->ir = malloc(sizeof *op->ir);
@@ -273,31 +323,12 @@ static int compileIr(BfIr *ir, BfhipOptions const *opts, BfhipOperator **out) {
   }
 
   if ((rc = bfdevMalloc(&op->dArena, (size_t)op->plan.arenaElems * op->plan.elemSize))) goto done;
-  for (uint64_t s = 0; s < op->plan.numStages && !rc; ++s) {
-    BfStage *st = &op->plan.stages[s];
-    rc = uploadArray(&st->dItems, st->items, st->numItems * sizeof(BfDevItem), &op->metaBytes);
-    if (!rc) rc = uploadArray(&st->dPieces, st->pieces, st->numPieces * sizeof(BfDevPiece), &op->metaBytes);
-    for (uint64_t r = 0; r < st->numReduce && !rc; ++r) {
-      BfReduce *rd = &st->reduce[r];
-      rc = uploadArray(&rd->dRowInterval, rd->rowInterval, rd->numRows * 4, &op->metaBytes);
-      if (!rc) rc = uploadArray(&rd->dIvBegin, rd->ivBegin, (rd->numIntervals + 1) * 4, &op->metaBytes);
-      if (!rc) rc = uploadArray(&rd->dSrcBias, rd->srcBias, rd->numSrc * 8, &op->metaBytes);
-    }
-  }
-  if (rc) goto done;
+  if ((rc = uploadPlanMeta(op, &op->plan))) goto done;
+  if (op->hasTplan && (rc = uploadPlanMeta(op, &op->tplan))) goto done;
   if ((rc = packLeaves(op, ir, o.seed, NULL))) goto done;
   /* host mirrors of the bulky per-piece arrays are no longer needed */
-  for (uint64_t s = 0; s < op->plan.numStages; ++s) {
-    BfStage *st = &op->plan.stages[s];
-    free(st->pieceSrc); st->pieceSrc = NULL;
-    free(st->pieces); st->pieces = NULL;
-    free(st->items); st->items = NULL;
-    for (uint64_t r = 0; r < st->numReduce; ++r) {
-      free(st->reduce[r].rowInterval); st->reduce[r].rowInterval = NULL;
-      free(st->reduce[r].ivBegin); st->reduce[r].ivBegin = NULL;
-      free(st->reduce[r].srcBias); st->reduce[r].srcBias = NULL;
-    }
-  }
+  dropPlanMirrors(&op->plan);
+  dropPlanMirrors(&op->tplan);
   if ((rc = ensureTemp(op, o.maxRhs ? o.maxRhs : 1))) goto done;
   if ((rc = bfdevMalloc(&op->dZero, 4096))) goto done;
   if ((rc = bfdevMemset(op->dZero, 0, 4096))) goto done;
@@ -373,7 +404,7 @@ int bfhipGetStageProfile(BfhipOperator *op, double *ms, uint64_t *launches, uint
 }
 
 /* ---- apply ------------------------------------------------------------------ */
-int bfhipApplyDevice(BfhipOperator *op, void const *dX, size_t nrhs, void *dY, void *stream) {
+static int runPlan(BfhipOperator *op, BfPlan *plan, void const *dX, size_t nrhs, void *dY, void *stream) {
   if (!op || !dX || !dY) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "NULL argument");
   if (nrhs == 0 || nrhs > 0xffffu) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "nrhs out of range");
   if (op->flags & BFHIP_FLAG_PLAN_ONLY) return bfhipFail(BFABI_ERROR_RUNTIME_ERROR, "operator was compiled with BFHIP_FLAG_PLAN_ONLY: no device operator exists");
@@ -386,13 +417,14 @@ int bfhipApplyDevice(BfhipOperator *op, void const *dX, size_t nrhs, void *dY, v
     if ((rc = bfdevSync(stream))) return rc;
     if ((rc = ensureTemp(op, (uint32_t)nrhs))) return rc;
   }
-  int const prof = (op->flags & BFHIP_FLAG_PROFILE) != 0;
+  int const prof = (op->flags & BFHIP_FLAG_PROFILE) != 0 && plan == &op->plan;
   if (prof && (rc = harvestEvents(op))) return rc;
-  for (uint64_t s = 0; s < op->plan.numStages; ++s) {
-    BfStage *st = &op->plan.stages[s];
+  for (uint64_t s = 0; s < plan->numStages; ++s) {
+    BfStage *st = &plan->stages[s];
     BfLaunchArgs a;
     a.arena = op->dArena; a.items = st->dItems; a.pieces = st->dPieces; a.numItems = st->numItems;
-    a.x = dX; a.y = dY; a.temp = op->dTemp; a.zero = op->dZero; a.nrhs = (uint32_t)nrhs; a.dtype = op->plan.dtype; a.maxRows = st->maxRows;
+    a.x = dX; a.y = dY; a.temp = op->dTemp; a.zero = op->dZero; a.nrhs = (uint32_t)nrhs; a.dtype = plan->dtype; a.maxRows = st->maxRows;
+    a.transposed = plan->transposed;
     if (prof && (rc = bfdevEventRecord(op->evStart[s], stream))) return rc;
     if ((rc = bfdevLaunchStage(&a, stream))) return rc;
     if (prof && (rc = bfdevEventRecord(op->evStop[s], stream))) return rc;
@@ -400,8 +432,8 @@ int bfhipApplyDevice(BfhipOperator *op, void const *dX, size_t nrhs, void *dY, v
       BfReduce *rd = &st->reduce[r];
       BfReduceArgs ra;
       ra.rowInterval = rd->dRowInterval; ra.ivBegin = rd->dIvBegin; ra.srcBias = rd->dSrcBias;
-      ra.numRows = rd->numRows; ra.temp = op->dTemp; ra.nrhs = (uint32_t)nrhs; ra.dtype = op->plan.dtype;
-      ra.dest = rd->destSpace == BF_SPACE_Y ? dY : (void *)((char *)op->dTemp + rd->destOff * nrhs * op->plan.elemSize);
+      ra.numRows = rd->numRows; ra.temp = op->dTemp; ra.nrhs = (uint32_t)nrhs; ra.dtype = plan->dtype;
+      ra.dest = rd->destSpace == BF_SPACE_Y ? dY : (void *)((char *)op->dTemp + rd->destOff * nrhs * plan->elemSize);
       if ((rc = bfdevLaunchReduce(&ra, stream))) return rc;
     }
   }
@@ -410,8 +442,20 @@ int bfhipApplyDevice(BfhipOperator *op, void const *dX, size_t nrhs, void *dY, v
   return 0;
 }
 
-int bfhipApply(BfhipOperator *op, void const *X, size_t ldx, size_t nrhs, void *Y, size_t ldy) {
+int bfhipApplyDevice(BfhipOperator *op, void const *dX, size_t nrhs, void *dY, void *stream) {
+  if (!op) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "NULL operator");
+  return runPlan(op, &op->plan, dX, nrhs, dY, stream);
+}
+
+int bfhipApplyTransposeDevice(BfhipOperator *op, void const *dX, size_t nrhs, void *dY, void *stream) {
+  if (!op) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "NULL operator");
+  if (!op->hasTplan) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "operator was not compiled with BFHIP_FLAG_ADJOINT");
+  return runPlan(op, &op->tplan, dX, nrhs, dY, stream);
+}
+
+static int applyHost(BfhipOperator *op, int transpose, void const *X, size_t ldx, size_t nrhs, void *Y, size_t ldy) {
   if (!op || !X || !Y) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "NULL argument");
+  if (transpose && !op->hasTplan) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "operator was not compiled with BFHIP_FLAG_ADJOINT");
   if (nrhs == 0 || ldx < nrhs || ldy < nrhs) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "bad nrhs / leading dimension");
   if (op->flags & BFHIP_FLAG_PLAN_ONLY) return bfhipFail(BFABI_ERROR_RUNTIME_ERROR, "operator was compiled with BFHIP_FLAG_PLAN_ONLY: no device operator exists");
   int rc;
@@ -420,11 +464,13 @@ int bfhipApply(BfhipOperator *op, void const *X, size_t ldx, size_t nrhs, void *
   if ((rc = bfdevSetDevice(op->device))) return rc;
   size_t es = op->plan.elemSize;
   size_t hostEs = op->srcDtype == BFHIP_C128 ? 16 : 8;      /* host side is always double precision */
-  uint64_t n = op->plan.numCols, m = op->plan.numRows;
+  uint64_t n = transpose ? op->plan.numRows : op->plan.numCols, m = transpose ? op->plan.numCols : op->plan.numRows;
+  uint64_t big = n > m ? n : m;
+  if (transpose && !op->hasTplan) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "operator was not compiled with BFHIP_FLAG_ADJOINT");
   if (op->xyRhs < nrhs) {
     bfdevFree(op->dX); bfdevFree(op->dY); op->dX = op->dY = NULL; op->xyRhs = 0;
-    if ((rc = bfdevMalloc(&op->dX, n * nrhs * es))) return rc;
-    if ((rc = bfdevMalloc(&op->dY, m * nrhs * es))) return rc;
+    if ((rc = bfdevMalloc(&op->dX, big * nrhs * es))) return rc;
+    if ((rc = bfdevMalloc(&op->dY, big * nrhs * es))) return rc;
     op->xyRhs = (uint32_t)nrhs;
   }
   /* pack to ld == nrhs (and demote if the operator computes in fp32) */
@@ -439,7 +485,7 @@ int bfhipApply(BfhipOperator *op, void const *X, size_t ldx, size_t nrhs, void *
   rc = bfdevMemcpyH2D(op->dX, needPackX ? hx : X, n * nrhs * es);
   free(hx);
   if (rc) return rc;
-  if ((rc = bfhipApplyDevice(op, op->dX, nrhs, op->dY, NULL))) return rc;
+  if ((rc = runPlan(op, transpose ? &op->tplan : &op->plan, op->dX, nrhs, op->dY, NULL))) return rc;
   if ((rc = bfdevSync(NULL))) return rc;
   if (needPackY) {
     hy = malloc(m && nrhs ? m * nrhs * es : 1);
@@ -455,6 +501,13 @@ int bfhipApply(BfhipOperator *op, void const *X, size_t ldx, size_t nrhs, void *
   }
   if (prev >= 0 && prev != op->device) bfdevSetDevice(prev);
   return rc;
+}
+
+int bfhipApply(BfhipOperator *op, void const *X, size_t ldx, size_t nrhs, void *Y, size_t ldy) {
+  return applyHost(op, 0, X, ldx, nrhs, Y, ldy);
+}
+int bfhipApplyTranspose(BfhipOperator *op, void const *X, size_t ldx, size_t nrhs, void *Y, size_t ldy) {
+  return applyHost(op, 1, X, ldx, nrhs, Y, ldy);
 }
 
 /* ---- introspection ---------------------------------------------------------- */
@@ -497,13 +550,17 @@ int bfhipPlanGetInfo(BfhipOperator const *op, BfhipPlanInfo *info) {
   info->dtype = pl->dtype; info->elemSize = pl->elemSize; info->epl = pl->epl; info->xcap = pl->xcap;
   info->numRows = pl->numRows; info->numCols = pl->numCols; info->numStages = pl->numStages;
   info->arenaElems = pl->arenaElems; info->tempElems = pl->tempElems;
+  info->numStagesT = op->hasTplan ? op->tplan.numStages : 0;
+  info->tempElemsT = op->hasTplan ? op->tplan.tempElems : 0;
   return 0;
 }
 int bfhipPlanGetStage(BfhipOperator const *op, uint64_t stage, BfhipStageView *v) {
   int rc = needPlanOnly(op);
   if (rc) return rc;
-  if (!v || v->structSize < sizeof *v || stage >= op->plan.numStages) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "bad stage view request");
-  BfStage const *st = &op->plan.stages[stage];
+  BfPlan const *pl = &op->plan;
+  if (stage >= pl->numStages && op->hasTplan) { stage -= pl->numStages; pl = &op->tplan; }
+  if (!v || v->structSize < sizeof *v || stage >= pl->numStages) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "bad stage view request");
+  BfStage const *st = &pl->stages[stage];
   v->numItems = st->numItems; v->numPieces = st->numPieces; v->numReduce = st->numReduce;
   v->items = st->items; v->pieces = st->pieces;
   return 0;
@@ -511,9 +568,11 @@ int bfhipPlanGetStage(BfhipOperator const *op, uint64_t stage, BfhipStageView *v
 int bfhipPlanGetReduce(BfhipOperator const *op, uint64_t stage, uint64_t index, BfhipReduceView *v) {
   int rc = needPlanOnly(op);
   if (rc) return rc;
-  if (!v || v->structSize < sizeof *v || stage >= op->plan.numStages || index >= op->plan.stages[stage].numReduce)
+  BfPlan const *pl = &op->plan;
+  if (stage >= pl->numStages && op->hasTplan) { stage -= pl->numStages; pl = &op->tplan; }
+  if (!v || v->structSize < sizeof *v || stage >= pl->numStages || index >= pl->stages[stage].numReduce)
     return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "bad reduce view request");
-  BfReduce const *rd = &op->plan.stages[stage].reduce[index];
+  BfReduce const *rd = &pl->stages[stage].reduce[index];
   v->destIsY = rd->destSpace == BF_SPACE_Y; v->destOff = rd->destOff; v->numRows = rd->numRows;
   v->numIntervals = rd->numIntervals; v->numSrc = rd->numSrc;
   v->rowInterval = rd->rowInterval; v->ivBegin = rd->ivBegin; v->srcBias = rd->srcBias;
@@ -610,7 +669,35 @@ static BfAbiVec *shimMulVec(BfAbiMat const *lhs, BfAbiVec const *vec) {
   return res;
 }
 
+/* z = x^T A as a vector (bfMatRmulVec): real operators, square (the result is a
+ * Copy of the argument), compiled with BFHIP_FLAG_ADJOINT */
+static BfAbiVec *shimRmulVec(BfAbiMat const *lhs, BfAbiVec const *vec) {
+  BfhipOperator *op = ((BfhipMat const *)lhs)->op;
+  if (!vec || !vec->vtbl) { bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "NULL vector"); return NULL; }
+  BfAbiVecGetTypeFn getType = (BfAbiVecGetTypeFn)vec->vtbl->slot[BFABI_VSLOT_GetType];
+  if (!getType || getType(vec) != BFABI_TYPE_VEC_REAL || op->srcDtype != BFHIP_F64) {
+    bfhipFail(BFABI_ERROR_NOT_IMPLEMENTED, "RmulVec needs a real operator and a BfVecReal");
+    return NULL;
+  }
+  if (vec->size != op->plan.numRows) { bfhipFail(BFABI_ERROR_NOT_IMPLEMENTED, "vector size mismatch"); return NULL; }
+  if (op->plan.numRows != op->plan.numCols) { bfhipFail(BFABI_ERROR_NOT_IMPLEMENTED, "RmulVec shim needs a square operator (result is a Copy of the argument)"); return NULL; }
+  BfAbiVecReal const *x = (BfAbiVecReal const *)vec;
+  BfAbiVecCopyFn copy = (BfAbiVecCopyFn)vec->vtbl->slot[BFABI_VSLOT_Copy];
+  if (!copy) { bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "vector has no Copy"); return NULL; }
+  BfAbiVec *res = copy(vec);
+  if (!res) { bfhipFail(BFABI_ERROR_MEMORY_ERROR, "vector Copy failed"); return NULL; }
+  BfAbiVecReal *y = (BfAbiVecReal *)res;
+  int rc = bfhipApplyTranspose(op, x->data, x->stride, 1, y->data, y->stride);
+  if (rc) {
+    BfAbiVecDeleteFn del = (BfAbiVecDeleteFn)res->vtbl->slot[BFABI_VSLOT_Delete];
+    if (del) del(&res);
+    return NULL;
+  }
+  return res;
+}
+
 static BfAbiMatVtable ShimVtable = {.slot = {
+  [BFABI_SLOT_RmulVec] = (void *)shimRmulVec,
   [BFABI_SLOT_Delete] = (void *)shimDelete,
   [BFABI_SLOT_GetType] = (void *)shimGetType,
   [BFABI_SLOT_NumBytes] = (void *)shimNumBytes,

@@ -414,6 +414,114 @@ __global__ __launch_bounds__(BF_WAVES_PER_WG * 64) void bfStageKernelReal(StageP
   }
 }
 
+
+// ---------------------------------------------------------------------------
+// transposed stage kernels: y = A^T x on the forward plan's packed pieces.
+// A forward piece is column-major (mrPad x ncols); here lanes own its COLUMNS
+// (one output each) and walk down them, so a lane reads consecutive addresses
+// and the 64 lanes of a load touch 64 different lines -- each line is then
+// consumed by the same lane over the next steps (the step loop is unrolled by
+// 8 so those hits are back to back).  No cross-lane reduction, one owner per
+// output, same slots + reduce machinery for overlapping outputs.
+// (reference: RmulVec of every container, see include/bfhip.h)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(BF_WAVES_PER_WG * 64) void bfStageKernelC128T(StageParams p) {
+  __shared__ __attribute__((aligned(16))) double2 lds[BF_WAVES_PER_WG][BF_XCAP];
+  int const wave = threadIdx.x >> 6;
+  int const lane = threadIdx.x & 63;
+  uint32_t item = __builtin_amdgcn_readfirstlane(blockIdx.x * BF_WAVES_PER_WG + wave);
+  if (item >= p.numItems) return;
+  BfDevItem const it = p.items[item];
+  uint32_t const mr = it.mrFlags & 0xffffu;           // columns of A in this item (<= 64)
+  bool const active = (uint32_t)lane < mr;
+  uint32_t const j = active ? (uint32_t)lane : mr - 1;
+  double2 *xs = lds[wave];
+  double2 const *arena = (double2 const *)p.arena;
+  uint32_t const nrhs = p.nrhs;
+  double2 *out = (it.mrFlags & BF_ITEM_OUT_Y) ? (double2 *)p.y : (double2 *)p.temp;
+  for (uint32_t q = 0; q < nrhs; ++q) {
+    double accr = 0.0, acci = 0.0;
+    for (uint32_t pi = 0; pi < it.numPieces; ++pi) {
+      BfDevPiece const pc = p.pieces[it.pieceBegin + pi];
+      double2 const *xin = (pc.flags & BF_PIECE_IN_X) ? (double2 const *)p.x : (double2 const *)p.temp;
+      xin += (uint64_t)pc.inOff * nrhs + q;
+      if (pc.flags & BF_PIECE_IDENTITY) {
+        if (active) { double2 v = xin[(uint64_t)j * nrhs]; accr += v.x; acci += v.y; }
+        continue;
+      }
+      uint32_t const n = pc.ncols;                     // steps = rows of the forward piece (<= 64)
+      waveSync();
+      for (uint32_t s = lane; s < n; s += 64) xs[s] = xin[(uint64_t)s * nrhs];
+      waveSync();
+      double2 const *ap = arena + pc.dataOff + (uint64_t)j * pc.ld;
+      uint32_t s = 0;
+      for (; s + 8 <= n; s += 8) {
+        double2 a[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a[u] = bfLoadStream(ap + s + u);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          double2 xv = xs[s + u];
+          accr = fma(a[u].x, xv.x, accr); accr = fma(-a[u].y, xv.y, accr);
+          acci = fma(a[u].x, xv.y, acci); acci = fma(a[u].y, xv.x, acci);
+        }
+      }
+      for (; s < n; ++s) {
+        double2 a = bfLoadStream(ap + s);
+        double2 xv = xs[s];
+        accr = fma(a.x, xv.x, accr); accr = fma(-a.y, xv.y, accr);
+        acci = fma(a.x, xv.y, acci); acci = fma(a.y, xv.x, acci);
+      }
+    }
+    if (active) out[((uint64_t)it.outOff + lane) * nrhs + q] = make_double2(accr, acci);
+  }
+}
+
+template <int DT>
+__global__ __launch_bounds__(BF_WAVES_PER_WG * 64) void bfStageKernelRealT(StageParams p) {
+  using S = typename Traits<DT>::S;
+  constexpr int EPL = Traits<DT>::EPL;
+  struct __attribute__((aligned(16))) V { S v[EPL]; };
+  __shared__ __attribute__((aligned(16))) unsigned char ldsRaw[BF_WAVES_PER_WG][BF_WAVE_LDS_BYTES];
+  int const wave = threadIdx.x >> 6;
+  int const lane = threadIdx.x & 63;
+  uint32_t item = __builtin_amdgcn_readfirstlane(blockIdx.x * BF_WAVES_PER_WG + wave);
+  if (item >= p.numItems) return;
+  BfDevItem const it = p.items[item];
+  uint32_t const mr = it.mrFlags & 0xffffu;
+  bool const active = (uint32_t)lane < mr;
+  uint32_t const j = active ? (uint32_t)lane : mr - 1;
+  S *xs = (S *)ldsRaw[wave];
+  S const *arena = (S const *)p.arena;
+  uint32_t const nrhs = p.nrhs;
+  S *out = (it.mrFlags & BF_ITEM_OUT_Y) ? (S *)p.y : (S *)p.temp;
+  for (uint32_t q = 0; q < nrhs; ++q) {
+    S acc = 0;
+    for (uint32_t pi = 0; pi < it.numPieces; ++pi) {
+      BfDevPiece const pc = p.pieces[it.pieceBegin + pi];
+      S const *xin = (pc.flags & BF_PIECE_IN_X) ? (S const *)p.x : (S const *)p.temp;
+      xin += (uint64_t)pc.inOff * nrhs + q;
+      if (pc.flags & BF_PIECE_IDENTITY) {
+        if (active) acc += xin[(uint64_t)j * nrhs];
+        continue;
+      }
+      uint32_t const n = pc.ncols;                     // rows of the forward piece; pc.ld = rows padded to EPL
+      waveSync();
+      for (uint32_t s = lane; s < pc.ld; s += 64) xs[s] = s < n ? xin[(uint64_t)s * nrhs] : (S)0;
+      waveSync();
+      V const *ap = (V const *)(arena + pc.dataOff + (uint64_t)j * pc.ld);   // 16-byte aligned: ld % EPL == 0
+      uint32_t const slots = pc.ld / EPL;
+#pragma unroll 4
+      for (uint32_t s = 0; s < slots; ++s) {
+        V a = bfLoadStreamV(ap + s);
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) acc = fma(a.v[e], xs[s * EPL + e], acc);
+      }
+    }
+    if (active) out[((uint64_t)it.outOff + lane) * nrhs + q] = acc;
+  }
+}
+
 // ---------------------------------------------------------------------------
 // deterministic reduce: dest[row] = sum over the row's interval sources, in
 // list order, of temp[srcBias + row]
@@ -649,6 +757,13 @@ int bfdevLaunchStage(BfLaunchArgs const *a, void *stream) {
   p.zero = a->zero;
   uint32_t grid = (uint32_t)((a->numItems + BF_WAVES_PER_WG - 1) / BF_WAVES_PER_WG);
   hipStream_t s = (hipStream_t)stream;
+  if (a->transposed) {
+    if (a->dtype == BFHIP_C128) hipLaunchKernelGGL(bfStageKernelC128T, dim3(grid), dim3(BF_WAVES_PER_WG * 64), 0, s, p);
+    else if (a->dtype == BFHIP_F64) hipLaunchKernelGGL(bfStageKernelRealT<BFHIP_F64>, dim3(grid), dim3(BF_WAVES_PER_WG * 64), 0, s, p);
+    else if (a->dtype == BFHIP_F32) hipLaunchKernelGGL(bfStageKernelRealT<BFHIP_F32>, dim3(grid), dim3(BF_WAVES_PER_WG * 64), 0, s, p);
+    else return bfhipFail(BFABI_ERROR_TYPE_ERROR, "unknown dtype %u", a->dtype);
+    return hipFail(hipGetLastError(), "transposed stage launch");
+  }
   if (a->dtype == BFHIP_C128 && a->nrhs >= 3) hipLaunchKernelGGL(bfStageKernelC128Mfma, dim3(grid), dim3(BF_WAVES_PER_WG * 64), 0, s, p);
   else if (a->dtype == BFHIP_C128) hipLaunchKernelGGL(bfStageKernelC128, dim3(grid), dim3(BF_WAVES_PER_WG * 64), 0, s, p);
   else if (a->dtype == BFHIP_F64) hipLaunchKernelGGL(bfStageKernelReal<BFHIP_F64>, dim3(grid), dim3(BF_WAVES_PER_WG * 64), 0, s, p);

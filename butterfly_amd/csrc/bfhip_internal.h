@@ -65,7 +65,7 @@ typedef struct BfDevPiece {
   uint32_t inOff;      /* element offset of column 0 in the input space */
   uint32_t ncols;
   uint32_t flags;      /* bit 0: input space is X (else vector arena); bit 1: identity piece */
-  uint32_t pad;
+  uint32_t ld;         /* transposed plans: element stride between the lanes' columns (forward mrPad); else 0 */
 } BfDevPiece;
 
 #define BF_ITEM_OUT_Y (1u << 16)
@@ -119,16 +119,31 @@ typedef struct BfPlan {
   uint64_t arenaElems;       /* leaf arena size in elements */
   uint64_t tempElems;        /* vector arena elements per RHS */
   uint64_t numLeaves, leafElems;
+  int transposed;            /* plan of A^T over the forward plan's arena */
 } BfPlan;
+
+/* where the forward plan put each (leaf, row chunk, column range): the
+ * transposed plan reads the same packed data with the roles of rows and
+ * columns exchanged */
+typedef struct BfFwdPiece {
+  uint64_t node;
+  uint64_t dataOff;
+  uint32_t row0, mr, mrPad, col0, ncols;
+} BfFwdPiece;
 
 typedef struct BfPlanOptions {
   uint32_t storeDtype;
   uint32_t itemRows;         /* rows per item cap (<= 64*epl); 0 -> default */
   uint32_t xcap;
   uint64_t rowBlockBegin, rowBlockEnd;
+  /* transposed plan (A^T x): pieces are located in the forward plan's arena */
+  BfFwdPiece const *fwdPieces;   /* sorted by (node, col0, row0); NULL -> forward plan */
+  uint64_t numFwdPieces;
 } BfPlanOptions;
 
 int bfPlanBuild(BfIr const *ir, BfPlanOptions const *po, BfPlan *plan);
+/* table of the forward plan's pieces (needs its host mirrors); caller frees */
+int bfPlanFwdPieces(BfPlan const *plan, BfFwdPiece **out, uint64_t *count);
 void bfPlanFree(BfPlan *plan);
 
 /* ------------------------------------------------------------------------
@@ -168,6 +183,7 @@ typedef struct BfLaunchArgs {
   uint32_t nrhs;
   uint32_t dtype;
   uint32_t maxRows;
+  int transposed;        /* pieces carry `ld`: lanes own columns of the forward pieces */
 } BfLaunchArgs;
 int bfdevLaunchStage(BfLaunchArgs const *a, void *stream);
 

@@ -126,6 +126,93 @@ static int emit(Builder *b, uint64_t node, uint32_t inBuf, uint64_t inOff, uint3
   return bfhipFail(BFABI_ERROR_TYPE_ERROR, "unknown node kind");
 }
 
+/* A^T: rows and columns trade places.  A Block child at (r0, c0) reads the
+ * input at +r0 and writes the output at +c0; (F0 ... F_{L-1})^T = F_{L-1}^T ...
+ * F0^T, so F_{L-1}^T is applied last (mat_product.c:314-345 walks the factors
+ * in the same order for RmulVec). */
+static int emitT(Builder *b, uint64_t node, uint32_t inBuf, uint64_t inOff, uint32_t outBuf, uint64_t outOff, int32_t stageEnd) {
+  BfIr const *ir = b->ir;
+  int rc;
+  switch (ir->kind[node]) {
+  case BFHIP_NODE_DENSE:
+  case BFHIP_NODE_IDENTITY: {
+    Task t;
+    memset(&t, 0, sizeof t);
+    t.stage = (uint32_t)stageEnd; t.leaf = node;
+    t.inBuf = inBuf; t.inOff = inOff; t.outBuf = outBuf; t.outOff = outOff;
+    t.rows = ir->cols[node]; t.cols = ir->rows[node];
+    return pushTask(b, &t);
+  }
+  case BFHIP_NODE_BLOCK:
+    for (uint64_t c = ir->childBegin[node]; c < ir->childBegin[node + 1]; ++c)
+      if ((rc = emitT(b, ir->childNode[c], inBuf, inOff + ir->childRow0[c], outBuf, outOff + ir->childCol0[c], stageEnd))) return rc;
+    return 0;
+  case BFHIP_NODE_PRODUCT: {
+    uint64_t cb = ir->childBegin[node], ce = ir->childBegin[node + 1];
+    uint32_t curOut = outBuf; uint64_t curOutOff = outOff;
+    int32_t se = stageEnd;
+    for (uint64_t c = ce; c-- > cb;) {          /* F_{L-1}^T is due last */
+      uint64_t f = ir->childNode[c];
+      uint32_t in = inBuf; uint64_t inO = inOff;
+      int32_t seNext = se - (int32_t)ir->depth[f];
+      if (c > cb) {
+        if ((rc = newBuf(b, ir->rows[f], seNext, &in))) return rc;   /* input of F_c^T has rows(F_c) entries */
+        inO = 0;
+      }
+      if ((rc = emitT(b, f, in, inO, curOut, curOutOff, se))) return rc;
+      se = seNext; curOut = in; curOutOff = 0;
+    }
+    return 0;
+  }
+  }
+  return bfhipFail(BFABI_ERROR_TYPE_ERROR, "unknown node kind");
+}
+
+static int cmpFwdPiece(void const *pa, void const *pb) {
+  BfFwdPiece const *a = pa, *b = pb;
+  if (a->node != b->node) return a->node < b->node ? -1 : 1;
+  if (a->col0 != b->col0) return a->col0 < b->col0 ? -1 : 1;
+  return a->row0 < b->row0 ? -1 : (a->row0 > b->row0);
+}
+
+int bfPlanFwdPieces(BfPlan const *plan, BfFwdPiece **out, uint64_t *count) {
+  uint64_t n = 0;
+  for (uint64_t s = 0; s < plan->numStages; ++s) n += plan->stages[s].numPieces;
+  BfFwdPiece *t = malloc((n ? n : 1) * sizeof *t);
+  if (!t) return bfhipFail(BFABI_ERROR_MEMORY_ERROR, "host OOM (forward piece table)");
+  uint64_t k = 0;
+  for (uint64_t s = 0; s < plan->numStages; ++s) {
+    BfStage const *st = &plan->stages[s];
+    if (st->numPieces && (!st->items || !st->pieces || !st->pieceSrc)) { free(t); return bfhipFail(BFABI_ERROR_RUNTIME_ERROR, "internal: forward plan mirrors already released"); }
+    for (uint64_t i = 0; i < st->numItems; ++i) {
+      BfDevItem const *it = &st->items[i];
+      uint32_t mr = it->mrFlags & 0xffffu;
+      for (uint32_t p = 0; p < it->numPieces; ++p) {
+        BfDevPiece const *pc = &st->pieces[it->pieceBegin + p];
+        if (pc->flags & BF_PIECE_IDENTITY) continue;
+        BfPieceSrc const *src = &st->pieceSrc[it->pieceBegin + p];
+        t[k].node = src->node; t[k].dataOff = pc->dataOff; t[k].row0 = src->row0; t[k].mr = mr;
+        t[k].mrPad = (mr + plan->epl - 1) / plan->epl * plan->epl; t[k].col0 = src->col0; t[k].ncols = pc->ncols;
+        ++k;
+      }
+    }
+  }
+  qsort(t, k, sizeof *t, cmpFwdPiece);
+  *out = t;
+  *count = k;
+  return 0;
+}
+
+/* first table entry of (node, column piece containing col) */
+static uint64_t findFwd(BfFwdPiece const *t, uint64_t n, uint64_t node, uint32_t colPiece0) {
+  uint64_t lo = 0, hi = n;
+  while (lo < hi) {
+    uint64_t mid = (lo + hi) / 2;
+    if (t[mid].node < node || (t[mid].node == node && t[mid].col0 < colPiece0)) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+
 /* sort tasks by (stage, outBuf, outOff, rows, seq) */
 static int cmpTask(void const *pa, void const *pb) {
   Task const *a = pa, *b = pb;
@@ -195,18 +282,27 @@ int bfPlanBuild(BfIr const *ir, BfPlanOptions const *po, BfPlan *plan) {
   plan->elemSize = plan->dtype == BFHIP_C128 ? 16 : (plan->dtype == BFHIP_F64 ? 8 : 4);
   plan->epl = 16 / plan->elemSize;
   plan->maxItemRows = 64 * plan->epl;
+  int const T = po->fwdPieces != NULL;
+  plan->transposed = T;
   uint32_t itemRows = po->itemRows ? po->itemRows : plan->maxItemRows;
   if (itemRows > plan->maxItemRows) itemRows = plan->maxItemRows;
   itemRows = (uint32_t)roundUp(itemRows, plan->epl);
   plan->xcap = po->xcap ? po->xcap : 256;
+  if (T) {
+    /* lanes own columns of A (one output each), whatever the element size */
+    itemRows = 64;
+    plan->maxItemRows = 64;
+    if (po->rowBlockEnd > 0) return bfhipFail(BFABI_ERROR_NOT_IMPLEMENTED, "transposed plan of a row-sharded operator");
+  }
 
   uint32_t bx, by;
   uint64_t root = ir->root;
   int32_t S = (int32_t)ir->depth[root];
-  uint64_t numRows = ir->rows[root];
+  uint64_t numRows = T ? ir->cols[root] : ir->rows[root];      /* rows of the operator this plan applies */
+  uint64_t numColsOp = T ? ir->rows[root] : ir->cols[root];
 
   /* ---- 1. schedule ------------------------------------------------------ */
-  if ((rc = newBuf(&b, ir->cols[root], -1, &bx))) goto fail;     /* buffer 0 = X */
+  if ((rc = newBuf(&b, numColsOp, -1, &bx))) goto fail;          /* buffer 0 = X */
   if (po->rowBlockEnd > 0) {
     /* row sharding: keep block rows [begin, end) of a BLOCK root */
     if (ir->kind[root] != BFHIP_NODE_BLOCK || !ir->topRowBlock) { rc = bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "row sharding needs a block-matrix root"); goto fail; }
@@ -245,10 +341,10 @@ int bfPlanBuild(BfIr const *ir, BfPlanOptions const *po, BfPlan *plan) {
     if (rc) goto fail;
   } else {
     if ((rc = newBuf(&b, numRows, S - 1, &by))) goto fail;        /* buffer 1 = Y */
-    if ((rc = emit(&b, root, bx, 0, by, 0, S - 1))) goto fail;
+    if ((rc = (T ? emitT : emit)(&b, root, bx, 0, by, 0, S - 1))) goto fail;
   }
   plan->numRows = numRows;
-  plan->numCols = ir->cols[root];
+  plan->numCols = numColsOp;
   plan->numStages = (uint64_t)S;
   plan->stages = calloc((size_t)S, sizeof(BfStage));
   if (!plan->stages) { rc = bfhipFail(BFABI_ERROR_MEMORY_ERROR, "host OOM"); goto fail; }
@@ -429,6 +525,7 @@ int bfPlanBuild(BfIr const *ir, BfPlanOptions const *po, BfPlan *plan) {
       for (uint64_t t = groups[g].taskBegin; t < groups[g].taskEnd; ++t) {
         Task const *tk = &b.tasks[t];
         if (ir->kind[tk->leaf] == BFHIP_NODE_IDENTITY) { piecesPerChunk += 1; colsSum += 1; }
+        else if (T) { piecesPerChunk += (tk->cols + 63) / 64 + 1; colsSum += tk->cols; }   /* upper bound: forward row chunks */
         else { piecesPerChunk += (tk->cols + plan->xcap - 1) / plan->xcap; colsSum += tk->cols; }
       }
       for (uint64_t r0 = 0; r0 < m; r0 += chunk) {
@@ -470,16 +567,37 @@ int bfPlanBuild(BfIr const *ir, BfPlanOptions const *po, BfPlan *plan) {
         if (!bufRead[tk->inBuf]) { bufRead[tk->inBuf] = 1; st->vecIn += b.bufs[tk->inBuf].len; }
         if (ir->kind[tk->leaf] == BFHIP_NODE_IDENTITY) {
           BfDevPiece *pc = &st->pieces[np];
-          pc->dataOff = 0; pc->inOff = (uint32_t)(inBase + r0); pc->ncols = mr; pc->flags = inFlag | BF_PIECE_IDENTITY; pc->pad = 0;
+          pc->dataOff = 0; pc->inOff = (uint32_t)(inBase + r0); pc->ncols = mr; pc->flags = inFlag | BF_PIECE_IDENTITY; pc->ld = 0;
           st->pieceSrc[np].node = tk->leaf; st->pieceSrc[np].row0 = r0; st->pieceSrc[np].col0 = 0;
           ++np;
+          continue;
+        }
+        if (T) {
+          /* every forward piece of this leaf whose column range holds this chunk of A's columns */
+          uint32_t colPiece0 = r0 / plan->xcap * plan->xcap;
+          uint64_t k = findFwd(po->fwdPieces, po->numFwdPieces, tk->leaf, colPiece0);
+          uint64_t found = 0;
+          for (; k < po->numFwdPieces && po->fwdPieces[k].node == tk->leaf && po->fwdPieces[k].col0 == colPiece0; ++k) {
+            BfFwdPiece const *fp = &po->fwdPieces[k];
+            if (np >= numPieces) { free(tmp); rc = bfhipFail(BFABI_ERROR_RUNTIME_ERROR, "internal: transposed piece count"); goto stage_fail; }
+            BfDevPiece *pc = &st->pieces[np];
+            if (inBase + fp->row0 >= 0xffffffffu) { free(tmp); rc = bfhipFail(BFABI_ERROR_RUNTIME_ERROR, "vector arena exceeds 32-bit offsets"); goto stage_fail; }
+            pc->dataOff = fp->dataOff + (uint64_t)(r0 - fp->col0) * fp->mrPad;
+            pc->inOff = (uint32_t)(inBase + fp->row0);
+            pc->ncols = fp->mr;            /* steps = rows of the forward piece */
+            pc->flags = inFlag;
+            pc->ld = fp->mrPad;
+            st->pieceSrc[np].node = tk->leaf; st->pieceSrc[np].row0 = fp->row0; st->pieceSrc[np].col0 = r0;
+            ++np; ++found;
+          }
+          if (!found) { free(tmp); rc = bfhipFail(BFABI_ERROR_RUNTIME_ERROR, "internal: leaf missing from the forward plan"); goto stage_fail; }
           continue;
         }
         for (uint64_t c0 = 0; c0 < tk->cols; c0 += plan->xcap) {
           uint64_t nc = tk->cols - c0 < plan->xcap ? tk->cols - c0 : plan->xcap;
           BfDevPiece *pc = &st->pieces[np];
           if (inBase + c0 >= 0xffffffffu) { free(tmp); rc = bfhipFail(BFABI_ERROR_RUNTIME_ERROR, "vector arena exceeds 32-bit offsets"); goto stage_fail; }
-          pc->dataOff = arenaTop; pc->inOff = (uint32_t)(inBase + c0); pc->ncols = (uint32_t)nc; pc->flags = inFlag; pc->pad = 0;
+          pc->dataOff = arenaTop; pc->inOff = (uint32_t)(inBase + c0); pc->ncols = (uint32_t)nc; pc->flags = inFlag; pc->ld = 0;
           st->pieceSrc[np].node = tk->leaf; st->pieceSrc[np].row0 = r0; st->pieceSrc[np].col0 = (uint32_t)c0;
           arenaTop += (uint64_t)mrPad * nc;
           ++np;

@@ -130,6 +130,33 @@ class HipOperator:
                                          C.c_void_p(s.cuda_stream)))
         return y
 
+    def apply_transpose_host(self, x: np.ndarray) -> np.ndarray:
+        """bfhipApplyTranspose: y = A^T x (plain transpose) on host arrays; the
+        operator must have been compiled with FLAG_ADJOINT."""
+        m, n = self.shape
+        src_dtype = np.complex128 if self.dtype == BFHIP_C128 else np.float64
+        x2 = np.ascontiguousarray(x, dtype=src_dtype)
+        one_d = x2.ndim == 1
+        if one_d:
+            x2 = x2[:, None]
+        if x2.shape[0] != m:
+            raise ValueError(f"operator has {m} rows, x has {x2.shape[0]} rows")
+        nrhs = x2.shape[1]
+        y = np.empty((n, nrhs), dtype=src_dtype)
+        check(self._lib.bfhipApplyTranspose(self._h, x2.ctypes.data, nrhs, nrhs, y.ctypes.data, nrhs))
+        return y[:, 0] if one_d else y
+
+    def apply_transpose_device(self, x, y=None, stream=None):
+        import torch
+        m, n = self.shape
+        nrhs = 1 if x.dim() == 1 else x.shape[1]
+        if y is None:
+            y = torch.empty((n,) if x.dim() == 1 else (n, nrhs), dtype=x.dtype, device=x.device)
+        s = stream if stream is not None else torch.cuda.current_stream(x.device)
+        check(self._lib.bfhipApplyTransposeDevice(self._h, C.c_void_p(x.data_ptr()), nrhs, C.c_void_p(y.data_ptr()),
+                                                  C.c_void_p(s.cuda_stream)))
+        return y
+
     # ---- GMRES ---------------------------------------------------------------
     def solve_gmres(self, b: np.ndarray, x0=None, tol=1e-12, max_num_iter=100):
         """bfhipSolveGMRES on host arrays; returns (x, num_iter, residual), as the

@@ -54,8 +54,10 @@ enum {
 enum {
   BFHIP_FLAG_NONE = 0,
   BFHIP_FLAG_PROFILE = 1u << 0,  /* record hipEvents around every stage launch */
-  BFHIP_FLAG_PLAN_ONLY = 1u << 1 /* build the host-side plan only: no device is touched, apply is refused;
+  BFHIP_FLAG_PLAN_ONLY = 1u << 1,/* build the host-side plan only: no device is touched, apply is refused;
                                     for inspecting the flattened layout (bfhipPlan* below) */
+  BFHIP_FLAG_ADJOINT = 1u << 2   /* also build the plan of A^T (bfhipApplyTranspose*, RmulVec of the shim):
+                                    index metadata only, the packed leaf data is shared */
 };
 
 typedef struct BfhipOptions {
@@ -139,6 +141,14 @@ int bfhipApply(BfhipOperator *op, const void *X, size_t ldx, size_t nrhs, void *
  * `stream` (hipStream_t, NULL = default stream) and asynchronous. */
 int bfhipApplyDevice(BfhipOperator *op, const void *dX, size_t nrhs, void *dY, void *stream);
 
+/* Y[numCols x nrhs] = A^T X[numRows x nrhs] (plain transpose, no conjugation): what the reference's
+ * bfMatRmulVec computes on a BfVecReal (x^T A as a vector: src/mat_product.c:314-345,
+ * src/mat_block_diag.c:458-505, src/mat_block_coo.c:476-520, src/mat_block_dense.c:696-758,
+ * src/mat_dense_real.c:1508-1542) and what `cov_matvec` needs for Phi^T v
+ * (examples/covariance/lbo_cov.c:48-60).  Needs BFHIP_FLAG_ADJOINT at compile. */
+int bfhipApplyTranspose(BfhipOperator *op, const void *X, size_t ldx, size_t nrhs, void *Y, size_t ldy);
+int bfhipApplyTransposeDevice(BfhipOperator *op, const void *dX, size_t nrhs, void *dY, void *stream);
+
 /* ---- GMRES (the production caller of the apply path) --------------------- */
 
 /* Solve A X = B with the operator as A, mirroring the reference's
@@ -179,10 +189,13 @@ int bfhipGetStageProfile(BfhipOperator *op, double *ms, uint64_t *launches, uint
  * operator compiled with BFHIP_FLAG_PLAN_ONLY (the host mirrors are dropped
  * after upload otherwise); pointers stay owned by the operator.  Record
  * layouts: BfDevItem = {u32 pieceBegin, numPieces, outOff, mrFlags},
- * BfDevPiece = {u64 dataOff; u32 inOff, ncols, flags, pad}. */
+ * BfDevPiece = {u64 dataOff; u32 inOff, ncols, flags, ld}; in the transposed
+ * plan a piece is a forward piece read with lanes on its columns: element
+ * (step s, lane j) = arena[dataOff + j*ld + s], ncols = number of steps. */
 typedef struct BfhipPlanInfo {
   uint32_t structSize, dtype, elemSize, epl, xcap, reserved;
   uint64_t numRows, numCols, numStages, arenaElems, tempElems;
+  uint64_t numStagesT, tempElemsT;   /* transposed plan (0 without BFHIP_FLAG_ADJOINT) */
 } BfhipPlanInfo;
 typedef struct BfhipStageView {
   uint32_t structSize, reserved;
@@ -197,6 +210,7 @@ typedef struct BfhipReduceView {
   const uint32_t *ivBegin;       /* [numIntervals+1] */
   const int64_t *srcBias;        /* [numSrc] */
 } BfhipReduceView;
+/* `stage` indices >= numStages address the transposed plan (BFHIP_FLAG_ADJOINT): stage - numStages */
 int bfhipPlanGetInfo(const BfhipOperator *op, BfhipPlanInfo *info);
 int bfhipPlanGetStage(const BfhipOperator *op, uint64_t stage, BfhipStageView *view);
 int bfhipPlanGetReduce(const BfhipOperator *op, uint64_t stage, uint64_t index, BfhipReduceView *view);

@@ -81,6 +81,9 @@ BfMat *bfMatMul(BfMat const *lhs, BfMat const *rhs) {
 BfVec *bfMatMulVec(BfMat const *lhs, BfVec const *rhs) {
   return SLOT(lhs, BFABI_SLOT_MulVec, BfAbiMulVecFn)(lhs, rhs);
 }
+BfVec *bfMatRmulVec(BfMat const *lhs, BfVec const *rhs) {
+  return SLOT(lhs, BFABI_SLOT_RmulVec, BfAbiMulVecFn)(lhs, rhs);
+}
 void bfMatDelete(BfMat **mat) {
   if (mat && *mat) SLOT(*mat, BFABI_SLOT_Delete, BfAbiDeleteFn)(mat);
 }
@@ -407,7 +410,32 @@ static BfVec *denseRealMulVec(BfMat const *mat, BfVec const *vec) {
   }
   return res;
 }
+/* :1508-1542 -> rmulVec_vecReal :1410-1440: result = new vec(n); dgemv with the opposite transpose */
+static BfVec *denseRealRmulVec(BfMat const *mat, BfVec const *vec) {
+  BfAbiMatDenseReal const *a = (BfAbiMatDenseReal const *)mat;
+  size_t m = bfMatGetNumRows(mat), n = bfMatGetNumCols(mat);
+  if (m != vec->size || m == 0) { setError(BFABI_ERROR_INVALID_ARGUMENTS); return NULL; }
+  if (((BfAbiVecGetTypeFn)vec->vtbl->slot[BFABI_VSLOT_GetType])(vec) != BFABI_TYPE_VEC_REAL) { setError(BFABI_ERROR_NOT_IMPLEMENTED); return NULL; }
+  if (mat->props & (BFABI_MAT_PROPS_TRANS | BFABI_MAT_PROPS_CONJ)) { setError(BFABI_ERROR_NOT_IMPLEMENTED); return NULL; }
+  BfAbiVecReal const *x = (BfAbiVecReal const *)vec;
+  BfVec *res = vecRealNewEmpty(n);
+  double *y = ((BfAbiVecReal *)res)->data;
+  ++counters.gemmCalls;
+  counters.macs += (uint64_t)m * n;
+  if (blas_dgemv) {
+    blas_dgemv(101, 112 /*CblasTrans*/, (int)m, (int)n, 1.0, a->data, (int)a->super.rowStride, x->data, (int)x->stride, 0.0, y, 1);
+  } else {
+    for (size_t j = 0; j < n; ++j) y[j] = 0;
+    for (size_t i = 0; i < m; ++i) {
+      double const *row = a->data + i * a->super.rowStride;
+      double xi = x->data[i * x->stride];
+      for (size_t j = 0; j < n; ++j) y[j] += row[j * a->super.colStride] * xi;
+    }
+  }
+  return res;
+}
 static BfAbiMatVtable MatDenseRealVtable = {.slot = {
+  [BFABI_SLOT_RmulVec] = (void *)denseRealRmulVec,
   [BFABI_SLOT_Delete] = (void *)denseRealDelete,
   [BFABI_SLOT_GetType] = (void *)denseRealGetType,
   [BFABI_SLOT_NumBytes] = (void *)denseRealNumBytes,
@@ -461,7 +489,10 @@ static BfVec *identityMulVec(BfMat const *mat, BfVec const *vec) {
   if (mat->numRows != mat->numCols) { setError(BFABI_ERROR_NOT_IMPLEMENTED); return NULL; }
   return ((BfAbiVecCopyFn)vec->vtbl->slot[BFABI_VSLOT_Copy])(vec);
 }
+/* src/mat_identity.c:183-198 RmulVec: square only, result = copy(vec) */
+static BfVec *identityRmulVec(BfMat const *mat, BfVec const *vec) { return identityMulVec(mat, vec); }
 static BfAbiMatVtable MatIdentityVtable = {.slot = {
+  [BFABI_SLOT_RmulVec] = (void *)identityRmulVec,
   [BFABI_SLOT_Delete] = (void *)identityDelete,
   [BFABI_SLOT_GetType] = (void *)identityGetType,
   [BFABI_SLOT_NumBytes] = (void *)identityNumBytes,
@@ -572,7 +603,30 @@ static BfVec *blockDiagMulVec(BfMat const *mat, BfVec const *vec) {
   }
   return result;
 }
+/* src/mat_block_diag.c:458-505 */
+static BfVec *blockDiagRmulVec(BfMat const *mat, BfVec const *vec) {
+  BfAbiMatBlock const *matBlock = (BfAbiMatBlock const *)mat;
+  if (bfMatGetNumRows(mat) != vec->size) { setError(BFABI_ERROR_NOT_IMPLEMENTED); return NULL; }
+  if (((BfAbiVecGetTypeFn)vec->vtbl->slot[BFABI_VSLOT_GetType])(vec) != BFABI_TYPE_VEC_REAL) { setError(BFABI_ERROR_NOT_IMPLEMENTED); return NULL; }
+  BfVec *result = vecRealNewEmpty(bfMatGetNumCols(mat));
+  size_t numBlocks = blockDiagNumBlocks(mat);
+  for (size_t k = 0; k < numBlocks; ++k) {
+    BfMat const *block = matBlock->block[k];
+    size_t i0 = matBlock->rowOffset[k];
+    size_t i1 = i0 + bfMatGetNumRows(block);
+    size_t j0 = matBlock->colOffset[k];
+    size_t j1 = j0 + bfMatGetNumCols(block);
+    BfVec *subvecView = vecRealGetSubvecView((BfVec *)vec, i0, i1);
+    BfVec *tmp = bfMatRmulVec(block, subvecView);
+    bfVecDelete(&subvecView);
+    if (tmp) vecRealSetRange(result, j0, j1, tmp);
+    bfVecDelete(&tmp);   /* the reference leaks tmp here (:497-499) */
+    if (currentError) { bfVecDelete(&result); return NULL; }
+  }
+  return result;
+}
 static BfAbiMatVtable MatBlockDiagVtable = {.slot = {
+  [BFABI_SLOT_RmulVec] = (void *)blockDiagRmulVec,
   [BFABI_SLOT_Delete] = (void *)blockDiagDelete,
   [BFABI_SLOT_GetType] = (void *)blockDiagGetType,
   [BFABI_SLOT_NumBytes] = (void *)blockDiagNumBytes,
@@ -668,7 +722,32 @@ static BfVec *blockCooMulVec(BfMat const *mat, BfVec const *vec) {
   }
   return result;
 }
+/* src/mat_block_coo.c:476-520 */
+static BfVec *blockCooRmulVec(BfMat const *mat, BfVec const *vec) {
+  BfAbiMatBlock const *matBlock = (BfAbiMatBlock const *)mat;
+  BfAbiMatBlockCoo const *coo = (BfAbiMatBlockCoo const *)mat;
+  if (bfMatGetNumRows(mat) != vec->size) { setError(BFABI_ERROR_NOT_IMPLEMENTED); return NULL; }
+  if (((BfAbiVecGetTypeFn)vec->vtbl->slot[BFABI_VSLOT_GetType])(vec) != BFABI_TYPE_VEC_REAL) { setError(BFABI_ERROR_NOT_IMPLEMENTED); return NULL; }
+  BfVec *result = vecRealNewWithValue(bfMatGetNumCols(mat), 0);
+  for (size_t k = 0; k < coo->numBlocks; ++k) {
+    BfMat const *block = matBlock->block[k];
+    size_t i0 = matBlock->rowOffset[coo->rowInd[k]];
+    size_t i1 = i0 + bfMatGetNumRows(block);
+    size_t j0 = matBlock->colOffset[coo->colInd[k]];
+    size_t j1 = j0 + bfMatGetNumCols(block);
+    BfVec *subvecView = vecRealGetSubvecView((BfVec *)vec, i0, i1);
+    BfVec *tmp = bfMatRmulVec(block, subvecView);
+    bfVecDelete(&subvecView);
+    BfVec *resultSubvecView = vecRealGetSubvecView(result, j0, j1);
+    if (tmp) vecRealAddInplace(resultSubvecView, tmp);
+    bfVecDelete(&resultSubvecView);
+    bfVecDelete(&tmp);
+    if (currentError) { bfVecDelete(&result); return NULL; }
+  }
+  return result;
+}
 static BfAbiMatVtable MatBlockCooVtable = {.slot = {
+  [BFABI_SLOT_RmulVec] = (void *)blockCooRmulVec,
   [BFABI_SLOT_Delete] = (void *)blockCooDelete,
   [BFABI_SLOT_GetType] = (void *)blockCooGetType,
   [BFABI_SLOT_NumBytes] = (void *)blockCooNumBytes,
@@ -768,7 +847,33 @@ static BfVec *blockDenseMulVec(BfMat const *mat, BfVec const *vec) {
   }
   return result;
 }
+/* src/mat_block_dense.c:696-758 */
+static BfVec *blockDenseRmulVec(BfMat const *mat, BfVec const *vec) {
+  BfAbiMatBlock const *matBlock = (BfAbiMatBlock const *)mat;
+  if (((BfAbiVecGetTypeFn)vec->vtbl->slot[BFABI_VSLOT_GetType])(vec) != BFABI_TYPE_VEC_REAL) { setError(BFABI_ERROR_NOT_IMPLEMENTED); return NULL; }
+  size_t numRowBlocks = mat->numRows, numColBlocks = mat->numCols;
+  BfVec *result = vecRealNewWithValue(bfMatGetNumCols(mat), 0);
+  for (size_t j = 0; j < numColBlocks; ++j) {
+    size_t j0 = matBlock->colOffset[j], j1 = matBlock->colOffset[j + 1];
+    if (j0 == j1) continue;
+    BfVec *resultSubvecView = vecRealGetSubvecView(result, j0, j1);
+    for (size_t i = 0; i < numRowBlocks; ++i) {
+      BfMat const *block = matBlock->block[i * numColBlocks + j];
+      size_t i0 = matBlock->rowOffset[i], i1 = matBlock->rowOffset[i + 1];
+      if (i0 == i1) continue;
+      BfVec *subvecView = vecRealGetSubvecView((BfVec *)vec, i0, i1);
+      BfVec *tmp = bfMatRmulVec(block, subvecView);
+      if (tmp) vecRealAddInplace(resultSubvecView, tmp);
+      bfVecDelete(&tmp);
+      bfVecDelete(&subvecView);
+      if (currentError) { bfVecDelete(&resultSubvecView); bfVecDelete(&result); return NULL; }
+    }
+    bfVecDelete(&resultSubvecView);
+  }
+  return result;
+}
 static BfAbiMatVtable MatBlockDenseVtable = {.slot = {
+  [BFABI_SLOT_RmulVec] = (void *)blockDenseRmulVec,
   [BFABI_SLOT_Delete] = (void *)blockDenseDelete,
   [BFABI_SLOT_GetType] = (void *)blockDenseGetType,
   [BFABI_SLOT_NumBytes] = (void *)blockDenseNumBytes,
@@ -835,7 +940,23 @@ static BfVec *productMulVec(BfMat const *matProduct, BfVec const *vec) {
   }
   return result;
 }
+/* src/mat_product.c:314-345: factors in order 0, 1, ..., L-1 */
+static BfVec *productRmulVec(BfMat const *matProduct, BfVec const *vec) {
+  size_t numFactors = productNumFactors(matProduct);
+  size_t i = 0;
+  BfVec *prev = bfMatRmulVec(productFactor(matProduct, i), vec);
+  BfVec *result = prev;
+  if (currentError) { bfVecDelete(&prev); return NULL; }
+  while (++i < numFactors) {
+    result = bfMatRmulVec(productFactor(matProduct, i), prev);
+    bfVecDelete(&prev);
+    if (currentError) { bfVecDelete(&result); return NULL; }
+    prev = result;
+  }
+  return result;
+}
 static BfAbiMatVtable MatProductVtable = {.slot = {
+  [BFABI_SLOT_RmulVec] = (void *)productRmulVec,
   [BFABI_SLOT_Delete] = (void *)productDelete,
   [BFABI_SLOT_GetType] = (void *)productGetType,
   [BFABI_SLOT_NumBytes] = (void *)productNumBytes,

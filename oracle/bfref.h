@@ -37,6 +37,7 @@ typedef BfAbiVec BfVec;
 /* ---- public interface, reference names (include/bf/mat.h:43-110) ---------- */
 BfMat *bfMatMul(BfMat const *lhs, BfMat const *rhs);          /* src/mat.c:183 */
 BfVec *bfMatMulVec(BfMat const *lhs, BfVec const *rhs);       /* src/mat.c:187 */
+BfVec *bfMatRmulVec(BfMat const *lhs, BfVec const *rhs);      /* src/mat.c:197: x^T A as a vector */
 void bfMatDelete(BfMat **mat);                                /* src/mat.c:43  */
 size_t bfMatGetNumRows(BfMat const *mat);                     /* src/mat.c:79  */
 size_t bfMatGetNumCols(BfMat const *mat);                     /* src/mat.c:83  */

@@ -37,6 +37,7 @@ def load():
     sz = C.c_size_t
     lib.bfMatMul.argtypes = [vp, vp]; lib.bfMatMul.restype = vp
     lib.bfMatMulVec.argtypes = [vp, vp]; lib.bfMatMulVec.restype = vp
+    lib.bfMatRmulVec.argtypes = [vp, vp]; lib.bfMatRmulVec.restype = vp
     lib.bfMatDelete.argtypes = [C.POINTER(vp)]; lib.bfMatDelete.restype = None
     lib.bfVecDelete.argtypes = [C.POINTER(vp)]; lib.bfVecDelete.restype = None
     for f in ("bfMatGetNumRows", "bfMatGetNumCols", "bfMatNumBytes"):
@@ -200,6 +201,24 @@ def mat_mul_vec(a: Mat, x: np.ndarray) -> np.ndarray:
         raise RuntimeError(f"oracle bfMatMulVec returned NULL (BfError {err})")
     m = a.shape[0]
     buf = (C.c_double * m).from_address(lib.bfVecRealData(r))
+    out = np.frombuffer(buf, dtype=np.float64).copy()
+    lib.bfVecDelete(C.byref(r))
+    return out
+
+
+def mat_rmul_vec(a: Mat, x: np.ndarray) -> np.ndarray:
+    """y = bfMatRmulVec(A, x) = A^T x with x a real vector of length numRows."""
+    lib = load()
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    v = C.c_void_p(lib.bfVecRealNewFromPtr(len(x), x.ctypes.data, 0))
+    r = C.c_void_p(lib.bfMatRmulVec(a.ptr, v))
+    lib.bfVecDelete(C.byref(v))
+    if not r:
+        err = lib.bfGetError()
+        lib.bfClearError()
+        raise RuntimeError(f"oracle bfMatRmulVec returned NULL (BfError {err})")
+    n = a.shape[1]
+    buf = (C.c_double * n).from_address(lib.bfVecRealData(r))
     out = np.frombuffer(buf, dtype=np.float64).copy()
     lib.bfVecDelete(C.byref(r))
     return out

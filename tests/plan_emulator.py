@@ -26,8 +26,9 @@ def _view(ptr, count, dtype):
     return np.frombuffer(buf, dtype=dtype)
 
 
-def run_plan(op, x):
-    """op: butterfly_amd.operator.HipOperator compiled with FLAG_PLAN_ONLY."""
+def run_plan(op, x, transpose=False):
+    """op: butterfly_amd.operator.HipOperator compiled with FLAG_PLAN_ONLY
+    (and FLAG_ADJOINT for transpose=True: the plan of A^T over the same arena)."""
     lib = _capi.load()
     info = _capi.BfhipPlanInfo()
     info.structSize = C.sizeof(info)
@@ -41,9 +42,13 @@ def run_plan(op, x):
     if one_d:
         x = x[:, None]
     nrhs = x.shape[1]
-    y = np.full((int(info.numRows), nrhs), np.nan, dtype=dt)
-    temp = np.full((int(info.tempElems), nrhs), np.nan, dtype=dt)
-    for s in range(int(info.numStages)):
+    stage0 = int(info.numStages) if transpose else 0
+    nstages = int(info.numStagesT) if transpose else int(info.numStages)
+    if transpose:
+        assert nstages > 0, "operator has no transposed plan (FLAG_ADJOINT)"
+    y = np.full((int(info.numCols if transpose else info.numRows), nrhs), np.nan, dtype=dt)
+    temp = np.full((int(max(info.tempElems, info.tempElemsT)), nrhs), np.nan, dtype=dt)
+    for s in range(stage0, stage0 + nstages):
         sv = _capi.BfhipStageView()
         sv.structSize = C.sizeof(sv)
         _capi.check(lib.bfhipPlanGetStage(op.handle, s, C.byref(sv)))
@@ -51,7 +56,7 @@ def run_plan(op, x):
         pieces = _view(sv.pieces, int(sv.numPieces), _capi.PIECE_DTYPE)
         for it in items:
             mr = int(it["mrFlags"]) & 0xFFFF
-            mr_pad = (mr + epl - 1) // epl * epl
+            mr_pad = mr if transpose else (mr + epl - 1) // epl * epl
             acc = np.zeros((mr, nrhs), dtype=dt)
             for pc in pieces[int(it["pieceBegin"]):int(it["pieceBegin"]) + int(it["numPieces"])]:
                 src = x if (int(pc["flags"]) & BF_PIECE_IN_X) else temp
@@ -59,8 +64,15 @@ def run_plan(op, x):
                 if int(pc["flags"]) & BF_PIECE_IDENTITY:
                     acc += src[io:io + mr]
                     continue
-                assert n <= info.xcap
                 d0 = int(pc["dataOff"])
+                if transpose:
+                    # lanes j < mr on the columns of a forward piece: element (step s, lane j) = arena[d0 + j*ld + s]
+                    ld = int(pc["ld"])
+                    assert ld >= n and mr <= 64
+                    idx = d0 + np.arange(mr)[:, None] * ld + np.arange(n)[None, :]
+                    acc += arena[idx] @ src[io:io + n]
+                    continue
+                assert n <= info.xcap
                 a = arena[d0:d0 + mr_pad * n].reshape(n, mr_pad).T[:mr]
                 acc += a @ src[io:io + n]
             dst = y if (int(it["mrFlags"]) & BF_ITEM_OUT_Y) else temp

@@ -289,3 +289,62 @@ def test_rhs_block_kernel_matches_oracle(helm2_cases, nrhs):
     y1 = op.apply_host(np.ascontiguousarray(x[:, 1]))
     assert rel(y[:, 1], y1) <= TOL
     op.close()
+
+
+# ---------------------------------------------------------------------------
+# adjoint apply (RmulVec of the reference): the plan of A^T over the same arena
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("seed", range(6))
+def test_transposed_apply_random_real_graphs_on_gpu(seed):
+    import randgraph
+    from butterfly_amd import _capi
+    from butterfly_amd.operator import HipOperator
+    from oracle import bfref
+    rng = np.random.default_rng(3000 + seed)
+    desc, vals = randgraph.random_real_operand(rng, depth=int(rng.integers(1, 5)), size_hint=int(rng.integers(8, 300)))
+    A = bfref.from_desc(desc, vals)
+    x = rng.standard_normal(desc.rows[desc.root])
+    want = bfref.mat_rmul_vec(A, x)
+    op = HipOperator.from_bfmat(A.ptr.value, flags=_capi.FLAG_ADJOINT)
+    assert rel(op.apply_transpose_host(x) + 1, want + 1) <= TOL
+    xf = rng.standard_normal(desc.cols[desc.root])
+    assert rel(op.apply_host(xf) + 1, bfref.mat_mul_vec(A, xf) + 1) <= TOL
+    op.close()
+    op32 = HipOperator.from_desc(desc, vals, flags=_capi.FLAG_ADJOINT, demote_to_f32=True)
+    assert rel(op32.apply_transpose_host(x) + 1, want + 1) <= 2e-5
+    op32.close()
+
+
+def test_transposed_apply_helm2_on_gpu(helm2_cases):
+    from butterfly_amd import _capi
+    from butterfly_amd.operator import HipOperator
+    from oracle import helm2_build as hb
+    n, k = 4096, 100
+    desc, tp, vals = helm2_cases(n, k)
+    op = HipOperator.from_desc(desc, vals, flags=_capi.FLAG_ADJOINT)
+    x = hb.complex_randn(n, 3)
+    y = op.apply_transpose_host(x)
+    assert rel(y, hb.kernel_matrix(k, tp, tp).T @ x) <= 1e-9
+    assert rel(y, op.apply_host(x)) <= 1e-9              # S^T = S for the single-layer kernel
+    op.close()
+
+
+def test_rmulvec_shim_real_operator():
+    """cov_matvec-style use: z = Phi (Phi^T v) through the vtable shim's RmulVec + MulVec
+    (examples/covariance/lbo_cov.c:48-60)."""
+    import randgraph
+    from butterfly_amd import _capi
+    from butterfly_amd.operator import HipOperator
+    from oracle import bfref
+    rng = np.random.default_rng(78)
+    desc, vals = randgraph.random_operand(rng, depth=3, size_hint=120, cplx=False, m=140, n=140)
+    A = bfref.from_desc(desc, vals)
+    v = rng.standard_normal(140)
+    want = bfref.mat_mul_vec(A, bfref.mat_rmul_vec(A, v))
+    op = HipOperator.from_bfmat(A.ptr.value, flags=_capi.FLAG_ADJOINT)
+    a_hip = C.c_void_p(op.as_bfmat())
+    h = type("H", (), {"ptr": a_hip, "shape": (140, 140)})()
+    got = bfref.mat_mul_vec(h, bfref.mat_rmul_vec(h, v))
+    assert rel(got, want) <= TOL
+    bfref.load().bfMatDelete(C.byref(a_hip))
+    op.close()

@@ -199,3 +199,44 @@ def test_unsupported_node_type_is_a_type_error():
     assert ERROR_NAMES[rc] == "BF_ERROR_TYPE_ERROR"
     p = C.c_void_p(shim)
     bfref.load().bfMatDelete(C.byref(p))
+
+
+# ---- adjoint plan (A^T x): RmulVec of the reference --------------------------
+ADJ = dict(flags=_capi.FLAG_PLAN_ONLY | _capi.FLAG_ADJOINT)
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_transposed_plan_random_real_graphs(seed):
+    rng = np.random.default_rng(3000 + seed)
+    desc, vals = randgraph.random_real_operand(rng, depth=int(rng.integers(1, 5)), size_hint=int(rng.integers(8, 300)))
+    m = desc.rows[desc.root]
+    x = rng.standard_normal(m)
+    A = bfref.from_desc(desc, vals)
+    want = bfref.mat_rmul_vec(A, x)                       # oracle: bfMatRmulVec
+    assert rel(want + 1, randgraph.densify(desc, vals, desc.root).T @ x + 1) < 1e-12
+    for demote in (False, True):
+        op = HipOperator.from_desc(desc, vals, demote_to_f32=demote, **ADJ)
+        assert rel(plan_emulator.run_plan(op, x, transpose=True) + 1, want + 1) < (2e-5 if demote else 1e-12)
+        # the forward plan is untouched by the adjoint flag
+        xf = rng.standard_normal(desc.cols[desc.root])
+        assert rel(plan_emulator.run_plan(op, xf) + 1, bfref.mat_mul_vec(A, xf) + 1) < (2e-5 if demote else 1e-12)
+
+
+def test_transposed_plan_helm2(helm2_cases):
+    n, k = 2048, 128
+    desc, tp, vals = helm2_cases(n, k)
+    x = hb.complex_randn(n, 4)
+    dense_t = hb.kernel_matrix(k, tp, tp).T @ x            # plain transpose, no conjugation
+    op = HipOperator.from_desc(desc, vals, **ADJ)
+    y = plan_emulator.run_plan(op, x, transpose=True)
+    assert rel(y, dense_t) < 1e-9
+    # single-layer kernel on a symmetric point set: S^T = S, so A^T x must agree with A x to truncation accuracy
+    assert rel(y, plan_emulator.run_plan(op, x)) < 1e-9
+
+
+def test_transpose_needs_the_adjoint_flag():
+    desc, vals, ex = load_fixture(os.path.join(GOLD, "helm2_one_block_n2048_k128.npz"))
+    op = HipOperator.from_desc(desc, vals, **PLAN)
+    with pytest.raises(_capi.BfhipError) as e:
+        op.apply_transpose_host(np.zeros(op.shape[0], dtype=complex))
+    assert e.value.code == 1
