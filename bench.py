@@ -109,6 +109,7 @@ def main():
     ap.add_argument("--dtype", choices=["c128", "f64", "f32"], default="c128",
                     help="c128: the fac_helm2 operand (headline).  f64 / f32: the SAME block layout with real values, a proxy "
                          "for the real BfMatDenseReal path (BASELINE.json configs[4]); fp32 is the build's extension")
+    ap.add_argument("--adjoint", action="store_true", help="also time y = A^T x (RmulVec path) and report it next to the headline")
     ap.add_argument("--pcie", action="store_true", help="also time the host-buffer path (H2D + apply + D2H)")
     ap.add_argument("--force-collective", action="store_true",
                     help="rehearsal: initialise RCCL and run the step's collective even with one rank")
@@ -173,7 +174,7 @@ def main():
         root, local_rows = hs.shard_desc(desc, mine)
     else:
         root, local_rows = hs.shard_desc_blocks(desc, mine), n
-    op = HipOperator.from_desc(desc, None, root=root, device=local_rank, flags=_capi.FLAG_PROFILE,
+    op = HipOperator.from_desc(desc, None, root=root, device=local_rank, flags=_capi.FLAG_PROFILE | (_capi.FLAG_ADJOINT if args.adjoint else 0),
                                seed=args.seed, max_rhs=args.nrhs, demote_to_f32=(args.dtype == "f32"))
     torch.cuda.synchronize()
     t_compile = time.time() - t0
@@ -279,6 +280,18 @@ def main():
             "roofline": roofline,
             "hbm_gbs_whole_step": (total_leaf * esz / 1e9) / (elapsed / args.steps),
         }
+        if args.adjoint and world == 1:
+            xt = torch.from_numpy(x_host).to(dev).to(tdtype)
+            for _ in range(2):
+                yt = op.apply_transpose_device(xt)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                yt = op.apply_transpose_device(xt)
+            torch.cuda.synchronize()
+            adj_ms = (time.perf_counter() - t1) / args.steps * 1e3
+            out["adjoint"] = {"ms_per_apply": adj_ms, "matvec_per_s": args.nrhs / (adj_ms / 1e3),
+                              "hbm_gbs": total_leaf * esz / 1e9 / (adj_ms / 1e3)}
         if args.pcie:
             out["pcie_inclusive"] = {"ms_per_apply": pcie_ms, "matvec_per_s": args.nrhs / (pcie_ms / 1e3),
                                      "note": "bfhipApply on pageable host buffers: H2D x + apply + D2H y"}

@@ -416,109 +416,115 @@ __global__ __launch_bounds__(BF_WAVES_PER_WG * 64) void bfStageKernelReal(StageP
 
 
 // ---------------------------------------------------------------------------
-// transposed stage kernels: y = A^T x on the forward plan's packed pieces.
-// A forward piece is column-major (mrPad x ncols); here lanes own its COLUMNS
-// (one output each) and walk down them, so a lane reads consecutive addresses
-// and the 64 lanes of a load touch 64 different lines -- each line is then
-// consumed by the same lane over the next steps (the step loop is unrolled by
-// 8 so those hits are back to back).  No cross-lane reduction, one owner per
-// output, same slots + reduce machinery for overlapping outputs.
-// (reference: RmulVec of every container, see include/bfhip.h)
+// transposed stage kernel: y = A^T x on the forward plan's packed pieces
+// (reference: RmulVec of every container, see include/bfhip.h).
+//
+// An item is <= 16 columns of A (16 outputs); a piece is a forward piece's
+// sub-block of those columns: column-major, `ld` elements per column, hence
+// ONE contiguous run of 16*ld elements.  The wave copies that run into LDS with
+// flat, fully coalesced 16-byte loads (HBM sees the same streaming pattern as
+// the forward kernel), then reads it back transposed: lane = (column jj,
+// row-group sg), 4 row groups per column, each lane walking the 16-byte units
+// of its column with a per-column skew ((t + jj) mod units) so that the 16
+// columns of a group hit 16 different LDS slots even when ld is a multiple of
+// 16.  Lanes own outputs: no cross-lane reduction in the loop; the 4 row
+// groups are combined once per item through LDS in fixed order.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(BF_WAVES_PER_WG * 64) void bfStageKernelC128T(StageParams p) {
-  __shared__ __attribute__((aligned(16))) double2 lds[BF_WAVES_PER_WG][BF_XCAP];
-  int const wave = threadIdx.x >> 6;
-  int const lane = threadIdx.x & 63;
-  uint32_t item = __builtin_amdgcn_readfirstlane(blockIdx.x * BF_WAVES_PER_WG + wave);
-  if (item >= p.numItems) return;
-  BfDevItem const it = p.items[item];
-  uint32_t const mr = it.mrFlags & 0xffffu;           // columns of A in this item (<= 64)
-  bool const active = (uint32_t)lane < mr;
-  uint32_t const j = active ? (uint32_t)lane : mr - 1;
-  double2 *xs = lds[wave];
-  double2 const *arena = (double2 const *)p.arena;
-  uint32_t const nrhs = p.nrhs;
-  double2 *out = (it.mrFlags & BF_ITEM_OUT_Y) ? (double2 *)p.y : (double2 *)p.temp;
-  for (uint32_t q = 0; q < nrhs; ++q) {
-    double accr = 0.0, acci = 0.0;
-    for (uint32_t pi = 0; pi < it.numPieces; ++pi) {
-      BfDevPiece const pc = p.pieces[it.pieceBegin + pi];
-      double2 const *xin = (pc.flags & BF_PIECE_IN_X) ? (double2 const *)p.x : (double2 const *)p.temp;
-      xin += (uint64_t)pc.inOff * nrhs + q;
-      if (pc.flags & BF_PIECE_IDENTITY) {
-        if (active) { double2 v = xin[(uint64_t)j * nrhs]; accr += v.x; acci += v.y; }
-        continue;
-      }
-      uint32_t const n = pc.ncols;                     // steps = rows of the forward piece (<= 64)
-      waveSync();
-      for (uint32_t s = lane; s < n; s += 64) xs[s] = xin[(uint64_t)s * nrhs];
-      waveSync();
-      double2 const *ap = arena + pc.dataOff + (uint64_t)j * pc.ld;
-      uint32_t s = 0;
-      for (; s + 8 <= n; s += 8) {
-        double2 a[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) a[u] = bfLoadStream(ap + s + u);
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          double2 xv = xs[s + u];
-          accr = fma(a[u].x, xv.x, accr); accr = fma(-a[u].y, xv.y, accr);
-          acci = fma(a[u].x, xv.y, acci); acci = fma(a[u].y, xv.x, acci);
-        }
-      }
-      for (; s < n; ++s) {
-        double2 a = bfLoadStream(ap + s);
-        double2 xv = xs[s];
-        accr = fma(a.x, xv.x, accr); accr = fma(-a.y, xv.y, accr);
-        acci = fma(a.x, xv.y, acci); acci = fma(a.y, xv.x, acci);
-      }
-    }
-    if (active) out[((uint64_t)it.outOff + lane) * nrhs + q] = make_double2(accr, acci);
-  }
-}
+#define BF_T_COLS 16
+#define BF_T_TILE_BYTES (BF_T_COLS * 1024)          /* 16 columns x (ld * elemSize <= 1 KiB) */
+#define BF_T_X_BYTES 1024
 
 template <int DT>
-__global__ __launch_bounds__(BF_WAVES_PER_WG * 64) void bfStageKernelRealT(StageParams p) {
+__global__ __launch_bounds__(BF_WAVES_PER_WG * 64) void bfStageKernelT(StageParams p) {
   using S = typename Traits<DT>::S;
-  constexpr int EPL = Traits<DT>::EPL;
-  struct __attribute__((aligned(16))) V { S v[EPL]; };
-  __shared__ __attribute__((aligned(16))) unsigned char ldsRaw[BF_WAVES_PER_WG][BF_WAVE_LDS_BYTES];
+  constexpr int EPL = Traits<DT>::EPL;              // rows per 16-byte unit (complex: 1)
+  constexpr int NC = Traits<DT>::CPLX ? 2 : 1;      // scalars per element
+  constexpr int UNIT = EPL * NC;                    // scalars per 16-byte unit
+  struct __attribute__((aligned(16))) U { S v[UNIT]; };
+  __shared__ __attribute__((aligned(16))) unsigned char ldsRaw[BF_WAVES_PER_WG][BF_T_TILE_BYTES + BF_T_X_BYTES];
   int const wave = threadIdx.x >> 6;
   int const lane = threadIdx.x & 63;
   uint32_t item = __builtin_amdgcn_readfirstlane(blockIdx.x * BF_WAVES_PER_WG + wave);
   if (item >= p.numItems) return;
   BfDevItem const it = p.items[item];
-  uint32_t const mr = it.mrFlags & 0xffffu;
-  bool const active = (uint32_t)lane < mr;
-  uint32_t const j = active ? (uint32_t)lane : mr - 1;
-  S *xs = (S *)ldsRaw[wave];
-  S const *arena = (S const *)p.arena;
+  uint32_t const mr = it.mrFlags & 0xffffu;          // columns of A in this item (<= 16)
+  uint32_t const jj = lane & 15, sg = lane >> 4;
+  bool const colOk = jj < mr;
+  uint32_t const jc = colOk ? jj : mr - 1;
+  U *tile = (U *)ldsRaw[wave];
+  S *xs = (S *)(ldsRaw[wave] + BF_T_TILE_BYTES);
+  U const *arena = (U const *)p.arena;               // 16-byte units
   uint32_t const nrhs = p.nrhs;
   S *out = (it.mrFlags & BF_ITEM_OUT_Y) ? (S *)p.y : (S *)p.temp;
+
   for (uint32_t q = 0; q < nrhs; ++q) {
-    S acc = 0;
+    S acc[NC];
+#pragma unroll
+    for (int k = 0; k < NC; ++k) acc[k] = 0;
     for (uint32_t pi = 0; pi < it.numPieces; ++pi) {
       BfDevPiece const pc = p.pieces[it.pieceBegin + pi];
       S const *xin = (pc.flags & BF_PIECE_IN_X) ? (S const *)p.x : (S const *)p.temp;
-      xin += (uint64_t)pc.inOff * nrhs + q;
+      xin += ((uint64_t)pc.inOff * nrhs + q) * NC;
       if (pc.flags & BF_PIECE_IDENTITY) {
-        if (active) acc += xin[(uint64_t)j * nrhs];
+        if (sg == 0 && colOk) {
+#pragma unroll
+          for (int k = 0; k < NC; ++k) acc[k] += xin[(uint64_t)jj * nrhs * NC + k];
+        }
         continue;
       }
-      uint32_t const n = pc.ncols;                     // rows of the forward piece; pc.ld = rows padded to EPL
-      waveSync();
-      for (uint32_t s = lane; s < pc.ld; s += 64) xs[s] = s < n ? xin[(uint64_t)s * nrhs] : (S)0;
-      waveSync();
-      V const *ap = (V const *)(arena + pc.dataOff + (uint64_t)j * pc.ld);   // 16-byte aligned: ld % EPL == 0
-      uint32_t const slots = pc.ld / EPL;
-#pragma unroll 4
-      for (uint32_t s = 0; s < slots; ++s) {
-        V a = bfLoadStreamV(ap + s);
+      uint32_t const n = pc.ncols;                   // rows of the forward piece
+      uint32_t const units = pc.ld / EPL;            // 16-byte units per column
+      uint32_t const total = mr * units;             // contiguous units of this piece
+      waveSync();                                    // previous piece fully consumed
+      U const *src = arena + pc.dataOff / EPL;
+      for (uint32_t e = lane; e < total; e += 256) { // 4 loads in flight per lane
+        U a0, a1, a2, a3;
+        uint32_t e1 = e + 64, e2 = e + 128, e3 = e + 192;
+        a0 = bfLoadStreamV(src + e);
+        if (e1 < total) a1 = bfLoadStreamV(src + e1);
+        if (e2 < total) a2 = bfLoadStreamV(src + e2);
+        if (e3 < total) a3 = bfLoadStreamV(src + e3);
+        tile[e] = a0;
+        if (e1 < total) tile[e1] = a1;
+        if (e2 < total) tile[e2] = a2;
+        if (e3 < total) tile[e3] = a3;
+      }
+      for (uint32_t s = lane; s < pc.ld; s += 64) {
 #pragma unroll
-        for (int e = 0; e < EPL; ++e) acc = fma(a.v[e], xs[s * EPL + e], acc);
+        for (int k = 0; k < NC; ++k) xs[s * NC + k] = s < n ? xin[(uint64_t)s * nrhs * NC + k] : (S)0;
+      }
+      waveSync();
+      U const *col = tile + jc * units;
+      uint32_t const skew = jc % units;
+      for (uint32_t t = sg; t < units; t += 4) {
+        uint32_t u = t + skew;
+        if (u >= units) u -= units;
+        U a = col[u];
+        if (Traits<DT>::CPLX) {
+          S xr = xs[2 * u], xi = xs[2 * u + 1];
+          acc[0] = fma(a.v[0], xr, acc[0]); acc[0] = fma(-a.v[1], xi, acc[0]);
+          acc[NC - 1] = fma(a.v[0], xi, acc[NC - 1]); acc[NC - 1] = fma(a.v[1], xr, acc[NC - 1]);
+        } else {
+#pragma unroll
+          for (int e = 0; e < EPL; ++e) acc[0] = fma(a.v[e], xs[u * EPL + e], acc[0]);
+        }
       }
     }
-    if (active) out[((uint64_t)it.outOff + lane) * nrhs + q] = acc;
+    // combine the 4 row groups of each column (fixed order) and store
+    waveSync();
+#pragma unroll
+    for (int k = 0; k < NC; ++k) xs[lane * NC + k] = acc[k];
+    waveSync();
+    if (sg == 0 && colOk) {
+      S r[NC];
+#pragma unroll
+      for (int k = 0; k < NC; ++k) r[k] = 0;
+      for (uint32_t g = 0; g < 4; ++g)
+#pragma unroll
+        for (int k = 0; k < NC; ++k) r[k] += xs[(g * 16 + jj) * NC + k];
+#pragma unroll
+      for (int k = 0; k < NC; ++k) out[(((uint64_t)it.outOff + jj) * nrhs + q) * NC + k] = r[k];
+    }
   }
 }
 
@@ -758,9 +764,9 @@ int bfdevLaunchStage(BfLaunchArgs const *a, void *stream) {
   uint32_t grid = (uint32_t)((a->numItems + BF_WAVES_PER_WG - 1) / BF_WAVES_PER_WG);
   hipStream_t s = (hipStream_t)stream;
   if (a->transposed) {
-    if (a->dtype == BFHIP_C128) hipLaunchKernelGGL(bfStageKernelC128T, dim3(grid), dim3(BF_WAVES_PER_WG * 64), 0, s, p);
-    else if (a->dtype == BFHIP_F64) hipLaunchKernelGGL(bfStageKernelRealT<BFHIP_F64>, dim3(grid), dim3(BF_WAVES_PER_WG * 64), 0, s, p);
-    else if (a->dtype == BFHIP_F32) hipLaunchKernelGGL(bfStageKernelRealT<BFHIP_F32>, dim3(grid), dim3(BF_WAVES_PER_WG * 64), 0, s, p);
+    if (a->dtype == BFHIP_C128) hipLaunchKernelGGL(bfStageKernelT<BFHIP_C128>, dim3(grid), dim3(BF_WAVES_PER_WG * 64), 0, s, p);
+    else if (a->dtype == BFHIP_F64) hipLaunchKernelGGL(bfStageKernelT<BFHIP_F64>, dim3(grid), dim3(BF_WAVES_PER_WG * 64), 0, s, p);
+    else if (a->dtype == BFHIP_F32) hipLaunchKernelGGL(bfStageKernelT<BFHIP_F32>, dim3(grid), dim3(BF_WAVES_PER_WG * 64), 0, s, p);
     else return bfhipFail(BFABI_ERROR_TYPE_ERROR, "unknown dtype %u", a->dtype);
     return hipFail(hipGetLastError(), "transposed stage launch");
   }

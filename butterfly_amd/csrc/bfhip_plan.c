@@ -289,9 +289,10 @@ int bfPlanBuild(BfIr const *ir, BfPlanOptions const *po, BfPlan *plan) {
   itemRows = (uint32_t)roundUp(itemRows, plan->epl);
   plan->xcap = po->xcap ? po->xcap : 256;
   if (T) {
-    /* lanes own columns of A (one output each), whatever the element size */
-    itemRows = 64;
-    plan->maxItemRows = 64;
+    /* an item is BF_T_COLS columns of A (one output each), whatever the element
+     * size: the transposed kernel tiles a forward piece as 16 columns x 4 row groups */
+    itemRows = 16;
+    plan->maxItemRows = 16;
     if (po->rowBlockEnd > 0) return bfhipFail(BFABI_ERROR_NOT_IMPLEMENTED, "transposed plan of a row-sharded operator");
   }
 
@@ -525,7 +526,7 @@ int bfPlanBuild(BfIr const *ir, BfPlanOptions const *po, BfPlan *plan) {
       for (uint64_t t = groups[g].taskBegin; t < groups[g].taskEnd; ++t) {
         Task const *tk = &b.tasks[t];
         if (ir->kind[tk->leaf] == BFHIP_NODE_IDENTITY) { piecesPerChunk += 1; colsSum += 1; }
-        else if (T) { piecesPerChunk += (tk->cols + 63) / 64 + 1; colsSum += tk->cols; }   /* upper bound: forward row chunks */
+        else if (T) { piecesPerChunk += (tk->cols + 63) / 64 + 1; colsSum += tk->cols; }   /* upper bound: forward row chunks (64*epl rows each) */
         else { piecesPerChunk += (tk->cols + plan->xcap - 1) / plan->xcap; colsSum += tk->cols; }
       }
       for (uint64_t r0 = 0; r0 < m; r0 += chunk) {
