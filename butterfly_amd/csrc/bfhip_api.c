@@ -139,7 +139,7 @@ static void packPiece(BfPlan const *pl, BfIr const *ir, BfDevPiece const *pc, Bf
       if (r < mr) {
         uint64_t i = src->row0 + r, j = src->col0 + c;
         if (data) {
-          if (cplx) { double const *e = A + 2 * (i * ldr + j * ldc); re = e[0]; im = e[1]; }
+          if (cplx && !ir->leafReal[node]) { double const *e = A + 2 * (i * ldr + j * ldc); re = e[0]; im = e[1]; }
           else re = A[i * ldr + j * ldc];
         } else {
           re = bfhip_synth_value(seed, vbase + i * n + j, 0) * scale;

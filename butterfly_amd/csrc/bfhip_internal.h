@@ -31,6 +31,7 @@ typedef struct BfIr {
   void const **leafData;       /* borrowed host pointers (valid during compile only) */
   uint64_t *leafRowStride;
   uint64_t *leafColStride;     /* element stride between columns (BfMat graphs may have colStride != 1) */
+  uint8_t *leafReal;           /* host values of this leaf are real doubles even in a complex operand (BfMatDiagReal terms) */
   uint64_t *synthBase;         /* per node: base index in the synthetic stream */
   uint64_t *topRowBlock;       /* per child of root, or NULL */
   uint32_t *depth;             /* stages needed by the subtree */

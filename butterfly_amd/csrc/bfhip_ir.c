@@ -22,7 +22,7 @@ void bfIrFree(BfIr *ir) {
   if (!ir) return;
   free(ir->kind); free(ir->rows); free(ir->cols); free(ir->childBegin);
   free(ir->childNode); free(ir->childRow0); free(ir->childCol0);
-  free(ir->leafData); free(ir->leafRowStride); free(ir->leafColStride);
+  free(ir->leafData); free(ir->leafRowStride); free(ir->leafColStride); free(ir->leafReal);
   free(ir->synthBase); free(ir->topRowBlock); free(ir->depth);
   memset(ir, 0, sizeof *ir);
 }
@@ -55,7 +55,8 @@ int bfIrFromDesc(BfhipDesc const *d, BfIr *ir) {
   ir->leafData = calloc(n, sizeof(void *));
   ir->leafRowStride = malloc(n * 8);
   ir->leafColStride = malloc(n * 8);
-  if (!ir->kind || !ir->rows || !ir->cols || !ir->childBegin || !ir->childNode || !ir->childRow0 ||
+  ir->leafReal = calloc(n ? n : 1, 1);
+  if (!ir->leafReal || !ir->kind || !ir->rows || !ir->cols || !ir->childBegin || !ir->childNode || !ir->childRow0 ||
       !ir->childCol0 || !ir->leafData || !ir->leafRowStride || !ir->leafColStride) {
     bfIrFree(ir);
     return bfhipFail(BFABI_ERROR_MEMORY_ERROR, "host OOM copying descriptor");
@@ -79,7 +80,7 @@ static int irReserveNodes(BfIr *ir, uint64_t want) {
   while (cap < want) cap *= 2;
 #define GROW(field, elt) do { void *p = realloc(ir->field, cap * (elt)); if (!p) return 1; ir->field = p; } while (0)
   GROW(kind, 1); GROW(rows, 8); GROW(cols, 8); GROW(leafData, sizeof(void *));
-  GROW(leafRowStride, 8); GROW(leafColStride, 8);
+  GROW(leafRowStride, 8); GROW(leafColStride, 8); GROW(leafReal, 1);
   { void *p = realloc(ir->childBegin, (cap + 1) * 8); if (!p) return 1; ir->childBegin = p; }
 #undef GROW
   ir->capNodes = cap;
@@ -127,6 +128,7 @@ static int walkNewNode(Walk *w, uint8_t kind, uint64_t rows, uint64_t cols, uint
   ir->leafData[i] = NULL;
   ir->leafRowStride[i] = cols;
   ir->leafColStride[i] = 1;
+  ir->leafReal[i] = 0;
   w->lists[i] = NULL;
   w->counts[i] = 0;
   *id = i;
@@ -265,6 +267,66 @@ static int walkMat(Walk *w, BfAbiMat const *mat, uint64_t *outId, int level) {
     w->ir->cols[id] = w->ir->cols[list[nf - 1].node];   /* mat_product.c:168-192 */
     w->lists[id] = list;
     w->counts[id] = nf;
+    *outId = id;
+    return 0;
+  }
+  case BFABI_TYPE_MAT_SUM: {
+    /* bfMatSumMul (src/mat_sum.c:54-83): zeros, then += every term's product.  What
+     * bfMatBlockDenseAddInplace leaves behind when a correction lands on a butterfly
+     * (src/mat_block_dense.c:486-497). */
+    BfAbiMatSum const *sum = (BfAbiMatSum const *)mat;
+    size_t nt = sum->termArr.num_elts;
+    if (!nt || !sum->termArr.data) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "sum has no terms");
+    uint64_t id;
+    if ((rc = walkNewNode(w, BFHIP_NODE_BLOCK, 0, 0, &id))) return rc;
+    WalkChild *list = malloc(nt * sizeof(WalkChild));
+    if (!list) return bfhipFail(BFABI_ERROR_MEMORY_ERROR, "host OOM while walking BfMat graph");
+    for (size_t i = 0; i < nt; ++i) {
+      uint64_t cid;
+      rc = walkMat(w, (BfAbiMat const *)sum->termArr.data[i], &cid, level + 1);
+      if (rc) { free(list); return rc; }
+      list[i].node = cid; list[i].r0 = 0; list[i].c0 = 0;
+      if (i && (w->ir->rows[cid] != w->ir->rows[list[0].node] || w->ir->cols[cid] != w->ir->cols[list[0].node])) {
+        free(list);
+        return bfhipFail(BFABI_ERROR_INCOMPATIBLE_SHAPES, "terms of a sum differ in shape");
+      }
+    }
+    w->ir->rows[id] = w->ir->rows[list[0].node];
+    w->ir->cols[id] = w->ir->cols[list[0].node];
+    w->lists[id] = list;
+    w->counts[id] = nt;
+    *outId = id;
+    return 0;
+  }
+  case BFABI_TYPE_MAT_COO_COMPLEX:
+  case BFABI_TYPE_MAT_DIAG_REAL: {
+    /* sparse corrections (Kapur-Rokhlin entries, 1/2 I): each stored entry becomes a 1 x 1
+     * leaf, entries of one row add up.  (The reference's own bfMatCooComplexMul *assigns*
+     * z * x_j to the result row, src/mat_coo_complex.c:248-251, so its last entry of a row
+     * wins; that is not reproduced.) */
+    size_t ne;
+    size_t const *ri = NULL, *ci = NULL;
+    double const *val;
+    int const isDiag = type == BFABI_TYPE_MAT_DIAG_REAL;
+    if (isDiag) { BfAbiMatDiagReal const *d = (BfAbiMatDiagReal const *)mat; ne = d->numElts; val = d->data; }
+    else { BfAbiMatCooComplex const *c = (BfAbiMatCooComplex const *)mat; ne = c->numElts; ri = c->rowInd; ci = c->colInd; val = c->value; w->sawComplex = 1; }
+    if (ne && (!val || (!isDiag && (!ri || !ci)))) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "sparse matrix arrays are NULL");
+    if (mat->props & (BFABI_MAT_PROPS_TRANS | BFABI_MAT_PROPS_CONJ)) return bfhipFail(BFABI_ERROR_NOT_IMPLEMENTED, "transposed sparse term");
+    uint64_t id;
+    if ((rc = walkNewNode(w, BFHIP_NODE_BLOCK, mat->numRows, mat->numCols, &id))) return rc;
+    WalkChild *list = malloc((ne ? ne : 1) * sizeof(WalkChild));
+    if (!list) return bfhipFail(BFABI_ERROR_MEMORY_ERROR, "host OOM while walking BfMat graph");
+    for (size_t k = 0; k < ne; ++k) {
+      size_t i = isDiag ? k : ri[k], j = isDiag ? k : ci[k];
+      if (i >= mat->numRows || j >= mat->numCols) { free(list); return bfhipFail(BFABI_ERROR_OUT_OF_RANGE, "sparse entry (%zu,%zu) out of range", i, j); }
+      uint64_t cid;
+      if ((rc = walkNewNode(w, BFHIP_NODE_DENSE, 1, 1, &cid))) { free(list); return rc; }
+      w->ir->leafData[cid] = isDiag ? (void const *)(val + k) : (void const *)(val + 2 * k);
+      w->ir->leafReal[cid] = (uint8_t)isDiag;
+      list[k].node = cid; list[k].r0 = i; list[k].c0 = j;
+    }
+    w->lists[id] = list;
+    w->counts[id] = ne;
     *outId = id;
     return 0;
   }

@@ -198,6 +198,29 @@ typedef struct BfAbiMatIdentity {
   BfAbiMat super;
 } BfAbiMatIdentity;
 
+/* mat_sum.h:15-18: terms are summed (bfMatSumMul, src/mat_sum.c:54-83) */
+typedef struct BfAbiMatSum {
+  BfAbiMat super;
+  BfAbiPtrArray termArr;
+} BfAbiMatSum;
+
+/* mat_coo_complex.h:19-30 */
+typedef struct BfAbiMatCooComplex {
+  BfAbiMat super;
+  size_t numElts;
+  size_t *rowInd;
+  size_t *colInd;
+  double *value;             /* interleaved re,im */
+  size_t capacity;
+} BfAbiMatCooComplex;
+
+/* mat_diag_real.h:15-19 */
+typedef struct BfAbiMatDiagReal {
+  BfAbiMat super;
+  size_t numElts;
+  double *data;
+} BfAbiMatDiagReal;
+
 typedef struct BfAbiVec {
   BfAbiVecVtable *vtbl;
   int props;
@@ -258,6 +281,10 @@ BFABI_SA(offsetof(BfAbiMatDense, rowStride) == 40, "dense rowStride@40");
 BFABI_SA(sizeof(BfAbiMatDenseReal) == 64, "BfMatDenseReal is 64 bytes");
 BFABI_SA(offsetof(BfAbiMatDenseReal, data) == 56, "real data@56");
 BFABI_SA(sizeof(BfAbiMatIdentity) == 32, "BfMatIdentity is 32 bytes");
+BFABI_SA(sizeof(BfAbiMatSum) == 64, "BfMatSum is 64 bytes");
+BFABI_SA(sizeof(BfAbiMatCooComplex) == 72, "BfMatCooComplex is 72 bytes");
+BFABI_SA(offsetof(BfAbiMatCooComplex, value) == 56, "coo value@56");
+BFABI_SA(sizeof(BfAbiMatDiagReal) == 48, "BfMatDiagReal is 48 bytes");
 BFABI_SA(sizeof(BfAbiVec) == 24, "BfVec is 24 bytes");
 BFABI_SA(sizeof(BfAbiVecReal) == 40, "BfVecReal is 40 bytes");
 BFABI_SA(offsetof(BfAbiVecReal, stride) == 24, "vec stride@24");

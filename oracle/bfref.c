@@ -979,6 +979,146 @@ BfMat *bfMatProductNewFromFactors(size_t numFactors, BfMat **factors) {
 }
 
 /* =========================================================================
+ * MatSum / MatCooComplex / MatDiagReal: the decorations bfMatBlockDenseAddInplace
+ * leaves in a system matrix (src/mat_block_dense.c:458-510)
+ * ========================================================================= */
+static BfAbiMatVtable MatSumVtable;
+static int sumGetType(BfMat const *m) { (void)m; return BFABI_TYPE_MAT_SUM; }
+static BfMat *sumTerm(BfMat const *m, size_t i) { return (BfMat *)((BfAbiMatSum const *)m)->termArr.data[i]; }
+static size_t sumNumTerms(BfMat const *m) { return ((BfAbiMatSum const *)m)->termArr.num_elts; }
+static size_t sumGetNumRows(BfMat const *m) { return bfMatGetNumRows(sumTerm(m, 0)); }
+static size_t sumGetNumCols(BfMat const *m) { return bfMatGetNumCols(sumTerm(m, 0)); }
+static size_t sumNumBytes(BfMat const *m) { size_t n = 0; for (size_t i = 0; i < sumNumTerms(m); ++i) n += bfMatNumBytes(sumTerm(m, i)); return n; }
+static void sumDelete(BfMat **mat) {
+  BfAbiMatSum *s = (BfAbiMatSum *)*mat;
+  for (size_t i = 0; i < s->termArr.num_elts; ++i) { BfMat *t = s->termArr.data[i]; bfMatDelete(&t); }
+  free(s->termArr.data);
+  free(s);
+  *mat = NULL;
+}
+/* src/mat_sum.c:54-83 */
+static BfMat *sumMul(BfMat const *mat, BfMat const *otherMat) {
+  size_t m = bfMatGetNumRows(mat), p = bfMatGetNumCols(mat), n = bfMatGetNumCols(otherMat);
+  if (p != bfMatGetNumRows(otherMat)) { setError(BFABI_ERROR_INVALID_ARGUMENTS); return NULL; }
+  BfMat *result = bfMatZerosLike(otherMat, m, n);
+  for (size_t i = 0; i < sumNumTerms(mat); ++i) {
+    BfMat *prod = bfMatMul(sumTerm(mat, i), otherMat);
+    if (prod) bfMatAddInplace(result, prod);
+    bfMatDelete(&prod);
+    if (currentError) { bfMatDelete(&result); return NULL; }
+  }
+  return result;
+}
+static BfAbiMatVtable MatSumVtable = {.slot = {
+  [BFABI_SLOT_Delete] = (void *)sumDelete,
+  [BFABI_SLOT_GetType] = (void *)sumGetType,
+  [BFABI_SLOT_NumBytes] = (void *)sumNumBytes,
+  [BFABI_SLOT_GetNumRows] = (void *)sumGetNumRows,
+  [BFABI_SLOT_GetNumCols] = (void *)sumGetNumCols,
+  [BFABI_SLOT_Mul] = (void *)sumMul,
+}};
+BfMat *bfMatSumNewFromTerms(size_t numTerms, BfMat **terms) {
+  BfAbiMatSum *s = xmalloc(sizeof *s);
+  s->super.vtbl = &MatSumVtable;
+  s->super.props = 0;
+  s->super.numRows = s->super.numCols = (size_t)-1;
+  s->termArr.data = xmalloc(numTerms * sizeof(void *));
+  memcpy(s->termArr.data, terms, numTerms * sizeof(void *));
+  s->termArr.capacity = s->termArr.num_elts = numTerms;
+  s->termArr.isView = false;
+  return &s->super;
+}
+
+static BfAbiMatVtable MatCooComplexVtable;
+static int cooComplexAssignQuirk = 0;
+void bfrefCooComplexAssignQuirk(int on) { cooComplexAssignQuirk = on; }
+static int cooComplexGetType(BfMat const *m) { (void)m; return BFABI_TYPE_MAT_COO_COMPLEX; }
+static size_t cooComplexNumBytes(BfMat const *m) { return ((BfAbiMatCooComplex const *)m)->numElts * (2 * sizeof(size_t) + sizeof(cplx)); }
+static void cooComplexDelete(BfMat **mat) {
+  BfAbiMatCooComplex *c = (BfAbiMatCooComplex *)*mat;
+  free(c->rowInd); free(c->colInd); free(c->value);
+  free(c);
+  *mat = NULL;
+}
+/* mul_denseComplex, src/mat_coo_complex.c:212-262.  The reference writes
+ * `*outPtr = *inPtr; *outPtr *= z;` (:248-251): the product of an entry
+ * REPLACES the result row, so the last stored entry of a row wins.  Default here
+ * is the evident intent (accumulate); bfrefCooComplexAssignQuirk(1) restates the
+ * code as written. */
+static BfMat *cooComplexMul(BfMat const *mat, BfMat const *otherMat) {
+  if (bfMatGetType(otherMat) != BFABI_TYPE_MAT_DENSE_COMPLEX) { setError(BFABI_ERROR_NOT_IMPLEMENTED); return NULL; }
+  BfAbiMatCooComplex const *c = (BfAbiMatCooComplex const *)mat;
+  BfAbiMatDenseComplex const *x = (BfAbiMatDenseComplex const *)otherMat;
+  size_t m = mat->numRows, n = mat->numCols, p = otherMat->numCols;
+  if (n != otherMat->numRows) { setError(BFABI_ERROR_INVALID_ARGUMENTS); return NULL; }
+  BfMat *result = bfMatZerosLike(otherMat, m, p);
+  BfAbiMatDenseComplex *y = (BfAbiMatDenseComplex *)result;
+  cplx *Y = (cplx *)y->data;
+  cplx const *X = (cplx const *)x->data;
+  for (size_t k = 0; k < c->numElts; ++k) {
+    size_t i = c->rowInd[k], j = c->colInd[k];
+    cplx z = ((cplx const *)c->value)[k];
+    for (size_t l = 0; l < p; ++l) {
+      cplx v = X[j * x->rowStride + l * x->colStride] * z;
+      if (cooComplexAssignQuirk) Y[i * y->rowStride + l] = v; else Y[i * y->rowStride + l] += v;
+    }
+  }
+  return result;
+}
+static BfAbiMatVtable MatCooComplexVtable = {.slot = {
+  [BFABI_SLOT_Delete] = (void *)cooComplexDelete,
+  [BFABI_SLOT_GetType] = (void *)cooComplexGetType,
+  [BFABI_SLOT_NumBytes] = (void *)cooComplexNumBytes,
+  [BFABI_SLOT_GetNumRows] = (void *)plainGetNumRows,
+  [BFABI_SLOT_GetNumCols] = (void *)plainGetNumCols,
+  [BFABI_SLOT_Mul] = (void *)cooComplexMul,
+}};
+BfMat *bfMatCooComplexNewFromArrays(size_t m, size_t n, size_t numElts, size_t const *rowInd, size_t const *colInd, double const *value) {
+  BfAbiMatCooComplex *c = xmalloc(sizeof *c);
+  c->super.vtbl = &MatCooComplexVtable;
+  c->super.props = 0;
+  c->super.numRows = m; c->super.numCols = n;
+  c->numElts = c->capacity = numElts;
+  c->rowInd = xmalloc(numElts * sizeof(size_t)); memcpy(c->rowInd, rowInd, numElts * sizeof(size_t));
+  c->colInd = xmalloc(numElts * sizeof(size_t)); memcpy(c->colInd, colInd, numElts * sizeof(size_t));
+  c->value = xmalloc(numElts * sizeof(cplx)); memcpy(c->value, value, numElts * sizeof(cplx));
+  return &c->super;
+}
+
+static BfAbiMatVtable MatDiagRealVtable;
+static int diagRealGetType(BfMat const *m) { (void)m; return BFABI_TYPE_MAT_DIAG_REAL; }
+static size_t diagRealNumBytes(BfMat const *m) { return ((BfAbiMatDiagReal const *)m)->numElts * sizeof(double); }
+static void diagRealDelete(BfMat **mat) { BfAbiMatDiagReal *d = (BfAbiMatDiagReal *)*mat; free(d->data); free(d); *mat = NULL; }
+/* bfMatDiagRealMulVec, src/mat_diag_real.c:168-: y = d .* x (real vectors) */
+static BfVec *diagRealMulVec(BfMat const *mat, BfVec const *vec) {
+  BfAbiMatDiagReal const *d = (BfAbiMatDiagReal const *)mat;
+  if (mat->numCols != vec->size) { setError(BFABI_ERROR_INVALID_ARGUMENTS); return NULL; }
+  BfAbiVecReal const *x = (BfAbiVecReal const *)vec;
+  BfVec *res = vecRealNewWithValue(mat->numRows, 0);
+  double *y = ((BfAbiVecReal *)res)->data;
+  for (size_t i = 0; i < d->numElts; ++i) y[i] = d->data[i] * x->data[i * x->stride];
+  return res;
+}
+static BfAbiMatVtable MatDiagRealVtable = {.slot = {
+  [BFABI_SLOT_Delete] = (void *)diagRealDelete,
+  [BFABI_SLOT_GetType] = (void *)diagRealGetType,
+  [BFABI_SLOT_NumBytes] = (void *)diagRealNumBytes,
+  [BFABI_SLOT_GetNumRows] = (void *)plainGetNumRows,
+  [BFABI_SLOT_GetNumCols] = (void *)plainGetNumCols,
+  [BFABI_SLOT_MulVec] = (void *)diagRealMulVec,
+  [BFABI_SLOT_RmulVec] = (void *)diagRealMulVec,
+}};
+BfMat *bfMatDiagRealNewFromPtr(size_t m, size_t n, size_t numElts, double const *data) {
+  BfAbiMatDiagReal *d = xmalloc(sizeof *d);
+  d->super.vtbl = &MatDiagRealVtable;
+  d->super.props = 0;
+  d->super.numRows = m; d->super.numCols = n;
+  d->numElts = numElts;
+  d->data = xmalloc(numElts * sizeof(double)); memcpy(d->data, data, numElts * sizeof(double));
+  return &d->super;
+}
+
+/* =========================================================================
  * Graph from a flat descriptor
  * ========================================================================= */
 static int cmp_size(void const *a, void const *b) {

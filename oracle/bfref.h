@@ -59,6 +59,12 @@ BfMat *bfMatBlockCooNewFromArrays(size_t numBlockRows, size_t numBlockCols, size
 BfMat *bfMatBlockDenseNewFromBlocks(size_t numBlockRows, size_t numBlockCols,
                                     size_t const *rowOffset, size_t const *colOffset, BfMat **blocks);
 BfMat *bfMatProductNewFromFactors(size_t numFactors, BfMat **factors);
+/* decorations of a system matrix (mat_sum.h, mat_coo_complex.h, mat_diag_real.h) */
+BfMat *bfMatSumNewFromTerms(size_t numTerms, BfMat **terms);
+BfMat *bfMatCooComplexNewFromArrays(size_t m, size_t n, size_t numElts, size_t const *rowInd, size_t const *colInd, double const *value);
+BfMat *bfMatDiagRealNewFromPtr(size_t m, size_t n, size_t numElts, double const *data);
+/* 1: bfMatCooComplexMul assigns instead of accumulating, as the reference's code does (src/mat_coo_complex.c:248-251) */
+void bfrefCooComplexAssignQuirk(int on);
 
 BfVec *bfVecRealNewFromPtr(size_t n, double *data, int policy);
 double *bfVecRealData(BfVec *vec);

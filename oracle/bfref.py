@@ -51,6 +51,10 @@ def load():
     lib.bfMatBlockCooNewFromArrays.argtypes = [sz, sz, sz, vp, vp, vp, vp, vp]; lib.bfMatBlockCooNewFromArrays.restype = vp
     lib.bfMatBlockDenseNewFromBlocks.argtypes = [sz, sz, vp, vp, vp]; lib.bfMatBlockDenseNewFromBlocks.restype = vp
     lib.bfMatProductNewFromFactors.argtypes = [sz, vp]; lib.bfMatProductNewFromFactors.restype = vp
+    lib.bfMatSumNewFromTerms.argtypes = [sz, vp]; lib.bfMatSumNewFromTerms.restype = vp
+    lib.bfMatCooComplexNewFromArrays.argtypes = [sz, sz, sz, vp, vp, vp]; lib.bfMatCooComplexNewFromArrays.restype = vp
+    lib.bfMatDiagRealNewFromPtr.argtypes = [sz, sz, sz, vp]; lib.bfMatDiagRealNewFromPtr.restype = vp
+    lib.bfrefCooComplexAssignQuirk.argtypes = [C.c_int]; lib.bfrefCooComplexAssignQuirk.restype = None
     lib.bfVecRealNewFromPtr.argtypes = [sz, vp, C.c_int]; lib.bfVecRealNewFromPtr.restype = vp
     lib.bfVecRealData.argtypes = [vp]; lib.bfVecRealData.restype = vp
     lib.bfMatDenseData.argtypes = [vp]; lib.bfMatDenseData.restype = vp
@@ -176,6 +180,22 @@ def block_dense(row_offset, col_offset, blocks):
 def product(factors):
     arr = _steal(factors)
     return Mat(load().bfMatProductNewFromFactors(len(factors), arr))
+
+
+def mat_sum(terms):
+    arr = _steal(terms)
+    return Mat(load().bfMatSumNewFromTerms(len(terms), arr))
+
+
+def coo_complex(m, n, row_ind, col_ind, values):
+    ri, ci = _idx(row_ind), _idx(col_ind)
+    v = np.ascontiguousarray(values, dtype=np.complex128)
+    return Mat(load().bfMatCooComplexNewFromArrays(m, n, len(v), ri.ctypes.data, ci.ctypes.data, v.ctypes.data))
+
+
+def diag_real(m, n, d):
+    d = np.ascontiguousarray(d, dtype=np.float64)
+    return Mat(load().bfMatDiagRealNewFromPtr(m, n, len(d), d.ctypes.data))
 
 
 def mat_mul(a: Mat, x: np.ndarray) -> np.ndarray:

@@ -23,6 +23,9 @@ PROBE_REF = r'''
 #include <bf/mat_dense_real.h>
 #include <bf/mat_identity.h>
 #include <bf/mat_product.h>
+#include <bf/mat_sum.h>
+#include <bf/mat_coo_complex.h>
+#include <bf/mat_diag_real.h>
 #include <bf/vec_real.h>
 #include <bf/vec_complex.h>
 #include <bf/error.h>
@@ -47,6 +50,10 @@ int main(void) {
   S(BfMatDense); O(BfMatDense, vtable); O(BfMatDense, rowStride); O(BfMatDense, colStride);
   S(BfMatDenseReal); O(BfMatDenseReal, data);
   S(BfMatIdentity);
+  S(BfMatSum); O(BfMatSum, termArr);
+  S(BfMatCooComplex); O(BfMatCooComplex, numElts); O(BfMatCooComplex, rowInd); O(BfMatCooComplex, colInd); O(BfMatCooComplex, value);
+  S(BfMatDiagReal); O(BfMatDiagReal, numElts); O(BfMatDiagReal, data);
+  E(BF_TYPE_MAT_COO_COMPLEX); E(BF_TYPE_MAT_DIAG_REAL);
   S(BfVec); O(BfVec, props); O(BfVec, size);
   S(BfVecReal); O(BfVecReal, stride); O(BfVecReal, data);
   S(BfVecComplex); O(BfVecComplex, stride); O(BfVecComplex, data);
@@ -69,7 +76,7 @@ typedef BfAbiMat BfMat; typedef BfAbiMatVtable BfMatVtable; typedef BfAbiVecVtab
 typedef BfAbiPtrArray BfPtrArray; typedef BfAbiMatProduct BfMatProduct; typedef BfAbiMatBlock BfMatBlock;
 typedef BfAbiMatBlockCoo BfMatBlockCoo; typedef BfAbiMatBlockDiag BfMatBlockDiag; typedef BfAbiMatBlockDense BfMatBlockDense;
 typedef BfAbiMatDenseComplex BfMatDenseComplex; typedef BfAbiMatDense BfMatDense; typedef BfAbiMatDenseReal BfMatDenseReal;
-typedef BfAbiMatIdentity BfMatIdentity; typedef BfAbiVec BfVec; typedef BfAbiVecReal BfVecReal; typedef BfAbiVecComplex BfVecComplex;
+typedef BfAbiMatIdentity BfMatIdentity; typedef BfAbiMatSum BfMatSum; typedef BfAbiMatCooComplex BfMatCooComplex; typedef BfAbiMatDiagReal BfMatDiagReal; typedef BfAbiVec BfVec; typedef BfAbiVecReal BfVecReal; typedef BfAbiVecComplex BfVecComplex;
 #undef V
 #define V(f) printf("slot_" #f " %d\n", (int)BFABI_SLOT_##f)
 #undef W
@@ -80,6 +87,8 @@ typedef BfAbiMatIdentity BfMatIdentity; typedef BfAbiVec BfVec; typedef BfAbiVec
 #define BFABI_BF_TYPE_MAT_IDENTITY BFABI_TYPE_MAT_IDENTITY
 #define BFABI_BF_TYPE_MAT_PRODUCT BFABI_TYPE_MAT_PRODUCT
 #define BFABI_BF_TYPE_MAT_SUM BFABI_TYPE_MAT_SUM
+#define BFABI_BF_TYPE_MAT_COO_COMPLEX BFABI_TYPE_MAT_COO_COMPLEX
+#define BFABI_BF_TYPE_MAT_DIAG_REAL BFABI_TYPE_MAT_DIAG_REAL
 #define BFABI_BF_TYPE_MAT_BLOCK_COO BFABI_TYPE_MAT_BLOCK_COO
 #define BFABI_BF_TYPE_MAT_BLOCK_DENSE BFABI_TYPE_MAT_BLOCK_DENSE
 #define BFABI_BF_TYPE_MAT_BLOCK_DIAG BFABI_TYPE_MAT_BLOCK_DIAG
