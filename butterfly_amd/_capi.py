@@ -151,6 +151,10 @@ def load():
     lib.bfhipPlanGetReduce.restype = C.c_int
     lib.bfhipPlanPackArena.argtypes = [vp, vp]
     lib.bfhipPlanPackArena.restype = C.c_int
+    lib.bfhipSave.argtypes = [vp, C.c_char_p]
+    lib.bfhipSave.restype = C.c_int
+    lib.bfhipLoad.argtypes = [C.c_char_p, C.POINTER(BfhipOptions), C.POINTER(vp)]
+    lib.bfhipLoad.restype = C.c_int
     lib.bfhipFree.argtypes = [C.POINTER(vp)]
     lib.bfhipFree.restype = None
     lib.bfhipMatNew.argtypes = [vp, C.c_int]

@@ -585,6 +585,200 @@ int bfhipPlanPackArena(BfhipOperator const *op, void *dst) {
   return packLeaves(op, op->ir, op->seed, dst);
 }
 
+
+/* =============================================================================
+ * Serialization: the flattened device layout is the
+ * natural on-disk form of a compiled operator.  The reference's bfMatDump is
+ * write-only and lacks a complex dense payload (src/mat.c:67-73,
+ * src/mat_dense_complex.c:173-222); here Save / Load round-trip the operator
+ * exactly (bit-identical applies) without the BfMat graph or a rebuild.
+ * File: "BFHIPOP1" | header | per plan: per stage {counts, items, pieces,
+ * reduces} | leaf arena bytes.  Little-endian, same-architecture format.
+ * ============================================================================= */
+#define BFHIP_FILE_MAGIC "BFHIPOP1"
+
+typedef struct FileHeader {
+  char magic[8];
+  uint32_t version, dtype, srcDtype, elemSize, epl, xcap, hasTplan, reserved;
+  uint64_t numRows, numCols, arenaElems, leafElems, numLeaves, leafBytesAlgorithmic;
+} FileHeader;
+
+typedef struct FilePlanHeader { uint64_t numStages, tempElems, numRows, numCols; uint32_t maxItemRows, transposed; } FilePlanHeader;
+typedef struct FileStageHeader { uint64_t numItems, numPieces, leafElems, vecIn, vecOut, numReduce; uint32_t maxRows, reserved; } FileStageHeader;
+typedef struct FileReduceHeader { uint64_t destOff, numRows, numIntervals, numSrc; uint32_t destSpace, reserved; } FileReduceHeader;
+
+static int writeAll(FILE *fp, void const *p, size_t n) { return n == 0 || fwrite(p, 1, n, fp) == n ? 0 : bfhipFail(BFABI_ERROR_FILE_ERROR, "short write"); }
+static int readAll(FILE *fp, void *p, size_t n) { return n == 0 || fread(p, 1, n, fp) == n ? 0 : bfhipFail(BFABI_ERROR_FILE_ERROR, "short read / truncated file"); }
+
+static int writeDeviceArray(FILE *fp, void const *d, size_t bytes) {
+  if (!bytes) return 0;
+  size_t const chunk = (size_t)64 << 20;
+  void *h = malloc(bytes < chunk ? bytes : chunk);
+  if (!h) return bfhipFail(BFABI_ERROR_MEMORY_ERROR, "host OOM");
+  int rc = 0;
+  for (size_t off = 0; off < bytes && !rc; off += chunk) {
+    size_t n = bytes - off < chunk ? bytes - off : chunk;
+    rc = bfdevMemcpyD2H(h, (char const *)d + off, n);
+    if (!rc) rc = writeAll(fp, h, n);
+  }
+  free(h);
+  return rc;
+}
+static int readDeviceArray(FILE *fp, void **d, size_t bytes, uint64_t *meta) {
+  int rc = bfdevMalloc(d, bytes);
+  if (rc || !bytes) return rc;
+  if (meta) *meta += bytes;
+  size_t const chunk = (size_t)64 << 20;
+  void *h = malloc(bytes < chunk ? bytes : chunk);
+  if (!h) return bfhipFail(BFABI_ERROR_MEMORY_ERROR, "host OOM");
+  for (size_t off = 0; off < bytes && !rc; off += chunk) {
+    size_t n = bytes - off < chunk ? bytes - off : chunk;
+    rc = readAll(fp, h, n);
+    if (!rc) rc = bfdevMemcpyH2D((char *)*d + off, h, n);
+  }
+  free(h);
+  return rc;
+}
+
+static int savePlan(FILE *fp, BfPlan const *pl) {
+  FilePlanHeader ph = {pl->numStages, pl->tempElems, pl->numRows, pl->numCols, pl->maxItemRows, (uint32_t)pl->transposed};
+  int rc = writeAll(fp, &ph, sizeof ph);
+  for (uint64_t s = 0; s < pl->numStages && !rc; ++s) {
+    BfStage const *st = &pl->stages[s];
+    FileStageHeader sh = {st->numItems, st->numPieces, st->leafElems, st->vecIn, st->vecOut, st->numReduce, st->maxRows, 0};
+    rc = writeAll(fp, &sh, sizeof sh);
+    if (!rc) rc = writeDeviceArray(fp, st->dItems, st->numItems * sizeof(BfDevItem));
+    if (!rc) rc = writeDeviceArray(fp, st->dPieces, st->numPieces * sizeof(BfDevPiece));
+    for (uint64_t r = 0; r < st->numReduce && !rc; ++r) {
+      BfReduce const *rd = &st->reduce[r];
+      FileReduceHeader rh = {rd->destOff, rd->numRows, rd->numIntervals, rd->numSrc, rd->destSpace, 0};
+      rc = writeAll(fp, &rh, sizeof rh);
+      if (!rc) rc = writeDeviceArray(fp, rd->dRowInterval, rd->numRows * 4);
+      if (!rc) rc = writeDeviceArray(fp, rd->dIvBegin, (rd->numIntervals + 1) * 4);
+      if (!rc) rc = writeDeviceArray(fp, rd->dSrcBias, rd->numSrc * 8);
+    }
+  }
+  return rc;
+}
+
+static int loadPlan(FILE *fp, BfhipOperator *op, BfPlan *pl, FileHeader const *fh) {
+  FilePlanHeader ph;
+  int rc = readAll(fp, &ph, sizeof ph);
+  if (rc) return rc;
+  if (ph.numStages > (1u << 20)) return bfhipFail(BFABI_ERROR_FILE_ERROR, "corrupt plan header");
+  pl->dtype = fh->dtype; pl->elemSize = fh->elemSize; pl->epl = fh->epl; pl->xcap = fh->xcap;
+  pl->maxItemRows = ph.maxItemRows; pl->transposed = (int)ph.transposed;
+  pl->numRows = ph.numRows; pl->numCols = ph.numCols; pl->numStages = ph.numStages; pl->tempElems = ph.tempElems;
+  pl->arenaElems = pl->transposed ? 0 : fh->arenaElems;
+  pl->leafElems = fh->leafElems; pl->numLeaves = fh->numLeaves;
+  pl->stages = calloc(ph.numStages ? ph.numStages : 1, sizeof(BfStage));
+  if (!pl->stages) return bfhipFail(BFABI_ERROR_MEMORY_ERROR, "host OOM");
+  for (uint64_t s = 0; s < pl->numStages && !rc; ++s) {
+    BfStage *st = &pl->stages[s];
+    FileStageHeader sh;
+    if ((rc = readAll(fp, &sh, sizeof sh))) break;
+    if (sh.numItems > 0xffffffffu || sh.numPieces > 0xffffffffu || sh.numReduce > (1u << 20)) { rc = bfhipFail(BFABI_ERROR_FILE_ERROR, "corrupt stage header"); break; }
+    st->numItems = sh.numItems; st->numPieces = sh.numPieces; st->leafElems = sh.leafElems; st->vecIn = sh.vecIn; st->vecOut = sh.vecOut;
+    st->maxRows = sh.maxRows;
+    rc = readDeviceArray(fp, &st->dItems, st->numItems * sizeof(BfDevItem), &op->metaBytes);
+    if (!rc) rc = readDeviceArray(fp, &st->dPieces, st->numPieces * sizeof(BfDevPiece), &op->metaBytes);
+    if (!rc && sh.numReduce) {
+      st->reduce = calloc(sh.numReduce, sizeof(BfReduce));
+      if (!st->reduce) rc = bfhipFail(BFABI_ERROR_MEMORY_ERROR, "host OOM");
+    }
+    for (uint64_t r = 0; r < sh.numReduce && !rc; ++r) {
+      BfReduce *rd = &st->reduce[r];
+      FileReduceHeader rh;
+      if ((rc = readAll(fp, &rh, sizeof rh))) break;
+      st->numReduce = r + 1;
+      rd->destOff = rh.destOff; rd->numRows = rh.numRows; rd->numIntervals = rh.numIntervals; rd->numSrc = rh.numSrc; rd->destSpace = rh.destSpace;
+      rc = readDeviceArray(fp, &rd->dRowInterval, rd->numRows * 4, &op->metaBytes);
+      if (!rc) rc = readDeviceArray(fp, &rd->dIvBegin, (rd->numIntervals + 1) * 4, &op->metaBytes);
+      if (!rc) rc = readDeviceArray(fp, &rd->dSrcBias, rd->numSrc * 8, &op->metaBytes);
+    }
+  }
+  return rc;
+}
+
+int bfhipSave(BfhipOperator *op, char const *path) {
+  if (!op || !path) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "NULL argument");
+  if (op->flags & BFHIP_FLAG_PLAN_ONLY) return bfhipFail(BFABI_ERROR_RUNTIME_ERROR, "a plan-only operator has no device data to save");
+  int prev = -1;
+  bfdevGetDevice(&prev);
+  int rc = bfdevSetDevice(op->device);
+  if (rc) return rc;
+  if ((rc = bfdevSync(NULL))) return rc;
+  FILE *fp = fopen(path, "wb");
+  if (!fp) return bfhipFail(BFABI_ERROR_FILE_ERROR, "cannot open %s for writing", path);
+  FileHeader fh;
+  memset(&fh, 0, sizeof fh);
+  memcpy(fh.magic, BFHIP_FILE_MAGIC, 8);
+  fh.version = 1; fh.dtype = op->plan.dtype; fh.srcDtype = op->srcDtype; fh.elemSize = op->plan.elemSize; fh.epl = op->plan.epl;
+  fh.xcap = op->plan.xcap; fh.hasTplan = (uint32_t)op->hasTplan;
+  fh.numRows = op->plan.numRows; fh.numCols = op->plan.numCols; fh.arenaElems = op->plan.arenaElems;
+  fh.leafElems = op->plan.leafElems; fh.numLeaves = op->plan.numLeaves; fh.leafBytesAlgorithmic = op->leafBytesAlgorithmic;
+  rc = writeAll(fp, &fh, sizeof fh);
+  if (!rc) rc = savePlan(fp, &op->plan);
+  if (!rc && op->hasTplan) rc = savePlan(fp, &op->tplan);
+  if (!rc) rc = writeDeviceArray(fp, op->dArena, (size_t)op->plan.arenaElems * op->plan.elemSize);
+  if (fclose(fp) != 0 && !rc) rc = bfhipFail(BFABI_ERROR_FILE_ERROR, "error closing %s", path);
+  if (prev >= 0 && prev != op->device) bfdevSetDevice(prev);
+  return rc;
+}
+
+int bfhipLoad(char const *path, BfhipOptions const *opts, BfhipOperator **out) {
+  if (!path || !out) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "NULL argument");
+  *out = NULL;
+  BfhipOptions o;
+  memset(&o, 0, sizeof o);
+  o.device = -1;
+  if (opts) {
+    if (opts->structSize < sizeof(BfhipOptions)) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "BfhipOptions.structSize too small");
+    o = *opts;
+  }
+  if (o.flags & BFHIP_FLAG_PLAN_ONLY) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "cannot load as plan-only");
+  FILE *fp = fopen(path, "rb");
+  if (!fp) return bfhipFail(BFABI_ERROR_FILE_ERROR, "cannot open %s", path);
+  FileHeader fh;
+  int rc = readAll(fp, &fh, sizeof fh);
+  if (!rc && (memcmp(fh.magic, BFHIP_FILE_MAGIC, 8) != 0 || fh.version != 1 || fh.dtype > BFHIP_F32 ||
+              fh.elemSize != (fh.dtype == BFHIP_C128 ? 16u : fh.dtype == BFHIP_F64 ? 8u : 4u)))
+    rc = bfhipFail(BFABI_ERROR_FILE_ERROR, "%s is not a bfhip operator file (bad magic / version / dtype)", path);
+  if (rc) { fclose(fp); return rc; }
+  BfhipOperator *op = calloc(1, sizeof *op);
+  if (!op) { fclose(fp); return bfhipFail(BFABI_ERROR_MEMORY_ERROR, "host OOM"); }
+  int prevDev = -1;
+  bfdevGetDevice(&prevDev);
+  op->flags = o.flags & ~(uint32_t)BFHIP_FLAG_ADJOINT;
+  op->srcDtype = fh.srcDtype;
+  op->leafBytesAlgorithmic = fh.leafBytesAlgorithmic;
+  if ((rc = bfdevSetDevice(o.device))) goto done;
+  if ((rc = bfdevGetDevice(&op->device))) goto done;
+  if ((rc = loadPlan(fp, op, &op->plan, &fh))) goto done;
+  if (fh.hasTplan) {
+    if ((rc = loadPlan(fp, op, &op->tplan, &fh))) goto done;
+    op->hasTplan = 1;
+    op->flags |= BFHIP_FLAG_ADJOINT;
+  }
+  if ((rc = readDeviceArray(fp, &op->dArena, (size_t)fh.arenaElems * fh.elemSize, NULL))) goto done;
+  if ((rc = ensureTemp(op, o.maxRhs ? o.maxRhs : 1))) goto done;
+  if ((rc = bfdevMalloc(&op->dZero, 4096))) goto done;
+  if ((rc = bfdevMemset(op->dZero, 0, 4096))) goto done;
+  if (op->flags & BFHIP_FLAG_PROFILE) {
+    uint64_t S = op->plan.numStages;
+    op->evStart = calloc(S, sizeof(void *)); op->evStop = calloc(S, sizeof(void *));
+    op->stageMs = calloc(S, sizeof(double)); op->stageLaunches = calloc(S, sizeof(uint64_t));
+    if (!op->evStart || !op->evStop || !op->stageMs || !op->stageLaunches) { rc = bfhipFail(BFABI_ERROR_MEMORY_ERROR, "host OOM"); goto done; }
+    for (uint64_t s = 0; s < S && !rc; ++s) { rc = bfdevEventCreate(&op->evStart[s]); if (!rc) rc = bfdevEventCreate(&op->evStop[s]); }
+  }
+done:
+  fclose(fp);
+  if (rc) { bfhipFree(&op); if (prevDev >= 0) bfdevSetDevice(prevDev); return rc; }
+  if (prevDev >= 0 && o.device >= 0) bfdevSetDevice(prevDev);
+  *out = op;
+  return 0;
+}
+
 /* =============================================================================
  * BfMat vtable shim
  * ============================================================================= */

@@ -59,6 +59,19 @@ class HipOperator:
         keep = [da] if (o.flags & _capi.FLAG_PLAN_ONLY) else []
         return cls(h.value, keep=keep)
 
+    @classmethod
+    def load(cls, path, **opts):
+        """bfhipLoad: a previously saved operator, straight into HBM."""
+        lib = _capi.load()
+        h = C.c_void_p()
+        o = _options(**opts)
+        check(lib.bfhipLoad(str(path).encode(), C.byref(o), C.byref(h)))
+        return cls(h.value)
+
+    def save(self, path):
+        """bfhipSave: packed leaf arena + index metadata of the compiled operator."""
+        check(self._lib.bfhipSave(self._h, str(path).encode()))
+
     def close(self):
         if self._h:
             self._lib.bfhipFree(C.byref(self._h))

@@ -219,6 +219,16 @@ int bfhipPlanGetReduce(const BfhipOperator *op, uint64_t stage, uint64_t index, 
  * are generated with the host copy of the value stream. */
 int bfhipPlanPackArena(const BfhipOperator *op, void *dst);
 
+/* ---- serialization ------------------------------------------------------- */
+/* Write / read a compiled operator (packed leaf arena + per-stage index
+ * metadata, both plans if BFHIP_FLAG_ADJOINT) -- the loader the reference's
+ * write-only bfMatDump never had (src/mat.c:67-73).  A loaded operator applies
+ * bit-identically to the saved one.  Errors: FILE_ERROR (cannot open, bad
+ * magic, truncated), MEMORY_ERROR, RUNTIME_ERROR.  `opts` of Load: device,
+ * maxRhs, BFHIP_FLAG_PROFILE are honoured. */
+int bfhipSave(BfhipOperator *op, const char *path);
+int bfhipLoad(const char *path, const BfhipOptions *opts, BfhipOperator **out);
+
 /* ---- lifetime ------------------------------------------------------------ */
 void bfhipFree(BfhipOperator **op);
 

@@ -348,3 +348,40 @@ def test_rmulvec_shim_real_operator():
     assert rel(got, want) <= TOL
     bfref.load().bfMatDelete(C.byref(a_hip))
     op.close()
+
+
+def test_save_load_round_trip(tmp_path, helm2_cases):
+    """bfhipSave / bfhipLoad: the loaded operator applies bit-identically (forward
+    and adjoint), without the BfMat graph; bad files are FILE_ERRORs."""
+    from butterfly_amd import _capi
+    from butterfly_amd.operator import HipOperator
+    from oracle import bfref, helm2_build as hb
+    n, k = 4096, 100
+    desc, tp, vals = helm2_cases(n, k)
+    op = HipOperator.from_desc(desc, vals, flags=_capi.FLAG_ADJOINT)
+    x = hb.complex_randn(n, 2)
+    y, yt = op.apply_host(x), op.apply_transpose_host(x)
+    path = tmp_path / "op.bfhip"
+    op.save(path)
+    st = op.stats()
+    op.close()
+    assert path.stat().st_size > st["leafBytes"]
+    op2 = HipOperator.load(path)
+    assert op2.shape == (n, n) and op2.stats()["leafBytes"] == st["leafBytes"] and op2.num_bytes() == st["leafBytes"]
+    assert np.array_equal(op2.apply_host(x), y)
+    assert np.array_equal(op2.apply_transpose_host(x), yt)
+    assert rel(y, bfref.mat_mul(bfref.from_desc(desc, vals), x)) <= TOL
+    op2.close()
+    with pytest.raises(_capi.BfhipError) as e:
+        HipOperator.load(tmp_path / "missing.bfhip")
+    assert e.value.code == 6
+    bad = tmp_path / "bad.bfhip"
+    bad.write_bytes(b"NOTANOPERATOR" * 10)
+    with pytest.raises(_capi.BfhipError) as e:
+        HipOperator.load(bad)
+    assert e.value.code == 6
+    trunc = tmp_path / "trunc.bfhip"
+    trunc.write_bytes(path.read_bytes()[:100000])
+    with pytest.raises(_capi.BfhipError) as e:
+        HipOperator.load(trunc)
+    assert e.value.code == 6
