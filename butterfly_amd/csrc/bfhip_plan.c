@@ -310,7 +310,6 @@ int bfPlanBuild(BfIr const *ir, BfPlanOptions const *po, BfPlan *plan) {
     uint64_t cb = ir->childBegin[root], ce = ir->childBegin[root + 1];
     uint64_t nb = 0;
     for (uint64_t c = cb; c < ce; ++c) if (ir->topRowBlock[c - cb] + 1 > nb) nb = ir->topRowBlock[c - cb] + 1;
-    if (po->rowBlockEnd > nb && nb) { /* allow end beyond the last non-empty row */ }
     uint64_t *lo = malloc((nb + 1) * 8), *hi = calloc(nb + 1, 8), *base = calloc(nb + 1, 8);
     if (!lo || !hi || !base) { free(lo); free(hi); free(base); rc = bfhipFail(BFABI_ERROR_MEMORY_ERROR, "host OOM"); goto fail; }
     for (uint64_t i = 0; i <= nb; ++i) lo[i] = UINT64_MAX;
@@ -407,13 +406,6 @@ int bfPlanBuild(BfIr const *ir, BfPlanOptions const *po, BfPlan *plan) {
     if (!st->reduce || !gaps) { free(groups); free(gaps); free(bufRead); rc = bfhipFail(BFABI_ERROR_MEMORY_ERROR, "host OOM"); goto fail; }
 #define PUSH_GAP(B, O, L) do { if ((L) > 0) { if (numGaps == capGaps) { capGaps *= 2; Gap *p_ = realloc(gaps, capGaps * sizeof(Gap)); if (!p_) { rc = bfhipFail(BFABI_ERROR_MEMORY_ERROR, "host OOM"); goto stage_fail; } gaps = p_; } gaps[numGaps].buf = (B); gaps[numGaps].off = (O); gaps[numGaps].len = (L); ++numGaps; } } while (0)
 
-    /* buffers written in this stage with no tasks at all must still be zeroed */
-    for (uint64_t bi = 1; bi < b.numBufs; ++bi) {
-      if (b.bufs[bi].stage != s) continue;
-      /* find its groups (binary search would do; stages have few buffers relative to groups, but
-       * products can have many: do a linear pass over groups once per stage instead) */
-      (void)bi;
-    }
     {
       /* walk groups buffer by buffer */
       uint64_t gi = 0;
@@ -603,7 +595,6 @@ int bfPlanBuild(BfIr const *ir, BfPlanOptions const *po, BfPlan *plan) {
           arenaTop += (uint64_t)mrPad * nc;
           ++np;
         }
-        if (r0 == 0) { /* count each leaf once */ }
       }
       it->numPieces = (uint32_t)(np - it->pieceBegin);
     }
