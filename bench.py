@@ -111,6 +111,9 @@ def main():
                          "for the real BfMatDenseReal path (BASELINE.json configs[4]); fp32 is the build's extension")
     ap.add_argument("--adjoint", action="store_true", help="also time y = A^T x (RmulVec path) and report it next to the headline")
     ap.add_argument("--pcie", action="store_true", help="also time the host-buffer path (H2D + apply + D2H)")
+    ap.add_argument("--emulate-world", type=int, default=0,
+                    help="diagnostic: on ONE GPU, time the shard that rank --emulate-rank of an N-rank job would own (no collective)")
+    ap.add_argument("--emulate-rank", type=int, default=0)
     ap.add_argument("--force-collective", action="store_true",
                     help="rehearsal: initialise RCCL and run the step's collective even with one rank")
     ap.add_argument("--shard", choices=["auto", "rows", "blocks"], default="auto",
@@ -153,14 +156,15 @@ def main():
     total_leaf = int(sum(weights))
     top_rows = desc.meta["top_rows"]
     row_offsets = np.concatenate([[0], np.cumsum(top_rows)]).astype(np.int64)
-    mode = choose_mode(desc, world, args.shard)
+    sworld, srank = (args.emulate_world, args.emulate_rank) if args.emulate_world > 1 else (world, rank)
+    mode = choose_mode(desc, sworld, args.shard)
     if mode == "rows":
-        owner, loads = assign_row_blocks(weights, world)
-        mine = [rb for rb in range(len(weights)) if owner[rb] == rank]
+        owner, loads = assign_row_blocks(weights, sworld)
+        mine = [rb for rb in range(len(weights)) if owner[rb] == srank]
     else:
         bw = block_weights(desc)
-        bowner, loads = assign_row_blocks(bw, world)
-        mine = [i for i in range(len(bw)) if bowner[i] == rank]
+        bowner, loads = assign_row_blocks(bw, sworld)
+        mine = [i for i in range(len(bw)) if bowner[i] == srank]
         owner = [0] * len(weights)
     if rank == 0:
         log(f"structure: N={n} k={k:g} nodes={desc.num_nodes} leafGB={total_leaf * 16 / 1e9:.2f} "
@@ -168,7 +172,7 @@ def main():
             f"{[round(l * 16 / 1e9, 2) for l in loads]}")
 
     t0 = time.time()
-    if world == 1:
+    if sworld == 1:
         root, local_rows = desc.root, n
     elif mode == "rows":
         root, local_rows = hs.shard_desc(desc, mine)
@@ -191,9 +195,11 @@ def main():
     else:
         x_host = (rng.standard_normal(shape) + 1j * rng.standard_normal(shape)) / np.sqrt(2)
     x = torch.from_numpy(x_host).to(dev).to(tdtype)
-    layout = ShardLayout(top_rows, owner, world)
-    assert mode == "blocks" or layout.rows_of[rank] == local_rows
-    step = ShardedApply(layout, rank, lambda xin, out: op.apply_device(xin, out), dev, tdtype, nrhs=args.nrhs,
+    layout = ShardLayout(top_rows, owner, sworld)
+    if args.emulate_world > 1:
+        layout.world = 1        # one process: run this shard's local apply only
+    assert mode == "blocks" or layout.rows_of[srank] == local_rows
+    step = ShardedApply(layout, srank, lambda xin, out: op.apply_device(xin, out), dev, tdtype, nrhs=args.nrhs,
                         mode=mode, force_collective=args.force_collective)
 
     for _ in range(args.warmup):
@@ -295,7 +301,10 @@ def main():
         if args.pcie:
             out["pcie_inclusive"] = {"ms_per_apply": pcie_ms, "matvec_per_s": args.nrhs / (pcie_ms / 1e3),
                                      "note": "bfhipApply on pageable host buffers: H2D x + apply + D2H y"}
-        if world == 1 and not args.no_cpu_baseline and not real:
+        if args.emulate_world > 1:
+            out["emulated_shard"] = {"world": args.emulate_world, "rank": args.emulate_rank, "mode": mode,
+                                     "shard_leaf_bytes": st["leafBytes"]}
+        if world == 1 and not args.no_cpu_baseline and not real and args.emulate_world <= 1:
             try:
                 y_host = y_full.cpu().numpy()
                 out["cpu_baseline"] = cpu_baseline(desc, args.seed, total_leaf, weights, args.cpu_budget_gb * 1e9,

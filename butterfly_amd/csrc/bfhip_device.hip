@@ -94,6 +94,35 @@ template <typename V> __device__ __forceinline__ V bfLoadStreamV(V const *p) {
 #endif
 }
 
+// one global_load_lds_dwordx4: lane l copies 16 bytes from its own global address to
+// LDS at (wave-uniform base) + 16*l
+__device__ __forceinline__ void bfGlds16(void const *g, void *ldsBase) {
+  __builtin_amdgcn_global_load_lds((__attribute__((address_space(1))) void const *)g,
+                                   (__attribute__((address_space(3))) void *)ldsBase, 16, 0, 0);
+}
+
+// a window of 64 piece descriptors held one per lane: a single vector load replaces one
+// dependent scalar load (an L2/HBM round trip) per piece; fields are broadcast by readlane
+struct BfPieceWin { uint32_t w[6]; };
+static_assert(sizeof(BfDevPiece) == 24, "BfDevPiece is 6 dwords");
+__device__ __forceinline__ BfPieceWin bfPieceWinLoad(BfDevPiece const *pieces, uint32_t n, int lane) {
+  BfPieceWin win;
+  uint2 const *src = (uint2 const *)(pieces + (lane < (int)n ? lane : 0));
+  uint2 a = src[0], b = src[1], c = src[2];
+  win.w[0] = a.x; win.w[1] = a.y; win.w[2] = b.x; win.w[3] = b.y; win.w[4] = c.x; win.w[5] = c.y;
+  return win;
+}
+__device__ __forceinline__ BfDevPiece bfPieceWinGet(BfPieceWin const &win, uint32_t i) {
+  BfDevPiece pc;
+  pc.dataOff = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)win.w[0], (int)i) |
+               ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)win.w[1], (int)i) << 32);
+  pc.inOff = (uint32_t)__builtin_amdgcn_readlane((int)win.w[2], (int)i);
+  pc.ncols = (uint32_t)__builtin_amdgcn_readlane((int)win.w[3], (int)i);
+  pc.flags = (uint32_t)__builtin_amdgcn_readlane((int)win.w[4], (int)i);
+  pc.ld = (uint32_t)__builtin_amdgcn_readlane((int)win.w[5], (int)i);
+  return pc;
+}
+
 __device__ __forceinline__ void waveSync() {
   // LDS traffic of one wave is issued in order; this only stops the compiler
   // from moving LDS accesses across the hand-off between lanes.
@@ -146,7 +175,7 @@ __global__ __launch_bounds__(BF_WAVES_PER_WG * 64) void bfStageKernelC128(StageP
       uint32_t const nfull = n / g;
       uint32_t j = c;
       uint32_t s = 0;
-#pragma unroll 4
+#pragma unroll 8
       for (; s < nfull; ++s) {
         double2 a = bfLoadStream(ap + (uint64_t)s * G);
         double2 xv = xs[j];
@@ -457,58 +486,85 @@ __global__ __launch_bounds__(BF_WAVES_PER_WG * 64) void bfStageKernelT(StagePara
   uint32_t const nrhs = p.nrhs;
   S *out = (it.mrFlags & BF_ITEM_OUT_Y) ? (S *)p.y : (S *)p.temp;
 
+  constexpr uint32_t XROWS = 64 * EPL;                // rows of x that fit the LDS x region (and 16 x that many units the tile)
   for (uint32_t q = 0; q < nrhs; ++q) {
     S acc[NC];
 #pragma unroll
     for (int k = 0; k < NC; ++k) acc[k] = 0;
-    for (uint32_t pi = 0; pi < it.numPieces; ++pi) {
-      BfDevPiece const pc = p.pieces[it.pieceBegin + pi];
-      S const *xin = (pc.flags & BF_PIECE_IN_X) ? (S const *)p.x : (S const *)p.temp;
-      xin += ((uint64_t)pc.inOff * nrhs + q) * NC;
-      if (pc.flags & BF_PIECE_IDENTITY) {
-        if (sg == 0 && colOk) {
+    // pieces are consumed in batches that fill the LDS tile: forward row chunks can be as
+    // thin as 16 rows, and one hand-off (two wave syncs) per 64 rows keeps the copy loop busy
+    for (uint32_t wbase = 0; wbase < it.numPieces; wbase += 64) {
+    uint32_t const wn = it.numPieces - wbase < 64 ? it.numPieces - wbase : 64;
+    BfPieceWin const win = bfPieceWinLoad(p.pieces + it.pieceBegin + wbase, wn, lane);
+    uint32_t pi = 0;
+    while (pi < wn) {
+      waveSync();                                    // previous batch fully consumed
+      uint32_t xo = 0, uo = 0, pe = pi;
+      for (; pe < wn; ++pe) {
+        BfDevPiece const pc = bfPieceWinGet(win, pe);
+        if (pc.flags & BF_PIECE_IDENTITY) continue;
+        if (xo && xo + pc.ld > XROWS) break;
+        uint32_t const units = pc.ld / EPL;          // 16-byte units per column
+        uint32_t const total = mr * units;           // contiguous units of this piece
+        // LDS-DMA: 64 lanes x 16 B land contiguously at a wave-uniform LDS base, which is
+        // exactly a flat copy of the run; no VGPR staging, so every load of the whole batch
+        // is in flight at once (the wait is after the x gather below)
+        U const *src = arena + pc.dataOff / EPL;
+        for (uint32_t e0 = 0; e0 < total; e0 += 64)
+          if (e0 + lane < total) bfGlds16(src + e0 + lane, tile + uo + e0);
+        uo += total;
+        xo += pc.ld;
+      }
+      // input sub-vectors of the batch (ordinary loads: their first use drains the DMA too)
+      xo = 0;
+      for (uint32_t pp = pi; pp < pe; ++pp) {
+        BfDevPiece const pc = bfPieceWinGet(win, pp);
+        if (pc.flags & BF_PIECE_IDENTITY) continue;
+        S const *xin = (pc.flags & BF_PIECE_IN_X) ? (S const *)p.x : (S const *)p.temp;
+        xin += ((uint64_t)pc.inOff * nrhs + q) * NC;
+        uint32_t const n = pc.ncols;                 // rows of the forward piece
+        for (uint32_t s = lane; s < pc.ld; s += 64) {
 #pragma unroll
-          for (int k = 0; k < NC; ++k) acc[k] += xin[(uint64_t)jj * nrhs * NC + k];
+          for (int k = 0; k < NC; ++k) xs[(xo + s) * NC + k] = s < n ? xin[(uint64_t)s * nrhs * NC + k] : (S)0;
         }
-        continue;
+        xo += pc.ld;
       }
-      uint32_t const n = pc.ncols;                   // rows of the forward piece
-      uint32_t const units = pc.ld / EPL;            // 16-byte units per column
-      uint32_t const total = mr * units;             // contiguous units of this piece
-      waveSync();                                    // previous piece fully consumed
-      U const *src = arena + pc.dataOff / EPL;
-      for (uint32_t e = lane; e < total; e += 256) { // 4 loads in flight per lane
-        U a0, a1, a2, a3;
-        uint32_t e1 = e + 64, e2 = e + 128, e3 = e + 192;
-        a0 = bfLoadStreamV(src + e);
-        if (e1 < total) a1 = bfLoadStreamV(src + e1);
-        if (e2 < total) a2 = bfLoadStreamV(src + e2);
-        if (e3 < total) a3 = bfLoadStreamV(src + e3);
-        tile[e] = a0;
-        if (e1 < total) tile[e1] = a1;
-        if (e2 < total) tile[e2] = a2;
-        if (e3 < total) tile[e3] = a3;
-      }
-      for (uint32_t s = lane; s < pc.ld; s += 64) {
-#pragma unroll
-        for (int k = 0; k < NC; ++k) xs[s * NC + k] = s < n ? xin[(uint64_t)s * nrhs * NC + k] : (S)0;
-      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the LDS-DMA of this batch has landed
       waveSync();
-      U const *col = tile + jc * units;
-      uint32_t const skew = jc % units;
-      for (uint32_t t = sg; t < units; t += 4) {
-        uint32_t u = t + skew;
-        if (u >= units) u -= units;
-        U a = col[u];
-        if (Traits<DT>::CPLX) {
-          S xr = xs[2 * u], xi = xs[2 * u + 1];
-          acc[0] = fma(a.v[0], xr, acc[0]); acc[0] = fma(-a.v[1], xi, acc[0]);
-          acc[NC - 1] = fma(a.v[0], xi, acc[NC - 1]); acc[NC - 1] = fma(a.v[1], xr, acc[NC - 1]);
-        } else {
+      xo = 0; uo = 0;
+      for (uint32_t pp = pi; pp < pe; ++pp) {
+        BfDevPiece const pc = bfPieceWinGet(win, pp);
+        if (pc.flags & BF_PIECE_IDENTITY) {
+          if (sg == 0 && colOk) {
+            S const *xin = (pc.flags & BF_PIECE_IN_X) ? (S const *)p.x : (S const *)p.temp;
+            xin += ((uint64_t)pc.inOff * nrhs + q) * NC;
 #pragma unroll
-          for (int e = 0; e < EPL; ++e) acc[0] = fma(a.v[e], xs[u * EPL + e], acc[0]);
+            for (int k = 0; k < NC; ++k) acc[k] += xin[(uint64_t)jj * nrhs * NC + k];
+          }
+          continue;
         }
+        uint32_t const units = pc.ld / EPL;
+        U const *col = tile + uo + jc * units;
+        S const *xp = xs + xo * NC;
+        uint32_t const skew = jc % units;
+        for (uint32_t t = sg; t < units; t += 4) {
+          uint32_t u = t + skew;
+          if (u >= units) u -= units;
+          U a = col[u];
+          if (Traits<DT>::CPLX) {
+            S xr = xp[2 * u], xi = xp[2 * u + 1];
+            acc[0] = fma(a.v[0], xr, acc[0]); acc[0] = fma(-a.v[1], xi, acc[0]);
+            acc[NC - 1] = fma(a.v[0], xi, acc[NC - 1]); acc[NC - 1] = fma(a.v[1], xr, acc[NC - 1]);
+          } else {
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) acc[0] = fma(a.v[e], xp[u * EPL + e], acc[0]);
+          }
+        }
+        uo += mr * units;
+        xo += pc.ld;
       }
+      pi = pe;
+    }
     }
     // combine the 4 row groups of each column (fixed order) and store
     waveSync();

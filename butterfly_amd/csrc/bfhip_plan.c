@@ -229,6 +229,8 @@ typedef struct Group {
   uint32_t outBuf;
   uint64_t slotOff;              /* vector-arena offset of its private slot, if reduced */
   int reduced;
+  uint64_t colsSum, piecesPerChunk;
+  uint32_t chunkRows;            /* rows per item of this group */
 } Group;
 
 typedef struct ItemTmp {
@@ -262,6 +264,9 @@ void bfPlanFree(BfPlan *plan) {
   free(plan->stages);
   memset(plan, 0, sizeof *plan);
 }
+
+/* target upper bound on the leaf bytes one item (one wavefront) streams */
+#define BF_ITEM_BYTES (128u << 10)
 
 /* vector-arena allocator: 4-element alignment keeps every segment 16-byte
  * aligned for all element types */
@@ -500,9 +505,33 @@ int bfPlanBuild(BfIr const *ir, BfPlanOptions const *po, BfPlan *plan) {
       free(seen);
     }
 
-    /* items */
+    /* items.  A group of m rows is cut into items of `chunkRows` rows: 64 row
+     * slots when the group's blocks are narrow, fewer when they are wide, so
+     * that no item streams much more than BF_ITEM_BYTES -- the run time of a
+     * launch is bounded below by its largest item (one wavefront), which is
+     * what limits small launches (row-sharded operators, N <= 65536).  16-row
+     * granularity keeps the MFMA kernel's slabs full; a short remainder still
+     * fills the GEMV kernel's lanes through column groups. */
     uint64_t numItems = 0;
-    for (uint64_t g = 0; g < numGroups; ++g) numItems += (groups[g].rows + itemRows - 1) / itemRows;
+    for (uint64_t g = 0; g < numGroups; ++g) {
+      Group *gr = &groups[g];
+      gr->colsSum = 0; gr->piecesPerChunk = 0;
+      for (uint64_t t = gr->taskBegin; t < gr->taskEnd; ++t) {
+        Task const *tk = &b.tasks[t];
+        if (ir->kind[tk->leaf] == BFHIP_NODE_IDENTITY) { gr->piecesPerChunk += 1; gr->colsSum += 1; }
+        else if (T) { gr->piecesPerChunk += (tk->cols + 15) / 16 + 1; gr->colsSum += tk->cols; }   /* upper bound: forward row chunks have >= 16 rows */
+        else { gr->piecesPerChunk += (tk->cols + plan->xcap - 1) / plan->xcap; gr->colsSum += tk->cols; }
+      }
+      uint64_t chunk = itemRows;
+      if (!T && gr->colsSum) {
+        uint64_t const gran = 16 * plan->epl;
+        uint64_t want = (BF_ITEM_BYTES / plan->elemSize) / gr->colsSum / gran * gran;
+        if (want < gran) want = gran;
+        if (want < chunk) chunk = want;
+      }
+      gr->chunkRows = (uint32_t)chunk;
+      numItems += (gr->rows + chunk - 1) / chunk;
+    }
     for (uint64_t z = 0; z < numGaps; ++z) numZeroItems += (gaps[z].len + plan->maxItemRows - 1) / plan->maxItemRows;
     ItemTmp *tmp = malloc((numItems + numZeroItems + 1) * sizeof(ItemTmp));
     if (!tmp) { rc = bfhipFail(BFABI_ERROR_MEMORY_ERROR, "host OOM"); goto stage_fail; }
@@ -510,17 +539,8 @@ int bfPlanBuild(BfIr const *ir, BfPlanOptions const *po, BfPlan *plan) {
     uint64_t numPieces = 0;
     for (uint64_t g = 0; g < numGroups; ++g) {
       uint64_t m = groups[g].rows;
-      /* full items of itemRows rows plus one remainder item: multiples of 16
-       * rows keep the MFMA (multi-RHS) kernel's 16-row slabs full, and a short
-       * remainder still fills the GEMV kernel's lanes through column groups */
-      uint64_t chunk = itemRows;
-      uint64_t colsSum = 0, piecesPerChunk = 0;
-      for (uint64_t t = groups[g].taskBegin; t < groups[g].taskEnd; ++t) {
-        Task const *tk = &b.tasks[t];
-        if (ir->kind[tk->leaf] == BFHIP_NODE_IDENTITY) { piecesPerChunk += 1; colsSum += 1; }
-        else if (T) { piecesPerChunk += (tk->cols + 63) / 64 + 1; colsSum += tk->cols; }   /* upper bound: forward row chunks (64*epl rows each) */
-        else { piecesPerChunk += (tk->cols + plan->xcap - 1) / plan->xcap; colsSum += tk->cols; }
-      }
+      uint64_t chunk = groups[g].chunkRows;
+      uint64_t colsSum = groups[g].colsSum, piecesPerChunk = groups[g].piecesPerChunk;
       for (uint64_t r0 = 0; r0 < m; r0 += chunk) {
         uint64_t rows = m - r0 < chunk ? m - r0 : chunk;
         tmp[ni].group = g; tmp[ni].rowBegin = (uint32_t)r0; tmp[ni].rows = (uint32_t)rows;

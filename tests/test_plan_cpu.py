@@ -104,8 +104,9 @@ def test_wide_and_tall_leaves_are_split():
     op = HipOperator.from_desc(d, vals, **PLAN)
     st = op.stats()
     assert st["numStages"] == 2
-    assert st["numItems"] == 3 + 11          # ceil(150/64) + ceil(700/64)
-    assert st["numPieces"] == 3 * 3 + 11     # 700 cols -> 3 column pieces per item
+    # wide leaf: 700 columns -> 16-row items (128 KiB cap) of 3 column pieces; tall narrow leaf: 64-row items
+    assert st["numItems"] == 10 + 11         # ceil(150/16) + ceil(700/64)
+    assert st["numPieces"] == 10 * 3 + 11
     assert rel(plan_emulator.run_plan(op, x), vals[a] @ (vals[b] @ x)) < 1e-13
 
 
