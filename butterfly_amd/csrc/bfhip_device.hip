@@ -450,18 +450,18 @@ __global__ __launch_bounds__(BF_WAVES_PER_WG * 64) void bfStageKernelReal(StageP
 //
 // An item is <= 16 columns of A (16 outputs); a piece is a forward piece's
 // sub-block of those columns: column-major, `ld` elements per column, hence
-// ONE contiguous run of 16*ld elements.  The wave copies that run into LDS with
-// flat, fully coalesced 16-byte loads (HBM sees the same streaming pattern as
-// the forward kernel), then reads it back transposed: lane = (column jj,
-// row-group sg), 4 row groups per column, each lane walking the 16-byte units
-// of its column with a per-column skew ((t + jj) mod units) so that the 16
-// columns of a group hit 16 different LDS slots even when ld is a multiple of
-// 16.  Lanes own outputs: no cross-lane reduction in the loop; the 4 row
-// groups are combined once per item through LDS in fixed order.
+// ONE contiguous run of 16*ld elements that is read exactly once.  Lane =
+// (c4 = lane / 16, r = lane % 16): one load instruction fetches, for each of 4
+// columns (c4 + 4*cq), 16 consecutive 16-byte units (256 contiguous bytes per
+// 16-lane row), so HBM sees full lines and the same streaming pattern as the
+// forward kernel.  A lane keeps one accumulator per column quad cq: 4 of them,
+// whatever the piece height, so nothing is staged in LDS and the kernel runs at
+// full occupancy; the 16 row-lanes of a column are combined once per item
+// with a fixed xor-butterfly inside the 16-lane row (deterministic).
 // ---------------------------------------------------------------------------
 #define BF_T_COLS 16
-#define BF_T_TILE_BYTES (BF_T_COLS * 1024)          /* 16 columns x (ld * elemSize <= 1 KiB) */
-#define BF_T_X_BYTES 1024
+
+template <typename S> __device__ __forceinline__ S bfRowXor(S v, int mask) { return __shfl_xor(v, mask, 16); }
 
 template <int DT>
 __global__ __launch_bounds__(BF_WAVES_PER_WG * 64) void bfStageKernelT(StageParams p) {
@@ -470,116 +470,82 @@ __global__ __launch_bounds__(BF_WAVES_PER_WG * 64) void bfStageKernelT(StagePara
   constexpr int NC = Traits<DT>::CPLX ? 2 : 1;      // scalars per element
   constexpr int UNIT = EPL * NC;                    // scalars per 16-byte unit
   struct __attribute__((aligned(16))) U { S v[UNIT]; };
-  __shared__ __attribute__((aligned(16))) unsigned char ldsRaw[BF_WAVES_PER_WG][BF_T_TILE_BYTES + BF_T_X_BYTES];
   int const wave = threadIdx.x >> 6;
   int const lane = threadIdx.x & 63;
   uint32_t item = __builtin_amdgcn_readfirstlane(blockIdx.x * BF_WAVES_PER_WG + wave);
   if (item >= p.numItems) return;
   BfDevItem const it = p.items[item];
   uint32_t const mr = it.mrFlags & 0xffffu;          // columns of A in this item (<= 16)
-  uint32_t const jj = lane & 15, sg = lane >> 4;
-  bool const colOk = jj < mr;
-  uint32_t const jc = colOk ? jj : mr - 1;
-  U *tile = (U *)ldsRaw[wave];
-  S *xs = (S *)(ldsRaw[wave] + BF_T_TILE_BYTES);
+  uint32_t const c4 = lane >> 4, r = lane & 15;
+  uint32_t jcol[4];                                  // this lane's 4 columns, clamped into the item:
+#pragma unroll                                       // the duplicates are summed but never stored
+  for (int cq = 0; cq < 4; ++cq) jcol[cq] = c4 + 4 * cq < mr ? c4 + 4 * cq : mr - 1;
   U const *arena = (U const *)p.arena;               // 16-byte units
   uint32_t const nrhs = p.nrhs;
   S *out = (it.mrFlags & BF_ITEM_OUT_Y) ? (S *)p.y : (S *)p.temp;
 
-  constexpr uint32_t XROWS = 64 * EPL;                // rows of x that fit the LDS x region (and 16 x that many units the tile)
   for (uint32_t q = 0; q < nrhs; ++q) {
-    S acc[NC];
+    S acc[4][NC];
 #pragma unroll
-    for (int k = 0; k < NC; ++k) acc[k] = 0;
-    // pieces are consumed in batches that fill the LDS tile: forward row chunks can be as
-    // thin as 16 rows, and one hand-off (two wave syncs) per 64 rows keeps the copy loop busy
+    for (int cq = 0; cq < 4; ++cq)
+#pragma unroll
+      for (int k = 0; k < NC; ++k) acc[cq][k] = 0;
     for (uint32_t wbase = 0; wbase < it.numPieces; wbase += 64) {
-    uint32_t const wn = it.numPieces - wbase < 64 ? it.numPieces - wbase : 64;
-    BfPieceWin const win = bfPieceWinLoad(p.pieces + it.pieceBegin + wbase, wn, lane);
-    uint32_t pi = 0;
-    while (pi < wn) {
-      waveSync();                                    // previous batch fully consumed
-      uint32_t xo = 0, uo = 0, pe = pi;
-      for (; pe < wn; ++pe) {
-        BfDevPiece const pc = bfPieceWinGet(win, pe);
-        if (pc.flags & BF_PIECE_IDENTITY) continue;
-        if (xo && xo + pc.ld > XROWS) break;
-        uint32_t const units = pc.ld / EPL;          // 16-byte units per column
-        uint32_t const total = mr * units;           // contiguous units of this piece
-        // LDS-DMA: 64 lanes x 16 B land contiguously at a wave-uniform LDS base, which is
-        // exactly a flat copy of the run; no VGPR staging, so every load of the whole batch
-        // is in flight at once (the wait is after the x gather below)
-        U const *src = arena + pc.dataOff / EPL;
-        for (uint32_t e0 = 0; e0 < total; e0 += 64)
-          if (e0 + lane < total) bfGlds16(src + e0 + lane, tile + uo + e0);
-        uo += total;
-        xo += pc.ld;
-      }
-      // input sub-vectors of the batch (ordinary loads: their first use drains the DMA too)
-      xo = 0;
-      for (uint32_t pp = pi; pp < pe; ++pp) {
-        BfDevPiece const pc = bfPieceWinGet(win, pp);
-        if (pc.flags & BF_PIECE_IDENTITY) continue;
+      uint32_t const wn = it.numPieces - wbase < 64 ? it.numPieces - wbase : 64;
+      BfPieceWin const win = bfPieceWinLoad(p.pieces + it.pieceBegin + wbase, wn, lane);
+      for (uint32_t pi = 0; pi < wn; ++pi) {
+        BfDevPiece const pc = bfPieceWinGet(win, pi);
         S const *xin = (pc.flags & BF_PIECE_IN_X) ? (S const *)p.x : (S const *)p.temp;
         xin += ((uint64_t)pc.inOff * nrhs + q) * NC;
-        uint32_t const n = pc.ncols;                 // rows of the forward piece
-        for (uint32_t s = lane; s < pc.ld; s += 64) {
-#pragma unroll
-          for (int k = 0; k < NC; ++k) xs[(xo + s) * NC + k] = s < n ? xin[(uint64_t)s * nrhs * NC + k] : (S)0;
-        }
-        xo += pc.ld;
-      }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the LDS-DMA of this batch has landed
-      waveSync();
-      xo = 0; uo = 0;
-      for (uint32_t pp = pi; pp < pe; ++pp) {
-        BfDevPiece const pc = bfPieceWinGet(win, pp);
         if (pc.flags & BF_PIECE_IDENTITY) {
-          if (sg == 0 && colOk) {
-            S const *xin = (pc.flags & BF_PIECE_IN_X) ? (S const *)p.x : (S const *)p.temp;
-            xin += ((uint64_t)pc.inOff * nrhs + q) * NC;
+          if (r == 0) {
 #pragma unroll
-            for (int k = 0; k < NC; ++k) acc[k] += xin[(uint64_t)jj * nrhs * NC + k];
+            for (int cq = 0; cq < 4; ++cq)
+#pragma unroll
+              for (int k = 0; k < NC; ++k) acc[cq][k] += xin[(uint64_t)jcol[cq] * nrhs * NC + k];
           }
           continue;
         }
-        uint32_t const units = pc.ld / EPL;
-        U const *col = tile + uo + jc * units;
-        S const *xp = xs + xo * NC;
-        uint32_t const skew = jc % units;
-        for (uint32_t t = sg; t < units; t += 4) {
-          uint32_t u = t + skew;
-          if (u >= units) u -= units;
-          U a = col[u];
-          if (Traits<DT>::CPLX) {
-            S xr = xp[2 * u], xi = xp[2 * u + 1];
-            acc[0] = fma(a.v[0], xr, acc[0]); acc[0] = fma(-a.v[1], xi, acc[0]);
-            acc[NC - 1] = fma(a.v[0], xi, acc[NC - 1]); acc[NC - 1] = fma(a.v[1], xr, acc[NC - 1]);
-          } else {
+        uint32_t const units = pc.ld / EPL;          // 16-byte units per column (multiple of 16)
+        uint32_t const n = pc.ncols;                 // rows of the forward piece
+        U const *src = arena + pc.dataOff / EPL + r;
+        for (uint32_t rb = 0; rb < units; rb += 16) {
+          U a[4];
 #pragma unroll
-            for (int e = 0; e < EPL; ++e) acc[0] = fma(a.v[e], xp[u * EPL + e], acc[0]);
+          for (int cq = 0; cq < 4; ++cq) a[cq] = bfLoadStreamV(src + jcol[cq] * units + rb);
+          S xv[UNIT];
+#pragma unroll
+          for (int e = 0; e < EPL; ++e) {
+            uint32_t const row = (rb + r) * EPL + e;
+#pragma unroll
+            for (int k = 0; k < NC; ++k) xv[e * NC + k] = row < n ? xin[(uint64_t)row * nrhs * NC + k] : (S)0;
+          }
+#pragma unroll
+          for (int cq = 0; cq < 4; ++cq) {
+            if (Traits<DT>::CPLX) {
+              acc[cq][0] = fma(a[cq].v[0], xv[0], acc[cq][0]); acc[cq][0] = fma(-a[cq].v[1], xv[NC - 1], acc[cq][0]);
+              acc[cq][NC - 1] = fma(a[cq].v[0], xv[NC - 1], acc[cq][NC - 1]); acc[cq][NC - 1] = fma(a[cq].v[1], xv[0], acc[cq][NC - 1]);
+            } else {
+#pragma unroll
+              for (int e = 0; e < EPL; ++e) acc[cq][0] = fma(a[cq].v[e], xv[e], acc[cq][0]);
+            }
           }
         }
-        uo += mr * units;
-        xo += pc.ld;
       }
-      pi = pe;
     }
-    }
-    // combine the 4 row groups of each column (fixed order) and store
-    waveSync();
+    // combine the 16 row lanes of every column (fixed butterfly order) and store
 #pragma unroll
-    for (int k = 0; k < NC; ++k) xs[lane * NC + k] = acc[k];
-    waveSync();
-    if (sg == 0 && colOk) {
-      S r[NC];
+    for (int m = 1; m < 16; m <<= 1)
 #pragma unroll
-      for (int k = 0; k < NC; ++k) r[k] = 0;
-      for (uint32_t g = 0; g < 4; ++g)
+      for (int cq = 0; cq < 4; ++cq)
 #pragma unroll
-        for (int k = 0; k < NC; ++k) r[k] += xs[(g * 16 + jj) * NC + k];
+        for (int k = 0; k < NC; ++k) acc[cq][k] += bfRowXor(acc[cq][k], m);
+    if (r == 0) {
 #pragma unroll
-      for (int k = 0; k < NC; ++k) out[(((uint64_t)it.outOff + jj) * nrhs + q) * NC + k] = r[k];
+      for (int cq = 0; cq < 4; ++cq)
+        if (c4 + 4 * cq < mr)
+#pragma unroll
+          for (int k = 0; k < NC; ++k) out[(((uint64_t)it.outOff + c4 + 4 * cq) * nrhs + q) * NC + k] = acc[cq][k];
     }
   }
 }
