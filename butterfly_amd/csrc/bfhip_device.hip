@@ -94,13 +94,6 @@ template <typename V> __device__ __forceinline__ V bfLoadStreamV(V const *p) {
 #endif
 }
 
-// one global_load_lds_dwordx4: lane l copies 16 bytes from its own global address to
-// LDS at (wave-uniform base) + 16*l
-__device__ __forceinline__ void bfGlds16(void const *g, void *ldsBase) {
-  __builtin_amdgcn_global_load_lds((__attribute__((address_space(1))) void const *)g,
-                                   (__attribute__((address_space(3))) void *)ldsBase, 16, 0, 0);
-}
-
 // a window of 64 piece descriptors held one per lane: a single vector load replaces one
 // dependent scalar load (an L2/HBM round trip) per piece; fields are broadcast by readlane
 struct BfPieceWin { uint32_t w[6]; };
@@ -415,7 +408,7 @@ __global__ __launch_bounds__(BF_WAVES_PER_WG * 64) void bfStageKernelReal(StageP
       uint32_t const nfull = n / g;
       uint32_t j = c;
       uint32_t s = 0;
-#pragma unroll 4
+#pragma unroll 8
       for (; s < nfull; ++s) {
         V a = bfLoadStreamV(ap + (uint64_t)s * G);
         S xv = xs[j];
