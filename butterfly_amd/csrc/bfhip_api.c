@@ -296,6 +296,7 @@ static int compileIr(BfIr *ir, BfhipOptions const *opts, BfhipOperator **out) {
     if (ir->dtype != BFHIP_F64) { rc = bfhipFail(BFABI_ERROR_TYPE_ERROR, "demoteToF32 applies to real operands only"); goto done; }
     po.storeDtype = BFHIP_F32;
   }
+  po.minChunkRows = o.maxRhs >= 3 ? 32 : 16;   /* operators compiled for RHS blocks run on the matrix-core kernel */
   po.rowBlockBegin = o.rowBlockBegin;
   po.rowBlockEnd = o.rowBlockEnd;
   if ((rc = bfPlanBuild(ir, &po, &op->plan))) goto done;

@@ -136,6 +136,7 @@ typedef struct BfPlanOptions {
   uint32_t storeDtype;
   uint32_t itemRows;         /* rows per item cap (<= 64*epl); 0 -> default */
   uint32_t xcap;
+  uint32_t minChunkRows;     /* lower bound of the adaptive item height, in 16-byte row units (0 -> 16): 32 keeps the RHS-block kernel's two-slab passes full */
   uint64_t rowBlockBegin, rowBlockEnd;
   /* transposed plan (A^T x): pieces are located in the forward plan's arena */
   BfFwdPiece const *fwdPieces;   /* sorted by (node, col0, row0); NULL -> forward plan */

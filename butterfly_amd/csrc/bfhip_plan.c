@@ -525,8 +525,9 @@ int bfPlanBuild(BfIr const *ir, BfPlanOptions const *po, BfPlan *plan) {
       uint64_t chunk = itemRows;
       if (!T && gr->colsSum) {
         uint64_t const gran = 16 * plan->epl;
+        uint64_t const floorRows = (po->minChunkRows ? po->minChunkRows : 16) * plan->epl;
         uint64_t want = (BF_ITEM_BYTES / plan->elemSize) / gr->colsSum / gran * gran;
-        if (want < gran) want = gran;
+        if (want < floorRows) want = floorRows;
         if (want < chunk) chunk = want;
       }
       gr->chunkRows = (uint32_t)chunk;
