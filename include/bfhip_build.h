@@ -1,0 +1,108 @@
+/* bfhip_build.h -- device builder for fac_helm2 operands.
+ *
+ * The apply engine (bfhip.h) takes an already-built factorization.  This
+ * extension computes the leaf VALUES of a 2-D Helmholtz butterfly on the
+ * MI355X, straight into the operator's packed arena, from the block layout
+ * (BfhipDesc) plus one recipe per dense leaf.  It replaces the value side of
+ *
+ *   bfFacHelm2MakeMultilevel / bfFacHelm2Make    src/fac_helm2.c:653-704, 943-1003
+ *     makeFirstFactor   :42-160    re-expansion  source points -> proxy circle
+ *     makeFactor        :222-401   re-expansion  child circle   -> parent circle
+ *     makeLastFactor    :403-509   evaluation    proxy circle   -> target points
+ *     dense near field  :888-915   kernel matrix points -> points
+ *   bfHelm2GetKernelMatrix (single layer)         src/helm2.c:93-125, 186-215
+ *   bfHelm2GetReexpansionMatrix                    src/helm2.c:321-365
+ *   bfMatDenseComplexDenseComplexLstSq             src/mat_dense_complex.c:1767-1849
+ *   bfCircle2SamplePoints                          src/circle.c:12-35
+ *
+ * (the structure side -- quadtree, level choice, ranks -- stays on the host:
+ * butterfly_amd/helm2_structure.py restates it; a C caller passes the layout
+ * of a reference-built operand).  Numerics: the kernel is (i/4) H0^(1)(k r), 0
+ * at r == 0; a re-expansion leaf is X = pinv_trunc(Z_equiv) Z_orig with the
+ * reference's truncation rule (singular values below max(m,n) eps s_max + eps
+ * dropped), computed by a one-sided Jacobi SVD instead of LAPACK zgesvd.
+ * Element-wise agreement with the CPU path is therefore at the level of the
+ * truncation (the dropped directions), while Z_equiv X, and hence every
+ * apply result, agrees to ~1e-12; see tests/test_gpu_build.py.
+ */
+#ifndef BFHIP_BUILD_H
+#define BFHIP_BUILD_H
+
+#include "bfhip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum {
+  BFHIP_PTS_TREE = 0,    /* points[first .. first+count) of the (quadtree-ordered) point array */
+  BFHIP_PTS_CIRCLE = 1   /* count points (cx + r cos(2 pi i/count), cy + r sin(2 pi i/count)), src/circle.c:12-35 */
+};
+
+typedef struct BfhipPointSet {
+  uint32_t kind;         /* BFHIP_PTS_* */
+  uint32_t count;
+  uint64_t first;        /* TREE only */
+  double cx, cy, r;      /* CIRCLE only */
+} BfhipPointSet;
+
+enum {
+  BFHIP_LEAF_KERNEL = 0, /* leaf[i][j] = G(tgt_i, src_j): rows = tgt.count, cols = src.count */
+  BFHIP_LEAF_REEXP = 1   /* leaf = lstsq(G(tgt, equiv), G(tgt, src)): rows = equiv.count, cols = src.count;
+                            needs tgt.count >= equiv.count */
+};
+
+typedef struct BfhipHelm2Recipe {
+  uint64_t node;         /* dense leaf of the descriptor this recipe fills */
+  uint32_t kind;         /* BFHIP_LEAF_* */
+  uint32_t reserved;
+  BfhipPointSet src;     /* original sources (columns of the leaf) */
+  BfhipPointSet equiv;   /* REEXP: equivalent sources (rows of the leaf) */
+  BfhipPointSet tgt;     /* KERNEL: targets (rows); REEXP: check points */
+} BfhipHelm2Recipe;
+
+typedef struct BfhipHelm2Problem {
+  uint32_t structSize;       /* = sizeof(BfhipHelm2Problem) */
+  uint32_t layerPot;         /* 0 = single layer (BF_LAYER_POTENTIAL_SINGLE); others: NOT_IMPLEMENTED */
+  double wavenumber;
+  const double *points;      /* [2 * numPoints] host, (x, y) pairs in quadtree order */
+  uint64_t numPoints;
+  const BfhipHelm2Recipe *recipes;
+  uint64_t numRecipes;
+  uint64_t workspaceBytes;   /* device scratch for one batch of leaves; 0 -> 8 GiB */
+} BfhipHelm2Problem;
+
+typedef struct BfhipBuildStats {
+  uint32_t structSize;
+  uint32_t numBatches;
+  uint64_t kernelLeaves, reexpLeaves;
+  uint64_t kernelEvals;      /* Hankel evaluations */
+  uint64_t maxSweeps;        /* largest Jacobi sweep count over all problems */
+  uint64_t notConverged;     /* problems that hit the sweep cap */
+  uint64_t truncated;        /* singular values dropped, total */
+  double seconds;            /* wall time of the value build (device work + orchestration) */
+} BfhipBuildStats;
+
+/* Compile `desc` (all dense leaves must have leafData == NULL and a recipe)
+ * and compute the leaf values on the device.  `opts` as bfhipCompileDesc
+ * (sharding keeps only the recipes whose leaves survive).  `stats` may be NULL. */
+int bfhipBuildHelm2(const BfhipDesc *desc, const BfhipHelm2Problem *prob, const BfhipOptions *opts,
+                    BfhipOperator **out, BfhipBuildStats *stats);
+
+/* One leaf, computed on the device and returned to the host row-major
+ * (rows x cols complex128) -- unit-level parity checks of the builder. */
+int bfhipHelm2BuildLeaf(const BfhipHelm2Problem *prob, uint64_t recipeIndex, int device, void *out);
+
+/* y = G x with the N x N single-layer kernel matrix evaluated on the fly
+ * (never stored): the reference examples' acceptance check at sizes where
+ * the dense matrix does not fit (examples/simple/bf_all_blocks.c:132-153).
+ * dX, dY: device, numPoints complex128; points: host. */
+int bfhipHelm2DenseApplyDevice(const double *points, uint64_t numPoints, double wavenumber, int device,
+                               const void *dX, void *dY, void *stream);
+int bfhipHelm2DenseApply(const double *points, uint64_t numPoints, double wavenumber, int device,
+                         const void *X, void *Y);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BFHIP_BUILD_H */
