@@ -64,6 +64,83 @@ ITEM_DTYPE = np.dtype([("pieceBegin", "<u4"), ("numPieces", "<u4"), ("outOff", "
 PIECE_DTYPE = np.dtype([("dataOff", "<u8"), ("inOff", "<u4"), ("ncols", "<u4"), ("flags", "<u4"), ("ld", "<u4")])
 
 
+# ---- include/bfhip_build.h -----------------------------------------------------
+PTS_TREE, PTS_CIRCLE = 0, 1
+LEAF_KERNEL, LEAF_REEXP = 0, 1
+
+POINT_SET_DTYPE = np.dtype([("kind", "<u4"), ("count", "<u4"), ("first", "<u8"), ("cx", "<f8"), ("cy", "<f8"), ("r", "<f8")])
+RECIPE_DTYPE = np.dtype([("node", "<u8"), ("kind", "<u4"), ("reserved", "<u4"),
+                         ("src", POINT_SET_DTYPE), ("equiv", POINT_SET_DTYPE), ("tgt", POINT_SET_DTYPE)])   # = BfhipHelm2Recipe
+
+
+class BfhipHelm2Problem(C.Structure):
+    _fields_ = [("structSize", C.c_uint32), ("layerPot", C.c_uint32), ("wavenumber", C.c_double),
+                ("points", C.c_void_p), ("numPoints", C.c_uint64), ("recipes", C.c_void_p),
+                ("numRecipes", C.c_uint64), ("workspaceBytes", C.c_uint64)]
+
+
+class BfhipBuildStats(C.Structure):
+    _fields_ = [("structSize", C.c_uint32), ("numBatches", C.c_uint32)] + [
+        (n, C.c_uint64) for n in ("kernelLeaves", "reexpLeaves", "kernelEvals", "maxSweeps", "notConverged", "truncated")] + [
+        ("seconds", C.c_double)]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_ if n != "structSize"}
+
+
+def _pts(rec, spec):
+    if spec[0] == "node":
+        rec["kind"], rec["first"], rec["count"] = PTS_TREE, spec[1], spec[2] - spec[1]
+    elif spec[0] == "circle":
+        rec["kind"], rec["cx"], rec["cy"], rec["r"], rec["count"] = PTS_CIRCLE, spec[1], spec[2], spec[3], spec[4]
+    else:
+        raise ValueError(spec)
+
+
+def recipe_array(recipes: dict) -> np.ndarray:
+    """helm2_structure recipes {leaf: ("kernel", src, tgt) | ("reexp", src, equiv, tgt)}
+    -> BfhipHelm2Recipe[] in leaf order."""
+    out = np.zeros(len(recipes), dtype=RECIPE_DTYPE)
+    for i, node in enumerate(sorted(recipes)):
+        rc = recipes[node]
+        r = out[i]
+        r["node"] = node
+        if rc[0] == "kernel":
+            r["kind"] = LEAF_KERNEL
+            _pts(r["src"], rc[1])
+            _pts(r["tgt"], rc[2])
+        elif rc[0] == "reexp":
+            r["kind"] = LEAF_REEXP
+            _pts(r["src"], rc[1])
+            _pts(r["equiv"], rc[2])
+            _pts(r["tgt"], rc[3])
+        else:
+            raise ValueError(rc)
+    return out
+
+
+class Helm2Problem:
+    """Keeps the arrays a BfhipHelm2Problem points to alive."""
+
+    def __init__(self, points, wavenumber, recipes, workspace_bytes=0):
+        self.points = np.ascontiguousarray(points, dtype=np.float64)
+        assert self.points.ndim == 2 and self.points.shape[1] == 2
+        self.recipes = recipes if isinstance(recipes, np.ndarray) else recipe_array(recipes)
+        assert self.recipes.dtype == RECIPE_DTYPE and self.recipes.flags.c_contiguous
+        s = self.struct = BfhipHelm2Problem()
+        s.structSize = C.sizeof(BfhipHelm2Problem)
+        s.layerPot = 0
+        s.wavenumber = float(wavenumber)
+        s.points = self.points.ctypes.data
+        s.numPoints = len(self.points)
+        s.recipes = self.recipes.ctypes.data
+        s.numRecipes = len(self.recipes)
+        s.workspaceBytes = int(workspace_bytes)
+
+    def byref(self):
+        return C.byref(self.struct)
+
+
 class DescArrays:
     """Keeps the numpy arrays behind a BfhipDesc alive."""
 
@@ -169,6 +246,15 @@ def load():
     lib.bfhipSyntheticValue.restype = C.c_double
     lib.bfhipSyntheticLeafBases.argtypes = [C.POINTER(BfhipDesc), vp]
     lib.bfhipSyntheticLeafBases.restype = C.c_int
+    lib.bfhipBuildHelm2.argtypes = [C.POINTER(BfhipDesc), C.POINTER(BfhipHelm2Problem), C.POINTER(BfhipOptions), C.POINTER(vp),
+                                    C.POINTER(BfhipBuildStats)]
+    lib.bfhipBuildHelm2.restype = C.c_int
+    lib.bfhipHelm2BuildLeaf.argtypes = [C.POINTER(BfhipHelm2Problem), C.c_uint64, C.c_int, vp]
+    lib.bfhipHelm2BuildLeaf.restype = C.c_int
+    lib.bfhipHelm2DenseApplyDevice.argtypes = [vp, C.c_uint64, C.c_double, C.c_int, vp, vp, vp]
+    lib.bfhipHelm2DenseApplyDevice.restype = C.c_int
+    lib.bfhipHelm2DenseApply.argtypes = [vp, C.c_uint64, C.c_double, C.c_int, vp, vp]
+    lib.bfhipHelm2DenseApply.restype = C.c_int
     _lib = lib
     return lib
 

@@ -268,7 +268,7 @@ static int ensureTemp(BfhipOperator *op, uint32_t nrhs) {
   return 0;
 }
 
-static int compileIr(BfIr *ir, BfhipOptions const *opts, BfhipOperator **out) {
+int bfhipCompileIrFill(BfIr *ir, BfhipOptions const *opts, BfFillFn fill, void *fillCtx, BfhipOperator **out) {
   BfhipOptions o;
   memset(&o, 0, sizeof o);
   o.device = -1;
@@ -326,7 +326,8 @@ static int compileIr(BfIr *ir, BfhipOptions const *opts, BfhipOperator **out) {
   if ((rc = bfdevMalloc(&op->dArena, (size_t)op->plan.arenaElems * op->plan.elemSize))) goto done;
   if ((rc = uploadPlanMeta(op, &op->plan))) goto done;
   if (op->hasTplan && (rc = uploadPlanMeta(op, &op->tplan))) goto done;
-  if ((rc = packLeaves(op, ir, o.seed, NULL))) goto done;
+  /* leaf values: computed on the device by the caller's builder, or packed / synthesized from the IR */
+  if ((rc = fill ? fill(&op->plan, ir, op->dArena, fillCtx) : packLeaves(op, ir, o.seed, NULL))) goto done;
   /* host mirrors of the bulky per-piece arrays are no longer needed */
   dropPlanMirrors(&op->plan);
   dropPlanMirrors(&op->tplan);
@@ -359,7 +360,7 @@ int bfhipCompile(void const *bfMat, BfhipOptions const *opts, BfhipOperator **ou
   BfIr ir;
   int rc = bfIrFromBfMat(bfMat, &ir);
   if (rc) return rc;
-  return compileIr(&ir, opts, out);
+  return bfhipCompileIrFill(&ir, opts, NULL, NULL, out);
 }
 
 int bfhipCompileDesc(BfhipDesc const *desc, BfhipOptions const *opts, BfhipOperator **out) {
@@ -368,7 +369,7 @@ int bfhipCompileDesc(BfhipDesc const *desc, BfhipOptions const *opts, BfhipOpera
   BfIr ir;
   int rc = bfIrFromDesc(desc, &ir);
   if (rc) return rc;
-  return compileIr(&ir, opts, out);
+  return bfhipCompileIrFill(&ir, opts, NULL, NULL, out);
 }
 
 /* ---- profiling helpers ------------------------------------------------------ */

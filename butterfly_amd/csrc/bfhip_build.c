@@ -1,0 +1,368 @@
+/* bfhip_build.c -- host side of the fac_helm2 value builder (include/bfhip_build.h).
+ *
+ * The reference builds one block at a time on the CPU (src/fac_helm2.c:42-509:
+ * kernel matrix, SVD-based least squares, store the block).  Here the dense
+ * leaves of the already laid-out operand are processed in batches that fit a
+ * device workspace: every kernel matrix of a batch in one launch, every
+ * least-squares problem of a batch in one Jacobi launch per size class, two
+ * batched GEMM launches, then one launch that copies the batch's leaves into
+ * the packed arena the apply kernels read.  Nothing but the recipes and the
+ * point coordinates crosses PCIe.
+ */
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+#include "bfhip_internal.h"
+#include "../../include/bfhip_abi.h"
+#include "../../include/bfhip_build.h"
+
+#define DEFAULT_WORKSPACE ((uint64_t)8 << 30)
+
+static double nowSeconds(void) {
+  struct timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+static BfBuildPts toPts(BfhipPointSet const *p) {
+  BfBuildPts q;
+  q.kind = p->kind; q.count = p->count; q.first = p->first; q.cx = p->cx; q.cy = p->cy; q.r = p->r;
+  return q;
+}
+
+static int checkPts(BfhipPointSet const *p, uint64_t numPoints, char const *what, uint64_t idx) {
+  if (p->count == 0) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "recipe %llu: empty %s point set", (unsigned long long)idx, what);
+  if (p->kind == BFHIP_PTS_TREE) {
+    if (p->first + p->count > numPoints)
+      return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "recipe %llu: %s points [%llu, %llu) exceed numPoints", (unsigned long long)idx, what,
+                       (unsigned long long)p->first, (unsigned long long)(p->first + p->count));
+  } else if (p->kind != BFHIP_PTS_CIRCLE) {
+    return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "recipe %llu: unknown point-set kind %u", (unsigned long long)idx, p->kind);
+  }
+  return 0;
+}
+
+static uint32_t leafRows(BfhipHelm2Recipe const *r) { return r->kind == BFHIP_LEAF_KERNEL ? r->tgt.count : r->equiv.count; }
+
+static int checkProblem(BfhipHelm2Problem const *prob) {
+  if (!prob) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "NULL problem");
+  if (prob->structSize < sizeof(BfhipHelm2Problem)) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "BfhipHelm2Problem.structSize too small");
+  if (prob->layerPot != 0) return bfhipFail(BFABI_ERROR_NOT_IMPLEMENTED, "only the single-layer potential is built on the device");
+  if (!prob->points || (!prob->recipes && prob->numRecipes)) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "NULL points / recipes");
+  if (!(prob->wavenumber > 0)) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "wavenumber must be positive");
+  return 0;
+}
+
+static int checkRecipe(BfhipHelm2Problem const *prob, uint64_t i) {
+  BfhipHelm2Recipe const *r = &prob->recipes[i];
+  int rc;
+  if ((rc = checkPts(&r->src, prob->numPoints, "source", i))) return rc;
+  if ((rc = checkPts(&r->tgt, prob->numPoints, "target", i))) return rc;
+  if (r->kind == BFHIP_LEAF_REEXP) {
+    if ((rc = checkPts(&r->equiv, prob->numPoints, "equivalent-source", i))) return rc;
+    if (r->tgt.count < r->equiv.count)
+      return bfhipFail(BFABI_ERROR_NOT_IMPLEMENTED, "recipe %llu: fewer check points (%u) than equivalent sources (%u)",
+                       (unsigned long long)i, r->tgt.count, r->equiv.count);
+  } else if (r->kind != BFHIP_LEAF_KERNEL) {
+    return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "recipe %llu: unknown kind %u", (unsigned long long)i, r->kind);
+  }
+  return 0;
+}
+
+/* workspace of one re-expansion problem, in complex elements */
+typedef struct ReexpWs { uint64_t zeq, v, zor, t, scale, total; } ReexpWs;
+static ReexpWs reexpWs(BfhipHelm2Recipe const *r) {
+  uint64_t const mt = r->tgt.count, me = r->equiv.count, n = r->src.count;
+  ReexpWs w;
+  w.zeq = 0;
+  w.v = w.zeq + mt * me;
+  w.zor = w.v + me * me;
+  w.t = w.zor + mt * n;
+  w.scale = w.t + me * n;
+  w.total = w.scale + (me + 1) / 2;
+  return w;
+}
+
+static uint64_t recipeCost(BfhipHelm2Recipe const *r) {
+  uint64_t c = (uint64_t)leafRows(r) * r->src.count;
+  if (r->kind == BFHIP_LEAF_REEXP) c += reexpWs(r).total;
+  return c;
+}
+
+/* Compute recipes idx[0..count) on the current device.  *dStore receives a
+ * device buffer holding the leaves column-major at storeOff[i] (elements). */
+static int buildBatch(BfhipHelm2Problem const *prob, uint64_t const *idx, uint64_t count, void const *dPoints,
+                      void **dStore, uint64_t *storeOff, BfhipBuildStats *st) {
+  int rc = 0;
+  *dStore = NULL;
+  void *dWs = NULL;
+  uint64_t storeElems = 0, wsElems = 0, numReexp = 0;
+  uint64_t *wsOff = malloc((count + 1) * sizeof *wsOff);
+  BfEvalMat *mats = malloc(2 * count * sizeof *mats);
+  uint64_t *prefix = malloc((2 * count + 1) * sizeof *prefix);
+  BfSvdProb *probs = malloc((count + 1) * sizeof *probs);
+  BfGemmJob *g1 = malloc((count + 1) * sizeof *g1), *g2 = malloc((count + 1) * sizeof *g2);
+  if (!wsOff || !mats || !prefix || !probs || !g1 || !g2) { rc = bfhipFail(BFABI_ERROR_MEMORY_ERROR, "host OOM (builder batch)"); goto done; }
+  for (uint64_t i = 0; i < count; ++i) {
+    BfhipHelm2Recipe const *r = &prob->recipes[idx[i]];
+    storeOff[i] = storeElems;
+    storeElems += (uint64_t)leafRows(r) * r->src.count;
+    wsOff[i] = wsElems;
+    if (r->kind == BFHIP_LEAF_REEXP) { wsElems += reexpWs(r).total; ++numReexp; }
+  }
+  if ((rc = bfdevMalloc(dStore, (size_t)(storeElems ? storeElems : 1) * 16))) goto done;
+  if (wsElems && (rc = bfdevMalloc(&dWs, (size_t)wsElems * 16))) goto done;
+  char *store = (char *)*dStore, *ws = (char *)dWs;
+  uint64_t nm = 0, np = 0;
+  prefix[0] = 0;
+  for (uint64_t i = 0; i < count; ++i) {
+    BfhipHelm2Recipe const *r = &prob->recipes[idx[i]];
+    if (r->kind == BFHIP_LEAF_KERNEL) {
+      mats[nm].src = toPts(&r->src); mats[nm].tgt = toPts(&r->tgt); mats[nm].dst = store + storeOff[i] * 16;
+      prefix[nm + 1] = prefix[nm] + ((uint64_t)r->tgt.count * r->src.count + BF_EVAL_TILE - 1) / BF_EVAL_TILE;
+      ++nm;
+      st->kernelLeaves += 1;
+      st->kernelEvals += (uint64_t)r->tgt.count * r->src.count;
+      continue;
+    }
+    ReexpWs const w = reexpWs(r);
+    char *base = ws + wsOff[i] * 16;
+    uint32_t const mt = r->tgt.count, me = r->equiv.count, n = r->src.count;
+    mats[nm].src = toPts(&r->equiv); mats[nm].tgt = toPts(&r->tgt); mats[nm].dst = base + w.zeq * 16;
+    prefix[nm + 1] = prefix[nm] + ((uint64_t)mt * me + BF_EVAL_TILE - 1) / BF_EVAL_TILE;
+    ++nm;
+    mats[nm].src = toPts(&r->src); mats[nm].tgt = toPts(&r->tgt); mats[nm].dst = base + w.zor * 16;
+    prefix[nm + 1] = prefix[nm] + ((uint64_t)mt * n + BF_EVAL_TILE - 1) / BF_EVAL_TILE;
+    ++nm;
+    probs[np].a = base + w.zeq * 16; probs[np].v = base + w.v * 16; probs[np].scale = (double *)(base + w.scale * 16);
+    probs[np].mt = mt; probs[np].me = me;
+    /* T = diag(1/sigma^2) (U Sigma)^H Z_orig */
+    memset(&g1[np], 0, sizeof g1[np]);
+    g1[np].a = probs[np].a; g1[np].b = base + w.zor * 16; g1[np].c = base + w.t * 16; g1[np].scale = probs[np].scale;
+    g1[np].M = me; g1[np].N = n; g1[np].K = mt; g1[np].lda = mt; g1[np].ldb = mt; g1[np].ldc = me; g1[np].transA = 1;
+    /* X = V T */
+    memset(&g2[np], 0, sizeof g2[np]);
+    g2[np].a = probs[np].v; g2[np].b = base + w.t * 16; g2[np].c = store + storeOff[i] * 16; g2[np].scale = NULL;
+    g2[np].M = me; g2[np].N = n; g2[np].K = me; g2[np].lda = me; g2[np].ldb = me; g2[np].ldc = me; g2[np].transA = 0;
+    ++np;
+    st->reexpLeaves += 1;
+    st->kernelEvals += (uint64_t)mt * me + (uint64_t)mt * n;
+  }
+  if ((rc = bfdevBuildEval(mats, prefix, nm, dPoints, prob->wavenumber))) goto done;
+  BfSvdStats ss = {st->maxSweeps, 0, 0};
+  if ((rc = bfdevBuildJacobi(probs, np, &ss))) goto done;
+  st->maxSweeps = ss.maxSweeps; st->notConverged += ss.notConverged; st->truncated += ss.truncated;
+  if ((rc = bfdevBuildGemm(g1, np))) goto done;
+  if ((rc = bfdevBuildGemm(g2, np))) goto done;
+  st->numBatches += 1;
+done:
+  bfdevFree(dWs);
+  if (rc) { bfdevFree(*dStore); *dStore = NULL; }
+  free(wsOff); free(mats); free(prefix); free(probs); free(g1); free(g2);
+  return rc;
+}
+
+/* ---- arena fill: called by the compile step instead of packing host values ---- */
+typedef struct BuildCtx {
+  BfhipHelm2Problem const *prob;
+  BfhipBuildStats *stats;
+} BuildCtx;
+
+typedef struct PieceRec { uint64_t rec, dataOff; uint32_t row0, col0, mr, mrPad, ncols; } PieceRec;
+
+static int fillArena(BfPlan const *pl, BfIr const *ir, void *dArena, void *vctx) {
+  BuildCtx *ctx = vctx;
+  BfhipHelm2Problem const *prob = ctx->prob;
+  BfhipBuildStats *st = ctx->stats;
+  int rc = 0;
+  if (pl->dtype != BFHIP_C128) return bfhipFail(BFABI_ERROR_TYPE_ERROR, "the Helmholtz builder fills complex128 operands");
+  uint64_t const R = prob->numRecipes;
+  int64_t *recOf = malloc((ir->numNodes + 1) * sizeof *recOf);
+  uint64_t *pieceBegin = calloc(R + 2, sizeof *pieceBegin);
+  PieceRec *pieces = NULL, *sorted = NULL;
+  uint64_t *batch = NULL, *storeOff = NULL;
+  BfPackPiece *pack = NULL;
+  void *dPoints = NULL;
+  if (!recOf || !pieceBegin) { rc = bfhipFail(BFABI_ERROR_MEMORY_ERROR, "host OOM (builder)"); goto done; }
+  for (uint64_t i = 0; i < ir->numNodes; ++i) recOf[i] = -1;
+  for (uint64_t i = 0; i < R && !rc; ++i) {
+    BfhipHelm2Recipe const *r = &prob->recipes[i];
+    if (r->node >= ir->numNodes || ir->kind[r->node] != BFHIP_NODE_DENSE)
+      rc = bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "recipe %llu: node %llu is not a dense leaf", (unsigned long long)i, (unsigned long long)r->node);
+    else if (recOf[r->node] >= 0)
+      rc = bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "recipe %llu: leaf %llu already has a recipe", (unsigned long long)i, (unsigned long long)r->node);
+    else if ((rc = checkRecipe(prob, i)) == 0) {
+      if (ir->rows[r->node] != leafRows(r) || ir->cols[r->node] != r->src.count)
+        rc = bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "recipe %llu: leaf %llu is %llu x %llu, recipe yields %u x %u", (unsigned long long)i,
+                       (unsigned long long)r->node, (unsigned long long)ir->rows[r->node], (unsigned long long)ir->cols[r->node],
+                       leafRows(r), r->src.count);
+      recOf[r->node] = (int64_t)i;
+    }
+  }
+  if (rc) goto done;
+
+  /* the plan's pieces, grouped by recipe (counting sort) */
+  uint64_t numPieces = 0;
+  for (uint64_t s = 0; s < pl->numStages; ++s) numPieces += pl->stages[s].numPieces;
+  pieces = malloc((numPieces + 1) * sizeof *pieces);
+  sorted = malloc((numPieces + 1) * sizeof *sorted);
+  if (!pieces || !sorted) { rc = bfhipFail(BFABI_ERROR_MEMORY_ERROR, "host OOM (builder pieces)"); goto done; }
+  uint64_t np = 0;
+  for (uint64_t s = 0; s < pl->numStages && !rc; ++s) {
+    BfStage const *stg = &pl->stages[s];
+    for (uint64_t i = 0; i < stg->numItems && !rc; ++i) {
+      BfDevItem const *it = &stg->items[i];
+      uint32_t const mr = it->mrFlags & 0xffffu;
+      uint32_t const mrPad = (mr + pl->epl - 1) / pl->epl * pl->epl;
+      for (uint32_t k = 0; k < it->numPieces; ++k) {
+        BfDevPiece const *pc = &stg->pieces[it->pieceBegin + k];
+        BfPieceSrc const *src = &stg->pieceSrc[it->pieceBegin + k];
+        if (pc->flags & BF_PIECE_IDENTITY) continue;
+        int64_t const rec = recOf[src->node];
+        if (rec < 0) { rc = bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "dense leaf %llu has no recipe", (unsigned long long)src->node); break; }
+        PieceRec *p = &pieces[np++];
+        p->rec = (uint64_t)rec; p->dataOff = pc->dataOff; p->row0 = src->row0; p->col0 = src->col0;
+        p->mr = mr; p->mrPad = mrPad; p->ncols = pc->ncols;
+        pieceBegin[rec + 1] += 1;
+      }
+    }
+  }
+  if (rc) goto done;
+  for (uint64_t i = 0; i < R; ++i) pieceBegin[i + 1] += pieceBegin[i];
+  {
+    uint64_t *cursor = malloc((R + 1) * sizeof *cursor);
+    if (!cursor) { rc = bfhipFail(BFABI_ERROR_MEMORY_ERROR, "host OOM (builder)"); goto done; }
+    memcpy(cursor, pieceBegin, (R + 1) * sizeof *cursor);
+    for (uint64_t i = 0; i < np; ++i) sorted[cursor[pieces[i].rec]++] = pieces[i];
+    free(cursor);
+  }
+
+  if ((rc = bfdevMalloc(&dPoints, (size_t)(prob->numPoints ? prob->numPoints : 1) * 16))) goto done;
+  if ((rc = bfdevMemcpyH2D(dPoints, prob->points, (size_t)prob->numPoints * 16))) goto done;
+
+  uint64_t const budget = (prob->workspaceBytes ? prob->workspaceBytes : DEFAULT_WORKSPACE) / 16;
+  batch = malloc((R + 1) * sizeof *batch);
+  storeOff = malloc((R + 1) * sizeof *storeOff);
+  if (!batch || !storeOff) { rc = bfhipFail(BFABI_ERROR_MEMORY_ERROR, "host OOM (builder)"); goto done; }
+  uint64_t i = 0;
+  while (i < R && !rc) {
+    /* next batch: recipes whose leaves survive in this plan, until the workspace is full */
+    uint64_t nb = 0, cost = 0, packCount = 0;
+    for (; i < R; ++i) {
+      if (pieceBegin[i + 1] == pieceBegin[i]) continue;          /* sharded away */
+      uint64_t const c = recipeCost(&prob->recipes[i]);
+      if (nb && cost + c > budget) break;
+      batch[nb++] = i; cost += c; packCount += pieceBegin[i + 1] - pieceBegin[i];
+    }
+    if (!nb) break;
+    void *dStore = NULL;
+    if ((rc = buildBatch(prob, batch, nb, dPoints, &dStore, storeOff, st))) break;
+    pack = malloc((packCount + 1) * sizeof *pack);
+    if (!pack) rc = bfhipFail(BFABI_ERROR_MEMORY_ERROR, "host OOM (builder pack list)");
+    uint64_t q = 0;
+    for (uint64_t b = 0; b < nb && !rc; ++b) {
+      uint64_t const rec = batch[b];
+      uint32_t const ld = leafRows(&prob->recipes[rec]);
+      for (uint64_t k = pieceBegin[rec]; k < pieceBegin[rec + 1]; ++k) {
+        PieceRec const *p = &sorted[k];
+        pack[q].dataOff = p->dataOff;
+        pack[q].srcOff = storeOff[b] + (uint64_t)p->col0 * ld + p->row0;
+        pack[q].srcLd = ld; pack[q].mr = p->mr; pack[q].mrPad = p->mrPad; pack[q].ncols = p->ncols;
+        ++q;
+      }
+    }
+    if (!rc) rc = bfdevBuildPack(dArena, dStore, pack, q);
+    free(pack); pack = NULL;
+    bfdevFree(dStore);
+  }
+done:
+  bfdevFree(dPoints);
+  free(recOf); free(pieceBegin); free(pieces); free(sorted); free(batch); free(storeOff);
+  return rc;
+}
+
+int bfhipBuildHelm2(BfhipDesc const *desc, BfhipHelm2Problem const *prob, BfhipOptions const *opts, BfhipOperator **out,
+                    BfhipBuildStats *stats) {
+  if (!desc || !out) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "NULL argument");
+  *out = NULL;
+  int rc = checkProblem(prob);
+  if (rc) return rc;
+  if (desc->dtype != BFHIP_C128) return bfhipFail(BFABI_ERROR_TYPE_ERROR, "the Helmholtz builder fills complex128 operands");
+  if (opts && (opts->flags & BFHIP_FLAG_PLAN_ONLY)) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "BFHIP_FLAG_PLAN_ONLY has no device to build on");
+  BfhipBuildStats local;
+  memset(&local, 0, sizeof local);
+  local.structSize = sizeof local;
+  BuildCtx ctx = {prob, &local};
+  BfIr ir;
+  if ((rc = bfIrFromDesc(desc, &ir))) return rc;
+  double const t0 = nowSeconds();
+  rc = bfhipCompileIrFill(&ir, opts, fillArena, &ctx, out);
+  local.seconds = nowSeconds() - t0;
+  if (!rc && stats) {
+    if (stats->structSize < sizeof local) { bfhipFree(out); return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "BfhipBuildStats.structSize too small"); }
+    *stats = local;
+  }
+  return rc;
+}
+
+int bfhipHelm2BuildLeaf(BfhipHelm2Problem const *prob, uint64_t recipeIndex, int device, void *out) {
+  int rc = checkProblem(prob);
+  if (rc) return rc;
+  if (!out || recipeIndex >= prob->numRecipes) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "bad recipe index / NULL output");
+  if ((rc = checkRecipe(prob, recipeIndex))) return rc;
+  int prev = -1;
+  bfdevGetDevice(&prev);
+  if ((rc = bfdevSetDevice(device))) return rc;
+  BfhipHelm2Recipe const *r = &prob->recipes[recipeIndex];
+  uint64_t const m = leafRows(r), n = r->src.count;
+  void *dPoints = NULL, *dStore = NULL;
+  double *tmp = malloc((size_t)m * n * 16);
+  BfhipBuildStats st;
+  memset(&st, 0, sizeof st);
+  uint64_t off = 0;
+  if (!tmp) rc = bfhipFail(BFABI_ERROR_MEMORY_ERROR, "host OOM");
+  if (!rc) rc = bfdevMalloc(&dPoints, (size_t)(prob->numPoints ? prob->numPoints : 1) * 16);
+  if (!rc) rc = bfdevMemcpyH2D(dPoints, prob->points, (size_t)prob->numPoints * 16);
+  if (!rc) rc = buildBatch(prob, &recipeIndex, 1, dPoints, &dStore, &off, &st);
+  if (!rc) rc = bfdevMemcpyD2H(tmp, dStore, (size_t)m * n * 16);
+  if (!rc) {
+    double *o = out;                                   /* column-major store -> row-major result */
+    for (uint64_t i = 0; i < m; ++i)
+      for (uint64_t j = 0; j < n; ++j) { o[2 * (i * n + j)] = tmp[2 * (j * m + i)]; o[2 * (i * n + j) + 1] = tmp[2 * (j * m + i) + 1]; }
+  }
+  bfdevFree(dStore); bfdevFree(dPoints); free(tmp);
+  if (prev >= 0) bfdevSetDevice(prev);
+  return rc;
+}
+
+int bfhipHelm2DenseApplyDevice(double const *points, uint64_t numPoints, double wavenumber, int device, void const *dX, void *dY, void *stream) {
+  if (!points || !dX || !dY) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "NULL argument");
+  int prev = -1, rc;
+  bfdevGetDevice(&prev);
+  if ((rc = bfdevSetDevice(device))) return rc;
+  void *dPoints = NULL;
+  rc = bfdevMalloc(&dPoints, (size_t)(numPoints ? numPoints : 1) * 16);
+  if (!rc) rc = bfdevMemcpyH2D(dPoints, points, (size_t)numPoints * 16);
+  if (!rc) rc = bfdevHelm2Dense(dPoints, numPoints, wavenumber, dX, dY, stream);
+  bfdevFree(dPoints);
+  if (prev >= 0) bfdevSetDevice(prev);
+  return rc;
+}
+
+int bfhipHelm2DenseApply(double const *points, uint64_t numPoints, double wavenumber, int device, void const *X, void *Y) {
+  if (!points || !X || !Y) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "NULL argument");
+  int prev = -1, rc;
+  bfdevGetDevice(&prev);
+  if ((rc = bfdevSetDevice(device))) return rc;
+  void *dX = NULL, *dY = NULL;
+  size_t const bytes = (size_t)(numPoints ? numPoints : 1) * 16;
+  rc = bfdevMalloc(&dX, bytes);
+  if (!rc) rc = bfdevMalloc(&dY, bytes);
+  if (!rc) rc = bfdevMemcpyH2D(dX, X, (size_t)numPoints * 16);
+  if (!rc) rc = bfhipHelm2DenseApplyDevice(points, numPoints, wavenumber, -1, dX, dY, NULL);
+  if (!rc) rc = bfdevMemcpyD2H(Y, dY, (size_t)numPoints * 16);
+  bfdevFree(dX); bfdevFree(dY);
+  if (prev >= 0) bfdevSetDevice(prev);
+  return rc;
+}

@@ -1,0 +1,461 @@
+// bfhip_build.hip -- gfx950 device layer of the fac_helm2 value builder
+// (include/bfhip_build.h).
+//
+// What runs here replaces, for every dense leaf of a Helmholtz butterfly,
+//   * bfHelm2GetKernelMatrix (single layer)        reference src/helm2.c:93-125
+//       -> bfEvalKernel: one Hankel evaluation per matrix element, all kernel
+//          matrices of a batch in one launch (flat tile list, binary search);
+//   * bfHelm2GetReexpansionMatrix                   src/helm2.c:321-365
+//     = bfMatDenseComplexDenseComplexLstSq          src/mat_dense_complex.c:1767-1849
+//       (LAPACK zgesvd + truncation + two zgemm)
+//       -> bfJacobiKernel: one-sided (Hestenes) Jacobi SVD, one workgroup per
+//          problem, column pairs of a round-robin step spread over lane groups;
+//          bfGemmKernel: T = diag(1/sigma^2) (U Sigma)^H Z_orig, X = V T;
+//   * the leaf -> packed-arena copy that bfhip_api.c does on the host for
+//     host-valued operands -> bfPackKernel.
+// Plus bfHelm2DenseKernel, the matrix-free N x N kernel matvec used as the
+// acceptance check (examples/simple/bf_all_blocks.c:132-153).
+//
+// None of these kernels is on the apply path; they are compute-bound FP64 VALU
+// work (Bessel functions, rotations) and are written for clarity first: fixed
+// summation orders, no atomics in any result.
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "bfhip_internal.h"
+#include "../../include/bfhip_abi.h"
+#include "../../include/bfhip_build.h"
+
+static int hipFailB(hipError_t e, char const *what) {
+  if (e == hipSuccess) return 0;
+  int code = (e == hipErrorOutOfMemory) ? BFABI_ERROR_MEMORY_ERROR : BFABI_ERROR_RUNTIME_ERROR;
+  return bfhipFail(code, "%s: %s", what, hipGetErrorString(e));
+}
+
+template <typename T> static int uploadArrayB(T **d, T const *h, uint64_t count, char const *what) {
+  *d = NULL;
+  int rc = hipFailB(hipMalloc((void **)d, count * sizeof(T)), what);
+  if (rc) return rc;
+  return hipFailB(hipMemcpy(*d, h, count * sizeof(T), hipMemcpyHostToDevice), what);
+}
+
+// ---------------------------------------------------------------------------
+// points and the kernel
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void bfPoint(BfBuildPts const &ps, uint32_t i, double const *pts, double &x, double &y) {
+  if (ps.kind == BFHIP_PTS_TREE) {
+    x = pts[2 * (ps.first + i)];
+    y = pts[2 * (ps.first + i) + 1];
+  } else {
+    // bfCircle2SamplePoints, src/circle.c:12-35
+    double const theta = (6.283185307179586 / (double)ps.count) * (double)i;
+    x = ps.r * cos(theta) + ps.cx;
+    y = ps.r * sin(theta) + ps.cy;
+  }
+}
+
+// (i/4) H0^(1)(k r) = -Y0(kr)/4 + i J0(kr)/4; 0 on r == 0 (src/helm2.c:111-117)
+__device__ __forceinline__ double2 bfHelm2G(double k, double dx, double dy) {
+  double const r = hypot(dx, dy);
+  if (r == 0.0) return make_double2(0.0, 0.0);
+  double const kr = k * r;
+  return make_double2(-0.25 * y0(kr), 0.25 * j0(kr));
+}
+
+__global__ __launch_bounds__(256) void bfEvalKernel(BfEvalMat const *mats, uint64_t const *prefix, uint32_t numMats,
+                                                    double const *pts, double k, uint64_t tileBase) {
+  uint64_t const tile = tileBase + blockIdx.x;
+  uint32_t lo = 0, hi = numMats;                   // prefix[lo] <= tile < prefix[hi]
+  while (hi - lo > 1) {
+    uint32_t const mid = (lo + hi) >> 1;
+    if (prefix[mid] <= tile) lo = mid; else hi = mid;
+  }
+  BfEvalMat const M = mats[lo];
+  uint64_t const total = (uint64_t)M.tgt.count * M.src.count;
+  uint64_t const e0 = (tile - prefix[lo]) * BF_EVAL_TILE;
+  double2 *dst = (double2 *)M.dst;
+#pragma unroll
+  for (int q = 0; q < (int)(BF_EVAL_TILE / 256); ++q) {
+    uint64_t const e = e0 + (uint64_t)q * 256 + threadIdx.x;
+    if (e >= total) break;
+    uint32_t const i = (uint32_t)(e % M.tgt.count), j = (uint32_t)(e / M.tgt.count);
+    double tx, ty, sx, sy;
+    bfPoint(M.tgt, i, pts, tx, ty);
+    bfPoint(M.src, j, pts, sx, sy);
+    dst[e] = bfHelm2G(k, tx - sx, ty - sy);
+  }
+}
+
+int bfdevBuildEval(BfEvalMat const *hostMats, uint64_t const *hostTilePrefix, uint64_t numMats, void const *dPoints, double wavenumber) {
+  if (!numMats) return 0;
+  BfEvalMat *dM = NULL;
+  uint64_t *dP = NULL;
+  int rc = uploadArrayB(&dM, hostMats, numMats, "eval matrices");
+  if (!rc) rc = uploadArrayB(&dP, hostTilePrefix, numMats + 1, "eval tile prefix");
+  uint64_t const tiles = hostTilePrefix[numMats];
+  for (uint64_t done = 0; done < tiles && !rc;) {
+    uint32_t const n = (uint32_t)(tiles - done > (1u << 30) ? (1u << 30) : tiles - done);
+    hipLaunchKernelGGL(bfEvalKernel, dim3(n), dim3(256), 0, 0, dM, dP, (uint32_t)numMats, (double const *)dPoints, wavenumber, done);
+    rc = hipFailB(hipGetLastError(), "kernel-matrix evaluation launch");
+    done += n;
+  }
+  if (!rc) rc = hipFailB(hipDeviceSynchronize(), "kernel-matrix evaluation");
+  (void)hipFree(dM);
+  (void)hipFree(dP);
+  return rc;
+}
+
+// ---------------------------------------------------------------------------
+// one-sided Jacobi SVD.  Round-robin ordering: M = me rounded up to even,
+// step s pairs (M-1, s) and ((s+k) mod (M-1), (s-k) mod (M-1)), k = 1..M/2-1,
+// so the M/2 pairs of a step touch disjoint columns and run concurrently on
+// the workgroup's lane groups (W lanes each; a workgroup barrier per step).
+// A rotation is the unitary J = [[c, s], [-s e^{-i phi}, c e^{-i phi}]] applied
+// on the right to columns (p, q) of A and of V, with phi = arg(a_p^H a_q) and
+// tan(theta) the small root of t^2 + 2 zeta t - 1, zeta = (|a_q|^2 - |a_p|^2) / (2 |a_p^H a_q|).
+// ---------------------------------------------------------------------------
+#define BF_JACOBI_MAX_SWEEPS 40
+#define BF_JACOBI_TOL 1e-15
+
+template <int W> __device__ __forceinline__ double bfGroupSum(double v) {
+#pragma unroll
+  for (int m = 1; m < W; m <<= 1) v += __shfl_xor(v, m, W);
+  return v;
+}
+
+template <int W>
+__global__ __launch_bounds__(1024) void bfJacobiKernel(BfSvdProb const *probs, uint32_t const *list, BfSvdStats *stats) {
+  BfSvdProb const P = probs[list[blockIdx.x]];
+  uint32_t const mt = P.mt, me = P.me;
+  double2 *A = (double2 *)P.a, *V = (double2 *)P.v;
+  uint32_t const nthreads = blockDim.x, tid = threadIdx.x;
+  uint32_t const groups = nthreads / W, g = tid / W, l = tid % W;
+  __shared__ int rotated;
+  __shared__ double sigMax;
+  for (uint64_t e = tid; e < (uint64_t)me * me; e += nthreads) V[e] = make_double2((e % me == e / me) ? 1.0 : 0.0, 0.0);
+  uint32_t const M = me + (me & 1u);
+  int sweep = 0;
+  bool converged = false;
+  __syncthreads();
+  for (; sweep < BF_JACOBI_MAX_SWEEPS; ++sweep) {
+    if (tid == 0) rotated = 0;
+    __syncthreads();
+    for (uint32_t s = 0; s + 1 < M; ++s) {
+      for (uint32_t kk = g; kk < M / 2; kk += groups) {
+        uint32_t p = kk == 0 ? M - 1 : (s + kk) % (M - 1);
+        uint32_t q = kk == 0 ? s : (s + (M - 1) - kk) % (M - 1);
+        if (p > q) { uint32_t t = p; p = q; q = t; }
+        if (q >= me) continue;                       // the dummy column of an odd me
+        double2 *ap = A + (uint64_t)p * mt, *aq = A + (uint64_t)q * mt;
+        double alpha = 0, beta = 0, gr = 0, gi = 0;
+        for (uint32_t r = l; r < mt; r += W) {
+          double2 const a = ap[r], b = aq[r];
+          alpha = fma(a.x, a.x, fma(a.y, a.y, alpha));
+          beta = fma(b.x, b.x, fma(b.y, b.y, beta));
+          gr = fma(a.x, b.x, fma(a.y, b.y, gr));     // conj(a) * b
+          gi = fma(a.x, b.y, fma(-a.y, b.x, gi));
+        }
+        alpha = bfGroupSum<W>(alpha); beta = bfGroupSum<W>(beta);
+        gr = bfGroupSum<W>(gr); gi = bfGroupSum<W>(gi);
+        double const g2 = gr * gr + gi * gi;
+        if (!(g2 > BF_JACOBI_TOL * BF_JACOBI_TOL * alpha * beta) || g2 == 0.0) continue;
+        double const gabs = sqrt(g2);
+        double const zeta = (beta - alpha) / (2.0 * gabs);
+        double const t = copysign(1.0, zeta) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+        double const c = 1.0 / sqrt(1.0 + t * t), sn = c * t;
+        double const er = gr / gabs, ei = -gi / gabs;        // e^{-i phi}
+        for (uint32_t r = l; r < mt; r += W) {
+          double2 const a = ap[r], b = aq[r];
+          double2 const bt = make_double2(er * b.x - ei * b.y, er * b.y + ei * b.x);
+          ap[r] = make_double2(c * a.x - sn * bt.x, c * a.y - sn * bt.y);
+          aq[r] = make_double2(sn * a.x + c * bt.x, sn * a.y + c * bt.y);
+        }
+        double2 *vp = V + (uint64_t)p * me, *vq = V + (uint64_t)q * me;
+        for (uint32_t r = l; r < me; r += W) {
+          double2 const a = vp[r], b = vq[r];
+          double2 const bt = make_double2(er * b.x - ei * b.y, er * b.y + ei * b.x);
+          vp[r] = make_double2(c * a.x - sn * bt.x, c * a.y - sn * bt.y);
+          vq[r] = make_double2(sn * a.x + c * bt.x, sn * a.y + c * bt.y);
+        }
+        if (l == 0) rotated = 1;
+      }
+      __syncthreads();
+    }
+    converged = rotated == 0;
+    __syncthreads();
+    if (converged) break;
+  }
+  // singular values and the reference's truncation rule (src/mat_dense_complex.c:1800-1812)
+  for (uint32_t j = g; j < me; j += groups) {
+    double2 const *aj = A + (uint64_t)j * mt;
+    double s2 = 0;
+    for (uint32_t r = l; r < mt; r += W) { double2 const a = aj[r]; s2 = fma(a.x, a.x, fma(a.y, a.y, s2)); }
+    s2 = bfGroupSum<W>(s2);
+    if (l == 0) P.scale[j] = s2;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    double mx = 0;
+    for (uint32_t j = 0; j < me; ++j) mx = fmax(mx, P.scale[j]);
+    sigMax = sqrt(mx);
+  }
+  __syncthreads();
+  double const eps = 2.220446049250313e-16;
+  double const tol = (double)(mt > me ? mt : me) * eps * sigMax + eps;
+  unsigned long long dropped = 0;
+  for (uint32_t j = tid; j < me; j += nthreads) {
+    double const s2 = P.scale[j];
+    bool const keep = sqrt(s2) >= tol;
+    P.scale[j] = keep ? 1.0 / s2 : 0.0;
+    dropped += keep ? 0 : 1;
+  }
+  // statistics only (not part of any result)
+  if (dropped) atomicAdd(&stats->truncated, dropped);
+  if (tid == 0) {
+    atomicMax(&stats->maxSweeps, (unsigned long long)(sweep + (converged ? 1 : 0)));
+    if (!converged) atomicAdd(&stats->notConverged, 1ull);
+  }
+}
+
+int bfdevBuildJacobi(BfSvdProb const *hostProbs, uint64_t numProbs, BfSvdStats *stats) {
+  if (!numProbs) return 0;
+  // classes: lane-group width by column length, workgroup size by column count
+  enum { NCLS = 6 };
+  uint32_t *lists[NCLS] = {0};
+  uint64_t counts[NCLS] = {0};
+  int rc = 0;
+  for (int c = 0; c < NCLS; ++c) {
+    lists[c] = (uint32_t *)malloc(numProbs * sizeof(uint32_t));
+    if (!lists[c]) rc = bfhipFail(BFABI_ERROR_MEMORY_ERROR, "host OOM");
+  }
+  for (uint64_t i = 0; i < numProbs && !rc; ++i) {
+    BfSvdProb const *p = &hostProbs[i];
+    int const w = p->mt <= 16 ? 0 : p->mt <= 32 ? 1 : 2;
+    int const big = p->me > 128;
+    int const c = w * 2 + big;
+    lists[c][counts[c]++] = (uint32_t)i;
+  }
+  BfSvdProb *dP = NULL;
+  BfSvdStats *dS = NULL;
+  if (!rc) rc = uploadArrayB(&dP, hostProbs, numProbs, "svd problems");
+  BfSvdStats zero = {0, 0, 0};
+  if (!rc) rc = uploadArrayB(&dS, &zero, 1, "svd stats");
+  for (int c = 0; c < NCLS && !rc; ++c) {
+    if (!counts[c]) continue;
+    uint32_t *dL = NULL;
+    rc = uploadArrayB(&dL, lists[c], counts[c], "svd class list");
+    if (!rc) {
+      dim3 const grid((uint32_t)counts[c]), block(c & 1 ? 1024 : 256);
+      switch (c >> 1) {
+        case 0: hipLaunchKernelGGL(bfJacobiKernel<16>, grid, block, 0, 0, dP, dL, dS); break;
+        case 1: hipLaunchKernelGGL(bfJacobiKernel<32>, grid, block, 0, 0, dP, dL, dS); break;
+        default: hipLaunchKernelGGL(bfJacobiKernel<64>, grid, block, 0, 0, dP, dL, dS); break;
+      }
+      rc = hipFailB(hipGetLastError(), "Jacobi SVD launch");
+      if (!rc) rc = hipFailB(hipDeviceSynchronize(), "Jacobi SVD");
+    }
+    (void)hipFree(dL);
+  }
+  if (!rc && stats) {
+    BfSvdStats got;
+    rc = hipFailB(hipMemcpy(&got, dS, sizeof got, hipMemcpyDeviceToHost), "svd stats");
+    if (!rc) {
+      if (got.maxSweeps > stats->maxSweeps) stats->maxSweeps = got.maxSweeps;
+      stats->notConverged += got.notConverged;
+      stats->truncated += got.truncated;
+    }
+  }
+  (void)hipFree(dP);
+  (void)hipFree(dS);
+  for (int c = 0; c < NCLS; ++c) free(lists[c]);
+  return rc;
+}
+
+// ---------------------------------------------------------------------------
+// batched small complex GEMM, 32 x 32 output tile per workgroup, K in steps of
+// 16 through LDS, 2 x 2 outputs per thread (fixed k order: deterministic)
+// ---------------------------------------------------------------------------
+#define BF_GT 32
+#define BF_GK 16
+
+__global__ __launch_bounds__(256) void bfGemmKernel(BfGemmJob const *jobs, uint64_t const *prefix, uint32_t numJobs, uint64_t tileBase) {
+  __shared__ double2 As[BF_GK][BF_GT + 1];
+  __shared__ double2 Bs[BF_GK][BF_GT + 1];
+  uint64_t const tile = tileBase + blockIdx.x;
+  uint32_t lo = 0, hi = numJobs;
+  while (hi - lo > 1) {
+    uint32_t const mid = (lo + hi) >> 1;
+    if (prefix[mid] <= tile) lo = mid; else hi = mid;
+  }
+  BfGemmJob const J = jobs[lo];
+  uint32_t const tilesM = (J.M + BF_GT - 1) / BF_GT;
+  uint32_t const tl = (uint32_t)(tile - prefix[lo]);
+  uint32_t const i0 = (tl % tilesM) * BF_GT, j0 = (tl / tilesM) * BF_GT;
+  double2 const *A = (double2 const *)J.a, *B = (double2 const *)J.b;
+  uint32_t const tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
+  double cr[2][2] = {{0, 0}, {0, 0}}, ci[2][2] = {{0, 0}, {0, 0}};
+  for (uint32_t k0 = 0; k0 < J.K; k0 += BF_GK) {
+    // stage op(A)[i0.., k0..] and B[k0.., j0..]
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      double2 a = make_double2(0.0, 0.0);
+      if (J.transA) {
+        uint32_t const kk = tid & 15, ii = (tid >> 4) + 16 * h;
+        if (k0 + kk < J.K && i0 + ii < J.M) { a = A[(uint64_t)(i0 + ii) * J.lda + k0 + kk]; a.y = -a.y; }
+        As[kk][ii] = a;
+      } else {
+        uint32_t const ii = tid & 31, kk = (tid >> 5) + 8 * h;
+        if (k0 + kk < J.K && i0 + ii < J.M) a = A[(uint64_t)(k0 + kk) * J.lda + i0 + ii];
+        As[kk][ii] = a;
+      }
+      uint32_t const kb = tid & 15, jj = (tid >> 4) + 16 * h;
+      double2 b = make_double2(0.0, 0.0);
+      if (k0 + kb < J.K && j0 + jj < J.N) b = B[(uint64_t)(j0 + jj) * J.ldb + k0 + kb];
+      Bs[kb][jj] = b;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < BF_GK; ++kk) {
+      double2 const a0 = As[kk][ty], a1 = As[kk][ty + 16], b0 = Bs[kk][tx], b1 = Bs[kk][tx + 16];
+      double2 const av[2] = {a0, a1}, bv[2] = {b0, b1};
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int v = 0; v < 2; ++v) {
+          cr[u][v] = fma(av[u].x, bv[v].x, cr[u][v]); cr[u][v] = fma(-av[u].y, bv[v].y, cr[u][v]);
+          ci[u][v] = fma(av[u].x, bv[v].y, ci[u][v]); ci[u][v] = fma(av[u].y, bv[v].x, ci[u][v]);
+        }
+    }
+    __syncthreads();
+  }
+  double2 *C = (double2 *)J.c;
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    uint32_t const i = i0 + ty + 16 * u;
+    if (i >= J.M) continue;
+    double const sc = J.scale ? J.scale[i] : 1.0;
+#pragma unroll
+    for (int v = 0; v < 2; ++v) {
+      uint32_t const j = j0 + tx + 16 * v;
+      if (j < J.N) C[(uint64_t)j * J.ldc + i] = make_double2(cr[u][v] * sc, ci[u][v] * sc);
+    }
+  }
+}
+
+int bfdevBuildGemm(BfGemmJob const *hostJobs, uint64_t numJobs) {
+  if (!numJobs) return 0;
+  uint64_t *prefix = (uint64_t *)malloc((numJobs + 1) * sizeof(uint64_t));
+  if (!prefix) return bfhipFail(BFABI_ERROR_MEMORY_ERROR, "host OOM");
+  prefix[0] = 0;
+  for (uint64_t i = 0; i < numJobs; ++i)
+    prefix[i + 1] = prefix[i] + (uint64_t)((hostJobs[i].M + BF_GT - 1) / BF_GT) * ((hostJobs[i].N + BF_GT - 1) / BF_GT);
+  BfGemmJob *dJ = NULL;
+  uint64_t *dP = NULL;
+  int rc = uploadArrayB(&dJ, hostJobs, numJobs, "gemm jobs");
+  if (!rc) rc = uploadArrayB(&dP, prefix, numJobs + 1, "gemm tile prefix");
+  uint64_t const tiles = prefix[numJobs];
+  for (uint64_t done = 0; done < tiles && !rc;) {
+    uint32_t const n = (uint32_t)(tiles - done > (1u << 30) ? (1u << 30) : tiles - done);
+    hipLaunchKernelGGL(bfGemmKernel, dim3(n), dim3(256), 0, 0, dJ, dP, (uint32_t)numJobs, done);
+    rc = hipFailB(hipGetLastError(), "builder gemm launch");
+    done += n;
+  }
+  if (!rc) rc = hipFailB(hipDeviceSynchronize(), "builder gemm");
+  (void)hipFree(dJ);
+  (void)hipFree(dP);
+  free(prefix);
+  return rc;
+}
+
+// ---------------------------------------------------------------------------
+// leaf store (column-major leaves of one batch) -> packed arena pieces
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bfPackKernel(double2 *arena, double2 const *store, BfPackPiece const *pieces, uint64_t base) {
+  BfPackPiece const pc = pieces[base + blockIdx.x];
+  uint32_t const total = pc.mrPad * pc.ncols;
+  double2 *dst = arena + pc.dataOff;
+  double2 const *src = store + pc.srcOff;
+  for (uint32_t e = threadIdx.x; e < total; e += 256) {
+    uint32_t const r = e % pc.mrPad, c = e / pc.mrPad;
+    dst[e] = r < pc.mr ? src[(uint64_t)c * pc.srcLd + r] : make_double2(0.0, 0.0);
+  }
+}
+
+int bfdevBuildPack(void *arena, void const *store, BfPackPiece const *hostPieces, uint64_t count) {
+  if (!count) return 0;
+  BfPackPiece *d = NULL;
+  int rc = uploadArrayB(&d, hostPieces, count, "pack pieces");
+  for (uint64_t done = 0; done < count && !rc;) {
+    uint32_t const n = (uint32_t)(count - done > (1u << 30) ? (1u << 30) : count - done);
+    hipLaunchKernelGGL(bfPackKernel, dim3(n), dim3(256), 0, 0, (double2 *)arena, (double2 const *)store, d, done);
+    rc = hipFailB(hipGetLastError(), "pack launch");
+    done += n;
+  }
+  if (!rc) rc = hipFailB(hipDeviceSynchronize(), "pack");
+  (void)hipFree(d);
+  return rc;
+}
+
+// ---------------------------------------------------------------------------
+// matrix-free dense apply: y_i = sum_j G(p_i, p_j) x_j.  A workgroup owns 256
+// targets and one slice of the sources (staged through LDS, 256 at a time);
+// slices are summed afterwards in fixed order.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bfHelm2DenseKernel(double const *pts, uint64_t n, double k, double2 const *x, double2 *partial,
+                                                          uint64_t sliceLen) {
+  __shared__ double sx[256], sy[256];
+  __shared__ double2 xv[256];
+  uint64_t const i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  uint64_t const j0 = (uint64_t)blockIdx.y * sliceLen;
+  uint64_t const j1 = j0 + sliceLen < n ? j0 + sliceLen : n;
+  double tx = 0, ty = 0;
+  if (i < n) { tx = pts[2 * i]; ty = pts[2 * i + 1]; }
+  double ar = 0, ai = 0;
+  for (uint64_t jb = j0; jb < j1; jb += 256) {
+    uint64_t const j = jb + threadIdx.x;
+    __syncthreads();
+    if (j < j1) { sx[threadIdx.x] = pts[2 * j]; sy[threadIdx.x] = pts[2 * j + 1]; xv[threadIdx.x] = x[j]; }
+    __syncthreads();
+    uint32_t const cnt = (uint32_t)(j1 - jb < 256 ? j1 - jb : 256);
+    if (i < n)
+      for (uint32_t t = 0; t < cnt; ++t) {
+        double2 const g = bfHelm2G(k, tx - sx[t], ty - sy[t]);
+        double2 const v = xv[t];
+        ar = fma(g.x, v.x, ar); ar = fma(-g.y, v.y, ar);
+        ai = fma(g.x, v.y, ai); ai = fma(g.y, v.x, ai);
+      }
+  }
+  if (i < n) partial[(uint64_t)blockIdx.y * n + i] = make_double2(ar, ai);
+}
+
+__global__ __launch_bounds__(256) void bfSliceSumKernel(double2 const *partial, uint64_t n, uint32_t slices, double2 *y) {
+  uint64_t const i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  double sr = 0, si = 0;
+  for (uint32_t s = 0; s < slices; ++s) { double2 const v = partial[(uint64_t)s * n + i]; sr += v.x; si += v.y; }
+  y[i] = make_double2(sr, si);
+}
+
+int bfdevHelm2Dense(void const *dPoints, uint64_t n, double wavenumber, void const *dX, void *dY, void *stream) {
+  if (!n) return 0;
+  hipStream_t const s = (hipStream_t)stream;
+  uint32_t const tb = (uint32_t)((n + 255) / 256);
+  // enough workgroups to fill 256 CUs several times over, slices of >= 256 sources
+  uint32_t slices = tb >= 4096 ? 1 : (4096 + tb - 1) / tb;
+  if ((uint64_t)slices * 256 > n) slices = (uint32_t)((n + 255) / 256);
+  uint64_t const sliceLen = ((n + slices - 1) / slices + 255) / 256 * 256;
+  slices = (uint32_t)((n + sliceLen - 1) / sliceLen);
+  double2 *partial = NULL;
+  int rc = hipFailB(hipMalloc((void **)&partial, (size_t)slices * n * sizeof(double2)), "hipMalloc(dense apply partials)");
+  if (rc) return rc;
+  hipLaunchKernelGGL(bfHelm2DenseKernel, dim3(tb, slices), dim3(256), 0, s, (double const *)dPoints, n, wavenumber, (double2 const *)dX, partial, sliceLen);
+  rc = hipFailB(hipGetLastError(), "dense apply launch");
+  if (!rc) {
+    hipLaunchKernelGGL(bfSliceSumKernel, dim3(tb), dim3(256), 0, s, partial, n, slices, (double2 *)dY);
+    rc = hipFailB(hipGetLastError(), "dense apply sum launch");
+  }
+  if (!rc) rc = hipFailB(hipStreamSynchronize(s), "dense apply");
+  (void)hipFree(partial);
+  return rc;
+}

@@ -148,6 +148,15 @@ int bfPlanBuild(BfIr const *ir, BfPlanOptions const *po, BfPlan *plan);
 int bfPlanFwdPieces(BfPlan const *plan, BfFwdPiece **out, uint64_t *count);
 void bfPlanFree(BfPlan *plan);
 
+/* compile step with a caller-supplied arena fill (bfhip_build.c): `fill` runs
+ * with the operator's device current, the plan's host mirrors still present
+ * and the arena allocated; it must write every non-identity piece.  Consumes
+ * `ir` like the plain compile. */
+typedef int (*BfFillFn)(BfPlan const *plan, BfIr const *ir, void *dArena, void *ctx);
+struct BfhipOptions;
+struct BfhipOperator;
+int bfhipCompileIrFill(BfIr *ir, struct BfhipOptions const *opts, BfFillFn fill, void *fillCtx, struct BfhipOperator **out);
+
 /* ------------------------------------------------------------------------
  * Device layer (implemented in bfhip_device.hip)
  * ---------------------------------------------------------------------- */
@@ -213,6 +222,58 @@ int bfdevGmresFinish(void const *W, void const *partialIn, void *Vout, void *hOu
 /* X = X0 + sum_{i<j} V_i * y[i] ; V = (j) vectors of n*nrhs, y = [j][nrhs] */
 int bfdevGmresUpdate(void const *X0, void const *V, void const *y, uint32_t j, void *X, uint64_t n, uint32_t nrhs, void *stream);
 int bfdevMemcpyD2HAsync(void *dst, void const *src, size_t bytes, void *stream);
+
+/* ------------------------------------------------------------------------
+ * Builder device layer (bfhip_build.hip; driven by bfhip_build.c).  All
+ * matrices are complex128, column-major; offsets are in complex elements
+ * relative to the base pointer named per call.
+ * ---------------------------------------------------------------------- */
+typedef struct BfBuildPts {        /* = BfhipPointSet (include/bfhip_build.h) */
+  uint32_t kind, count;
+  uint64_t first;
+  double cx, cy, r;
+} BfBuildPts;
+
+/* one kernel matrix to evaluate: dst[i + j*tgt.count] = G(tgt_i, src_j) */
+typedef struct BfEvalMat {
+  BfBuildPts src, tgt;
+  void *dst;
+} BfEvalMat;
+/* tilePrefix[numMats+1]: prefix sums of ceil(rows*cols / BF_EVAL_TILE) */
+#define BF_EVAL_TILE 1024u
+int bfdevBuildEval(BfEvalMat const *hostMats, uint64_t const *hostTilePrefix, uint64_t numMats,
+                   void const *dPoints, double wavenumber);
+
+/* one-sided Jacobi SVD of A (mt x me, mt >= me), in place: on return the
+ * columns of A are U*Sigma, V (me x me) holds the right singular vectors and
+ * scale[j] = 1/sigma_j^2 (0 for truncated sigma_j < max(mt,me) eps sigma_max + eps) */
+typedef struct BfSvdProb {
+  void *a, *v;
+  double *scale;         /* [me] */
+  uint32_t mt, me;
+} BfSvdProb;
+typedef struct BfSvdStats { unsigned long long maxSweeps, notConverged, truncated; } BfSvdStats;
+int bfdevBuildJacobi(BfSvdProb const *hostProbs, uint64_t numProbs, BfSvdStats *stats);
+
+/* C (M x N) = op(A) * B with optional row scaling C[i,:] *= scale[i];
+ * transA: op(A)[i,k] = conj(A[k + i*lda]) (A stored K x M), else A[i + k*lda] */
+typedef struct BfGemmJob {
+  void const *a, *b;
+  void *c;
+  double const *scale;   /* NULL: none */
+  uint32_t M, N, K, lda, ldb, ldc, transA, pad;
+} BfGemmJob;
+int bfdevBuildGemm(BfGemmJob const *hostJobs, uint64_t numJobs);
+
+/* arena[dataOff + c*mrPad + r] = r < mr ? store[srcOff + c*srcLd + r] : 0 */
+typedef struct BfPackPiece {
+  uint64_t dataOff, srcOff;
+  uint32_t srcLd, mr, mrPad, ncols;
+} BfPackPiece;
+int bfdevBuildPack(void *arena, void const *store, BfPackPiece const *hostPieces, uint64_t count);
+
+/* y = G x, N x N single-layer kernel evaluated on the fly; scratch is allocated inside */
+int bfdevHelm2Dense(void const *dPoints, uint64_t n, double wavenumber, void const *dX, void *dY, void *stream);
 int bfdevMemcpyH2DAsync(void *dst, void const *src, size_t bytes, void *stream);
 int bfdevMemcpyD2DAsync(void *dst, void const *src, size_t bytes, void *stream);
 

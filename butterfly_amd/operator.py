@@ -60,6 +60,21 @@ class HipOperator:
         return cls(h.value, keep=keep)
 
     @classmethod
+    def build_helm2(cls, desc, points, wavenumber, root=None, workspace_bytes=0, **opts):
+        """bfhipBuildHelm2: lay out `desc` (helm2_structure with recipes=True) and
+        compute every leaf on the device from its recipe.  `points`: [N, 2] in
+        quadtree order.  Returns (operator, build statistics)."""
+        lib = _capi.load()
+        da = DescArrays(desc, root=root)
+        prob = _capi.Helm2Problem(points, wavenumber, desc.recipe, workspace_bytes)
+        st = _capi.BfhipBuildStats()
+        st.structSize = C.sizeof(st)
+        h = C.c_void_p()
+        o = _options(**opts)
+        check(lib.bfhipBuildHelm2(da.byref(), prob.byref(), C.byref(o), C.byref(h), C.byref(st)))
+        return cls(h.value), st.as_dict()
+
+    @classmethod
     def load(cls, path, **opts):
         """bfhipLoad: a previously saved operator, straight into HBM."""
         lib = _capi.load()
@@ -222,3 +237,32 @@ class HipOperator:
         if not p:
             raise _capi.BfhipError(1, self._lib.bfhipLastErrorMessage().decode())
         return p
+
+
+def helm2_build_leaf(points, wavenumber, recipe, device=-1) -> np.ndarray:
+    """One leaf of a Helmholtz butterfly computed on the device (bfhipHelm2BuildLeaf);
+    `recipe` as in helm2_structure ("kernel", src, tgt) / ("reexp", src, equiv, tgt)."""
+    prob = _capi.Helm2Problem(points, wavenumber, {0: recipe})
+    r = prob.recipes[0]
+    rows = int(r["tgt"]["count"] if r["kind"] == _capi.LEAF_KERNEL else r["equiv"]["count"])
+    out = np.empty((rows, int(r["src"]["count"])), dtype=np.complex128)
+    check(_capi.load().bfhipHelm2BuildLeaf(prob.byref(), 0, device, out.ctypes.data))
+    return out
+
+
+def helm2_dense_apply(points, wavenumber, x, device=-1):
+    """y = G x with the dense single-layer kernel matrix evaluated on the fly on
+    the device (bfhipHelm2DenseApply[Device]); x: numpy [N] or a CUDA tensor."""
+    pts = np.ascontiguousarray(points, dtype=np.float64)
+    lib = _capi.load()
+    if isinstance(x, np.ndarray):
+        xs = np.ascontiguousarray(x, dtype=np.complex128)
+        y = np.empty_like(xs)
+        check(lib.bfhipHelm2DenseApply(pts.ctypes.data, len(pts), float(wavenumber), device, xs.ctypes.data, y.ctypes.data))
+        return y
+    import torch
+    y = torch.empty_like(x)
+    s = torch.cuda.current_stream(x.device)
+    check(lib.bfhipHelm2DenseApplyDevice(pts.ctypes.data, len(pts), float(wavenumber), x.device.index, C.c_void_p(x.data_ptr()),
+                                         C.c_void_p(y.data_ptr()), C.c_void_p(s.cuda_stream)))
+    return y

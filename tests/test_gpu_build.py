@@ -1,0 +1,125 @@
+"""Device builder (include/bfhip_build.h) against the numpy restatement of the
+reference's value side (oracle/helm2_build.py: kernel matrix src/helm2.c:93-125,
+re-expansion src/helm2.c:321-365, truncated-SVD least squares
+src/mat_dense_complex.c:1767-1849) and against the dense kernel matvec."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    return float(np.linalg.norm(np.ravel(a) - np.ravel(b)) / np.linalg.norm(np.ravel(b)))
+
+
+def _pts(n):
+    from butterfly_amd import helm2_structure as hs
+    return hs.circle_points(n)
+
+
+@pytest.mark.parametrize("n,k", [(300, 40.0), (1500, 250.0)])
+def test_dense_apply_matches_numpy(n, k):
+    from butterfly_amd.operator import helm2_dense_apply
+    from oracle import helm2_build as hb
+    pts = _pts(n) * np.array([1.0, 0.7])                    # an ellipse: distances are not all alike
+    x = hb.complex_randn(n, 3)
+    y = helm2_dense_apply(pts, k, x)
+    want = hb.kernel_matrix(k, pts, pts) @ x
+    # device j0/y0 vs scipy's: a few ulp each, summed over n terms
+    assert rel(y, want) <= 1e-13
+
+
+def test_kernel_leaves_match_numpy():
+    from butterfly_amd.operator import helm2_build_leaf
+    from oracle import helm2_build as hb
+    pts = _pts(512)
+    k = 300.0
+    cases = [("kernel", ("node", 40, 97), ("node", 300, 411)),                      # near field: points -> points
+             ("kernel", ("circle", 0.3, -0.2, 0.25, 37), ("node", 100, 164)),        # evaluation: proxy circle -> points
+             ("kernel", ("node", 7, 8), ("circle", -1.0, 2.0, 0.5, 16))]
+    for rc in cases:
+        got = helm2_build_leaf(pts, k, rc)
+        want = hb.kernel_matrix(k, hb.resolve_points(rc[1], pts), hb.resolve_points(rc[2], pts))
+        assert got.shape == want.shape
+        assert np.max(np.abs(got - want)) <= 1e-14 * max(1.0, np.max(np.abs(want))) + 2e-15, rc
+    # r == 0 -> 0 (src/helm2.c:114), not a NaN from Y0(0)
+    diag = helm2_build_leaf(pts, k, ("kernel", ("node", 10, 20), ("node", 10, 20)))
+    assert np.all(np.diag(diag) == 0) and np.all(np.isfinite(diag))
+
+
+@pytest.mark.parametrize("m,n,k", [(17, 23, 60.0), (32, 64, 200.0), (45, 31, 400.0), (150, 170, 1500.0)])
+def test_reexpansion_leaf_matches_truncated_svd_least_squares(m, n, k):
+    """A child circle's field re-expanded on its parent circle, checked on a far
+    target circle (makeFactor, src/fac_helm2.c:338-358)."""
+    from butterfly_amd.operator import helm2_build_leaf
+    from oracle import helm2_build as hb
+    pts = _pts(16)
+    rc = ("reexp", ("circle", 0.55, 0.05, 0.08, n), ("circle", 0.5, 0.0, 0.16, m), ("circle", -0.6, 0.1, 0.2, m))
+    X = helm2_build_leaf(pts, k, rc)
+    src, eq, tgt = (hb.resolve_points(s, pts) for s in rc[1:])
+    z_or, z_eq = hb.kernel_matrix(k, src, tgt), hb.kernel_matrix(k, eq, tgt)
+    want = hb.lstsq_truncated(z_eq, z_or)
+    assert X.shape == want.shape == (m, n)
+    # Z_equiv is numerically rank deficient by construction (its singular values reach the
+    # truncation threshold), so the components of X along singular values of ~1e-15 s_max are
+    # rounding noise in LAPACK's zgesvd and in the Jacobi SVD alike and differ element-wise;
+    # what the factorization uses -- and what must agree -- is the field Z_equiv X reproduces.
+    res_gpu = np.linalg.norm(z_eq @ X - z_or) / np.linalg.norm(z_or)
+    res_ref = np.linalg.norm(z_eq @ want - z_or) / np.linalg.norm(z_or)
+    assert res_gpu <= 2 * res_ref + 1e-13, (res_gpu, res_ref)
+    assert rel(z_eq @ X, z_eq @ want) <= 1e-10
+    assert np.linalg.norm(X) <= 1.5 * np.linalg.norm(want)      # truncation did happen: no 1/sigma blow-up
+
+
+@pytest.mark.parametrize("n,k", [(1024, 100.0), (4096, 100.0), (4096, 256.0)])
+def test_built_operator_matches_oracle_and_dense(helm2_cases, n, k):
+    import torch
+    from butterfly_amd.operator import HipOperator, helm2_dense_apply
+    from oracle import bfref, helm2_build as hb
+    desc, tp, vals = helm2_cases(n, k)
+    op, st = HipOperator.build_helm2(desc, tp, k)
+    assert st["kernelLeaves"] + st["reexpLeaves"] == len(desc.recipe) and st["notConverged"] == 0
+    x = hb.complex_randn(n, 0)
+    y = op.apply_host(x)
+    # same operand built on the CPU (numpy/LAPACK) and applied by the oracle
+    y_cpu = bfref.mat_mul(bfref.from_desc(desc, vals), x)
+    assert rel(y, y_cpu) <= 1e-10
+    # the reference examples' acceptance check (examples/simple/bf_all_blocks.c:149-153)
+    y_dense = hb.kernel_matrix(k, tp, tp) @ x
+    assert rel(y, y_dense) <= 1e-9
+    y_dense_gpu = helm2_dense_apply(tp, k, torch.from_numpy(x).cuda()).cpu().numpy()
+    assert rel(y_dense_gpu, y_dense) <= 1e-13
+    # a small workspace forces many batches: same arena
+    op2, st2 = HipOperator.build_helm2(desc, tp, k, workspace_bytes=4 << 20)
+    assert st2["numBatches"] > st["numBatches"]
+    assert np.array_equal(op2.apply_host(x), y)
+    op.close(); op2.close()
+
+
+def test_builder_on_a_row_shard_and_argument_errors(helm2_cases):
+    from butterfly_amd import _capi
+    from butterfly_amd.operator import HipOperator
+    from oracle import bfref, helm2_build as hb
+    n, k = 4096, 100.0
+    desc, tp, vals = helm2_cases(n, k)
+    x = hb.complex_randn(n, 0)
+    y_cpu = bfref.mat_mul(bfref.from_desc(desc, vals), x)
+    nrb = len(desc.meta["top_rows"])
+    parts = []
+    for b, e in ((0, 5), (5, nrb)):
+        op, st = HipOperator.build_helm2(desc, tp, k, row_blocks=(b, e))
+        assert st["kernelLeaves"] + st["reexpLeaves"] < len(desc.recipe)      # only the surviving leaves are built
+        parts.append(op.apply_host(x))
+        op.close()
+    assert rel(np.concatenate(parts), y_cpu) <= 1e-10
+    # a leaf without a recipe is refused, not synthesized
+    some = sorted(desc.recipe)[3]
+    saved = desc.recipe.pop(some)
+    try:
+        with pytest.raises(_capi.BfhipError) as ei:
+            HipOperator.build_helm2(desc, tp, k)
+        assert ei.value.code == 1 and "no recipe" in str(ei.value)
+    finally:
+        desc.recipe[some] = saved
+    with pytest.raises(_capi.BfhipError):
+        HipOperator.build_helm2(desc, tp, -1.0)
