@@ -1,5 +1,5 @@
 """The C-ABI library loads without a GPU and exports every function that
-include/bfhip.h declares (no compute calls here)."""
+include/*.h declare (no compute calls here)."""
 import ctypes as C
 import os
 import re
@@ -8,16 +8,19 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def declared_functions():
-    src = open(os.path.join(ROOT, "include", "bfhip.h")).read()
-    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\b(bfhip[A-Z]\w*)\s*\(", src)))
+    names = set()
+    for hdr in ("bfhip.h", "bfhip_build.h"):
+        src = open(os.path.join(ROOT, "include", hdr)).read()
+        src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+        names |= set(re.findall(r"\b(bfhip[A-Z]\w*)\s*\(", src))
+    return sorted(names)
 
 
 def test_every_declared_symbol_is_exported():
     from butterfly_amd import _capi
     lib = _capi.load()
     names = declared_functions()
-    assert len(names) >= 18
+    assert len(names) >= 22 and "bfhipBuildHelm2" in names
     missing = [n for n in names if not hasattr(lib, n)]
     assert not missing, missing
 
@@ -44,3 +47,34 @@ def test_product_does_not_link_the_oracle():
     assert "bfref" not in out
     syms = subprocess.check_output(["nm", "-D", "--defined-only", _capi.LIB_PATH], text=True)
     assert "bfMatMul" not in syms and "bfref" not in syms
+
+
+def test_builder_structs_match_the_header_and_arguments_are_checked(tmp_path):
+    """ctypes / numpy mirrors of include/bfhip_build.h have the C sizes; bad
+    arguments are refused before any device is touched."""
+    import subprocess
+    import numpy as np
+    from butterfly_amd import _capi
+    src = tmp_path / "sz.c"
+    src.write_text('#include <stdio.h>\n#include "bfhip_build.h"\nint main(void){printf("%zu %zu %zu %zu\\n", sizeof(BfhipPointSet), '
+                   'sizeof(BfhipHelm2Recipe), sizeof(BfhipHelm2Problem), sizeof(BfhipBuildStats));return 0;}\n')
+    exe = tmp_path / "sz"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    sizes = [int(v) for v in subprocess.check_output([str(exe)]).split()]
+    assert sizes == [_capi.POINT_SET_DTYPE.itemsize, _capi.RECIPE_DTYPE.itemsize, C.sizeof(_capi.BfhipHelm2Problem),
+                     C.sizeof(_capi.BfhipBuildStats)]
+    rec = _capi.recipe_array({5: ("kernel", ("node", 3, 9), ("circle", 0.5, -0.25, 2.0, 17)),
+                              2: ("reexp", ("circle", 0, 0, 1, 4), ("circle", 0, 0, 2, 6), ("circle", 3, 0, 1, 6))})
+    assert list(rec["node"]) == [2, 5] and list(rec["kind"]) == [_capi.LEAF_REEXP, _capi.LEAF_KERNEL]
+    assert rec[1]["src"]["first"] == 3 and rec[1]["src"]["count"] == 6 and rec[1]["tgt"]["r"] == 2.0 and rec[0]["equiv"]["count"] == 6
+    lib = _capi.load()
+    pts = np.zeros((4, 2))
+    out = np.zeros(64, dtype=complex)
+    prob = _capi.Helm2Problem(pts, 1.0, {0: ("kernel", ("node", 0, 9), ("node", 0, 2))})          # 9 points of 4
+    assert lib.bfhipHelm2BuildLeaf(prob.byref(), 0, -1, out.ctypes.data) == 1
+    assert b"exceed numPoints" in lib.bfhipLastErrorMessage()
+    prob = _capi.Helm2Problem(pts, 1.0, {0: ("reexp", ("node", 0, 2), ("circle", 0, 0, 1, 8), ("circle", 3, 0, 1, 4))})
+    assert lib.bfhipHelm2BuildLeaf(prob.byref(), 0, -1, out.ctypes.data) == 3                      # fewer check points than unknowns
+    prob = _capi.Helm2Problem(pts, 0.0, {0: ("kernel", ("node", 0, 2), ("node", 0, 2))})
+    assert lib.bfhipHelm2BuildLeaf(prob.byref(), 0, -1, out.ctypes.data) == 1                      # wavenumber
+    assert lib.bfhipHelm2DenseApply(None, 4, 1.0, -1, out.ctypes.data, out.ctypes.data) == 1
