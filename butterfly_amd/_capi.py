@@ -81,7 +81,7 @@ class BfhipHelm2Problem(C.Structure):
 
 class BfhipBuildStats(C.Structure):
     _fields_ = [("structSize", C.c_uint32), ("numBatches", C.c_uint32)] + [
-        (n, C.c_uint64) for n in ("kernelLeaves", "reexpLeaves", "kernelEvals", "maxSweeps", "notConverged", "truncated")] + [
+        (n, C.c_uint64) for n in ("kernelLeaves", "reexpLeaves", "kernelEvals", "maxSweeps", "notConverged", "truncated", "sumSweeps")] + [
         ("seconds", C.c_double)]
 
     def as_dict(self):

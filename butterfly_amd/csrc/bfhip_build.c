@@ -150,9 +150,9 @@ static int buildBatch(BfhipHelm2Problem const *prob, uint64_t const *idx, uint64
     st->kernelEvals += (uint64_t)mt * me + (uint64_t)mt * n;
   }
   if ((rc = bfdevBuildEval(mats, prefix, nm, dPoints, prob->wavenumber))) goto done;
-  BfSvdStats ss = {st->maxSweeps, 0, 0};
+  BfSvdStats ss = {st->maxSweeps, 0, 0, 0};
   if ((rc = bfdevBuildJacobi(probs, np, &ss))) goto done;
-  st->maxSweeps = ss.maxSweeps; st->notConverged += ss.notConverged; st->truncated += ss.truncated;
+  st->maxSweeps = ss.maxSweeps; st->notConverged += ss.notConverged; st->truncated += ss.truncated; st->sumSweeps += ss.sumSweeps;
   if ((rc = bfdevBuildGemm(g1, np))) goto done;
   if ((rc = bfdevBuildGemm(g2, np))) goto done;
   st->numBatches += 1;
@@ -241,7 +241,15 @@ static int fillArena(BfPlan const *pl, BfIr const *ir, void *dArena, void *vctx)
   if ((rc = bfdevMalloc(&dPoints, (size_t)(prob->numPoints ? prob->numPoints : 1) * 16))) goto done;
   if ((rc = bfdevMemcpyH2D(dPoints, prob->points, (size_t)prob->numPoints * 16))) goto done;
 
-  uint64_t const budget = (prob->workspaceBytes ? prob->workspaceBytes : DEFAULT_WORKSPACE) / 16;
+  /* default workspace: half of what is free once the arena is allocated, at least 8 GiB asked for --
+   * large batches keep all CUs busy through the tail of the biggest least-squares problems */
+  uint64_t wsBytes = prob->workspaceBytes;
+  if (!wsBytes) {
+    uint64_t freeBytes = 0;
+    if ((rc = bfdevMemFree(&freeBytes))) goto done;
+    wsBytes = freeBytes / 2 > DEFAULT_WORKSPACE ? freeBytes / 2 : DEFAULT_WORKSPACE;
+  }
+  uint64_t const budget = wsBytes / 16;
   batch = malloc((R + 1) * sizeof *batch);
   storeOff = malloc((R + 1) * sizeof *storeOff);
   if (!batch || !storeOff) { rc = bfhipFail(BFABI_ERROR_MEMORY_ERROR, "host OOM (builder)"); goto done; }

@@ -107,16 +107,25 @@ int bfdevBuildEval(BfEvalMat const *hostMats, uint64_t const *hostTilePrefix, ui
 }
 
 // ---------------------------------------------------------------------------
-// one-sided Jacobi SVD.  Round-robin ordering: M = me rounded up to even,
-// step s pairs (M-1, s) and ((s+k) mod (M-1), (s-k) mod (M-1)), k = 1..M/2-1,
-// so the M/2 pairs of a step touch disjoint columns and run concurrently on
-// the workgroup's lane groups (W lanes each; a workgroup barrier per step).
-// A rotation is the unitary J = [[c, s], [-s e^{-i phi}, c e^{-i phi}]] applied
-// on the right to columns (p, q) of A and of V, with phi = arg(a_p^H a_q) and
-// tan(theta) the small root of t^2 + 2 zeta t - 1, zeta = (|a_q|^2 - |a_p|^2) / (2 |a_p^H a_q|).
+// one-sided (Hestenes) Jacobi SVD, block form.  One workgroup per problem.
+//
+// The stacked matrix S = [A; V] (mt + me rows) carries the right singular
+// vectors along: a rotation J = [[c, s], [-s e^{-i phi}, c e^{-i phi}]] of columns
+// (p, q) -- phi = arg(a_p^H a_q), tan(theta) the small root of t^2 + 2 zeta t - 1,
+// zeta = (|a_q|^2 - |a_p|^2) / (2 |a_p^H a_q|) -- is applied to all of S, the inner
+// products use the A rows only.
+//
+// Traffic is what bounds this kernel: a plain sweep streams every column pair
+// from memory (~80 m^3 bytes per sweep, ~30 sweeps).  So the columns are cut in
+// blocks of b; a pair of blocks (2b stacked columns) is staged in LDS, swept
+// completely there (round-robin over the 2b columns: b disjoint pairs per step
+// on the workgroup's lane groups), and written back; block pairs follow the same
+// round-robin ordering.  Memory traffic per sweep drops by ~2.5 b, and when all
+// columns fit (me <= 2b, the bulk of the problems) the matrix is loaded once
+// and never leaves LDS until it has converged.
 // ---------------------------------------------------------------------------
 #define BF_JACOBI_MAX_SWEEPS 40
-#define BF_JACOBI_TOL 1e-15
+#define BF_JACOBI_LDS_MAX (144u << 10)
 
 template <int W> __device__ __forceinline__ double bfGroupSum(double v) {
 #pragma unroll
@@ -124,68 +133,137 @@ template <int W> __device__ __forceinline__ double bfGroupSum(double v) {
   return v;
 }
 
+// pair kk of step s of a round-robin tournament over M (even) players
+__device__ __forceinline__ void bfRoundRobin(uint32_t M, uint32_t s, uint32_t kk, uint32_t &p, uint32_t &q) {
+  p = kk == 0 ? M - 1 : (s + kk) % (M - 1);
+  q = kk == 0 ? s : (s + (M - 1) - kk) % (M - 1);
+  if (p > q) { uint32_t const t = p; p = q; q = t; }
+}
+
 template <int W>
-__global__ __launch_bounds__(1024) void bfJacobiKernel(BfSvdProb const *probs, uint32_t const *list, BfSvdStats *stats) {
+__global__ __launch_bounds__(1024) void bfJacobiKernel(BfSvdProb const *probs, uint32_t const *list, BfSvdStats *stats, uint32_t ldsBytes) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char bfJacobiLds[];
+  double2 *tile = (double2 *)bfJacobiLds;
+  __shared__ int rotated;
+  __shared__ double sigMax;
+  __shared__ unsigned long long maxNormBits;
   BfSvdProb const P = probs[list[blockIdx.x]];
   uint32_t const mt = P.mt, me = P.me;
   double2 *A = (double2 *)P.a, *V = (double2 *)P.v;
   uint32_t const nthreads = blockDim.x, tid = threadIdx.x;
   uint32_t const groups = nthreads / W, g = tid / W, l = tid % W;
-  __shared__ int rotated;
-  __shared__ double sigMax;
-  for (uint64_t e = tid; e < (uint64_t)me * me; e += nthreads) V[e] = make_double2((e % me == e / me) ? 1.0 : 0.0, 0.0);
-  uint32_t const M = me + (me & 1u);
+  uint32_t const R = mt + me, Rp = R | 1u;          // odd stride (in 16-byte units): groups of a wave spread over the banks
+  uint32_t C = (ldsBytes / 16u) / Rp;               // stacked columns the tile holds
+  C = C < 2 ? 2 : C & ~1u;
+  uint32_t const b = C / 2 < (me + 1) / 2 ? C / 2 : (me + 1) / 2;
+  uint32_t const nb = (me + b - 1) / b;             // >= 2
+  uint32_t const NB = nb + (nb & 1u);
+  bool const resident = nb == 2;
+  double const tol2 = (double)mt * 2.220446049250313e-16 * 2.220446049250313e-16;   // xGESVJ: sqrt(mt) eps
+
+  // slot -> global column of the block pair (I, J); >= me: empty slot
+  auto slotCol = [&](uint32_t I, uint32_t J, uint32_t slot) -> uint32_t {
+    uint32_t const blk = slot < b ? I : J, off = slot < b ? slot : slot - b;
+    uint32_t const c = blk * b + off;
+    return (blk * b + off < (blk + 1) * b && c < me) ? c : 0xffffffffu;
+  };
+  auto loadPair = [&](uint32_t I, uint32_t J, bool first) {
+    for (uint32_t e = tid; e < 2 * b * R; e += nthreads) {
+      uint32_t const slot = e / R, r = e - slot * R;
+      uint32_t const c = slotCol(I, J, slot);
+      if (c == 0xffffffffu) continue;
+      double2 v;
+      if (r < mt) v = A[(uint64_t)c * mt + r];
+      else if (first) v = make_double2(r - mt == c ? 1.0 : 0.0, 0.0);       // V starts as the identity
+      else v = V[(uint64_t)c * me + (r - mt)];
+      tile[slot * Rp + r] = v;
+    }
+  };
+  auto storePair = [&](uint32_t I, uint32_t J) {
+    for (uint32_t e = tid; e < 2 * b * R; e += nthreads) {
+      uint32_t const slot = e / R, r = e - slot * R;
+      uint32_t const c = slotCol(I, J, slot);
+      if (c == 0xffffffffu) continue;
+      double2 const v = tile[slot * Rp + r];
+      if (r < mt) A[(uint64_t)c * mt + r] = v; else V[(uint64_t)c * me + (r - mt)] = v;
+    }
+  };
+
+  // Columns below the truncation threshold (relative to the largest column norm, a lower bound of
+  // sigma_max) are never rotated: they will be dropped, and what they carry is below the rounding
+  // error of the matrix.  Left alone they would keep the sweeps busy orthogonalising noise.
+  if (tid == 0) maxNormBits = 0;
+  __syncthreads();
+  for (uint32_t j = g; j < me; j += groups) {
+    double2 const *aj = A + (uint64_t)j * mt;
+    double s2 = 0;
+    for (uint32_t r = l; r < mt; r += W) { double2 const a = aj[r]; s2 = fma(a.x, a.x, fma(a.y, a.y, s2)); }
+    s2 = bfGroupSum<W>(s2);
+    if (l == 0) atomicMax(&maxNormBits, (unsigned long long)__double_as_longlong(s2));   // order-independent
+  }
+  __syncthreads();
+  double const deadRel = (double)(mt > me ? mt : me) * 2.220446049250313e-16;
+  double const dead2 = deadRel * deadRel * __longlong_as_double((long long)maxNormBits);
+  if (resident) loadPair(0, 1, true);
+  else {
+    for (uint64_t e = tid; e < (uint64_t)me * me; e += nthreads) V[e] = make_double2((e % me == e / me) ? 1.0 : 0.0, 0.0);
+  }
   int sweep = 0;
   bool converged = false;
   __syncthreads();
   for (; sweep < BF_JACOBI_MAX_SWEEPS; ++sweep) {
     if (tid == 0) rotated = 0;
     __syncthreads();
-    for (uint32_t s = 0; s + 1 < M; ++s) {
-      for (uint32_t kk = g; kk < M / 2; kk += groups) {
-        uint32_t p = kk == 0 ? M - 1 : (s + kk) % (M - 1);
-        uint32_t q = kk == 0 ? s : (s + (M - 1) - kk) % (M - 1);
-        if (p > q) { uint32_t t = p; p = q; q = t; }
-        if (q >= me) continue;                       // the dummy column of an odd me
-        double2 *ap = A + (uint64_t)p * mt, *aq = A + (uint64_t)q * mt;
-        double alpha = 0, beta = 0, gr = 0, gi = 0;
-        for (uint32_t r = l; r < mt; r += W) {
-          double2 const a = ap[r], b = aq[r];
-          alpha = fma(a.x, a.x, fma(a.y, a.y, alpha));
-          beta = fma(b.x, b.x, fma(b.y, b.y, beta));
-          gr = fma(a.x, b.x, fma(a.y, b.y, gr));     // conj(a) * b
-          gi = fma(a.x, b.y, fma(-a.y, b.x, gi));
+    for (uint32_t S = 0; S + 1 < NB; ++S) {
+      for (uint32_t KK = 0; KK < NB / 2; ++KK) {
+        uint32_t I, J;
+        bfRoundRobin(NB, S, KK, I, J);
+        if (J >= nb) continue;                       // the dummy block of an odd block count
+        if (!resident) { loadPair(I, J, false); __syncthreads(); }
+        // one complete sweep over the 2b staged columns
+        for (uint32_t s = 0; s + 1 < 2 * b; ++s) {
+          for (uint32_t kk = g; kk < b; kk += groups) {
+            uint32_t p, q;
+            bfRoundRobin(2 * b, s, kk, p, q);
+            if (slotCol(I, J, p) == 0xffffffffu || slotCol(I, J, q) == 0xffffffffu) continue;
+            double2 *sp = tile + p * Rp, *sq = tile + q * Rp;
+            double alpha = 0, beta = 0, gr = 0, gi = 0;
+            for (uint32_t r = l; r < mt; r += W) {
+              double2 const x = sp[r], y = sq[r];
+              alpha = fma(x.x, x.x, fma(x.y, x.y, alpha));
+              beta = fma(y.x, y.x, fma(y.y, y.y, beta));
+              gr = fma(x.x, y.x, fma(x.y, y.y, gr));     // conj(x) * y
+              gi = fma(x.x, y.y, fma(-x.y, y.x, gi));
+            }
+            alpha = bfGroupSum<W>(alpha); beta = bfGroupSum<W>(beta);
+            gr = bfGroupSum<W>(gr); gi = bfGroupSum<W>(gi);
+            double const g2 = gr * gr + gi * gi;
+            if (alpha < dead2 || beta < dead2) continue;
+            if (!(g2 > tol2 * alpha * beta) || g2 == 0.0) continue;
+            double const gabs = sqrt(g2);
+            double const zeta = (beta - alpha) / (2.0 * gabs);
+            double const t = copysign(1.0, zeta) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+            double const c = 1.0 / sqrt(1.0 + t * t), sn = c * t;
+            double const er = gr / gabs, ei = -gi / gabs;    // e^{-i phi}
+            for (uint32_t r = l; r < R; r += W) {
+              double2 const x = sp[r], y = sq[r];
+              double2 const yt = make_double2(er * y.x - ei * y.y, er * y.y + ei * y.x);
+              sp[r] = make_double2(c * x.x - sn * yt.x, c * x.y - sn * yt.y);
+              sq[r] = make_double2(sn * x.x + c * yt.x, sn * x.y + c * yt.y);
+            }
+            if (l == 0) rotated = 1;
+          }
+          __syncthreads();
         }
-        alpha = bfGroupSum<W>(alpha); beta = bfGroupSum<W>(beta);
-        gr = bfGroupSum<W>(gr); gi = bfGroupSum<W>(gi);
-        double const g2 = gr * gr + gi * gi;
-        if (!(g2 > BF_JACOBI_TOL * BF_JACOBI_TOL * alpha * beta) || g2 == 0.0) continue;
-        double const gabs = sqrt(g2);
-        double const zeta = (beta - alpha) / (2.0 * gabs);
-        double const t = copysign(1.0, zeta) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-        double const c = 1.0 / sqrt(1.0 + t * t), sn = c * t;
-        double const er = gr / gabs, ei = -gi / gabs;        // e^{-i phi}
-        for (uint32_t r = l; r < mt; r += W) {
-          double2 const a = ap[r], b = aq[r];
-          double2 const bt = make_double2(er * b.x - ei * b.y, er * b.y + ei * b.x);
-          ap[r] = make_double2(c * a.x - sn * bt.x, c * a.y - sn * bt.y);
-          aq[r] = make_double2(sn * a.x + c * bt.x, sn * a.y + c * bt.y);
-        }
-        double2 *vp = V + (uint64_t)p * me, *vq = V + (uint64_t)q * me;
-        for (uint32_t r = l; r < me; r += W) {
-          double2 const a = vp[r], b = vq[r];
-          double2 const bt = make_double2(er * b.x - ei * b.y, er * b.y + ei * b.x);
-          vp[r] = make_double2(c * a.x - sn * bt.x, c * a.y - sn * bt.y);
-          vq[r] = make_double2(sn * a.x + c * bt.x, sn * a.y + c * bt.y);
-        }
-        if (l == 0) rotated = 1;
+        if (!resident) { storePair(I, J); __syncthreads(); }
       }
-      __syncthreads();
     }
     converged = rotated == 0;
     __syncthreads();
     if (converged) break;
   }
+  if (resident) storePair(0, 1);
+  __syncthreads();
   // singular values and the reference's truncation rule (src/mat_dense_complex.c:1800-1812)
   for (uint32_t j = g; j < me; j += groups) {
     double2 const *aj = A + (uint64_t)j * mt;
@@ -214,49 +292,91 @@ __global__ __launch_bounds__(1024) void bfJacobiKernel(BfSvdProb const *probs, u
   if (dropped) atomicAdd(&stats->truncated, dropped);
   if (tid == 0) {
     atomicMax(&stats->maxSweeps, (unsigned long long)(sweep + (converged ? 1 : 0)));
+    atomicAdd(&stats->sumSweeps, (unsigned long long)(sweep + (converged ? 1 : 0)));
     if (!converged) atomicAdd(&stats->notConverged, 1ull);
   }
 }
 
+// Launch classes.  Workgroup: 256 threads for <= 64 columns, 1024 above.  LDS: the smallest of
+// 16/32/64/144 KiB that holds the whole stacked matrix (several small problems then share a
+// CU), else 144 KiB and block sweeps.  Lane-group width W: the largest power of two that still
+// gives each of the b column pairs of an inner step its own group, at most the column length.
+static uint32_t const kJacobiLds[4] = {16u << 10, 32u << 10, 64u << 10, BF_JACOBI_LDS_MAX};
+
+static int jacobiClass(BfSvdProb const *p, int *wlog, int *big, int *ldsClass) {
+  uint64_t const R = (uint64_t)p->mt + p->me, Rp = R | 1u;
+  if (2 * Rp * 16 > BF_JACOBI_LDS_MAX)
+    return bfhipFail(BFABI_ERROR_NOT_IMPLEMENTED, "least-squares problem with %u + %u rows does not fit the LDS tile", p->mt, p->me);
+  uint64_t const meEven = p->me + (p->me & 1u);
+  int lc = 3;
+  for (int c = 0; c < 3; ++c)
+    if (meEven * Rp * 16 <= kJacobiLds[c]) { lc = c; break; }
+  uint32_t C = (uint32_t)((kJacobiLds[lc] / 16u) / Rp);
+  C = C < 2 ? 2 : C & ~1u;
+  uint32_t const b = C / 2 < (p->me + 1) / 2 ? C / 2 : (p->me + 1) / 2;
+  *ldsClass = lc;
+  *big = p->me > 64;
+  uint32_t const threads = *big ? 1024 : 256;
+  uint32_t w = 64;
+  while (w > 4 && (threads / w < b || w / 2 >= p->mt)) w >>= 1;
+  int l = 0;
+  while ((4u << l) < w) ++l;
+  *wlog = l;                                       // W = 4 << l, l = 0..4
+  return 0;
+}
+
+template <int W> static int jacobiLaunch(uint32_t count, uint32_t threads, uint32_t lds, BfSvdProb const *dP, uint32_t const *dL, BfSvdStats *dS) {
+  int rc = hipFailB(hipFuncSetAttribute((void const *)bfJacobiKernel<W>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BF_JACOBI_LDS_MAX),
+                    "hipFuncSetAttribute(Jacobi LDS)");
+  if (rc) return rc;
+  hipLaunchKernelGGL(bfJacobiKernel<W>, dim3(count), dim3(threads), lds, 0, dP, dL, dS, lds);
+  return hipFailB(hipGetLastError(), "Jacobi SVD launch");
+}
+
 int bfdevBuildJacobi(BfSvdProb const *hostProbs, uint64_t numProbs, BfSvdStats *stats) {
   if (!numProbs) return 0;
-  // classes: lane-group width by column length, workgroup size by column count
-  enum { NCLS = 6 };
+  enum { NW = 5, NL = 4, NCLS = 2 * NW * NL };
   uint32_t *lists[NCLS] = {0};
   uint64_t counts[NCLS] = {0};
-  int rc = 0;
-  for (int c = 0; c < NCLS; ++c) {
-    lists[c] = (uint32_t *)malloc(numProbs * sizeof(uint32_t));
-    if (!lists[c]) rc = bfhipFail(BFABI_ERROR_MEMORY_ERROR, "host OOM");
-  }
+  uint8_t *cls = (uint8_t *)malloc(numProbs);
+  int rc = cls ? 0 : bfhipFail(BFABI_ERROR_MEMORY_ERROR, "host OOM");
   for (uint64_t i = 0; i < numProbs && !rc; ++i) {
-    BfSvdProb const *p = &hostProbs[i];
-    int const w = p->mt <= 16 ? 0 : p->mt <= 32 ? 1 : 2;
-    int const big = p->me > 128;
-    int const c = w * 2 + big;
-    lists[c][counts[c]++] = (uint32_t)i;
+    int wlog, big, lc;
+    rc = jacobiClass(&hostProbs[i], &wlog, &big, &lc);
+    cls[i] = (uint8_t)((wlog * 2 + big) * NL + lc);
+    counts[cls[i]] += 1;
   }
+  for (int c = 0; c < NCLS && !rc; ++c) {
+    if (!counts[c]) continue;
+    lists[c] = (uint32_t *)malloc(counts[c] * sizeof(uint32_t));
+    if (!lists[c]) rc = bfhipFail(BFABI_ERROR_MEMORY_ERROR, "host OOM");
+    counts[c] = 0;
+  }
+  for (uint64_t i = 0; i < numProbs && !rc; ++i) lists[cls[i]][counts[cls[i]]++] = (uint32_t)i;
   BfSvdProb *dP = NULL;
   BfSvdStats *dS = NULL;
   if (!rc) rc = uploadArrayB(&dP, hostProbs, numProbs, "svd problems");
-  BfSvdStats zero = {0, 0, 0};
+  BfSvdStats zero = {0, 0, 0, 0};
   if (!rc) rc = uploadArrayB(&dS, &zero, 1, "svd stats");
-  for (int c = 0; c < NCLS && !rc; ++c) {
-    if (!counts[c]) continue;
-    uint32_t *dL = NULL;
-    rc = uploadArrayB(&dL, lists[c], counts[c], "svd class list");
-    if (!rc) {
-      dim3 const grid((uint32_t)counts[c]), block(c & 1 ? 1024 : 256);
-      switch (c >> 1) {
-        case 0: hipLaunchKernelGGL(bfJacobiKernel<16>, grid, block, 0, 0, dP, dL, dS); break;
-        case 1: hipLaunchKernelGGL(bfJacobiKernel<32>, grid, block, 0, 0, dP, dL, dS); break;
-        default: hipLaunchKernelGGL(bfJacobiKernel<64>, grid, block, 0, 0, dP, dL, dS); break;
+  uint32_t *dL[NCLS] = {0};
+  // classes are launched back to back (largest tiles first: they run longest) and synchronised once
+  for (int lc = NL - 1; lc >= 0 && !rc; --lc)
+    for (int wb = 0; wb < 2 * NW && !rc; ++wb) {
+      int const c = wb * NL + lc;
+      if (!counts[c]) continue;
+      rc = uploadArrayB(&dL[c], lists[c], counts[c], "svd class list");
+      if (rc) break;
+      uint32_t const threads = wb & 1 ? 1024 : 256, lds = kJacobiLds[lc], n = (uint32_t)counts[c];
+      switch (wb >> 1) {
+        case 0: rc = jacobiLaunch<4>(n, threads, lds, dP, dL[c], dS); break;
+        case 1: rc = jacobiLaunch<8>(n, threads, lds, dP, dL[c], dS); break;
+        case 2: rc = jacobiLaunch<16>(n, threads, lds, dP, dL[c], dS); break;
+        case 3: rc = jacobiLaunch<32>(n, threads, lds, dP, dL[c], dS); break;
+        default: rc = jacobiLaunch<64>(n, threads, lds, dP, dL[c], dS); break;
       }
-      rc = hipFailB(hipGetLastError(), "Jacobi SVD launch");
-      if (!rc) rc = hipFailB(hipDeviceSynchronize(), "Jacobi SVD");
     }
-    (void)hipFree(dL);
-  }
+  if (!rc) rc = hipFailB(hipDeviceSynchronize(), "Jacobi SVD");
+  for (int c = 0; c < NCLS; ++c) (void)hipFree(dL[c]);
   if (!rc && stats) {
     BfSvdStats got;
     rc = hipFailB(hipMemcpy(&got, dS, sizeof got, hipMemcpyDeviceToHost), "svd stats");
@@ -264,11 +384,13 @@ int bfdevBuildJacobi(BfSvdProb const *hostProbs, uint64_t numProbs, BfSvdStats *
       if (got.maxSweeps > stats->maxSweeps) stats->maxSweeps = got.maxSweeps;
       stats->notConverged += got.notConverged;
       stats->truncated += got.truncated;
+      stats->sumSweeps += got.sumSweeps;
     }
   }
   (void)hipFree(dP);
   (void)hipFree(dS);
   for (int c = 0; c < NCLS; ++c) free(lists[c]);
+  free(cls);
   return rc;
 }
 
@@ -435,6 +557,13 @@ __global__ __launch_bounds__(256) void bfSliceSumKernel(double2 const *partial, 
   double sr = 0, si = 0;
   for (uint32_t s = 0; s < slices; ++s) { double2 const v = partial[(uint64_t)s * n + i]; sr += v.x; si += v.y; }
   y[i] = make_double2(sr, si);
+}
+
+int bfdevMemFree(uint64_t *freeBytes) {
+  size_t f = 0, t = 0;
+  int rc = hipFailB(hipMemGetInfo(&f, &t), "hipMemGetInfo");
+  *freeBytes = f;
+  return rc;
 }
 
 int bfdevHelm2Dense(void const *dPoints, uint64_t n, double wavenumber, void const *dX, void *dY, void *stream) {

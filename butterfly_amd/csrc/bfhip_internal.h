@@ -252,7 +252,7 @@ typedef struct BfSvdProb {
   double *scale;         /* [me] */
   uint32_t mt, me;
 } BfSvdProb;
-typedef struct BfSvdStats { unsigned long long maxSweeps, notConverged, truncated; } BfSvdStats;
+typedef struct BfSvdStats { unsigned long long maxSweeps, notConverged, truncated, sumSweeps; } BfSvdStats;
 int bfdevBuildJacobi(BfSvdProb const *hostProbs, uint64_t numProbs, BfSvdStats *stats);
 
 /* C (M x N) = op(A) * B with optional row scaling C[i,:] *= scale[i];
@@ -271,6 +271,8 @@ typedef struct BfPackPiece {
   uint32_t srcLd, mr, mrPad, ncols;
 } BfPackPiece;
 int bfdevBuildPack(void *arena, void const *store, BfPackPiece const *hostPieces, uint64_t count);
+
+int bfdevMemFree(uint64_t *freeBytes);    /* free device memory right now */
 
 /* y = G x, N x N single-layer kernel evaluated on the fly; scratch is allocated inside */
 int bfdevHelm2Dense(void const *dPoints, uint64_t n, double wavenumber, void const *dX, void *dY, void *stream);

@@ -69,7 +69,7 @@ typedef struct BfhipHelm2Problem {
   uint64_t numPoints;
   const BfhipHelm2Recipe *recipes;
   uint64_t numRecipes;
-  uint64_t workspaceBytes;   /* device scratch for one batch of leaves; 0 -> 8 GiB */
+  uint64_t workspaceBytes;   /* device scratch for one batch of leaves; 0 -> half of the free device memory */
 } BfhipHelm2Problem;
 
 typedef struct BfhipBuildStats {
@@ -80,6 +80,7 @@ typedef struct BfhipBuildStats {
   uint64_t maxSweeps;        /* largest Jacobi sweep count over all problems */
   uint64_t notConverged;     /* problems that hit the sweep cap */
   uint64_t truncated;        /* singular values dropped, total */
+  uint64_t sumSweeps;        /* Jacobi sweeps summed over all problems */
   double seconds;            /* wall time of the value build (device work + orchestration) */
 } BfhipBuildStats;
 

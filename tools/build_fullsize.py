@@ -18,7 +18,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--npoints", type=int, default=65536)
     ap.add_argument("--wavenumber", type=float, default=None)
-    ap.add_argument("--workspace-gb", type=float, default=8.0)
+    ap.add_argument("--workspace-gb", type=float, default=0.0, help="0: library default (half of free HBM)")
     ap.add_argument("--no-dense-check", action="store_true")
     ap.add_argument("--steps", type=int, default=10)
     args = ap.parse_args()
