@@ -430,13 +430,16 @@ static int runPlan(BfhipOperator *op, BfPlan *plan, void const *dX, size_t nrhs,
     if (prof && (rc = bfdevEventRecord(op->evStart[s], stream))) return rc;
     if ((rc = bfdevLaunchStage(&a, stream))) return rc;
     if (prof && (rc = bfdevEventRecord(op->evStop[s], stream))) return rc;
-    for (uint64_t r = 0; r < st->numReduce; ++r) {
-      BfReduce *rd = &st->reduce[r];
-      BfReduceArgs ra;
-      ra.rowInterval = rd->dRowInterval; ra.ivBegin = rd->dIvBegin; ra.srcBias = rd->dSrcBias;
-      ra.numRows = rd->numRows; ra.temp = op->dTemp; ra.nrhs = (uint32_t)nrhs; ra.dtype = plan->dtype;
-      ra.dest = rd->destSpace == BF_SPACE_Y ? dY : (void *)((char *)op->dTemp + rd->destOff * nrhs * plan->elemSize);
-      if ((rc = bfdevLaunchReduce(&ra, stream))) return rc;
+    for (uint64_t r0 = 0; r0 < st->numReduce; r0 += 16) {
+      BfReduceArgs ra[16];
+      uint32_t const cnt = (uint32_t)(st->numReduce - r0 < 16 ? st->numReduce - r0 : 16);
+      for (uint32_t r = 0; r < cnt; ++r) {
+        BfReduce *rd = &st->reduce[r0 + r];
+        ra[r].rowInterval = rd->dRowInterval; ra[r].ivBegin = rd->dIvBegin; ra[r].srcBias = rd->dSrcBias;
+        ra[r].numRows = rd->numRows; ra[r].temp = op->dTemp; ra[r].nrhs = (uint32_t)nrhs; ra[r].dtype = plan->dtype;
+        ra[r].dest = rd->destSpace == BF_SPACE_Y ? dY : (void *)((char *)op->dTemp + rd->destOff * nrhs * plan->elemSize);
+      }
+      if ((rc = bfdevLaunchReduce(ra, cnt, stream))) return rc;
     }
   }
   if (prof) { op->evPending = 1; op->lastNrhs = (uint32_t)nrhs; }

@@ -547,26 +547,47 @@ __global__ __launch_bounds__(BF_WAVES_PER_WG * 64) void bfStageKernelT(StagePara
 // deterministic reduce: dest[row] = sum over the row's interval sources, in
 // list order, of temp[srcBias + row]
 // ---------------------------------------------------------------------------
+// All reduces of a stage run in one launch (they are a few microseconds each: 12 separate
+// launches cost 5 % of an apply at N = 65536): the descriptors travel by value in the kernel
+// arguments, a workgroup finds its reduce by scanning <= BF_REDUCE_BATCH block offsets.
+#define BF_REDUCE_BATCH 16
+struct ReduceBatch {
+  uint32_t count, nrhs;
+  void const *temp;
+  struct Entry {
+    uint32_t const *rowInterval, *ivBegin;
+    int64_t const *srcBias;
+    uint64_t numRows;
+    void *dest;
+    uint32_t blockBegin, pad;
+  } e[BF_REDUCE_BATCH];
+};
+
 template <typename T, int NC>   // NC = scalar components per element
-__global__ __launch_bounds__(256) void bfReduceKernel(uint32_t const *rowInterval, uint32_t const *ivBegin, int64_t const *srcBias,
-                                                      uint64_t numRows, T const *temp, T *dest, uint32_t nrhs) {
-  uint64_t idx = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-  uint64_t total = numRows * nrhs;
+__global__ __launch_bounds__(256) void bfReduceKernel(ReduceBatch const B) {
+  uint32_t k = 0;
+  while (k + 1 < B.count && B.e[k + 1].blockBegin <= blockIdx.x) ++k;
+  ReduceBatch::Entry const &E = B.e[k];
+  uint32_t const nrhs = B.nrhs;
+  uint64_t idx = (uint64_t)(blockIdx.x - E.blockBegin) * 256 + threadIdx.x;
+  uint64_t total = E.numRows * nrhs;
   if (idx >= total) return;
   uint64_t row = idx / nrhs;
   uint32_t q = (uint32_t)(idx - row * nrhs);
-  uint32_t iv = rowInterval[row];
-  uint32_t b = ivBegin[iv], e = ivBegin[iv + 1];
+  uint32_t iv = E.rowInterval[row];
+  uint32_t b = E.ivBegin[iv], e = E.ivBegin[iv + 1];
+  T const *temp = (T const *)B.temp;
+  T *dest = (T *)E.dest;
   T acc[NC];
 #pragma unroll
-  for (int k = 0; k < NC; ++k) acc[k] = 0;
+  for (int c = 0; c < NC; ++c) acc[c] = 0;
   for (uint32_t s = b; s < e; ++s) {
-    T const *src = temp + ((uint64_t)(srcBias[s] + (int64_t)row) * nrhs + q) * NC;
+    T const *src = temp + ((uint64_t)(E.srcBias[s] + (int64_t)row) * nrhs + q) * NC;
 #pragma unroll
-    for (int k = 0; k < NC; ++k) acc[k] += src[k];
+    for (int c = 0; c < NC; ++c) acc[c] += src[c];
   }
 #pragma unroll
-  for (int k = 0; k < NC; ++k) dest[idx * NC + k] = acc[k];
+  for (int c = 0; c < NC; ++c) dest[idx * NC + c] = acc[c];
 }
 
 // ---------------------------------------------------------------------------
@@ -793,17 +814,30 @@ int bfdevLaunchStage(BfLaunchArgs const *a, void *stream) {
   return hipFail(hipGetLastError(), "stage launch");
 }
 
-int bfdevLaunchReduce(BfReduceArgs const *a, void *stream) {
-  uint64_t total = a->numRows * a->nrhs;
-  if (!total) return 0;
-  uint32_t grid = (uint32_t)((total + 255) / 256);
+int bfdevLaunchReduce(BfReduceArgs const *a, uint32_t count, void *stream) {
   hipStream_t s = (hipStream_t)stream;
-  uint32_t const *ri = (uint32_t const *)a->rowInterval, *ib = (uint32_t const *)a->ivBegin;
-  int64_t const *sb = (int64_t const *)a->srcBias;
-  if (a->dtype == BFHIP_C128) hipLaunchKernelGGL((bfReduceKernel<double, 2>), dim3(grid), dim3(256), 0, s, ri, ib, sb, a->numRows, (double const *)a->temp, (double *)a->dest, a->nrhs);
-  else if (a->dtype == BFHIP_F64) hipLaunchKernelGGL((bfReduceKernel<double, 1>), dim3(grid), dim3(256), 0, s, ri, ib, sb, a->numRows, (double const *)a->temp, (double *)a->dest, a->nrhs);
-  else hipLaunchKernelGGL((bfReduceKernel<float, 1>), dim3(grid), dim3(256), 0, s, ri, ib, sb, a->numRows, (float const *)a->temp, (float *)a->dest, a->nrhs);
-  return hipFail(hipGetLastError(), "reduce launch");
+  for (uint32_t base = 0; base < count; base += BF_REDUCE_BATCH) {
+    ReduceBatch B;
+    B.count = count - base < BF_REDUCE_BATCH ? count - base : BF_REDUCE_BATCH;
+    B.nrhs = a[base].nrhs;
+    B.temp = a[base].temp;
+    uint32_t blocks = 0;
+    for (uint32_t k = 0; k < B.count; ++k) {
+      BfReduceArgs const *r = &a[base + k];
+      B.e[k].rowInterval = (uint32_t const *)r->rowInterval; B.e[k].ivBegin = (uint32_t const *)r->ivBegin;
+      B.e[k].srcBias = (int64_t const *)r->srcBias; B.e[k].numRows = r->numRows; B.e[k].dest = r->dest;
+      B.e[k].blockBegin = blocks; B.e[k].pad = 0;
+      blocks += (uint32_t)((r->numRows * r->nrhs + 255) / 256);
+    }
+    if (!blocks) continue;
+    uint32_t const dtype = a[base].dtype;
+    if (dtype == BFHIP_C128) hipLaunchKernelGGL((bfReduceKernel<double, 2>), dim3(blocks), dim3(256), 0, s, B);
+    else if (dtype == BFHIP_F64) hipLaunchKernelGGL((bfReduceKernel<double, 1>), dim3(blocks), dim3(256), 0, s, B);
+    else hipLaunchKernelGGL((bfReduceKernel<float, 1>), dim3(blocks), dim3(256), 0, s, B);
+    int rc = hipFail(hipGetLastError(), "reduce launch");
+    if (rc) return rc;
+  }
+  return 0;
 }
 
 int bfdevGmresResidual(void const *B, void const *AX0, void *W, void *partialOut, uint64_t n, uint32_t nrhs, uint32_t nb, void *stream) {

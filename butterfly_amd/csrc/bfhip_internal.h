@@ -206,7 +206,8 @@ typedef struct BfReduceArgs {
   uint32_t nrhs;
   uint32_t dtype;
 } BfReduceArgs;
-int bfdevLaunchReduce(BfReduceArgs const *a, void *stream);
+/* all `count` reduces (one stage; same temp / nrhs / dtype) in as few launches as possible */
+int bfdevLaunchReduce(BfReduceArgs const *a, uint32_t count, void *stream);
 
 /* device-resident GMRES building blocks (complex128; bfhip_gmres.c drives them).
  * Vectors are n x nrhs row-major; reductions are per RHS column, two-stage and
