@@ -67,6 +67,7 @@ PIECE_DTYPE = np.dtype([("dataOff", "<u8"), ("inOff", "<u4"), ("ncols", "<u4"), 
 # ---- include/bfhip_build.h -----------------------------------------------------
 PTS_TREE, PTS_CIRCLE = 0, 1
 LEAF_KERNEL, LEAF_REEXP = 0, 1
+LAYER_POTENTIALS = {"S": 1, "Sp": 3}      # reference BfLayerPotential values (include/bf/layer_pot.h:27-42)
 
 POINT_SET_DTYPE = np.dtype([("kind", "<u4"), ("count", "<u4"), ("first", "<u8"), ("cx", "<f8"), ("cy", "<f8"), ("r", "<f8")])
 RECIPE_DTYPE = np.dtype([("node", "<u8"), ("kind", "<u4"), ("reserved", "<u4"),
@@ -76,7 +77,8 @@ RECIPE_DTYPE = np.dtype([("node", "<u8"), ("kind", "<u4"), ("reserved", "<u4"),
 class BfhipHelm2Problem(C.Structure):
     _fields_ = [("structSize", C.c_uint32), ("layerPot", C.c_uint32), ("wavenumber", C.c_double),
                 ("points", C.c_void_p), ("numPoints", C.c_uint64), ("recipes", C.c_void_p),
-                ("numRecipes", C.c_uint64), ("workspaceBytes", C.c_uint64)]
+                ("numRecipes", C.c_uint64), ("workspaceBytes", C.c_uint64),
+                ("normals", C.c_void_p), ("colWeights", C.c_void_p), ("selfValue", C.c_double * 2)]
 
 
 class BfhipBuildStats(C.Structure):
@@ -122,20 +124,31 @@ def recipe_array(recipes: dict) -> np.ndarray:
 class Helm2Problem:
     """Keeps the arrays a BfhipHelm2Problem points to alive."""
 
-    def __init__(self, points, wavenumber, recipes, workspace_bytes=0):
+    def __init__(self, points, wavenumber, recipes=None, workspace_bytes=0, layer_pot="S", normals=None,
+                 col_weights=None, self_value=0.0):
         self.points = np.ascontiguousarray(points, dtype=np.float64)
         assert self.points.ndim == 2 and self.points.shape[1] == 2
+        if recipes is None:
+            recipes = np.zeros(0, dtype=RECIPE_DTYPE)
         self.recipes = recipes if isinstance(recipes, np.ndarray) else recipe_array(recipes)
         assert self.recipes.dtype == RECIPE_DTYPE and self.recipes.flags.c_contiguous
+        self.normals = None if normals is None else np.ascontiguousarray(normals, dtype=np.float64)
+        self.col_weights = None if col_weights is None else np.ascontiguousarray(col_weights, dtype=np.float64)
+        assert self.normals is None or self.normals.shape == self.points.shape
+        assert self.col_weights is None or self.col_weights.shape == (len(self.points),)
         s = self.struct = BfhipHelm2Problem()
         s.structSize = C.sizeof(BfhipHelm2Problem)
-        s.layerPot = 0
+        s.layerPot = LAYER_POTENTIALS.get(layer_pot, layer_pot)
         s.wavenumber = float(wavenumber)
         s.points = self.points.ctypes.data
         s.numPoints = len(self.points)
-        s.recipes = self.recipes.ctypes.data
+        s.recipes = self.recipes.ctypes.data if len(self.recipes) else None
         s.numRecipes = len(self.recipes)
         s.workspaceBytes = int(workspace_bytes)
+        s.normals = None if self.normals is None else self.normals.ctypes.data
+        s.colWeights = None if self.col_weights is None else self.col_weights.ctypes.data
+        sv = complex(self_value)
+        s.selfValue[0], s.selfValue[1] = sv.real, sv.imag
 
     def byref(self):
         return C.byref(self.struct)
@@ -251,9 +264,9 @@ def load():
     lib.bfhipBuildHelm2.restype = C.c_int
     lib.bfhipHelm2BuildLeaf.argtypes = [C.POINTER(BfhipHelm2Problem), C.c_uint64, C.c_int, vp]
     lib.bfhipHelm2BuildLeaf.restype = C.c_int
-    lib.bfhipHelm2DenseApplyDevice.argtypes = [vp, C.c_uint64, C.c_double, C.c_int, vp, vp, vp]
+    lib.bfhipHelm2DenseApplyDevice.argtypes = [C.POINTER(BfhipHelm2Problem), C.c_int, vp, vp, vp]
     lib.bfhipHelm2DenseApplyDevice.restype = C.c_int
-    lib.bfhipHelm2DenseApply.argtypes = [vp, C.c_uint64, C.c_double, C.c_int, vp, vp]
+    lib.bfhipHelm2DenseApply.argtypes = [C.POINTER(BfhipHelm2Problem), C.c_int, vp, vp]
     lib.bfhipHelm2DenseApply.restype = C.c_int
     _lib = lib
     return lib

@@ -48,7 +48,10 @@ static uint32_t leafRows(BfhipHelm2Recipe const *r) { return r->kind == BFHIP_LE
 static int checkProblem(BfhipHelm2Problem const *prob) {
   if (!prob) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "NULL problem");
   if (prob->structSize < sizeof(BfhipHelm2Problem)) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "BfhipHelm2Problem.structSize too small");
-  if (prob->layerPot != 0) return bfhipFail(BFABI_ERROR_NOT_IMPLEMENTED, "only the single-layer potential is built on the device");
+  if (prob->layerPot != BFHIP_LAYER_POTENTIAL_SINGLE && prob->layerPot != BFHIP_LAYER_POTENTIAL_PV_NORMAL_DERIV_SINGLE)
+    return bfhipFail(BFABI_ERROR_NOT_IMPLEMENTED, "layer potential %u is not built on the device (S = 1 and S' = 3 are)", prob->layerPot);
+  if (prob->layerPot == BFHIP_LAYER_POTENTIAL_PV_NORMAL_DERIV_SINGLE && !prob->normals)
+    return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "S' needs the unit normals at the points");
   if (!prob->points || (!prob->recipes && prob->numRecipes)) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "NULL points / recipes");
   if (!(prob->wavenumber > 0)) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "wavenumber must be positive");
   return 0;
@@ -66,7 +69,33 @@ static int checkRecipe(BfhipHelm2Problem const *prob, uint64_t i) {
                        (unsigned long long)i, r->tgt.count, r->equiv.count);
   } else if (r->kind != BFHIP_LEAF_KERNEL) {
     return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "recipe %llu: unknown kind %u", (unsigned long long)i, r->kind);
+  } else if (prob->layerPot == BFHIP_LAYER_POTENTIAL_PV_NORMAL_DERIV_SINGLE && r->tgt.kind != BFHIP_PTS_TREE) {
+    return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "recipe %llu: an S' kernel leaf needs target normals, i.e. tree-point targets", (unsigned long long)i);
   }
+  return 0;
+}
+
+/* device copies of what every kernel evaluation reads */
+typedef struct DevEnv { BfEvalEnv env; void *dPoints, *dNormals, *dWeights; } DevEnv;
+
+static void envFree(DevEnv *e) { bfdevFree(e->dPoints); bfdevFree(e->dNormals); bfdevFree(e->dWeights); memset(e, 0, sizeof *e); }
+
+static int envUpload(BfhipHelm2Problem const *prob, DevEnv *e) {
+  memset(e, 0, sizeof *e);
+  size_t const n = (size_t)(prob->numPoints ? prob->numPoints : 1);
+  int rc = bfdevMalloc(&e->dPoints, n * 16);
+  if (!rc) rc = bfdevMemcpyH2D(e->dPoints, prob->points, (size_t)prob->numPoints * 16);
+  if (!rc && prob->normals) {
+    rc = bfdevMalloc(&e->dNormals, n * 16);
+    if (!rc) rc = bfdevMemcpyH2D(e->dNormals, prob->normals, (size_t)prob->numPoints * 16);
+  }
+  if (!rc && prob->colWeights) {
+    rc = bfdevMalloc(&e->dWeights, n * 8);
+    if (!rc) rc = bfdevMemcpyH2D(e->dWeights, prob->colWeights, (size_t)prob->numPoints * 8);
+  }
+  if (rc) { envFree(e); return rc; }
+  e->env.dPoints = e->dPoints; e->env.dNormals = e->dNormals; e->env.dColWeights = e->dWeights;
+  e->env.wavenumber = prob->wavenumber; e->env.selfRe = prob->selfValue[0]; e->env.selfIm = prob->selfValue[1];
   return 0;
 }
 
@@ -92,7 +121,7 @@ static uint64_t recipeCost(BfhipHelm2Recipe const *r) {
 
 /* Compute recipes idx[0..count) on the current device.  *dStore receives a
  * device buffer holding the leaves column-major at storeOff[i] (elements). */
-static int buildBatch(BfhipHelm2Problem const *prob, uint64_t const *idx, uint64_t count, void const *dPoints,
+static int buildBatch(BfhipHelm2Problem const *prob, uint64_t const *idx, uint64_t count, BfEvalEnv const *env,
                       void **dStore, uint64_t *storeOff, BfhipBuildStats *st) {
   int rc = 0;
   *dStore = NULL;
@@ -116,10 +145,12 @@ static int buildBatch(BfhipHelm2Problem const *prob, uint64_t const *idx, uint64
   char *store = (char *)*dStore, *ws = (char *)dWs;
   uint64_t nm = 0, np = 0;
   prefix[0] = 0;
+  uint32_t const leafPot = prob->layerPot == BFHIP_LAYER_POTENTIAL_PV_NORMAL_DERIV_SINGLE ? 1 : 0;
   for (uint64_t i = 0; i < count; ++i) {
     BfhipHelm2Recipe const *r = &prob->recipes[idx[i]];
     if (r->kind == BFHIP_LEAF_KERNEL) {
       mats[nm].src = toPts(&r->src); mats[nm].tgt = toPts(&r->tgt); mats[nm].dst = store + storeOff[i] * 16;
+      mats[nm].pot = leafPot; mats[nm].decorate = 1;
       prefix[nm + 1] = prefix[nm] + ((uint64_t)r->tgt.count * r->src.count + BF_EVAL_TILE - 1) / BF_EVAL_TILE;
       ++nm;
       st->kernelLeaves += 1;
@@ -129,10 +160,13 @@ static int buildBatch(BfhipHelm2Problem const *prob, uint64_t const *idx, uint64
     ReexpWs const w = reexpWs(r);
     char *base = ws + wsOff[i] * 16;
     uint32_t const mt = r->tgt.count, me = r->equiv.count, n = r->src.count;
+    /* re-expansions use the proxy potential S; the column weights of the operator scale Z_orig */
     mats[nm].src = toPts(&r->equiv); mats[nm].tgt = toPts(&r->tgt); mats[nm].dst = base + w.zeq * 16;
+    mats[nm].pot = 0; mats[nm].decorate = 0;
     prefix[nm + 1] = prefix[nm] + ((uint64_t)mt * me + BF_EVAL_TILE - 1) / BF_EVAL_TILE;
     ++nm;
     mats[nm].src = toPts(&r->src); mats[nm].tgt = toPts(&r->tgt); mats[nm].dst = base + w.zor * 16;
+    mats[nm].pot = 0; mats[nm].decorate = 1;
     prefix[nm + 1] = prefix[nm] + ((uint64_t)mt * n + BF_EVAL_TILE - 1) / BF_EVAL_TILE;
     ++nm;
     probs[np].a = base + w.zeq * 16; probs[np].v = base + w.v * 16; probs[np].scale = (double *)(base + w.scale * 16);
@@ -149,7 +183,7 @@ static int buildBatch(BfhipHelm2Problem const *prob, uint64_t const *idx, uint64
     st->reexpLeaves += 1;
     st->kernelEvals += (uint64_t)mt * me + (uint64_t)mt * n;
   }
-  if ((rc = bfdevBuildEval(mats, prefix, nm, dPoints, prob->wavenumber))) goto done;
+  if ((rc = bfdevBuildEval(mats, prefix, nm, env))) goto done;
   BfSvdStats ss = {st->maxSweeps, 0, 0, 0};
   if ((rc = bfdevBuildJacobi(probs, np, &ss))) goto done;
   st->maxSweeps = ss.maxSweeps; st->notConverged += ss.notConverged; st->truncated += ss.truncated; st->sumSweeps += ss.sumSweeps;
@@ -183,7 +217,8 @@ static int fillArena(BfPlan const *pl, BfIr const *ir, void *dArena, void *vctx)
   PieceRec *pieces = NULL, *sorted = NULL;
   uint64_t *batch = NULL, *storeOff = NULL;
   BfPackPiece *pack = NULL;
-  void *dPoints = NULL;
+  DevEnv dev;
+  memset(&dev, 0, sizeof dev);
   if (!recOf || !pieceBegin) { rc = bfhipFail(BFABI_ERROR_MEMORY_ERROR, "host OOM (builder)"); goto done; }
   for (uint64_t i = 0; i < ir->numNodes; ++i) recOf[i] = -1;
   for (uint64_t i = 0; i < R && !rc; ++i) {
@@ -238,8 +273,7 @@ static int fillArena(BfPlan const *pl, BfIr const *ir, void *dArena, void *vctx)
     free(cursor);
   }
 
-  if ((rc = bfdevMalloc(&dPoints, (size_t)(prob->numPoints ? prob->numPoints : 1) * 16))) goto done;
-  if ((rc = bfdevMemcpyH2D(dPoints, prob->points, (size_t)prob->numPoints * 16))) goto done;
+  if ((rc = envUpload(prob, &dev))) goto done;
 
   /* default workspace: half of what is free once the arena is allocated, at least 8 GiB asked for --
    * large batches keep all CUs busy through the tail of the biggest least-squares problems */
@@ -265,7 +299,7 @@ static int fillArena(BfPlan const *pl, BfIr const *ir, void *dArena, void *vctx)
     }
     if (!nb) break;
     void *dStore = NULL;
-    if ((rc = buildBatch(prob, batch, nb, dPoints, &dStore, storeOff, st))) break;
+    if ((rc = buildBatch(prob, batch, nb, &dev.env, &dStore, storeOff, st))) break;
     pack = malloc((packCount + 1) * sizeof *pack);
     if (!pack) rc = bfhipFail(BFABI_ERROR_MEMORY_ERROR, "host OOM (builder pack list)");
     uint64_t q = 0;
@@ -285,7 +319,7 @@ static int fillArena(BfPlan const *pl, BfIr const *ir, void *dArena, void *vctx)
     bfdevFree(dStore);
   }
 done:
-  bfdevFree(dPoints);
+  envFree(&dev);
   free(recOf); free(pieceBegin); free(pieces); free(sorted); free(batch); free(storeOff);
   return rc;
 }
@@ -324,52 +358,56 @@ int bfhipHelm2BuildLeaf(BfhipHelm2Problem const *prob, uint64_t recipeIndex, int
   if ((rc = bfdevSetDevice(device))) return rc;
   BfhipHelm2Recipe const *r = &prob->recipes[recipeIndex];
   uint64_t const m = leafRows(r), n = r->src.count;
-  void *dPoints = NULL, *dStore = NULL;
+  void *dStore = NULL;
+  DevEnv dev;
+  memset(&dev, 0, sizeof dev);
   double *tmp = malloc((size_t)m * n * 16);
   BfhipBuildStats st;
   memset(&st, 0, sizeof st);
   uint64_t off = 0;
   if (!tmp) rc = bfhipFail(BFABI_ERROR_MEMORY_ERROR, "host OOM");
-  if (!rc) rc = bfdevMalloc(&dPoints, (size_t)(prob->numPoints ? prob->numPoints : 1) * 16);
-  if (!rc) rc = bfdevMemcpyH2D(dPoints, prob->points, (size_t)prob->numPoints * 16);
-  if (!rc) rc = buildBatch(prob, &recipeIndex, 1, dPoints, &dStore, &off, &st);
+  if (!rc) rc = envUpload(prob, &dev);
+  if (!rc) rc = buildBatch(prob, &recipeIndex, 1, &dev.env, &dStore, &off, &st);
   if (!rc) rc = bfdevMemcpyD2H(tmp, dStore, (size_t)m * n * 16);
   if (!rc) {
     double *o = out;                                   /* column-major store -> row-major result */
     for (uint64_t i = 0; i < m; ++i)
       for (uint64_t j = 0; j < n; ++j) { o[2 * (i * n + j)] = tmp[2 * (j * m + i)]; o[2 * (i * n + j) + 1] = tmp[2 * (j * m + i) + 1]; }
   }
-  bfdevFree(dStore); bfdevFree(dPoints); free(tmp);
+  bfdevFree(dStore); envFree(&dev); free(tmp);
   if (prev >= 0) bfdevSetDevice(prev);
   return rc;
 }
 
-int bfhipHelm2DenseApplyDevice(double const *points, uint64_t numPoints, double wavenumber, int device, void const *dX, void *dY, void *stream) {
-  if (!points || !dX || !dY) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "NULL argument");
-  int prev = -1, rc;
+int bfhipHelm2DenseApplyDevice(BfhipHelm2Problem const *prob, int device, void const *dX, void *dY, void *stream) {
+  int rc = checkProblem(prob);
+  if (rc) return rc;
+  if (!dX || !dY) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "NULL argument");
+  int prev = -1;
   bfdevGetDevice(&prev);
   if ((rc = bfdevSetDevice(device))) return rc;
-  void *dPoints = NULL;
-  rc = bfdevMalloc(&dPoints, (size_t)(numPoints ? numPoints : 1) * 16);
-  if (!rc) rc = bfdevMemcpyH2D(dPoints, points, (size_t)numPoints * 16);
-  if (!rc) rc = bfdevHelm2Dense(dPoints, numPoints, wavenumber, dX, dY, stream);
-  bfdevFree(dPoints);
+  DevEnv dev;
+  rc = envUpload(prob, &dev);
+  if (!rc) rc = bfdevHelm2Dense(&dev.env, prob->layerPot == BFHIP_LAYER_POTENTIAL_PV_NORMAL_DERIV_SINGLE ? 1 : 0, prob->numPoints, dX, dY, stream);
+  envFree(&dev);
   if (prev >= 0) bfdevSetDevice(prev);
   return rc;
 }
 
-int bfhipHelm2DenseApply(double const *points, uint64_t numPoints, double wavenumber, int device, void const *X, void *Y) {
-  if (!points || !X || !Y) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "NULL argument");
-  int prev = -1, rc;
+int bfhipHelm2DenseApply(BfhipHelm2Problem const *prob, int device, void const *X, void *Y) {
+  int rc = checkProblem(prob);
+  if (rc) return rc;
+  if (!X || !Y) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "NULL argument");
+  int prev = -1;
   bfdevGetDevice(&prev);
   if ((rc = bfdevSetDevice(device))) return rc;
   void *dX = NULL, *dY = NULL;
-  size_t const bytes = (size_t)(numPoints ? numPoints : 1) * 16;
+  size_t const bytes = (size_t)(prob->numPoints ? prob->numPoints : 1) * 16;
   rc = bfdevMalloc(&dX, bytes);
   if (!rc) rc = bfdevMalloc(&dY, bytes);
-  if (!rc) rc = bfdevMemcpyH2D(dX, X, (size_t)numPoints * 16);
-  if (!rc) rc = bfhipHelm2DenseApplyDevice(points, numPoints, wavenumber, -1, dX, dY, NULL);
-  if (!rc) rc = bfdevMemcpyD2H(Y, dY, (size_t)numPoints * 16);
+  if (!rc) rc = bfdevMemcpyH2D(dX, X, (size_t)prob->numPoints * 16);
+  if (!rc) rc = bfhipHelm2DenseApplyDevice(prob, -1, dX, dY, NULL);
+  if (!rc) rc = bfdevMemcpyD2H(Y, dY, (size_t)prob->numPoints * 16);
   bfdevFree(dX); bfdevFree(dY);
   if (prev >= 0) bfdevSetDevice(prev);
   return rc;

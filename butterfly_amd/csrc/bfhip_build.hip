@@ -55,16 +55,52 @@ __device__ __forceinline__ void bfPoint(BfBuildPts const &ps, uint32_t i, double
   }
 }
 
-// (i/4) H0^(1)(k r) = -Y0(kr)/4 + i J0(kr)/4; 0 on r == 0 (src/helm2.c:111-117)
+// S : (i/4) H0^(1)(k r)                       = (-Y0 + i J0)(kr) / 4          src/helm2.c:111-117
+// S': (i/4) k H1^(1)(k r)/r  n_tgt.(x_tgt-x_src) = (-Y1 + i J1)(kr) k dot / (4 r)  src/helm2.c:155-163
+// both 0 at r == 0
 __device__ __forceinline__ double2 bfHelm2G(double k, double dx, double dy) {
   double const r = hypot(dx, dy);
   if (r == 0.0) return make_double2(0.0, 0.0);
   double const kr = k * r;
   return make_double2(-0.25 * y0(kr), 0.25 * j0(kr));
 }
+__device__ __forceinline__ double2 bfHelm2Sp(double k, double dx, double dy, double nx, double ny) {
+  double const r = hypot(dx, dy);
+  if (r == 0.0) return make_double2(0.0, 0.0);
+  double const kr = k * r;
+  double const sc = 0.25 * k * (nx * dx + ny * dy) / r;
+  return make_double2(-sc * y1(kr), sc * j1(kr));
+}
 
-__global__ __launch_bounds__(256) void bfEvalKernel(BfEvalMat const *mats, uint64_t const *prefix, uint32_t numMats,
-                                                    double const *pts, double k, uint64_t tileBase) {
+struct EvalEnvDev {
+  double const *pts, *normals, *colWeights;
+  double k, selfRe, selfIm;
+};
+
+// one entry of a kernel matrix: target i of `tgt`, source j of `src`
+__device__ __forceinline__ double2 bfKernelEntry(EvalEnvDev const &E, BfBuildPts const &src, BfBuildPts const &tgt, uint32_t i, uint32_t j,
+                                                  uint32_t pot, uint32_t decorate) {
+  double tx, ty, sx, sy;
+  bfPoint(tgt, i, E.pts, tx, ty);
+  bfPoint(src, j, E.pts, sx, sy);
+  bool const bothTree = src.kind == BFHIP_PTS_TREE && tgt.kind == BFHIP_PTS_TREE;
+  if (decorate && bothTree && tgt.first + i == src.first + j) return make_double2(E.selfRe, E.selfIm);
+  double2 g;
+  if (pot == 1) {
+    uint64_t const ti = tgt.first + i;               // S' leaves have tree targets (checked on the host)
+    g = bfHelm2Sp(E.k, tx - sx, ty - sy, E.normals[2 * ti], E.normals[2 * ti + 1]);
+  } else {
+    g = bfHelm2G(E.k, tx - sx, ty - sy);
+  }
+  if (decorate && E.colWeights && src.kind == BFHIP_PTS_TREE) {
+    double const w = E.colWeights[src.first + j];
+    g.x *= w; g.y *= w;
+  }
+  return g;
+}
+
+__global__ __launch_bounds__(256) void bfEvalKernel(BfEvalMat const *mats, uint64_t const *prefix, uint32_t numMats, EvalEnvDev const E,
+                                                    uint64_t tileBase) {
   uint64_t const tile = tileBase + blockIdx.x;
   uint32_t lo = 0, hi = numMats;                   // prefix[lo] <= tile < prefix[hi]
   while (hi - lo > 1) {
@@ -80,14 +116,18 @@ __global__ __launch_bounds__(256) void bfEvalKernel(BfEvalMat const *mats, uint6
     uint64_t const e = e0 + (uint64_t)q * 256 + threadIdx.x;
     if (e >= total) break;
     uint32_t const i = (uint32_t)(e % M.tgt.count), j = (uint32_t)(e / M.tgt.count);
-    double tx, ty, sx, sy;
-    bfPoint(M.tgt, i, pts, tx, ty);
-    bfPoint(M.src, j, pts, sx, sy);
-    dst[e] = bfHelm2G(k, tx - sx, ty - sy);
+    dst[e] = bfKernelEntry(E, M.src, M.tgt, i, j, M.pot, M.decorate);
   }
 }
 
-int bfdevBuildEval(BfEvalMat const *hostMats, uint64_t const *hostTilePrefix, uint64_t numMats, void const *dPoints, double wavenumber) {
+static EvalEnvDev toDev(BfEvalEnv const *env) {
+  EvalEnvDev E;
+  E.pts = (double const *)env->dPoints; E.normals = (double const *)env->dNormals; E.colWeights = (double const *)env->dColWeights;
+  E.k = env->wavenumber; E.selfRe = env->selfRe; E.selfIm = env->selfIm;
+  return E;
+}
+
+int bfdevBuildEval(BfEvalMat const *hostMats, uint64_t const *hostTilePrefix, uint64_t numMats, BfEvalEnv const *env) {
   if (!numMats) return 0;
   BfEvalMat *dM = NULL;
   uint64_t *dP = NULL;
@@ -96,7 +136,7 @@ int bfdevBuildEval(BfEvalMat const *hostMats, uint64_t const *hostTilePrefix, ui
   uint64_t const tiles = hostTilePrefix[numMats];
   for (uint64_t done = 0; done < tiles && !rc;) {
     uint32_t const n = (uint32_t)(tiles - done > (1u << 30) ? (1u << 30) : tiles - done);
-    hipLaunchKernelGGL(bfEvalKernel, dim3(n), dim3(256), 0, 0, dM, dP, (uint32_t)numMats, (double const *)dPoints, wavenumber, done);
+    hipLaunchKernelGGL(bfEvalKernel, dim3(n), dim3(256), 0, 0, dM, dP, (uint32_t)numMats, toDev(env), done);
     rc = hipFailB(hipGetLastError(), "kernel-matrix evaluation launch");
     done += n;
   }
@@ -524,25 +564,36 @@ int bfdevBuildPack(void *arena, void const *store, BfPackPiece const *hostPieces
 // targets and one slice of the sources (staged through LDS, 256 at a time);
 // slices are summed afterwards in fixed order.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void bfHelm2DenseKernel(double const *pts, uint64_t n, double k, double2 const *x, double2 *partial,
+__global__ __launch_bounds__(256) void bfHelm2DenseKernel(EvalEnvDev const E, uint32_t pot, uint64_t n, double2 const *x, double2 *partial,
                                                           uint64_t sliceLen) {
-  __shared__ double sx[256], sy[256];
+  __shared__ double sx[256], sy[256], sw[256];
   __shared__ double2 xv[256];
   uint64_t const i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   uint64_t const j0 = (uint64_t)blockIdx.y * sliceLen;
   uint64_t const j1 = j0 + sliceLen < n ? j0 + sliceLen : n;
-  double tx = 0, ty = 0;
-  if (i < n) { tx = pts[2 * i]; ty = pts[2 * i + 1]; }
+  double tx = 0, ty = 0, nx = 0, ny = 0;
+  if (i < n) {
+    tx = E.pts[2 * i]; ty = E.pts[2 * i + 1];
+    if (pot == 1) { nx = E.normals[2 * i]; ny = E.normals[2 * i + 1]; }
+  }
   double ar = 0, ai = 0;
   for (uint64_t jb = j0; jb < j1; jb += 256) {
     uint64_t const j = jb + threadIdx.x;
     __syncthreads();
-    if (j < j1) { sx[threadIdx.x] = pts[2 * j]; sy[threadIdx.x] = pts[2 * j + 1]; xv[threadIdx.x] = x[j]; }
+    if (j < j1) {
+      sx[threadIdx.x] = E.pts[2 * j]; sy[threadIdx.x] = E.pts[2 * j + 1]; xv[threadIdx.x] = x[j];
+      sw[threadIdx.x] = E.colWeights ? E.colWeights[j] : 1.0;
+    }
     __syncthreads();
     uint32_t const cnt = (uint32_t)(j1 - jb < 256 ? j1 - jb : 256);
     if (i < n)
       for (uint32_t t = 0; t < cnt; ++t) {
-        double2 const g = bfHelm2G(k, tx - sx[t], ty - sy[t]);
+        double2 g;
+        if (jb + t == i) g = make_double2(E.selfRe, E.selfIm);
+        else {
+          g = pot == 1 ? bfHelm2Sp(E.k, tx - sx[t], ty - sy[t], nx, ny) : bfHelm2G(E.k, tx - sx[t], ty - sy[t]);
+          g.x *= sw[t]; g.y *= sw[t];
+        }
         double2 const v = xv[t];
         ar = fma(g.x, v.x, ar); ar = fma(-g.y, v.y, ar);
         ai = fma(g.x, v.y, ai); ai = fma(g.y, v.x, ai);
@@ -566,7 +617,7 @@ int bfdevMemFree(uint64_t *freeBytes) {
   return rc;
 }
 
-int bfdevHelm2Dense(void const *dPoints, uint64_t n, double wavenumber, void const *dX, void *dY, void *stream) {
+int bfdevHelm2Dense(BfEvalEnv const *env, uint32_t pot, uint64_t n, void const *dX, void *dY, void *stream) {
   if (!n) return 0;
   hipStream_t const s = (hipStream_t)stream;
   uint32_t const tb = (uint32_t)((n + 255) / 256);
@@ -578,7 +629,7 @@ int bfdevHelm2Dense(void const *dPoints, uint64_t n, double wavenumber, void con
   double2 *partial = NULL;
   int rc = hipFailB(hipMalloc((void **)&partial, (size_t)slices * n * sizeof(double2)), "hipMalloc(dense apply partials)");
   if (rc) return rc;
-  hipLaunchKernelGGL(bfHelm2DenseKernel, dim3(tb, slices), dim3(256), 0, s, (double const *)dPoints, n, wavenumber, (double2 const *)dX, partial, sliceLen);
+  hipLaunchKernelGGL(bfHelm2DenseKernel, dim3(tb, slices), dim3(256), 0, s, toDev(env), pot, n, (double2 const *)dX, partial, sliceLen);
   rc = hipFailB(hipGetLastError(), "dense apply launch");
   if (!rc) {
     hipLaunchKernelGGL(bfSliceSumKernel, dim3(tb), dim3(256), 0, s, partial, n, slices, (double2 *)dY);

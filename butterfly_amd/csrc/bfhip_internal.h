@@ -239,11 +239,17 @@ typedef struct BfBuildPts {        /* = BfhipPointSet (include/bfhip_build.h) */
 typedef struct BfEvalMat {
   BfBuildPts src, tgt;
   void *dst;
+  uint32_t pot;          /* 0: S, 1: S' (needs target normals; tree targets) */
+  uint32_t decorate;     /* 1: apply column weights / self value (leaves of the operator, not Z_equiv) */
 } BfEvalMat;
+/* what every kernel evaluation needs besides the two points */
+typedef struct BfEvalEnv {
+  void const *dPoints, *dNormals, *dColWeights;   /* device; normals / weights may be NULL */
+  double wavenumber, selfRe, selfIm;
+} BfEvalEnv;
 /* tilePrefix[numMats+1]: prefix sums of ceil(rows*cols / BF_EVAL_TILE) */
 #define BF_EVAL_TILE 1024u
-int bfdevBuildEval(BfEvalMat const *hostMats, uint64_t const *hostTilePrefix, uint64_t numMats,
-                   void const *dPoints, double wavenumber);
+int bfdevBuildEval(BfEvalMat const *hostMats, uint64_t const *hostTilePrefix, uint64_t numMats, BfEvalEnv const *env);
 
 /* one-sided Jacobi SVD of A (mt x me, mt >= me), in place: on return the
  * columns of A are U*Sigma, V (me x me) holds the right singular vectors and
@@ -276,7 +282,7 @@ int bfdevBuildPack(void *arena, void const *store, BfPackPiece const *hostPieces
 int bfdevMemFree(uint64_t *freeBytes);    /* free device memory right now */
 
 /* y = G x, N x N single-layer kernel evaluated on the fly; scratch is allocated inside */
-int bfdevHelm2Dense(void const *dPoints, uint64_t n, double wavenumber, void const *dX, void *dY, void *stream);
+int bfdevHelm2Dense(BfEvalEnv const *env, uint32_t pot, uint64_t n, void const *dX, void *dY, void *stream);
 int bfdevMemcpyH2DAsync(void *dst, void const *src, size_t bytes, void *stream);
 int bfdevMemcpyD2DAsync(void *dst, void const *src, size_t bytes, void *stream);
 

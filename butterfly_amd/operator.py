@@ -60,13 +60,16 @@ class HipOperator:
         return cls(h.value, keep=keep)
 
     @classmethod
-    def build_helm2(cls, desc, points, wavenumber, root=None, workspace_bytes=0, **opts):
+    def build_helm2(cls, desc, points, wavenumber, root=None, workspace_bytes=0, layer_pot="S", normals=None,
+                    col_weights=None, self_value=0.0, **opts):
         """bfhipBuildHelm2: lay out `desc` (helm2_structure with recipes=True) and
-        compute every leaf on the device from its recipe.  `points`: [N, 2] in
-        quadtree order.  Returns (operator, build statistics)."""
+        compute every leaf on the device from its recipe.  `points` (and
+        `normals` for layer_pot="Sp"): [N, 2] in quadtree order.  The operator
+        built is  self_value * I + K diag(col_weights).  Returns (operator,
+        build statistics)."""
         lib = _capi.load()
         da = DescArrays(desc, root=root)
-        prob = _capi.Helm2Problem(points, wavenumber, desc.recipe, workspace_bytes)
+        prob = _capi.Helm2Problem(points, wavenumber, desc.recipe, workspace_bytes, layer_pot, normals, col_weights, self_value)
         st = _capi.BfhipBuildStats()
         st.structSize = C.sizeof(st)
         h = C.c_void_p()
@@ -239,10 +242,11 @@ class HipOperator:
         return p
 
 
-def helm2_build_leaf(points, wavenumber, recipe, device=-1) -> np.ndarray:
+def helm2_build_leaf(points, wavenumber, recipe, device=-1, **problem) -> np.ndarray:
     """One leaf of a Helmholtz butterfly computed on the device (bfhipHelm2BuildLeaf);
-    `recipe` as in helm2_structure ("kernel", src, tgt) / ("reexp", src, equiv, tgt)."""
-    prob = _capi.Helm2Problem(points, wavenumber, {0: recipe})
+    `recipe` as in helm2_structure ("kernel", src, tgt) / ("reexp", src, equiv, tgt);
+    `problem`: layer_pot, normals, col_weights, self_value."""
+    prob = _capi.Helm2Problem(points, wavenumber, {0: recipe}, **problem)
     r = prob.recipes[0]
     rows = int(r["tgt"]["count"] if r["kind"] == _capi.LEAF_KERNEL else r["equiv"]["count"])
     out = np.empty((rows, int(r["src"]["count"])), dtype=np.complex128)
@@ -250,19 +254,20 @@ def helm2_build_leaf(points, wavenumber, recipe, device=-1) -> np.ndarray:
     return out
 
 
-def helm2_dense_apply(points, wavenumber, x, device=-1):
-    """y = G x with the dense single-layer kernel matrix evaluated on the fly on
-    the device (bfhipHelm2DenseApply[Device]); x: numpy [N] or a CUDA tensor."""
-    pts = np.ascontiguousarray(points, dtype=np.float64)
+def helm2_dense_apply(points, wavenumber, x, device=-1, **problem):
+    """y = (self_value I + K diag(col_weights)) x with the dense layer-potential
+    matrix K evaluated on the fly on the device (bfhipHelm2DenseApply[Device]);
+    x: numpy [N] or a CUDA tensor; `problem`: layer_pot, normals, col_weights, self_value."""
+    prob = _capi.Helm2Problem(points, wavenumber, None, **problem)
     lib = _capi.load()
     if isinstance(x, np.ndarray):
         xs = np.ascontiguousarray(x, dtype=np.complex128)
         y = np.empty_like(xs)
-        check(lib.bfhipHelm2DenseApply(pts.ctypes.data, len(pts), float(wavenumber), device, xs.ctypes.data, y.ctypes.data))
+        check(lib.bfhipHelm2DenseApply(prob.byref(), device, xs.ctypes.data, y.ctypes.data))
         return y
     import torch
     y = torch.empty_like(x)
     s = torch.cuda.current_stream(x.device)
-    check(lib.bfhipHelm2DenseApplyDevice(pts.ctypes.data, len(pts), float(wavenumber), x.device.index, C.c_void_p(x.data_ptr()),
-                                         C.c_void_p(y.data_ptr()), C.c_void_p(s.cuda_stream)))
+    check(lib.bfhipHelm2DenseApplyDevice(prob.byref(), x.device.index, C.c_void_p(x.data_ptr()), C.c_void_p(y.data_ptr()),
+                                         C.c_void_p(s.cuda_stream)))
     return y

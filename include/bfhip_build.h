@@ -61,15 +61,28 @@ typedef struct BfhipHelm2Recipe {
   BfhipPointSet tgt;     /* KERNEL: targets (rows); REEXP: check points */
 } BfhipHelm2Recipe;
 
+/* layer potentials, numbered as the reference's BfLayerPotential (include/bf/layer_pot.h:27-42) */
+enum {
+  BFHIP_LAYER_POTENTIAL_SINGLE = 1,                 /* S : G(x,y) = (i/4) H0(k r)                  src/helm2.c:93-125  */
+  BFHIP_LAYER_POTENTIAL_PV_NORMAL_DERIV_SINGLE = 3  /* S': (i/4) k H1(k r)/r  n_tgt.(x_tgt - x_src)  src/helm2.c:126-171 */
+};
+
 typedef struct BfhipHelm2Problem {
   uint32_t structSize;       /* = sizeof(BfhipHelm2Problem) */
-  uint32_t layerPot;         /* 0 = single layer (BF_LAYER_POTENTIAL_SINGLE); others: NOT_IMPLEMENTED */
+  uint32_t layerPot;         /* BFHIP_LAYER_POTENTIAL_*; others: NOT_IMPLEMENTED.  As in the reference, only
+                                KERNEL leaves (evaluation factor, dense near field) use S'; re-expansions use
+                                the proxy potential S (BF_PROXY_LAYER_POT, layer_pot.h:63-69, fac_helm2.c:59,231) */
   double wavenumber;
   const double *points;      /* [2 * numPoints] host, (x, y) pairs in quadtree order */
   uint64_t numPoints;
   const BfhipHelm2Recipe *recipes;
   uint64_t numRecipes;
   uint64_t workspaceBytes;   /* device scratch for one batch of leaves; 0 -> half of the free device memory */
+  const double *normals;     /* [2 * numPoints] unit normals at the points (S': target normals); else may be NULL */
+  /* system-matrix decorations folded into the values (reference: bfMatScaleCols + bfMatAddInplace of c I,
+   * examples/simple/helm2_bie.c:109-121): the built operator is  selfValue * I + K * diag(colWeights) */
+  const double *colWeights;  /* [numPoints] or NULL: columns whose sources are points j are scaled by colWeights[j] */
+  double selfValue[2];       /* (re, im) of the entries with target point == source point (the kernel has 0 there) */
 } BfhipHelm2Problem;
 
 typedef struct BfhipBuildStats {
@@ -97,11 +110,10 @@ int bfhipHelm2BuildLeaf(const BfhipHelm2Problem *prob, uint64_t recipeIndex, int
 /* y = G x with the N x N single-layer kernel matrix evaluated on the fly
  * (never stored): the reference examples' acceptance check at sizes where
  * the dense matrix does not fit (examples/simple/bf_all_blocks.c:132-153).
- * dX, dY: device, numPoints complex128; points: host. */
-int bfhipHelm2DenseApplyDevice(const double *points, uint64_t numPoints, double wavenumber, int device,
-                               const void *dX, void *dY, void *stream);
-int bfhipHelm2DenseApply(const double *points, uint64_t numPoints, double wavenumber, int device,
-                         const void *X, void *Y);
+ * Uses points, wavenumber, layerPot, normals, colWeights and selfValue of `prob`
+ * (recipes are ignored).  dX, dY: device, numPoints complex128. */
+int bfhipHelm2DenseApplyDevice(const BfhipHelm2Problem *prob, int device, const void *dX, void *dY, void *stream);
+int bfhipHelm2DenseApply(const BfhipHelm2Problem *prob, int device, const void *X, void *Y);
 
 #ifdef __cplusplus
 }

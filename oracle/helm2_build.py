@@ -5,6 +5,7 @@ builder, used only to manufacture real operands and known answers for parity
 tests (the engine itself never builds factorizations):
 
   kernel matrix (single layer, (i/4) H0(k r), 0 on r == 0)   reference src/helm2.c:93-125
+  S' kernel matrix ((i/4) k H1(k r)/r n_tgt.(x_tgt-x_src))    src/helm2.c:126-171
   proxy-circle sampling                                       src/circle.c:12-35
   re-expansion matrix Z_equiv \\ Z_orig                        src/helm2.c:321-365
   truncated-SVD least squares (rtol = max(m,n) eps)           src/mat_dense_complex.c:1767-1849
@@ -22,7 +23,7 @@ from __future__ import annotations
 import math
 
 import numpy as np
-from scipy.special import j0, y0
+from scipy.special import j0, j1, y0, y1
 
 EPS_MACH = 2.220446049250313e-16
 TWO_PI = 6.283185307179586
@@ -53,6 +54,19 @@ def kernel_matrix(k, src, tgt):
     return z
 
 
+def kernel_matrix_sp(k, src, tgt, ntgt):
+    """get_Sp_kernel_matrix, src/helm2.c:126-171: (i/4) k H1(k r)/r n_tgt.(x_tgt - x_src), 0 on r == 0."""
+    dx = tgt[:, None, 0] - src[None, :, 0]
+    dy = tgt[:, None, 1] - src[None, :, 1]
+    r = np.hypot(dx, dy)
+    z = np.zeros(r.shape, dtype=np.complex128)
+    nz = r != 0
+    dot = (ntgt[:, None, 0] * dx + ntgt[:, None, 1] * dy)[nz]
+    kr = k * r[nz]
+    z[nz] = 0.25j * k * (j1(kr) + 1j * y1(kr)) / r[nz] * dot
+    return z
+
+
 def lstsq_truncated(lhs, rhs):
     """bfMatDenseComplexDenseComplexLstSq, src/mat_dense_complex.c:1767-1849."""
     m, n = lhs.shape
@@ -72,15 +86,36 @@ def reexpansion_matrix(k, src_orig, src_equiv, tgt):
     return lstsq_truncated(z_equiv, z_orig)
 
 
-def leaf_values(desc, k, tree_points):
-    """Evaluate every dense leaf's recipe -> {node: complex128 array}."""
+def leaf_values(desc, k, tree_points, layer_pot="S", normals=None, col_weights=None, self_value=0.0):
+    """Evaluate every dense leaf's recipe -> {node: complex128 array}.
+
+    layer_pot "Sp": kernel leaves (evaluation factor src/fac_helm2.c:403-509, dense near field
+    :745-760) use S' with the target normals; re-expansions use the proxy potential S
+    (BF_PROXY_LAYER_POT, include/bf/layer_pot.h:63-69).  col_weights / self_value fold the
+    reference's bfMatScaleCols and bfMatAddInplace(c I) (examples/simple/helm2_bie.c:109-121) into
+    the values: the operand is  self_value I + K diag(col_weights)."""
+    def scaled(z, src_spec):
+        if col_weights is not None and src_spec[0] == "node":
+            z = z * col_weights[src_spec[1]:src_spec[2]][None, :]
+        return z
+
     out = {}
     for node, rc in desc.recipe.items():
         if rc[0] == "kernel":
-            z = kernel_matrix(k, resolve_points(rc[1], tree_points), resolve_points(rc[2], tree_points))
+            src, tgt = resolve_points(rc[1], tree_points), resolve_points(rc[2], tree_points)
+            if layer_pot == "Sp":
+                assert rc[2][0] == "node"
+                z = kernel_matrix_sp(k, src, tgt, normals[rc[2][1]:rc[2][2]])
+            else:
+                z = kernel_matrix(k, src, tgt)
+            z = scaled(z, rc[1])
+            if rc[1][0] == "node" and rc[2][0] == "node":
+                # target point == source point: the identity term of the system matrix
+                same = (np.arange(rc[2][1], rc[2][2])[:, None] == np.arange(rc[1][1], rc[1][2])[None, :])
+                z = np.where(same, self_value, z)
         elif rc[0] == "reexp":
-            z = reexpansion_matrix(k, resolve_points(rc[1], tree_points), resolve_points(rc[2], tree_points),
-                                   resolve_points(rc[3], tree_points))
+            src, eq, tgt = (resolve_points(sp, tree_points) for sp in rc[1:])
+            z = lstsq_truncated(kernel_matrix(k, eq, tgt), scaled(kernel_matrix(k, src, tgt), rc[1]))
         else:
             raise ValueError(rc)
         assert z.shape == (desc.rows[node], desc.cols[node]), (z.shape, desc.rows[node], desc.cols[node], rc[0])

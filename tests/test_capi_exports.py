@@ -77,4 +77,10 @@ def test_builder_structs_match_the_header_and_arguments_are_checked(tmp_path):
     assert lib.bfhipHelm2BuildLeaf(prob.byref(), 0, -1, out.ctypes.data) == 3                      # fewer check points than unknowns
     prob = _capi.Helm2Problem(pts, 0.0, {0: ("kernel", ("node", 0, 2), ("node", 0, 2))})
     assert lib.bfhipHelm2BuildLeaf(prob.byref(), 0, -1, out.ctypes.data) == 1                      # wavenumber
-    assert lib.bfhipHelm2DenseApply(None, 4, 1.0, -1, out.ctypes.data, out.ctypes.data) == 1
+    assert lib.bfhipHelm2DenseApply(None, -1, out.ctypes.data, out.ctypes.data) == 1
+    prob = _capi.Helm2Problem(pts, 1.0, {0: ("kernel", ("node", 0, 2), ("node", 0, 2))}, layer_pot="Sp")   # S' without normals
+    assert lib.bfhipHelm2BuildLeaf(prob.byref(), 0, -1, out.ctypes.data) == 1 and b"normals" in lib.bfhipLastErrorMessage()
+    prob = _capi.Helm2Problem(pts, 1.0, {0: ("kernel", ("node", 0, 2), ("circle", 0, 0, 1, 4))}, layer_pot="Sp", normals=pts)
+    assert lib.bfhipHelm2BuildLeaf(prob.byref(), 0, -1, out.ctypes.data) == 1                      # S' leaf with circle targets
+    prob = _capi.Helm2Problem(pts, 1.0, {0: ("kernel", ("node", 0, 2), ("node", 0, 2))}, layer_pot=2)         # PV double layer
+    assert lib.bfhipHelm2BuildLeaf(prob.byref(), 0, -1, out.ctypes.data) == 3

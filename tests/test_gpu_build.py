@@ -123,3 +123,58 @@ def test_builder_on_a_row_shard_and_argument_errors(helm2_cases):
         desc.recipe[some] = saved
     with pytest.raises(_capi.BfhipError):
         HipOperator.build_helm2(desc, tp, -1.0)
+
+
+def test_sp_kernel_leaf_and_decorations_match_numpy():
+    """S' = normal derivative of the single layer at the targets (src/helm2.c:126-171), column
+    weights and the self value, on a near-field (points -> points) leaf."""
+    from butterfly_amd.operator import helm2_build_leaf
+    from oracle import helm2_build as hb
+    n, k = 512, 300.0
+    pts = _pts(n) * np.array([1.0, 0.6])
+    t = 2 * np.pi * np.arange(n) / n
+    nrm = np.stack([0.6 * np.cos(t), np.sin(t)], axis=1)
+    nrm /= np.linalg.norm(nrm, axis=1)[:, None]
+    w = 0.5 + np.random.default_rng(1).random(n)
+    for src, tgt in ((("node", 40, 97), ("node", 300, 411)), (("node", 100, 160), ("node", 90, 170)),
+                     (("circle", 0.3, -0.2, 0.25, 37), ("node", 100, 164))):
+        got = helm2_build_leaf(pts, k, ("kernel", src, tgt), layer_pot="Sp", normals=nrm, col_weights=w, self_value=0.5 - 0.25j)
+        want = hb.kernel_matrix_sp(k, hb.resolve_points(src, pts), hb.resolve_points(tgt, pts), nrm[tgt[1]:tgt[2]])
+        if src[0] == "node":
+            want = want * w[src[1]:src[2]][None, :]
+            same = np.arange(tgt[1], tgt[2])[:, None] == np.arange(src[1], src[2])[None, :]
+            want = np.where(same, 0.5 - 0.25j, want)
+        # device j1/y1 vs scipy's: a few ulp of O(1) values, scaled by k |n.d| / (4 r) ~ 75 here
+        assert np.max(np.abs(got - want)) <= 5e-13 * max(1.0, np.max(np.abs(want))), (src, tgt)
+
+
+@pytest.mark.parametrize("n,k", [(2048, 64.0), (4096, 256.0)])
+def test_second_kind_system_built_and_solved_on_the_device(helm2_cases, n, k):
+    """The operator examples/simple/helm2_bie.c hands to bfSolveGMRES, minus the KR quadrature
+    correction:  A = I/2 + S' diag(w)  (S' via fac_helm2 with PV_NORMAL_DERIV_SINGLE, bfMatScaleCols
+    by the trapezoid weights, bfMatAddInplace of I/2; helm2_bie.c:93-121) -- values computed, applied
+    and solved on the GPU; numpy/LAPACK-built operand, dense matrix and dense solve as checks."""
+    import torch
+    from butterfly_amd.operator import HipOperator, helm2_dense_apply
+    from oracle import bfref, helm2_build as hb
+    desc, tp, _ = helm2_cases(n, k)
+    nrm = tp.copy()                                  # unit circle: the outward normal is the point itself
+    w = np.full(n, 2 * np.pi / n)
+    deco = dict(layer_pot="Sp", normals=nrm, col_weights=w, self_value=0.5)
+    op, st = HipOperator.build_helm2(desc, tp, k, **deco)
+    assert st["notConverged"] == 0
+    x = hb.complex_randn(n, 0)
+    y = op.apply_host(x)
+    dense = 0.5 * np.eye(n) + hb.kernel_matrix_sp(k, tp, tp, nrm) * w[None, :]
+    assert rel(y, dense @ x) <= 1e-9
+    assert rel(helm2_dense_apply(tp, k, x, **deco), dense @ x) <= 1e-13
+    assert rel(helm2_dense_apply(tp, k, torch.from_numpy(x).cuda(), **deco).cpu().numpy(), dense @ x) <= 1e-13
+    vals = hb.leaf_values(desc, k, tp, **deco)       # the same operand through numpy / LAPACK
+    assert rel(y, bfref.mat_mul(bfref.from_desc(desc, vals), x)) <= 1e-10
+    # scattering-type right-hand side: normal derivative of a plane wave on the circle
+    d = np.array([np.cos(0.3), np.sin(0.3)])
+    b = 1j * k * (nrm @ d) * np.exp(1j * k * (tp @ d))
+    sigma, iters, res = op.solve_gmres(b, tol=1e-9, max_num_iter=400)      # the operand itself is a 1e-10 approximation
+    want = np.linalg.solve(dense, b)
+    assert iters < 400 and rel(sigma, want) <= 1e-6, (iters, res, rel(sigma, want))
+    op.close()
