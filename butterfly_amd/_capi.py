@@ -78,7 +78,8 @@ class BfhipHelm2Problem(C.Structure):
     _fields_ = [("structSize", C.c_uint32), ("layerPot", C.c_uint32), ("wavenumber", C.c_double),
                 ("points", C.c_void_p), ("numPoints", C.c_uint64), ("recipes", C.c_void_p),
                 ("numRecipes", C.c_uint64), ("workspaceBytes", C.c_uint64),
-                ("normals", C.c_void_p), ("colWeights", C.c_void_p), ("selfValue", C.c_double * 2)]
+                ("normals", C.c_void_p), ("colWeights", C.c_void_p), ("selfValue", C.c_double * 2),
+                ("origIndex", C.c_void_p), ("krOrder", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class BfhipBuildStats(C.Structure):
@@ -125,7 +126,7 @@ class Helm2Problem:
     """Keeps the arrays a BfhipHelm2Problem points to alive."""
 
     def __init__(self, points, wavenumber, recipes=None, workspace_bytes=0, layer_pot="S", normals=None,
-                 col_weights=None, self_value=0.0):
+                 col_weights=None, self_value=0.0, kr_order=0, orig_index=None):
         self.points = np.ascontiguousarray(points, dtype=np.float64)
         assert self.points.ndim == 2 and self.points.shape[1] == 2
         if recipes is None:
@@ -149,6 +150,10 @@ class Helm2Problem:
         s.colWeights = None if self.col_weights is None else self.col_weights.ctypes.data
         sv = complex(self_value)
         s.selfValue[0], s.selfValue[1] = sv.real, sv.imag
+        self.orig_index = None if orig_index is None else np.ascontiguousarray(orig_index, dtype=np.uint64)
+        assert self.orig_index is None or self.orig_index.shape == (len(self.points),)
+        s.origIndex = None if self.orig_index is None else self.orig_index.ctypes.data
+        s.krOrder = int(kr_order)
 
     def byref(self):
         return C.byref(self.struct)

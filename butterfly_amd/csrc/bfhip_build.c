@@ -52,6 +52,11 @@ static int checkProblem(BfhipHelm2Problem const *prob) {
     return bfhipFail(BFABI_ERROR_NOT_IMPLEMENTED, "layer potential %u is not built on the device (S = 1 and S' = 3 are)", prob->layerPot);
   if (prob->layerPot == BFHIP_LAYER_POTENTIAL_PV_NORMAL_DERIV_SINGLE && !prob->normals)
     return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "S' needs the unit normals at the points");
+  if (prob->krOrder != 0 && prob->krOrder != 2 && prob->krOrder != 6 && prob->krOrder != 10)
+    return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "Kapur-Rokhlin order must be 0, 2, 6 or 10");    /* src/quadrature.c:106 */
+  if (prob->krOrder && !prob->origIndex) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "the KR correction needs origIndex");
+  if (prob->krOrder && prob->numPoints < 2 * (uint64_t)prob->krOrder + 1)
+    return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "too few points for the KR correction");          /* src/quadrature.c:115 */
   if (!prob->points || (!prob->recipes && prob->numRecipes)) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "NULL points / recipes");
   if (!(prob->wavenumber > 0)) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "wavenumber must be positive");
   return 0;
@@ -76,9 +81,9 @@ static int checkRecipe(BfhipHelm2Problem const *prob, uint64_t i) {
 }
 
 /* device copies of what every kernel evaluation reads */
-typedef struct DevEnv { BfEvalEnv env; void *dPoints, *dNormals, *dWeights; } DevEnv;
+typedef struct DevEnv { BfEvalEnv env; void *dPoints, *dNormals, *dWeights, *dOrig, *dHits; } DevEnv;
 
-static void envFree(DevEnv *e) { bfdevFree(e->dPoints); bfdevFree(e->dNormals); bfdevFree(e->dWeights); memset(e, 0, sizeof *e); }
+static void envFree(DevEnv *e) { bfdevFree(e->dPoints); bfdevFree(e->dNormals); bfdevFree(e->dWeights); bfdevFree(e->dOrig); bfdevFree(e->dHits); memset(e, 0, sizeof *e); }
 
 static int envUpload(BfhipHelm2Problem const *prob, DevEnv *e) {
   memset(e, 0, sizeof *e);
@@ -93,7 +98,15 @@ static int envUpload(BfhipHelm2Problem const *prob, DevEnv *e) {
     rc = bfdevMalloc(&e->dWeights, n * 8);
     if (!rc) rc = bfdevMemcpyH2D(e->dWeights, prob->colWeights, (size_t)prob->numPoints * 8);
   }
+  if (!rc && prob->krOrder) {
+    rc = bfdevMalloc(&e->dOrig, n * 8);
+    if (!rc) rc = bfdevMemcpyH2D(e->dOrig, prob->origIndex, (size_t)prob->numPoints * 8);
+    if (!rc) rc = bfdevMalloc(&e->dHits, 8);
+    if (!rc) rc = bfdevMemset(e->dHits, 0, 8);
+  }
   if (rc) { envFree(e); return rc; }
+  e->env.dOrigIndex = e->dOrig; e->env.numPoints = prob->numPoints; e->env.krOrder = prob->krOrder;
+  e->env.dKrHits = (unsigned long long *)e->dHits;
   e->env.dPoints = e->dPoints; e->env.dNormals = e->dNormals; e->env.dColWeights = e->dWeights;
   e->env.wavenumber = prob->wavenumber; e->env.selfRe = prob->selfValue[0]; e->env.selfIm = prob->selfValue[1];
   return 0;
@@ -317,6 +330,15 @@ static int fillArena(BfPlan const *pl, BfIr const *ir, void *dArena, void *vctx)
     if (!rc) rc = bfdevBuildPack(dArena, dStore, pack, q);
     free(pack); pack = NULL;
     bfdevFree(dStore);
+  }
+  /* every KR pair must have been met exactly once by a dense near-field leaf; a pair inside a
+   * butterflied block cannot be corrected through the values */
+  if (!rc && prob->krOrder && pl->numRows == prob->numPoints && pl->numCols == prob->numPoints) {
+    unsigned long long hits = 0;
+    rc = bfdevMemcpyD2H(&hits, dev.dHits, 8);
+    if (!rc && hits != 2ull * prob->krOrder * prob->numPoints)
+      rc = bfhipFail(BFABI_ERROR_RUNTIME_ERROR, "KR correction: %llu of %llu near-diagonal entries lie in dense leaves",
+                     hits, 2ull * prob->krOrder * prob->numPoints);
   }
 done:
   envFree(&dev);

@@ -72,10 +72,31 @@ __device__ __forceinline__ double2 bfHelm2Sp(double k, double dx, double dy, dou
   return make_double2(-sc * y1(kr), sc * j1(kr));
 }
 
+// Kapur-Rokhlin end-point corrections of the punctured trapezoid rule for a log-singular kernel
+// (Kapur & Rokhlin, SIAM J. Numer. Anal. 34, 1997); the values are the tables the reference applies
+// (src/quadrature.c:12-41, order 10 as printed there).
+__constant__ double bfKrWeights[18] = {
+    1.825748064736159, -1.325748064736159,
+    4.967362978287758, -16.20501504859126, 25.85153761832639, -22.22599466791883, 9.930104998037539, -1.817995878141594,
+    7.832432020568779, -4.565161670374749, 1.452168846354677, -2.901348302886379, 3.870862162579900, -3.523821383570681,
+    2.172421547519342, -8.707796087382991, 2.053584266072635, -2.166984103403823};
+
 struct EvalEnvDev {
   double const *pts, *normals, *colWeights;
+  uint64_t const *orig;
   double k, selfRe, selfIm;
+  uint64_t n;
+  uint32_t krOrder, krBase;          // krBase: offset of the order's table in bfKrWeights
+  unsigned long long *krHits;
 };
+
+// 1 + w_KR[d-1] if original indices a, b are d = 1..order apart on the closed curve, else 1
+__device__ __forceinline__ double bfKrFactor(EvalEnvDev const &E, uint64_t a, uint64_t b, bool &hit) {
+  uint64_t const fwd = a >= b ? a - b : a + E.n - b;        // (a - b) mod n
+  uint64_t const d = fwd <= E.n - fwd ? fwd : E.n - fwd;
+  hit = d >= 1 && d <= E.krOrder;
+  return hit ? 1.0 + bfKrWeights[E.krBase + d - 1] : 1.0;
+}
 
 // one entry of a kernel matrix: target i of `tgt`, source j of `src`
 __device__ __forceinline__ double2 bfKernelEntry(EvalEnvDev const &E, BfBuildPts const &src, BfBuildPts const &tgt, uint32_t i, uint32_t j,
@@ -91,6 +112,12 @@ __device__ __forceinline__ double2 bfKernelEntry(EvalEnvDev const &E, BfBuildPts
     g = bfHelm2Sp(E.k, tx - sx, ty - sy, E.normals[2 * ti], E.normals[2 * ti + 1]);
   } else {
     g = bfHelm2G(E.k, tx - sx, ty - sy);
+  }
+  if (decorate && E.krOrder && bothTree) {
+    bool hit;
+    double const f = bfKrFactor(E, E.orig[tgt.first + i], E.orig[src.first + j], hit);
+    g.x *= f; g.y *= f;
+    if (hit && E.krHits) atomicAdd(E.krHits, 1ull);          // bookkeeping only: every pair must be met exactly once
   }
   if (decorate && E.colWeights && src.kind == BFHIP_PTS_TREE) {
     double const w = E.colWeights[src.first + j];
@@ -124,6 +151,10 @@ static EvalEnvDev toDev(BfEvalEnv const *env) {
   EvalEnvDev E;
   E.pts = (double const *)env->dPoints; E.normals = (double const *)env->dNormals; E.colWeights = (double const *)env->dColWeights;
   E.k = env->wavenumber; E.selfRe = env->selfRe; E.selfIm = env->selfIm;
+  E.orig = (uint64_t const *)env->dOrigIndex; E.n = env->numPoints;
+  E.krOrder = env->dOrigIndex ? env->krOrder : 0;
+  E.krBase = env->krOrder == 2 ? 0 : env->krOrder == 6 ? 2 : 8;
+  E.krHits = env->dKrHits;
   return E;
 }
 
@@ -568,13 +599,16 @@ __global__ __launch_bounds__(256) void bfHelm2DenseKernel(EvalEnvDev const E, ui
                                                           uint64_t sliceLen) {
   __shared__ double sx[256], sy[256], sw[256];
   __shared__ double2 xv[256];
+  __shared__ uint64_t so[256];
   uint64_t const i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   uint64_t const j0 = (uint64_t)blockIdx.y * sliceLen;
   uint64_t const j1 = j0 + sliceLen < n ? j0 + sliceLen : n;
   double tx = 0, ty = 0, nx = 0, ny = 0;
+  uint64_t oi = 0;
   if (i < n) {
     tx = E.pts[2 * i]; ty = E.pts[2 * i + 1];
     if (pot == 1) { nx = E.normals[2 * i]; ny = E.normals[2 * i + 1]; }
+    if (E.krOrder) oi = E.orig[i];
   }
   double ar = 0, ai = 0;
   for (uint64_t jb = j0; jb < j1; jb += 256) {
@@ -583,6 +617,7 @@ __global__ __launch_bounds__(256) void bfHelm2DenseKernel(EvalEnvDev const E, ui
     if (j < j1) {
       sx[threadIdx.x] = E.pts[2 * j]; sy[threadIdx.x] = E.pts[2 * j + 1]; xv[threadIdx.x] = x[j];
       sw[threadIdx.x] = E.colWeights ? E.colWeights[j] : 1.0;
+      so[threadIdx.x] = E.krOrder ? E.orig[j] : 0;
     }
     __syncthreads();
     uint32_t const cnt = (uint32_t)(j1 - jb < 256 ? j1 - jb : 256);
@@ -592,7 +627,9 @@ __global__ __launch_bounds__(256) void bfHelm2DenseKernel(EvalEnvDev const E, ui
         if (jb + t == i) g = make_double2(E.selfRe, E.selfIm);
         else {
           g = pot == 1 ? bfHelm2Sp(E.k, tx - sx[t], ty - sy[t], nx, ny) : bfHelm2G(E.k, tx - sx[t], ty - sy[t]);
-          g.x *= sw[t]; g.y *= sw[t];
+          bool hit;
+          double const f = sw[t] * (E.krOrder ? bfKrFactor(E, oi, so[t], hit) : 1.0);
+          g.x *= f; g.y *= f;
         }
         double2 const v = xv[t];
         ar = fma(g.x, v.x, ar); ar = fma(-g.y, v.y, ar);

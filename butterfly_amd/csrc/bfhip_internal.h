@@ -245,7 +245,11 @@ typedef struct BfEvalMat {
 /* what every kernel evaluation needs besides the two points */
 typedef struct BfEvalEnv {
   void const *dPoints, *dNormals, *dColWeights;   /* device; normals / weights may be NULL */
+  void const *dOrigIndex;                         /* device uint64[numPoints] or NULL */
   double wavenumber, selfRe, selfIm;
+  uint64_t numPoints;
+  uint32_t krOrder;                               /* 0, 2, 6, 10 */
+  unsigned long long *dKrHits;                    /* device counter of corrected entries (consistency check) or NULL */
 } BfEvalEnv;
 /* tilePrefix[numMats+1]: prefix sums of ceil(rows*cols / BF_EVAL_TILE) */
 #define BF_EVAL_TILE 1024u

@@ -83,6 +83,15 @@ typedef struct BfhipHelm2Problem {
    * examples/simple/helm2_bie.c:109-121): the built operator is  selfValue * I + K * diag(colWeights) */
   const double *colWeights;  /* [numPoints] or NULL: columns whose sources are points j are scaled by colWeights[j] */
   double selfValue[2];       /* (re, im) of the entries with target point == source point (the kernel has 0 there) */
+  /* Kapur-Rokhlin correction of the punctured trapezoid rule on a closed curve
+   * (bfHelm2ApplyKrCorrectionTree -> bfQuadKrApplyCorrectionTree, src/quadrature.c:126-199;
+   * helm2_bie.c:113): entry (i, j) of the layer potential is multiplied by 1 + w_KR[d-1] when the
+   * points are d = 1..krOrder apart along the curve (cyclic distance of their ORIGINAL indices).
+   * Folded into the dense near-field leaves; the build fails if such a pair lies in a butterflied
+   * block.  krOrder: 0 (none), 2, 6 or 10; origIndex[t] = original index of tree position t. */
+  const uint64_t *origIndex; /* [numPoints] or NULL (needed iff krOrder != 0) */
+  uint32_t krOrder;
+  uint32_t reserved;
 } BfhipHelm2Problem;
 
 typedef struct BfhipBuildStats {

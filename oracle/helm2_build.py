@@ -86,7 +86,30 @@ def reexpansion_matrix(k, src_orig, src_equiv, tgt):
     return lstsq_truncated(z_equiv, z_orig)
 
 
-def leaf_values(desc, k, tree_points, layer_pot="S", normals=None, col_weights=None, self_value=0.0):
+# Kapur-Rokhlin weights as the reference tabulates them (src/quadrature.c:12-41)
+KR_WEIGHTS = {
+    2: [1.825748064736159, -1.325748064736159],
+    6: [4.967362978287758, -16.20501504859126, 25.85153761832639, -22.22599466791883, 9.930104998037539, -1.817995878141594],
+    10: [7.832432020568779, -4.565161670374749, 1.452168846354677, -2.901348302886379, 3.870862162579900, -3.523821383570681,
+         2.172421547519342, -8.707796087382991, 2.053584266072635, -2.166984103403823],
+}
+
+
+def kr_factors(order, orig_tgt, orig_src, n):
+    """1 + w_KR[d-1] where the original indices are d = 1..order apart on the closed curve, else 1:
+    adding w_KR[p] K(i, j) at j = i +- (p+1) mod n (bf_get_KR_corr_block_spmat, src/quadrature.c:126-166)
+    is multiplying K(i, j) by that factor."""
+    fwd = (np.asarray(orig_tgt, dtype=np.int64)[:, None] - np.asarray(orig_src, dtype=np.int64)[None, :]) % n
+    d = np.minimum(fwd, n - fwd)
+    f = np.ones(d.shape)
+    w = KR_WEIGHTS[order]
+    for p in range(order):
+        f[d == p + 1] += w[p]
+    return f
+
+
+def leaf_values(desc, k, tree_points, layer_pot="S", normals=None, col_weights=None, self_value=0.0, kr_order=0,
+                orig_index=None):
     """Evaluate every dense leaf's recipe -> {node: complex128 array}.
 
     layer_pot "Sp": kernel leaves (evaluation factor src/fac_helm2.c:403-509, dense near field
@@ -108,6 +131,8 @@ def leaf_values(desc, k, tree_points, layer_pot="S", normals=None, col_weights=N
                 z = kernel_matrix_sp(k, src, tgt, normals[rc[2][1]:rc[2][2]])
             else:
                 z = kernel_matrix(k, src, tgt)
+            if kr_order and rc[1][0] == "node" and rc[2][0] == "node":
+                z = z * kr_factors(kr_order, orig_index[rc[2][1]:rc[2][2]], orig_index[rc[1][1]:rc[1][2]], len(tree_points))
             z = scaled(z, rc[1])
             if rc[1][0] == "node" and rc[2][0] == "node":
                 # target point == source point: the identity term of the system matrix

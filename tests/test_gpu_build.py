@@ -178,3 +178,40 @@ def test_second_kind_system_built_and_solved_on_the_device(helm2_cases, n, k):
     want = np.linalg.solve(dense, b)
     assert iters < 400 and rel(sigma, want) <= 1e-6, (iters, res, rel(sigma, want))
     op.close()
+
+
+@pytest.mark.parametrize("n,k", [(2048, 20.0), (4096, 64.0)])
+def test_helm2_bie_acceptance_check_on_the_device(n, k):
+    """examples/simple/helm2_bie.c end to end, on the GPU: S' butterfly + 6th-order Kapur-Rokhlin
+    correction + trapezoid weights + I/2 (:91-121) built by bfhipBuildHelm2, GMRES on the device
+    (:170-176), then the example's own acceptance check (:180-214): the single-layer potential of
+    the solution reproduces the field of the interior point source at exterior targets."""
+    from butterfly_amd import helm2_structure as hs
+    from butterfly_amd.operator import HipOperator, helm2_dense_apply
+    from oracle import bfref, helm2_build as hb
+    pts = hs.circle_points(n)
+    desc, _, perm = hs.helm2_multilevel_structure(pts, k, recipes=True)
+    tp, nrm, w = pts[perm], pts[perm].copy(), np.full(n, 2 * np.pi / n)
+    deco = dict(layer_pot="Sp", normals=nrm, col_weights=w, self_value=0.5, kr_order=6, orig_index=perm)
+    op, st = HipOperator.build_helm2(desc, tp, k, **deco)
+    # the assembled matrix of helm2_bie.c:91-104, in quadtree order
+    dense = 0.5 * np.eye(n) + hb.kernel_matrix_sp(k, tp, tp, nrm) * hb.kr_factors(6, perm, perm, n) * w[None, :]
+    x = hb.complex_randn(n, 0)
+    assert rel(op.apply_host(x), dense @ x) <= 1e-9
+    assert rel(helm2_dense_apply(tp, k, x, **deco), dense @ x) <= 1e-13
+    vals = hb.leaf_values(desc, k, tp, **deco)
+    assert rel(op.apply_host(x), bfref.mat_mul(bfref.from_desc(desc, vals), x)) <= 1e-10
+    src = np.array([[0.1, 0.2]])
+    tgt = hb.sample_circle(0.0, 0.0, 2.0, 32)
+    phi_in = hb.kernel_matrix_sp(k, src, tp, nrm)[:, 0]                     # helm2_bie.c:76
+    sigma, iters, res = op.solve_gmres(phi_in, tol=1e-10, max_num_iter=256)  # :44-47
+    assert iters < 256
+    assert rel(sigma, np.linalg.solve(dense, phi_in)) <= 1e-6
+    phi = (hb.kernel_matrix(k, tp, tgt) * w[None, :]) @ sigma               # :182-190
+    phi_exact = hb.kernel_matrix(k, src, tgt)[:, 0]
+    err = rel(phi, phi_exact)
+    # without the KR correction the punctured trapezoid rule is only 2nd-order accurate here
+    plain = 0.5 * np.eye(n) + hb.kernel_matrix_sp(k, tp, tp, nrm) * w[None, :]
+    err_plain = rel((hb.kernel_matrix(k, tp, tgt) * w[None, :]) @ np.linalg.solve(plain, phi_in), phi_exact)
+    assert err <= 1e-7 and err < 1e-2 * err_plain, (err, err_plain)
+    op.close()

@@ -2,8 +2,10 @@
 """The reference's BIE driver (examples/simple/helm2_bie.c:93-171) with every heavy step on the GPU:
 S' factorization values (bfhipBuildHelm2, PV_NORMAL_DERIV_SINGLE), trapezoid column weights and
 the I/2 term folded into the values, unrestarted GMRES with the Krylov basis in HBM
-(bfhipSolveGMRESDevice), and the residual of the solution against the DENSE system evaluated
-matrix-free (bfhipHelm2DenseApply).  No KR quadrature correction (helm2_bie.c:100-107).
+(bfhipSolveGMRESDevice), the residual of the solution against the DENSE system evaluated
+matrix-free (bfhipHelm2DenseApply), and the example's acceptance check (helm2_bie.c:180-214): the
+single-layer potential of the solution against the field of the interior point source at exterior
+targets.  6th-order Kapur-Rokhlin correction folded into the values (helm2_bie.c:14,113).
 Prints one JSON line.   usage: tools/helm2_bie_device.py [--npoints N] [--wavenumber K]"""
 import argparse
 import json
@@ -33,13 +35,17 @@ def main():
     desc, _, perm = hs.helm2_multilevel_structure(pts, k, recipes=True)
     tp = pts[perm]
     t_struct = time.time() - t0
-    deco = dict(layer_pot="Sp", normals=tp.copy(), col_weights=np.full(n, 2 * np.pi / n), self_value=0.5)
+    w = np.full(n, 2 * np.pi / n)
+    deco = dict(layer_pot="Sp", normals=tp.copy(), col_weights=w, self_value=0.5, kr_order=6, orig_index=perm)
     t0 = time.time()
     op, st = HipOperator.build_helm2(desc, tp, k, device=0, **deco)
     torch.cuda.synchronize()
     t_build = time.time() - t0
-    d = np.array([np.cos(0.3), np.sin(0.3)])
-    b = torch.from_numpy(1j * k * (tp @ d) * np.exp(1j * k * (tp @ d))).cuda()      # d/dn of a plane wave on the unit circle
+    from scipy.special import hankel1
+    src = np.array([0.1, 0.2])                                                       # interior point source
+    dxy = tp - src[None, :]
+    r = np.hypot(dxy[:, 0], dxy[:, 1])
+    b = torch.from_numpy(0.25j * k * hankel1(1, k * r) / r * np.sum(tp * dxy, axis=1)).cuda()   # S' kernel, helm2_bie.c:76
     t0 = time.time()
     sigma, iters, res = op.solve_gmres_device(b, tol=args.tol, max_num_iter=args.max_iter)
     torch.cuda.synchronize()
@@ -48,12 +54,18 @@ def main():
     r = helm2_dense_apply(tp, k, sigma, **deco) - b
     torch.cuda.synchronize()
     t_dense = time.time() - t0
+    th = 2 * np.pi * np.arange(64) / 64
+    tgt = 2.0 * np.stack([np.cos(th), np.sin(th)], axis=1)                           # exterior targets
+    ws = w * sigma.cpu().numpy()
+    phi = np.array([np.sum(0.25j * hankel1(0, k * np.hypot(tp[:, 0] - t[0], tp[:, 1] - t[1])) * ws) for t in tgt])
+    phi_exact = 0.25j * hankel1(0, k * np.hypot(tgt[:, 0] - src[0], tgt[:, 1] - src[1]))
     print(json.dumps({
-        "workload": f"second-kind BIE (I/2 + S' w) sigma = dn u_inc, unit circle, N={n}, k={k:g}, butterfly built/applied/solved on one MI355X",
+        "workload": f"exterior Neumann BIE (I/2 + S' KR6 w) sigma = dn G(. - x0), unit circle, N={n}, k={k:g}, butterfly built/applied/solved on one MI355X",
         "leaf_bytes": op.stats()["leafBytes"], "structure_seconds": t_struct, "build_seconds": t_build, "build_stats": st,
         "gmres_iterations": iters, "gmres_reported_residual": res, "gmres_seconds": t_solve,
         "gmres_ms_per_iteration": t_solve / max(iters, 1) * 1e3,
-        "dense_residual_rel_l2": float((torch.linalg.norm(r) / torch.linalg.norm(b)).item()), "dense_apply_seconds": t_dense}))
+        "dense_residual_rel_l2": float((torch.linalg.norm(r) / torch.linalg.norm(b)).item()), "dense_apply_seconds": t_dense,
+        "exterior_field_rel_l2_error": float(np.linalg.norm(phi - phi_exact) / np.linalg.norm(phi_exact))}))
 
 
 if __name__ == "__main__":
