@@ -67,7 +67,7 @@ PIECE_DTYPE = np.dtype([("dataOff", "<u8"), ("inOff", "<u4"), ("ncols", "<u4"), 
 # ---- include/bfhip_build.h -----------------------------------------------------
 PTS_TREE, PTS_CIRCLE = 0, 1
 LEAF_KERNEL, LEAF_REEXP = 0, 1
-LAYER_POTENTIALS = {"S": 1, "Sp": 3}      # reference BfLayerPotential values (include/bf/layer_pot.h:27-42)
+LAYER_POTENTIALS = {"S": 1, "D": 2, "Sp": 3, "combined": 5}      # reference BfLayerPotential values (include/bf/layer_pot.h:27-42)
 
 POINT_SET_DTYPE = np.dtype([("kind", "<u4"), ("count", "<u4"), ("first", "<u8"), ("cx", "<f8"), ("cy", "<f8"), ("r", "<f8")])
 RECIPE_DTYPE = np.dtype([("node", "<u8"), ("kind", "<u4"), ("reserved", "<u4"),
@@ -79,7 +79,8 @@ class BfhipHelm2Problem(C.Structure):
                 ("points", C.c_void_p), ("numPoints", C.c_uint64), ("recipes", C.c_void_p),
                 ("numRecipes", C.c_uint64), ("workspaceBytes", C.c_uint64),
                 ("normals", C.c_void_p), ("colWeights", C.c_void_p), ("selfValue", C.c_double * 2),
-                ("origIndex", C.c_void_p), ("krOrder", C.c_uint32), ("reserved", C.c_uint32)]
+                ("origIndex", C.c_void_p), ("krOrder", C.c_uint32), ("reserved", C.c_uint32),
+                ("alpha", C.c_double * 2), ("beta", C.c_double * 2)]
 
 
 class BfhipBuildStats(C.Structure):
@@ -126,7 +127,7 @@ class Helm2Problem:
     """Keeps the arrays a BfhipHelm2Problem points to alive."""
 
     def __init__(self, points, wavenumber, recipes=None, workspace_bytes=0, layer_pot="S", normals=None,
-                 col_weights=None, self_value=0.0, kr_order=0, orig_index=None):
+                 col_weights=None, self_value=0.0, kr_order=0, orig_index=None, alpha=0.0, beta=0.0):
         self.points = np.ascontiguousarray(points, dtype=np.float64)
         assert self.points.ndim == 2 and self.points.shape[1] == 2
         if recipes is None:
@@ -154,6 +155,8 @@ class Helm2Problem:
         assert self.orig_index is None or self.orig_index.shape == (len(self.points),)
         s.origIndex = None if self.orig_index is None else self.orig_index.ctypes.data
         s.krOrder = int(kr_order)
+        al, be = complex(alpha), complex(beta)
+        s.alpha[0], s.alpha[1], s.beta[0], s.beta[1] = al.real, al.imag, be.real, be.imag
 
     def byref(self):
         return C.byref(self.struct)

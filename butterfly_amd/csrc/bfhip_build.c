@@ -48,10 +48,12 @@ static uint32_t leafRows(BfhipHelm2Recipe const *r) { return r->kind == BFHIP_LE
 static int checkProblem(BfhipHelm2Problem const *prob) {
   if (!prob) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "NULL problem");
   if (prob->structSize < sizeof(BfhipHelm2Problem)) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "BfhipHelm2Problem.structSize too small");
-  if (prob->layerPot != BFHIP_LAYER_POTENTIAL_SINGLE && prob->layerPot != BFHIP_LAYER_POTENTIAL_PV_NORMAL_DERIV_SINGLE)
-    return bfhipFail(BFABI_ERROR_NOT_IMPLEMENTED, "layer potential %u is not built on the device (S = 1 and S' = 3 are)", prob->layerPot);
-  if (prob->layerPot == BFHIP_LAYER_POTENTIAL_PV_NORMAL_DERIV_SINGLE && !prob->normals)
-    return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "S' needs the unit normals at the points");
+  if (prob->layerPot != BFHIP_LAYER_POTENTIAL_SINGLE && prob->layerPot != BFHIP_LAYER_POTENTIAL_PV_NORMAL_DERIV_SINGLE &&
+      prob->layerPot != BFHIP_LAYER_POTENTIAL_PV_DOUBLE && prob->layerPot != BFHIP_LAYER_POTENTIAL_COMBINED_FIELD)
+    return bfhipFail(BFABI_ERROR_NOT_IMPLEMENTED, "layer potential %u is not built on the device (S = 1, D = 2, S' = 3, combined = 5 are)",
+                     prob->layerPot);                 /* as bfHelm2GetKernelMatrix, src/helm2.c:296-316 */
+  if (prob->layerPot != BFHIP_LAYER_POTENTIAL_SINGLE && !prob->normals)
+    return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "this layer potential needs the unit normals at the points");
   if (prob->krOrder != 0 && prob->krOrder != 2 && prob->krOrder != 6 && prob->krOrder != 10)
     return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "Kapur-Rokhlin order must be 0, 2, 6 or 10");    /* src/quadrature.c:106 */
   if (prob->krOrder && !prob->origIndex) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "the KR correction needs origIndex");
@@ -78,6 +80,16 @@ static int checkRecipe(BfhipHelm2Problem const *prob, uint64_t i) {
     return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "recipe %llu: an S' kernel leaf needs target normals, i.e. tree-point targets", (unsigned long long)i);
   }
   return 0;
+}
+
+/* potential codes of the device layer: what the operator's own leaves use, and what the two
+ * matrices of a re-expansion use (BF_PROXY_LAYER_POT, include/bf/layer_pot.h:63-69) */
+static uint32_t leafPotCode(uint32_t layerPot) {
+  return layerPot == BFHIP_LAYER_POTENTIAL_PV_NORMAL_DERIV_SINGLE ? 1 : layerPot == BFHIP_LAYER_POTENTIAL_PV_DOUBLE ? 2
+       : layerPot == BFHIP_LAYER_POTENTIAL_COMBINED_FIELD ? 3 : 0;
+}
+static uint32_t proxyPotCode(uint32_t layerPot) {
+  return layerPot == BFHIP_LAYER_POTENTIAL_PV_DOUBLE ? 2 : layerPot == BFHIP_LAYER_POTENTIAL_COMBINED_FIELD ? 3 : 0;
 }
 
 /* device copies of what every kernel evaluation reads */
@@ -109,6 +121,7 @@ static int envUpload(BfhipHelm2Problem const *prob, DevEnv *e) {
   e->env.dKrHits = (unsigned long long *)e->dHits;
   e->env.dPoints = e->dPoints; e->env.dNormals = e->dNormals; e->env.dColWeights = e->dWeights;
   e->env.wavenumber = prob->wavenumber; e->env.selfRe = prob->selfValue[0]; e->env.selfIm = prob->selfValue[1];
+  e->env.alphaRe = prob->alpha[0]; e->env.alphaIm = prob->alpha[1]; e->env.betaRe = prob->beta[0]; e->env.betaIm = prob->beta[1];
   return 0;
 }
 
@@ -158,7 +171,7 @@ static int buildBatch(BfhipHelm2Problem const *prob, uint64_t const *idx, uint64
   char *store = (char *)*dStore, *ws = (char *)dWs;
   uint64_t nm = 0, np = 0;
   prefix[0] = 0;
-  uint32_t const leafPot = prob->layerPot == BFHIP_LAYER_POTENTIAL_PV_NORMAL_DERIV_SINGLE ? 1 : 0;
+  uint32_t const leafPot = leafPotCode(prob->layerPot), proxyPot = proxyPotCode(prob->layerPot);
   for (uint64_t i = 0; i < count; ++i) {
     BfhipHelm2Recipe const *r = &prob->recipes[idx[i]];
     if (r->kind == BFHIP_LEAF_KERNEL) {
@@ -173,13 +186,13 @@ static int buildBatch(BfhipHelm2Problem const *prob, uint64_t const *idx, uint64
     ReexpWs const w = reexpWs(r);
     char *base = ws + wsOff[i] * 16;
     uint32_t const mt = r->tgt.count, me = r->equiv.count, n = r->src.count;
-    /* re-expansions use the proxy potential S; the column weights of the operator scale Z_orig */
+    /* re-expansions use the proxy potential; the column weights of the operator scale Z_orig */
     mats[nm].src = toPts(&r->equiv); mats[nm].tgt = toPts(&r->tgt); mats[nm].dst = base + w.zeq * 16;
-    mats[nm].pot = 0; mats[nm].decorate = 0;
+    mats[nm].pot = proxyPot; mats[nm].decorate = 0;
     prefix[nm + 1] = prefix[nm] + ((uint64_t)mt * me + BF_EVAL_TILE - 1) / BF_EVAL_TILE;
     ++nm;
     mats[nm].src = toPts(&r->src); mats[nm].tgt = toPts(&r->tgt); mats[nm].dst = base + w.zor * 16;
-    mats[nm].pot = 0; mats[nm].decorate = 1;
+    mats[nm].pot = proxyPot; mats[nm].decorate = 1;
     prefix[nm + 1] = prefix[nm] + ((uint64_t)mt * n + BF_EVAL_TILE - 1) / BF_EVAL_TILE;
     ++nm;
     probs[np].a = base + w.zeq * 16; probs[np].v = base + w.v * 16; probs[np].scale = (double *)(base + w.scale * 16);
@@ -410,7 +423,7 @@ int bfhipHelm2DenseApplyDevice(BfhipHelm2Problem const *prob, int device, void c
   if ((rc = bfdevSetDevice(device))) return rc;
   DevEnv dev;
   rc = envUpload(prob, &dev);
-  if (!rc) rc = bfdevHelm2Dense(&dev.env, prob->layerPot == BFHIP_LAYER_POTENTIAL_PV_NORMAL_DERIV_SINGLE ? 1 : 0, prob->numPoints, dX, dY, stream);
+  if (!rc) rc = bfdevHelm2Dense(&dev.env, leafPotCode(prob->layerPot), prob->numPoints, dX, dY, stream);
   envFree(&dev);
   if (prev >= 0) bfdevSetDevice(prev);
   return rc;

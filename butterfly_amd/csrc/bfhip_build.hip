@@ -55,9 +55,11 @@ __device__ __forceinline__ void bfPoint(BfBuildPts const &ps, uint32_t i, double
   }
 }
 
-// S : (i/4) H0^(1)(k r)                       = (-Y0 + i J0)(kr) / 4          src/helm2.c:111-117
-// S': (i/4) k H1^(1)(k r)/r  n_tgt.(x_tgt-x_src) = (-Y1 + i J1)(kr) k dot / (4 r)  src/helm2.c:155-163
-// both 0 at r == 0
+// S : (i/4) H0^(1)(k r)                           = (-Y0 + i J0)(kr) / 4            src/helm2.c:111-117
+// S': (i/4) k H1^(1)(k r)/r  n_tgt.(x_tgt - x_src)  = (-Y1 + i J1)(kr) k dot / (4 r)  src/helm2.c:155-163
+// D : the same with the SOURCE normal                                                src/helm2.c:200-208
+// combined field: alpha S + beta D                                                   src/helm2.c:253-266
+// all 0 at r == 0.  (dx, dy) = x_tgt - x_src; (nx, ny) = the normal the potential uses.
 __device__ __forceinline__ double2 bfHelm2G(double k, double dx, double dy) {
   double const r = hypot(dx, dy);
   if (r == 0.0) return make_double2(0.0, 0.0);
@@ -85,6 +87,7 @@ struct EvalEnvDev {
   double const *pts, *normals, *colWeights;
   uint64_t const *orig;
   double k, selfRe, selfIm;
+  double2 alpha, beta;
   uint64_t n;
   uint32_t krOrder, krBase;          // krBase: offset of the order's table in bfKrWeights
   unsigned long long *krHits;
@@ -98,6 +101,34 @@ __device__ __forceinline__ double bfKrFactor(EvalEnvDev const &E, uint64_t a, ui
   return hit ? 1.0 + bfKrWeights[E.krBase + d - 1] : 1.0;
 }
 
+// kernel value for potential `pot`: (sx, sy) source normal, (tx, ty) target normal (used as needed)
+__device__ __forceinline__ double2 bfKernelValue(EvalEnvDev const &E, uint32_t pot, double dx, double dy, double snx, double sny,
+                                                  double tnx, double tny) {
+  switch (pot) {
+    case 1: return bfHelm2Sp(E.k, dx, dy, tnx, tny);
+    case 2: return bfHelm2Sp(E.k, dx, dy, snx, sny);
+    case 3: {
+      double2 const S = bfHelm2G(E.k, dx, dy), D = bfHelm2Sp(E.k, dx, dy, snx, sny);
+      return make_double2(E.alpha.x * S.x - E.alpha.y * S.y + E.beta.x * D.x - E.beta.y * D.y,
+                          E.alpha.x * S.y + E.alpha.y * S.x + E.beta.x * D.y + E.beta.y * D.x);
+    }
+    default: return bfHelm2G(E.k, dx, dy);
+  }
+}
+
+// unit normal at point i of a point set: stored normals for tree points, the radial direction for a
+// sampled circle (bfCircle2SampleUnitNormals, src/circle.c:36-58)
+__device__ __forceinline__ void bfNormal(EvalEnvDev const &E, BfBuildPts const &ps, uint32_t i, double &nx, double &ny) {
+  if (ps.kind == BFHIP_PTS_TREE) {
+    nx = E.normals[2 * (ps.first + i)];
+    ny = E.normals[2 * (ps.first + i) + 1];
+  } else {
+    double const theta = (6.283185307179586 / (double)ps.count) * (double)i;
+    nx = cos(theta);
+    ny = sin(theta);
+  }
+}
+
 // one entry of a kernel matrix: target i of `tgt`, source j of `src`
 __device__ __forceinline__ double2 bfKernelEntry(EvalEnvDev const &E, BfBuildPts const &src, BfBuildPts const &tgt, uint32_t i, uint32_t j,
                                                   uint32_t pot, uint32_t decorate) {
@@ -106,13 +137,10 @@ __device__ __forceinline__ double2 bfKernelEntry(EvalEnvDev const &E, BfBuildPts
   bfPoint(src, j, E.pts, sx, sy);
   bool const bothTree = src.kind == BFHIP_PTS_TREE && tgt.kind == BFHIP_PTS_TREE;
   if (decorate && bothTree && tgt.first + i == src.first + j) return make_double2(E.selfRe, E.selfIm);
-  double2 g;
-  if (pot == 1) {
-    uint64_t const ti = tgt.first + i;               // S' leaves have tree targets (checked on the host)
-    g = bfHelm2Sp(E.k, tx - sx, ty - sy, E.normals[2 * ti], E.normals[2 * ti + 1]);
-  } else {
-    g = bfHelm2G(E.k, tx - sx, ty - sy);
-  }
+  double snx = 0, sny = 0, tnx = 0, tny = 0;
+  if (pot == 1) bfNormal(E, tgt, i, tnx, tny);       // S' leaves have tree targets (checked on the host)
+  if (pot >= 2) bfNormal(E, src, j, snx, sny);
+  double2 g = bfKernelValue(E, pot, tx - sx, ty - sy, snx, sny, tnx, tny);
   if (decorate && E.krOrder && bothTree) {
     bool hit;
     double const f = bfKrFactor(E, E.orig[tgt.first + i], E.orig[src.first + j], hit);
@@ -151,6 +179,7 @@ static EvalEnvDev toDev(BfEvalEnv const *env) {
   EvalEnvDev E;
   E.pts = (double const *)env->dPoints; E.normals = (double const *)env->dNormals; E.colWeights = (double const *)env->dColWeights;
   E.k = env->wavenumber; E.selfRe = env->selfRe; E.selfIm = env->selfIm;
+  E.alpha = make_double2(env->alphaRe, env->alphaIm); E.beta = make_double2(env->betaRe, env->betaIm);
   E.orig = (uint64_t const *)env->dOrigIndex; E.n = env->numPoints;
   E.krOrder = env->dOrigIndex ? env->krOrder : 0;
   E.krBase = env->krOrder == 2 ? 0 : env->krOrder == 6 ? 2 : 8;
@@ -600,6 +629,7 @@ __global__ __launch_bounds__(256) void bfHelm2DenseKernel(EvalEnvDev const E, ui
   __shared__ double sx[256], sy[256], sw[256];
   __shared__ double2 xv[256];
   __shared__ uint64_t so[256];
+  __shared__ double snx[256], sny[256];
   uint64_t const i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   uint64_t const j0 = (uint64_t)blockIdx.y * sliceLen;
   uint64_t const j1 = j0 + sliceLen < n ? j0 + sliceLen : n;
@@ -618,6 +648,8 @@ __global__ __launch_bounds__(256) void bfHelm2DenseKernel(EvalEnvDev const E, ui
       sx[threadIdx.x] = E.pts[2 * j]; sy[threadIdx.x] = E.pts[2 * j + 1]; xv[threadIdx.x] = x[j];
       sw[threadIdx.x] = E.colWeights ? E.colWeights[j] : 1.0;
       so[threadIdx.x] = E.krOrder ? E.orig[j] : 0;
+      snx[threadIdx.x] = pot >= 2 ? E.normals[2 * j] : 0.0;
+      sny[threadIdx.x] = pot >= 2 ? E.normals[2 * j + 1] : 0.0;
     }
     __syncthreads();
     uint32_t const cnt = (uint32_t)(j1 - jb < 256 ? j1 - jb : 256);
@@ -626,7 +658,7 @@ __global__ __launch_bounds__(256) void bfHelm2DenseKernel(EvalEnvDev const E, ui
         double2 g;
         if (jb + t == i) g = make_double2(E.selfRe, E.selfIm);
         else {
-          g = pot == 1 ? bfHelm2Sp(E.k, tx - sx[t], ty - sy[t], nx, ny) : bfHelm2G(E.k, tx - sx[t], ty - sy[t]);
+          g = bfKernelValue(E, pot, tx - sx[t], ty - sy[t], snx[t], sny[t], nx, ny);
           bool hit;
           double const f = sw[t] * (E.krOrder ? bfKrFactor(E, oi, so[t], hit) : 1.0);
           g.x *= f; g.y *= f;

@@ -239,7 +239,7 @@ typedef struct BfBuildPts {        /* = BfhipPointSet (include/bfhip_build.h) */
 typedef struct BfEvalMat {
   BfBuildPts src, tgt;
   void *dst;
-  uint32_t pot;          /* 0: S, 1: S' (needs target normals; tree targets) */
+  uint32_t pot;          /* 0: S, 1: S' (target normals; tree targets), 2: D (source normals), 3: alpha S + beta D */
   uint32_t decorate;     /* 1: apply column weights / self value (leaves of the operator, not Z_equiv) */
 } BfEvalMat;
 /* what every kernel evaluation needs besides the two points */
@@ -247,6 +247,7 @@ typedef struct BfEvalEnv {
   void const *dPoints, *dNormals, *dColWeights;   /* device; normals / weights may be NULL */
   void const *dOrigIndex;                         /* device uint64[numPoints] or NULL */
   double wavenumber, selfRe, selfIm;
+  double alphaRe, alphaIm, betaRe, betaIm;
   uint64_t numPoints;
   uint32_t krOrder;                               /* 0, 2, 6, 10 */
   unsigned long long *dKrHits;                    /* device counter of corrected entries (consistency check) or NULL */

@@ -61,7 +61,7 @@ class HipOperator:
 
     @classmethod
     def build_helm2(cls, desc, points, wavenumber, root=None, workspace_bytes=0, layer_pot="S", normals=None,
-                    col_weights=None, self_value=0.0, kr_order=0, orig_index=None, **opts):
+                    col_weights=None, self_value=0.0, kr_order=0, orig_index=None, alpha=0.0, beta=0.0, **opts):
         """bfhipBuildHelm2: lay out `desc` (helm2_structure with recipes=True) and
         compute every leaf on the device from its recipe.  `points` (and
         `normals` for layer_pot="Sp"): [N, 2] in quadtree order.  The operator
@@ -71,7 +71,7 @@ class HipOperator:
         lib = _capi.load()
         da = DescArrays(desc, root=root)
         prob = _capi.Helm2Problem(points, wavenumber, desc.recipe, workspace_bytes, layer_pot, normals, col_weights, self_value,
-                                  kr_order, orig_index)
+                                  kr_order, orig_index, alpha, beta)
         st = _capi.BfhipBuildStats()
         st.structSize = C.sizeof(st)
         h = C.c_void_p()

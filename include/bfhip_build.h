@@ -63,22 +63,28 @@ typedef struct BfhipHelm2Recipe {
 
 /* layer potentials, numbered as the reference's BfLayerPotential (include/bf/layer_pot.h:27-42) */
 enum {
-  BFHIP_LAYER_POTENTIAL_SINGLE = 1,                 /* S : G(x,y) = (i/4) H0(k r)                  src/helm2.c:93-125  */
-  BFHIP_LAYER_POTENTIAL_PV_NORMAL_DERIV_SINGLE = 3  /* S': (i/4) k H1(k r)/r  n_tgt.(x_tgt - x_src)  src/helm2.c:126-171 */
+  BFHIP_LAYER_POTENTIAL_SINGLE = 1,                 /* S : G(x,y) = (i/4) H0(k r)                    src/helm2.c:93-125  */
+  BFHIP_LAYER_POTENTIAL_PV_DOUBLE = 2,              /* D : (i/4) k H1(k r)/r  n_src.(x_tgt - x_src)  src/helm2.c:173-218 */
+  BFHIP_LAYER_POTENTIAL_PV_NORMAL_DERIV_SINGLE = 3, /* S': (i/4) k H1(k r)/r  n_tgt.(x_tgt - x_src)  src/helm2.c:126-171 */
+  BFHIP_LAYER_POTENTIAL_COMBINED_FIELD = 5          /* alpha S + beta D                              src/helm2.c:220-279 */
 };
 
 typedef struct BfhipHelm2Problem {
   uint32_t structSize;       /* = sizeof(BfhipHelm2Problem) */
-  uint32_t layerPot;         /* BFHIP_LAYER_POTENTIAL_*; others: NOT_IMPLEMENTED.  As in the reference, only
-                                KERNEL leaves (evaluation factor, dense near field) use S'; re-expansions use
-                                the proxy potential S (BF_PROXY_LAYER_POT, layer_pot.h:63-69, fac_helm2.c:59,231) */
+  uint32_t layerPot;         /* BFHIP_LAYER_POTENTIAL_*; others: NOT_IMPLEMENTED.  As in the reference, for S' only
+                                KERNEL leaves (evaluation factor, dense near field) use S' and re-expansions use
+                                the proxy potential S; D and the combined field are their own proxy potential
+                                (BF_PROXY_LAYER_POT, layer_pot.h:63-69, fac_helm2.c:59,231).  Source normals of a
+                                circle point set are its radial unit vectors (bfCircle2SampleUnitNormals,
+                                src/circle.c:36-58). */
   double wavenumber;
   const double *points;      /* [2 * numPoints] host, (x, y) pairs in quadtree order */
   uint64_t numPoints;
   const BfhipHelm2Recipe *recipes;
   uint64_t numRecipes;
   uint64_t workspaceBytes;   /* device scratch for one batch of leaves; 0 -> half of the free device memory */
-  const double *normals;     /* [2 * numPoints] unit normals at the points (S': target normals); else may be NULL */
+  const double *normals;     /* [2 * numPoints] unit normals at the points (S': target, D / combined: source
+                                normals); may be NULL for S */
   /* system-matrix decorations folded into the values (reference: bfMatScaleCols + bfMatAddInplace of c I,
    * examples/simple/helm2_bie.c:109-121): the built operator is  selfValue * I + K * diag(colWeights) */
   const double *colWeights;  /* [numPoints] or NULL: columns whose sources are points j are scaled by colWeights[j] */
@@ -92,6 +98,7 @@ typedef struct BfhipHelm2Problem {
   const uint64_t *origIndex; /* [numPoints] or NULL (needed iff krOrder != 0) */
   uint32_t krOrder;
   uint32_t reserved;
+  double alpha[2], beta[2];  /* COMBINED_FIELD: complex coefficients (BfHelm2.alpha, .beta, include/bf/helm2.h:13-14) */
 } BfhipHelm2Problem;
 
 typedef struct BfhipBuildStats {

@@ -67,6 +67,41 @@ def kernel_matrix_sp(k, src, tgt, ntgt):
     return z
 
 
+def kernel_matrix_d(k, src, tgt, nsrc):
+    """get_D_kernel_matrix, src/helm2.c:173-218: (i/4) k H1(k r)/r n_src.(x_tgt - x_src), 0 on r == 0."""
+    dx = tgt[:, None, 0] - src[None, :, 0]
+    dy = tgt[:, None, 1] - src[None, :, 1]
+    r = np.hypot(dx, dy)
+    z = np.zeros(r.shape, dtype=np.complex128)
+    nz = r != 0
+    dot = (nsrc[None, :, 0] * dx + nsrc[None, :, 1] * dy)[nz]
+    kr = k * r[nz]
+    z[nz] = 0.25j * k * (j1(kr) + 1j * y1(kr)) / r[nz] * dot
+    return z
+
+
+def resolve_normals(spec, normals):
+    """Unit normals of a point set: stored ones for tree points, radial for a sampled circle
+    (bfCircle2SampleUnitNormals, src/circle.c:36-58)."""
+    if spec[0] == "node":
+        return normals[spec[1]:spec[2]]
+    theta = (TWO_PI / float(spec[4])) * np.arange(spec[4])
+    return np.stack([np.cos(theta), np.sin(theta)], axis=1)
+
+
+def layer_matrix(layer_pot, k, src_spec, tgt_spec, tree_points, normals, alpha=0.0, beta=0.0):
+    """bfHelm2GetKernelMatrix (src/helm2.c:281-318) for S, D and the combined field alpha S + beta D
+    (get_S_plus_D_kernel_matrix, :220-279)."""
+    src, tgt = resolve_points(src_spec, tree_points), resolve_points(tgt_spec, tree_points)
+    if layer_pot == "S":
+        return kernel_matrix(k, src, tgt)
+    d = kernel_matrix_d(k, src, tgt, resolve_normals(src_spec, normals))
+    if layer_pot == "D":
+        return d
+    assert layer_pot == "combined"
+    return alpha * kernel_matrix(k, src, tgt) + beta * d
+
+
 def lstsq_truncated(lhs, rhs):
     """bfMatDenseComplexDenseComplexLstSq, src/mat_dense_complex.c:1767-1849."""
     m, n = lhs.shape
@@ -109,7 +144,7 @@ def kr_factors(order, orig_tgt, orig_src, n):
 
 
 def leaf_values(desc, k, tree_points, layer_pot="S", normals=None, col_weights=None, self_value=0.0, kr_order=0,
-                orig_index=None):
+                orig_index=None, alpha=0.0, beta=0.0):
     """Evaluate every dense leaf's recipe -> {node: complex128 array}.
 
     layer_pot "Sp": kernel leaves (evaluation factor src/fac_helm2.c:403-509, dense near field
@@ -130,7 +165,7 @@ def leaf_values(desc, k, tree_points, layer_pot="S", normals=None, col_weights=N
                 assert rc[2][0] == "node"
                 z = kernel_matrix_sp(k, src, tgt, normals[rc[2][1]:rc[2][2]])
             else:
-                z = kernel_matrix(k, src, tgt)
+                z = layer_matrix(layer_pot, k, rc[1], rc[2], tree_points, normals, alpha, beta)
             if kr_order and rc[1][0] == "node" and rc[2][0] == "node":
                 z = z * kr_factors(kr_order, orig_index[rc[2][1]:rc[2][2]], orig_index[rc[1][1]:rc[1][2]], len(tree_points))
             z = scaled(z, rc[1])
@@ -139,8 +174,11 @@ def leaf_values(desc, k, tree_points, layer_pot="S", normals=None, col_weights=N
                 same = (np.arange(rc[2][1], rc[2][2])[:, None] == np.arange(rc[1][1], rc[1][2])[None, :])
                 z = np.where(same, self_value, z)
         elif rc[0] == "reexp":
-            src, eq, tgt = (resolve_points(sp, tree_points) for sp in rc[1:])
-            z = lstsq_truncated(kernel_matrix(k, eq, tgt), scaled(kernel_matrix(k, src, tgt), rc[1]))
+            # proxy potential: S for S and S', the potential itself for D and the combined field
+            proxy = "S" if layer_pot in ("S", "Sp") else layer_pot
+            z_eq = layer_matrix(proxy, k, rc[2], rc[3], tree_points, normals, alpha, beta)
+            z_or = layer_matrix(proxy, k, rc[1], rc[3], tree_points, normals, alpha, beta)
+            z = lstsq_truncated(z_eq, scaled(z_or, rc[1]))
         else:
             raise ValueError(rc)
         assert z.shape == (desc.rows[node], desc.cols[node]), (z.shape, desc.rows[node], desc.cols[node], rc[0])

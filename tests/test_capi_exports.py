@@ -82,5 +82,9 @@ def test_builder_structs_match_the_header_and_arguments_are_checked(tmp_path):
     assert lib.bfhipHelm2BuildLeaf(prob.byref(), 0, -1, out.ctypes.data) == 1 and b"normals" in lib.bfhipLastErrorMessage()
     prob = _capi.Helm2Problem(pts, 1.0, {0: ("kernel", ("node", 0, 2), ("circle", 0, 0, 1, 4))}, layer_pot="Sp", normals=pts)
     assert lib.bfhipHelm2BuildLeaf(prob.byref(), 0, -1, out.ctypes.data) == 1                      # S' leaf with circle targets
-    prob = _capi.Helm2Problem(pts, 1.0, {0: ("kernel", ("node", 0, 2), ("node", 0, 2))}, layer_pot=2)         # PV double layer
-    assert lib.bfhipHelm2BuildLeaf(prob.byref(), 0, -1, out.ctypes.data) == 3
+    prob = _capi.Helm2Problem(pts, 1.0, {0: ("kernel", ("node", 0, 2), ("node", 0, 2))}, layer_pot=4)         # PV_NORMAL_DERIV_DOUBLE:
+    assert lib.bfhipHelm2BuildLeaf(prob.byref(), 0, -1, out.ctypes.data) == 3                      # no kernel in the reference either
+    prob = _capi.Helm2Problem(pts, 1.0, {0: ("kernel", ("node", 0, 2), ("node", 0, 2))}, layer_pot="D")       # source normals missing
+    assert lib.bfhipHelm2BuildLeaf(prob.byref(), 0, -1, out.ctypes.data) == 1
+    prob = _capi.Helm2Problem(pts, 1.0, {0: ("kernel", ("node", 0, 2), ("node", 0, 2))}, kr_order=4, orig_index=np.arange(4))
+    assert lib.bfhipHelm2BuildLeaf(prob.byref(), 0, -1, out.ctypes.data) == 1                      # KR order must be 2, 6 or 10

@@ -248,3 +248,31 @@ def test_other_geometries_built_on_the_device_match_the_dense_kernel(shape):
     rows = np.array([0, 17, n // 2, n - 1])
     assert rel(yd[rows], hb.kernel_matrix(k, tp, tp[rows]) @ x) <= 1e-12
     op.close()
+
+
+@pytest.mark.parametrize("pot,coef", [("D", {}), ("combined", dict(alpha=0.5 - 1.0j, beta=2.0 + 0.25j))])
+def test_double_layer_and_combined_field_operators(helm2_cases, pot, coef):
+    """PV double layer and alpha S + beta D (what examples/multiple_scattering factorizes): these are
+    their own proxy potential, so re-expansions carry source normals -- stored ones for points, radial
+    ones for proxy circles (src/fac_helm2.c:93-118, 347-365, 452-464)."""
+    from butterfly_amd.operator import HipOperator, helm2_build_leaf, helm2_dense_apply
+    from oracle import bfref, helm2_build as hb
+    n, k = 4096, 100.0
+    desc, tp, _ = helm2_cases(n, k)
+    nrm = tp.copy()
+    deco = dict(layer_pot=pot, normals=nrm, **coef)
+    # unit level: a proxy-circle -> points evaluation leaf and a near-field leaf
+    for src, tgt in ((("circle", 0.3, -0.2, 0.25, 37), ("node", 100, 164)), (("node", 40, 97), ("node", 60, 140))):
+        got = helm2_build_leaf(tp, k, ("kernel", src, tgt), **deco)
+        want = hb.layer_matrix(pot, k, src, tgt, tp, nrm, coef.get("alpha", 0), coef.get("beta", 0))
+        assert np.max(np.abs(got - want)) <= 5e-13 * max(1.0, np.max(np.abs(want)))
+    op, st = HipOperator.build_helm2(desc, tp, k, **deco)
+    assert st["notConverged"] == 0
+    x = hb.complex_randn(n, 0)
+    y = op.apply_host(x)
+    dense = hb.layer_matrix(pot, k, ("node", 0, n), ("node", 0, n), tp, nrm, coef.get("alpha", 0), coef.get("beta", 0))
+    assert rel(helm2_dense_apply(tp, k, x, **deco), dense @ x) <= 1e-13
+    assert rel(y, dense @ x) <= 1e-8, rel(y, dense @ x)
+    vals = hb.leaf_values(desc, k, tp, **deco)
+    assert rel(y, bfref.mat_mul(bfref.from_desc(desc, vals), x)) <= 1e-9
+    op.close()
