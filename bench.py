@@ -143,6 +143,7 @@ def main():
     ap.add_argument("--emulate-world", type=int, default=0,
                     help="diagnostic: on ONE GPU, time the shard that rank --emulate-rank of an N-rank job would own (no collective)")
     ap.add_argument("--emulate-rank", type=int, default=0)
+    ap.add_argument("--python-layout", action="store_true", help="lay the operand out with butterfly_amd/helm2_structure.py instead of the C layout")
     ap.add_argument("--force-collective", action="store_true",
                     help="rehearsal: initialise RCCL and run the step's collective even with one rank")
     ap.add_argument("--shard", choices=["auto", "rows", "blocks"], default="auto",
@@ -174,7 +175,11 @@ def main():
     n = args.n
     k = args.k if args.k is not None else n / 16.0
     t0 = time.time()
-    desc, qroot, perm = hs.helm2_multilevel_structure(hs.circle_points(n), k)
+    # block layout of the operand: the native layout (bfhip_layout.c) unless the Python restatement is asked for
+    if args.python_layout:
+        desc, _, perm = hs.helm2_multilevel_structure(hs.circle_points(n), k)
+    else:
+        desc, perm = hs.native_multilevel_structure(hs.circle_points(n), k)
     t_struct = time.time() - t0
     real = args.dtype != "c128"
     if real:

@@ -162,6 +162,42 @@ class Helm2Problem:
         return C.byref(self.struct)
 
 
+class Helm2Layout:
+    """bfhipHelm2LayoutCreate: the native (C) counterpart of helm2_structure.helm2_multilevel_structure.
+    Exposes numpy copies of the descriptor arrays (`arrays()`, as Desc.arrays()), the recipes
+    (RECIPE_DTYPE), the quadtree permutation and the tree-ordered points."""
+
+    def __init__(self, points, wavenumber):
+        lib = load()
+        pts = np.ascontiguousarray(points, dtype=np.float64)
+        h = C.c_void_p()
+        check(lib.bfhipHelm2LayoutCreate(pts.ctypes.data, len(pts), float(wavenumber), C.byref(h)))
+        try:
+            d = lib.bfhipHelm2LayoutGetDesc(h).contents
+            n, nch = int(d.numNodes), None
+
+            def arr(ptr, count, dt):
+                return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), (count * np.dtype(dt).itemsize,)).view(dt).copy()
+            begin = arr(d.childBegin, n + 1, np.uint64)
+            nch = int(begin[-1])
+            self._arrays = dict(kind=arr(d.kind, n, np.uint8), rows=arr(d.rows, n, np.uint64), cols=arr(d.cols, n, np.uint64),
+                                childBegin=begin, childNode=arr(d.childNode, nch, np.uint64), childRow0=arr(d.childRow0, nch, np.uint64),
+                                childCol0=arr(d.childCol0, nch, np.uint64), blockKind=arr(d.blockKind, n, np.uint8))
+            self.dtype, self.root, self.num_nodes = int(d.dtype), int(d.root), n
+            rb, re = int(begin[self.root]), int(begin[self.root + 1])
+            self.top_row_block = arr(d.topRowBlock, re - rb, np.uint64).astype(np.int64).tolist()
+            cnt = C.c_uint64(0)
+            rp = lib.bfhipHelm2LayoutGetRecipes(h, C.byref(cnt))
+            self.recipes = arr(rp, int(cnt.value), RECIPE_DTYPE) if cnt.value else np.zeros(0, dtype=RECIPE_DTYPE)
+            self.perm = arr(lib.bfhipHelm2LayoutGetPerm(h), len(pts), np.uint64).astype(np.int64)
+            self.tree_points = arr(lib.bfhipHelm2LayoutGetTreePoints(h), 2 * len(pts), np.float64).reshape(-1, 2)
+        finally:
+            lib.bfhipHelm2LayoutFree(C.byref(h))
+
+    def arrays(self):
+        return self._arrays
+
+
 class DescArrays:
     """Keeps the numpy arrays behind a BfhipDesc alive."""
 
@@ -276,6 +312,21 @@ def load():
     lib.bfhipHelm2DenseApplyDevice.restype = C.c_int
     lib.bfhipHelm2DenseApply.argtypes = [C.POINTER(BfhipHelm2Problem), C.c_int, vp, vp]
     lib.bfhipHelm2DenseApply.restype = C.c_int
+    lib.bfhipHelm2LayoutCreate.argtypes = [vp, C.c_uint64, C.c_double, C.POINTER(vp)]
+    lib.bfhipHelm2LayoutCreate.restype = C.c_int
+    lib.bfhipHelm2LayoutGetDesc.argtypes = [vp]
+    lib.bfhipHelm2LayoutGetDesc.restype = C.POINTER(BfhipDesc)
+    lib.bfhipHelm2LayoutGetRecipes.argtypes = [vp, C.POINTER(C.c_uint64)]
+    lib.bfhipHelm2LayoutGetRecipes.restype = vp
+    lib.bfhipHelm2LayoutGetPerm.argtypes = [vp]
+    lib.bfhipHelm2LayoutGetPerm.restype = vp
+    lib.bfhipHelm2LayoutGetTreePoints.argtypes = [vp]
+    lib.bfhipHelm2LayoutGetTreePoints.restype = vp
+    lib.bfhipHelm2LayoutFree.argtypes = [C.POINTER(vp)]
+    lib.bfhipHelm2LayoutFree.restype = None
+    lib.bfhipFacHelm2MakeMultilevel.argtypes = [vp, vp, vp, C.c_uint64, C.POINTER(BfhipHelm2Problem), C.POINTER(BfhipOptions), C.POINTER(vp),
+                                                vp, C.POINTER(BfhipBuildStats)]
+    lib.bfhipFacHelm2MakeMultilevel.restype = C.c_int
     _lib = lib
     return lib
 

@@ -30,9 +30,14 @@ from . import helm2_structure as hs
 
 def row_block_weights(desc):
     """Leaf elements under each top-level block row."""
+    w = [0] * len(desc.meta["top_rows"])
+    if hasattr(desc, "subtree_leaf_elems"):                      # array-backed (native layout)
+        tot = desc.subtree_leaf_elems()
+        for (c, _, _), rb in zip(desc.children[desc.root], desc.top_row_block):
+            w[rb] += int(tot[c])
+        return w
     kind = np.asarray(desc.kind)
     own = np.asarray(desc.rows, dtype=np.int64) * np.asarray(desc.cols, dtype=np.int64) * (kind == hs.NODE_DENSE)
-    w = [0] * len(desc.meta["top_rows"])
     for (c, _, _), rb in zip(desc.children[desc.root], desc.top_row_block):
         tot, stack = 0, [c]
         while stack:
@@ -57,6 +62,9 @@ def assign_row_blocks(weights, world):
 
 def block_weights(desc):
     """Leaf elements under each top-level (row, col) block, in child order."""
+    if hasattr(desc, "subtree_leaf_elems"):
+        tot = desc.subtree_leaf_elems()
+        return [int(tot[c]) for (c, _, _) in desc.children[desc.root]]
     kind = np.asarray(desc.kind)
     own = np.asarray(desc.rows, dtype=np.int64) * np.asarray(desc.cols, dtype=np.int64) * (kind == hs.NODE_DENSE)
     w = []

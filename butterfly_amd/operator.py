@@ -70,7 +70,9 @@ class HipOperator:
         Returns (operator, build statistics)."""
         lib = _capi.load()
         da = DescArrays(desc, root=root)
-        prob = _capi.Helm2Problem(points, wavenumber, desc.recipe, workspace_bytes, layer_pot, normals, col_weights, self_value,
+        recipes = getattr(desc, "recipe_array", None)
+        prob = _capi.Helm2Problem(points, wavenumber, recipes if recipes is not None else desc.recipe, workspace_bytes, layer_pot, normals,
+                                  col_weights, self_value,
                                   kr_order, orig_index, alpha, beta)
         st = _capi.BfhipBuildStats()
         st.structSize = C.sizeof(st)
@@ -78,6 +80,26 @@ class HipOperator:
         o = _options(**opts)
         check(lib.bfhipBuildHelm2(da.byref(), prob.byref(), C.byref(o), C.byref(h), C.byref(st)))
         return cls(h.value), st.as_dict()
+
+    @classmethod
+    def fac_helm2_make_multilevel(cls, points, wavenumber, normals=None, col_weights=None, layer_pot="S", self_value=0.0,
+                                  kr_order=0, alpha=0.0, beta=0.0, workspace_bytes=0, **opts):
+        """bfhipFacHelm2MakeMultilevel: points (original order) -> device operator in one native
+        call (C layout + device build).  Returns (operator, perm, build statistics); the operator
+        acts on vectors in quadtree order: x_tree = x[perm]."""
+        lib = _capi.load()
+        pts = np.ascontiguousarray(points, dtype=np.float64)
+        nrm = None if normals is None else np.ascontiguousarray(normals, dtype=np.float64)
+        w = None if col_weights is None else np.ascontiguousarray(col_weights, dtype=np.float64)
+        params = _capi.Helm2Problem(pts, wavenumber, None, workspace_bytes, layer_pot, None, None, self_value, kr_order, None, alpha, beta)
+        st = _capi.BfhipBuildStats()
+        st.structSize = C.sizeof(st)
+        perm = np.empty(len(pts), dtype=np.uint64)
+        h = C.c_void_p()
+        o = _options(**opts)
+        check(lib.bfhipFacHelm2MakeMultilevel(pts.ctypes.data, None if nrm is None else nrm.ctypes.data, None if w is None else w.ctypes.data,
+                                              len(pts), params.byref(), C.byref(o), C.byref(h), perm.ctypes.data, C.byref(st)))
+        return cls(h.value), perm.astype(np.int64), st.as_dict()
 
     @classmethod
     def load(cls, path, **opts):

@@ -119,6 +119,29 @@ typedef struct BfhipBuildStats {
 int bfhipBuildHelm2(const BfhipDesc *desc, const BfhipHelm2Problem *prob, const BfhipOptions *opts,
                     BfhipOperator **out, BfhipBuildStats *stats);
 
+/* ---- layout: points -> block structure + recipes (host only) ------------------------------
+ * What bfFacHelm2MakeMultilevel(helm, quadtree, quadtree) would lay out for `points` (quadtree with
+ * leaf size 1, src tree = tgt tree: src/fac_helm2.c:943-1002 and callees, see bfhip_layout.c): the
+ * flat descriptor bfhipCompileDesc / bfhipBuildHelm2 take, one recipe per dense leaf, and the
+ * quadtree permutation.  All returned pointers belong to the layout. */
+typedef struct BfhipHelm2Layout BfhipHelm2Layout;
+int bfhipHelm2LayoutCreate(const double *points, uint64_t numPoints, double wavenumber, BfhipHelm2Layout **out);
+const BfhipDesc *bfhipHelm2LayoutGetDesc(const BfhipHelm2Layout *layout);
+const BfhipHelm2Recipe *bfhipHelm2LayoutGetRecipes(const BfhipHelm2Layout *layout, uint64_t *count);
+const uint64_t *bfhipHelm2LayoutGetPerm(const BfhipHelm2Layout *layout);        /* perm[t] = original index of tree position t */
+const double *bfhipHelm2LayoutGetTreePoints(const BfhipHelm2Layout *layout);    /* [2 * numPoints], tree order */
+void bfhipHelm2LayoutFree(BfhipHelm2Layout **layout);
+
+/* Points -> device operator in one call (layout + bfhipBuildHelm2): the device counterpart of
+ * bfFacHelm2MakeMultilevel followed by the decorations of examples/simple/helm2_bie.c.  `points`,
+ * `normals` (may be NULL for S), `colWeights` (may be NULL) are in the caller's ORIGINAL order;
+ * `params` supplies layerPot, wavenumber, selfValue, krOrder, alpha, beta, workspaceBytes (its
+ * pointer fields are ignored).  The operator acts on vectors in quadtree order, as the
+ * reference's does; permOut[t] (may be NULL) = original index of position t. */
+int bfhipFacHelm2MakeMultilevel(const double *points, const double *normals, const double *colWeights, uint64_t numPoints,
+                                const BfhipHelm2Problem *params, const BfhipOptions *opts, BfhipOperator **out, uint64_t *permOut,
+                                BfhipBuildStats *stats);
+
 /* One leaf, computed on the device and returned to the host row-major
  * (rows x cols complex128) -- unit-level parity checks of the builder. */
 int bfhipHelm2BuildLeaf(const BfhipHelm2Problem *prob, uint64_t recipeIndex, int device, void *out);

@@ -276,3 +276,24 @@ def test_double_layer_and_combined_field_operators(helm2_cases, pot, coef):
     vals = hb.leaf_values(desc, k, tp, **deco)
     assert rel(y, bfref.mat_mul(bfref.from_desc(desc, vals), x)) <= 1e-9
     op.close()
+
+
+def test_points_to_operator_in_one_native_call():
+    """bfhipFacHelm2MakeMultilevel: the C layout + the device build from points, normals and weights
+    in the caller's order -- helm2_bie.c's system matrix without the reference's CPU build."""
+    from butterfly_amd.operator import HipOperator
+    from oracle import helm2_build as hb
+    n, k = 3000, 90.0
+    t = 2 * np.pi * np.arange(n) / n
+    pts = np.stack([np.cos(t), 0.5 * np.sin(t)], axis=1)
+    nrm = np.stack([0.5 * np.cos(t), np.sin(t)], axis=1)
+    nrm /= np.linalg.norm(nrm, axis=1)[:, None]
+    w = (2 * np.pi / n) * np.hypot(np.sin(t), 0.5 * np.cos(t))                    # trapezoid weights: |dx/dt| 2 pi / n
+    op, perm, st = HipOperator.fac_helm2_make_multilevel(pts, k, normals=nrm, col_weights=w, layer_pot="Sp", self_value=0.5, kr_order=6)
+    assert sorted(perm.tolist()) == list(range(n)) and st["notConverged"] == 0
+    idx = np.arange(n)
+    dense = 0.5 * np.eye(n) + hb.kernel_matrix_sp(k, pts, pts, nrm) * hb.kr_factors(6, idx, idx, n) * w[None, :]   # original order
+    x = hb.complex_randn(n, 2)
+    y_tree = op.apply_host(x[perm])
+    assert rel(y_tree, (dense @ x)[perm]) <= 1e-8
+    op.close()

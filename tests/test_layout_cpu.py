@@ -1,0 +1,82 @@
+"""The native layout (bfhip_layout.c, bfhipHelm2LayoutCreate) against the Python restatement of the
+reference's structure logic (butterfly_amd/helm2_structure.py, itself pinned to the survey's probe
+of the real reference in test_structure.py): identical descriptor arrays, recipes and permutation."""
+import numpy as np
+import pytest
+
+from butterfly_amd import _capi
+from butterfly_amd import helm2_structure as hs
+
+
+def shapes():
+    t = lambda n: 2 * np.pi * np.arange(n) / n
+    yield "circle-4096-k100", hs.circle_points(4096), 100.0
+    yield "circle-16384-k1024", hs.circle_points(16384), 1024.0
+    yield "ellipse-6000-k150", np.stack([np.cos(t(6000)), 0.35 * np.sin(t(6000))], axis=1), 150.0
+    yield "kite-5000-k80", np.stack([np.cos(t(5000)) + 0.65 * np.cos(2 * t(5000)) - 0.65, 1.5 * np.sin(t(5000))], axis=1) / 1.5, 80.0
+    h = 2500
+    yield "two-circles-5000-k120", np.concatenate([np.stack([0.5 * np.cos(t(h)) - 0.6, 0.5 * np.sin(t(h))], axis=1),
+                                                   np.stack([0.25 * np.cos(t(h)) + 0.55, 0.25 * np.sin(t(h)) + 0.2], axis=1)]), 120.0
+    rng = np.random.default_rng(3)
+    yield "random-3000-k60", rng.random((3000, 2)), 60.0
+
+
+@pytest.mark.parametrize("name,pts,k", list(shapes()), ids=[s[0] for s in shapes()])
+def test_native_layout_equals_the_python_restatement(name, pts, k):
+    desc, _, perm = hs.helm2_multilevel_structure(pts, k, recipes=True)
+    lay = _capi.Helm2Layout(pts, k)
+    assert np.array_equal(lay.perm, perm)
+    assert np.array_equal(lay.tree_points, pts[perm])
+    want = desc.arrays()
+    got = lay.arrays()
+    assert lay.num_nodes == desc.num_nodes and lay.root == desc.root and lay.dtype == desc.dtype
+    for key in ("kind", "rows", "cols", "childBegin", "childNode", "childRow0", "childCol0", "blockKind"):
+        assert np.array_equal(got[key], want[key]), key
+    assert lay.top_row_block == desc.top_row_block
+    ref = _capi.recipe_array(desc.recipe)
+    assert lay.recipes.shape == ref.shape
+    for f in ("node", "kind"):
+        assert np.array_equal(lay.recipes[f], ref[f]), f
+    for ps in ("src", "equiv", "tgt"):
+        for f in ("kind", "count", "first", "cx", "cy", "r"):
+            assert np.array_equal(lay.recipes[ps][f], ref[ps][f]), (ps, f)
+
+
+def test_layout_argument_errors():
+    lib = _capi.load()
+    import ctypes as C
+    h = C.c_void_p()
+    pts = np.zeros((8, 2))                       # coincident points: refused, not an endless subdivision
+    assert lib.bfhipHelm2LayoutCreate(pts.ctypes.data, 8, 1.0, C.byref(h)) == 1 and not h.value
+    pts = hs.circle_points(64)
+    assert lib.bfhipHelm2LayoutCreate(pts.ctypes.data, 64, 0.0, C.byref(h)) == 1
+    assert lib.bfhipHelm2LayoutCreate(None, 64, 1.0, C.byref(h)) == 1
+    assert lib.bfhipHelm2LayoutCreate(pts.ctypes.data, 1, 1.0, C.byref(h)) == 1
+
+
+def test_array_backed_descriptor_shards_like_the_python_one():
+    """bench.py runs on the native layout: weights, row shards and block shards must be the ones the
+    Python descriptor gives (compared through the planner: identical stage / item / piece counts)."""
+    from butterfly_amd.dist import assign_row_blocks, block_weights, choose_mode, row_block_weights
+    from butterfly_amd.operator import HipOperator
+    pts, k = hs.circle_points(8192), 512.0
+    d_py, _, perm = hs.helm2_multilevel_structure(pts, k)
+    d_c, perm_c = hs.native_multilevel_structure(pts, k)
+    assert np.array_equal(perm, perm_c) and d_c.meta["top_rows"] == d_py.meta["top_rows"]
+    assert d_c.meta["stats"] == d_py.meta["stats"] and d_c.leaf_elems() == d_py.leaf_elems()
+    assert row_block_weights(d_c) == row_block_weights(d_py) and block_weights(d_c) == block_weights(d_py)
+    assert choose_mode(d_c, 8) == choose_mode(d_py, 8)
+    owner, _ = assign_row_blocks(row_block_weights(d_py), 3)
+    mine = [rb for rb, o in enumerate(owner) if o == 1]
+    stats = []
+    for d in (d_py, d_c):
+        root, nloc = hs.shard_desc(d, mine)
+        broot = hs.shard_desc_blocks(d, [3, 17, 40, 41])
+        row = []
+        for r in (None, root, broot):
+            op = HipOperator.from_desc(d, None, root=r, flags=_capi.FLAG_PLAN_ONLY)
+            st = op.stats()
+            row.append((nloc, st["numRows"], st["numCols"], st["numStages"], st["numItems"], st["numPieces"], st["leafElems"], st["tempElems"]))
+            op.close()
+        stats.append(row)
+    assert stats[0] == stats[1]

@@ -30,10 +30,10 @@ def main():
     k = args.wavenumber if args.wavenumber is not None else n / 16.0
     t0 = time.time()
     pts = hs.circle_points(n)
-    desc, _, perm = hs.helm2_multilevel_structure(pts, k, recipes=True)
+    desc, perm = hs.native_multilevel_structure(pts, k)
     tp = pts[perm]
     t_struct = time.time() - t0
-    print(f"structure: N={n} k={k:g} leaves={len(desc.recipe)} [{t_struct:.1f}s]", file=sys.stderr, flush=True)
+    print(f"structure: N={n} k={k:g} leaves={len(desc.recipe_array)} [{t_struct:.1f}s]", file=sys.stderr, flush=True)
     t0 = time.time()
     op, st = HipOperator.build_helm2(desc, tp, k, device=0, flags=_capi.FLAG_PROFILE, workspace_bytes=int(args.workspace_gb * 2**30))
     torch.cuda.synchronize()

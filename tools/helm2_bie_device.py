@@ -32,7 +32,7 @@ def main():
     k = args.wavenumber if args.wavenumber is not None else n / 16.0
     t0 = time.time()
     pts = hs.circle_points(n)
-    desc, _, perm = hs.helm2_multilevel_structure(pts, k, recipes=True)
+    desc, perm = hs.native_multilevel_structure(pts, k)
     tp = pts[perm]
     t_struct = time.time() - t0
     w = np.full(n, 2 * np.pi / n)
