@@ -322,6 +322,9 @@ __device__ __forceinline__ void bfMfmaPass(StageParams const &p, BfDevItem const
 
 #define BF_MFMA_PASS bfMfmaPass
 #define BF_MFMA_WAVES_PER_SIMD 2
+#ifndef BF_MFMA_MIN_RHS
+#define BF_MFMA_MIN_RHS 3
+#endif
 
 template <int MS>
 __device__ __forceinline__ void bfMfmaDispatch(uint32_t nt, StageParams const &p, BfDevItem const &it, uint32_t mr,
@@ -806,7 +809,7 @@ int bfdevLaunchStage(BfLaunchArgs const *a, void *stream) {
     else return bfhipFail(BFABI_ERROR_TYPE_ERROR, "unknown dtype %u", a->dtype);
     return hipFail(hipGetLastError(), "transposed stage launch");
   }
-  if (a->dtype == BFHIP_C128 && a->nrhs >= 3) hipLaunchKernelGGL(bfStageKernelC128Mfma, dim3(grid), dim3(BF_WAVES_PER_WG * 64), 0, s, p);
+  if (a->dtype == BFHIP_C128 && a->nrhs >= BF_MFMA_MIN_RHS) hipLaunchKernelGGL(bfStageKernelC128Mfma, dim3(grid), dim3(BF_WAVES_PER_WG * 64), 0, s, p);
   else if (a->dtype == BFHIP_C128) hipLaunchKernelGGL(bfStageKernelC128, dim3(grid), dim3(BF_WAVES_PER_WG * 64), 0, s, p);
   else if (a->dtype == BFHIP_F64) hipLaunchKernelGGL(bfStageKernelReal<BFHIP_F64>, dim3(grid), dim3(BF_WAVES_PER_WG * 64), 0, s, p);
   else if (a->dtype == BFHIP_F32) hipLaunchKernelGGL(bfStageKernelReal<BFHIP_F32>, dim3(grid), dim3(BF_WAVES_PER_WG * 64), 0, s, p);
