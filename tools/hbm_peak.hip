@@ -1,0 +1,51 @@
+// Achievable HBM bandwidth of this GPU for the access pattern of the stage kernels: every wave
+// streams its own contiguous chunk with 16-byte non-temporal loads, 8 in flight per lane
+// ("confirm the box's achievable BW ... and report both").  Also a plain
+// hipMemcpyDtoD for the copy figure.
+//   hipcc -O3 --offload-arch=gfx950 tools/hbm_peak.hip -o /tmp/hbm_peak && /tmp/hbm_peak
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+
+template <bool NT>
+__global__ __launch_bounds__(256) void readStream(u4 const *src, uint64_t unitsPerWave, unsigned *sink) {
+  uint64_t const wave = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  u4 const *p = src + wave * unitsPerWave + (threadIdx.x & 63);
+  unsigned acc = 0;
+  for (uint64_t i = 0; i < unitsPerWave; i += 64 * 8) {
+    u4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = NT ? __builtin_nontemporal_load(p + i + 64 * u) : p[i + 64 * u];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc ^= v[u].x ^ v[u].y ^ v[u].z ^ v[u].w;
+  }
+  if (acc == 0x12345678u) *sink = acc;      // never true for zeroed memory: keeps the loads alive
+}
+
+int main() {
+  uint64_t const bytes = 64ull << 30, waves = 256ull * 8 * 4 * 16;      // 128 KiB... chunks sized below
+  uint64_t const unitsPerWave = bytes / 16 / waves / 512 * 512;
+  void *a, *b; unsigned *sink;
+  if (hipMalloc(&a, bytes) != hipSuccess || hipMalloc(&b, bytes) != hipSuccess) { printf("alloc failed\n"); return 1; }
+  hipMalloc((void **)&sink, 4);
+  hipMemset(a, 0, bytes); hipMemset(b, 0, bytes);
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  float ms;
+  double res[3];
+  for (int mode = 0; mode < 3; ++mode) {
+    for (int rep = 0; rep < 2; ++rep) {
+      hipEventRecord(e0);
+      if (mode == 0) readStream<true><<<(unsigned)(waves / 4), 256>>>((u4 const *)a, unitsPerWave, sink);
+      else if (mode == 1) readStream<false><<<(unsigned)(waves / 4), 256>>>((u4 const *)a, unitsPerWave, sink);
+      else hipMemcpyAsync(b, a, bytes, hipMemcpyDeviceToDevice, 0);
+      hipEventRecord(e1); hipEventSynchronize(e1);
+      hipEventElapsedTime(&ms, e0, e1);
+    }
+    double const moved = mode == 2 ? 2.0 * bytes : (double)unitsPerWave * 16 * waves;
+    res[mode] = moved / ms / 1e6;
+  }
+  printf("{\"read_nt_gbs\": %.1f, \"read_plain_gbs\": %.1f, \"memcpy_d2d_read_plus_write_gbs\": %.1f, \"bytes\": %llu}\n", res[0], res[1], res[2],
+         (unsigned long long)bytes);
+  return 0;
+}
