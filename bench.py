@@ -292,6 +292,14 @@ def main():
                 roofline["traffic_source"] = f"profiles/r1_pmc_summary.json [{key}]: HBM bytes per launch of this command under rocprofv3 --pmc"
             except Exception:
                 pass
+        # context for `frac` (informational; `peak` stays the guide's figure): what a pure stream of
+        # non-temporal reads / a bare loop of these MFMAs reaches on an MI355X of this pool
+        for key, fn, fld in (("measured_stream_read_gbs", "r1_hbm_peak.json", "read_nt_gbs"), ("measured_mfma_loop_tflops", "r1_mfma_peak.json", "fp64_mfma_16x16x4_tflops")):
+            if (roofline["bound"] == "hbm") == (fld == "read_nt_gbs"):
+                try:
+                    roofline[key] = json.load(open(os.path.join(ROOT, "profiles", fn)))[fld]
+                except Exception:
+                    pass
         if args.pcie:
             # host-buffer path (bfhipApply): H2D of x, all stages, D2H of y -- never the headline value
             t1 = time.perf_counter()
