@@ -297,3 +297,38 @@ def test_points_to_operator_in_one_native_call():
     y_tree = op.apply_host(x[perm])
     assert rel(y_tree, (dense @ x)[perm]) <= 1e-8
     op.close()
+
+
+@pytest.mark.parametrize("n,k", [(16384, 1024.0), (65536, 4096.0), (65536, 100.0)])
+def test_reference_checksums_at_the_survey_sizes(n, k):
+    """||A_BF x||^2 for x = bfMatDenseComplexNewRandn after bfSeed(0), recorded by the survey from the
+    REAL reference (tests/golden/survey_probe_stats.json).  The CPU test pins
+    N = 4096; with the values computed on the device the larger cases are affordable: layout with the
+    reference's own sift order, device build, device apply, restated PRNG.  The operand differs from
+    the reference's only by the SVD implementation behind the least squares, so the agreement is at
+    the butterfly's own accuracy, not to the last digit."""
+    import json
+    import os
+    import torch
+    from butterfly_amd import helm2_structure as hs
+    from butterfly_amd.operator import HipOperator, helm2_dense_apply
+    from oracle import helm2_build as hb
+    gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "survey_probe_stats.json")))
+    want = [c for c in gold["cases"] if (c["n"], float(c["k"])) == (n, k)][0]["y_norm2"]
+    pts = hs.circle_points(n)
+    desc, _, perm = hs.helm2_multilevel_structure(pts, k, recipes=True, exact_sift=True)
+    tp = pts[perm]
+    op, st = HipOperator.build_helm2(desc, tp, k)
+    assert st["notConverged"] == 0
+    x = torch.from_numpy(hb.complex_randn(n, 0)).cuda()
+    y = op.apply_device(x)
+    got = float(torch.sum(torch.abs(y) ** 2).item())
+    yd = helm2_dense_apply(tp, k, x)
+    got_dense = float(torch.sum(torch.abs(yd) ** 2).item())
+    err = float((torch.linalg.norm(y - yd) / torch.linalg.norm(yd)).item())
+    assert err <= 2e-8, err                                  # 6e-12 at k = 4096, 9e-9 at k = 100
+    assert abs(got_dense - want) / want <= 1e-8, (got_dense, want)
+    # measured 8e-14, 7e-14, 9e-16: the device-built butterfly reproduces the reference's butterfly, its
+    # truncation error included (at k = 100 the dense checksum is 1e-9 away, the butterfly's 9e-16)
+    assert abs(got - want) / want <= 1e-12, (got, want)
+    op.close()
