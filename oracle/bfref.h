@@ -7,15 +7,18 @@
  * allocate-view / multiply / accumulate sequence).  Each function cites the
  * reference file:line it follows.
  *
- * PARITY STATUS: "parity unpinned" by reference goldens -- the reference's
- * tests hold no fixture for this path and the reference
- * itself cannot be built in this image without stand-in BLAS/LAPACKE headers
- * (include/bf/blas.h:3-9 needs <openblas/cblas.h>, <lapacke.h>; absent).  The
- * restatement is instead pinned by analytic known answers (dense Helmholtz
- * kernel matvecs, the reference examples' own acceptance check
- * examples/simple/bf_all_blocks.c:149-153) and by the ||y||^2 checksums the
- * survey recorded from the real reference; see
- * tests/test_oracle_golden.py.
+ * PARITY STATUS: the reference's tests hold no fixture for this path (SURVEY.md
+ * section 4) and the reference itself cannot be built in this image without
+ * stand-in BLAS/LAPACKE headers (include/bf/blas.h:3-9 needs <openblas/cblas.h>,
+ * <lapacke.h>; absent), so there is no oracle/_ref: "parity unpinned" by
+ * reference test fixtures.  The restatement is pinned instead by outputs of the
+ * REAL reference that the survey recorded: the
+ * ||A_BF x||^2 checksums of four configurations (N = 4096 ... 65536), reproduced
+ * to 13-15 digits (tests/test_oracle_golden.py on the CPU for N = 4096,
+ * tests/test_gpu_build.py for all four), the exact block-layout statistics of
+ * two configurations (tests/test_structure.py), and analytic known answers
+ * (dense Helmholtz kernel matvecs, the reference examples' own acceptance check
+ * examples/simple/bf_all_blocks.c:149-153).
  *
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
  * use this library.  The shipped engine (libbfhip.so) never links or loads it.
