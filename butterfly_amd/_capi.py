@@ -65,7 +65,7 @@ PIECE_DTYPE = np.dtype([("dataOff", "<u8"), ("inOff", "<u4"), ("ncols", "<u4"), 
 
 
 # ---- include/bfhip_build.h -----------------------------------------------------
-PTS_TREE, PTS_CIRCLE = 0, 1
+PTS_TREE, PTS_CIRCLE, PTS_TREE_TGT = 0, 1, 2
 LEAF_KERNEL, LEAF_REEXP = 0, 1
 LAYER_POTENTIALS = {"S": 1, "D": 2, "Sp": 3, "combined": 5}      # reference BfLayerPotential values (include/bf/layer_pot.h:27-42)
 
@@ -80,7 +80,8 @@ class BfhipHelm2Problem(C.Structure):
                 ("numRecipes", C.c_uint64), ("workspaceBytes", C.c_uint64),
                 ("normals", C.c_void_p), ("colWeights", C.c_void_p), ("selfValue", C.c_double * 2),
                 ("origIndex", C.c_void_p), ("krOrder", C.c_uint32), ("reserved", C.c_uint32),
-                ("alpha", C.c_double * 2), ("beta", C.c_double * 2)]
+                ("alpha", C.c_double * 2), ("beta", C.c_double * 2),
+                ("tgtPoints", C.c_void_p), ("numTgtPoints", C.c_uint64), ("tgtNormals", C.c_void_p)]
 
 
 class BfhipBuildStats(C.Structure):
@@ -93,8 +94,8 @@ class BfhipBuildStats(C.Structure):
 
 
 def _pts(rec, spec):
-    if spec[0] == "node":
-        rec["kind"], rec["first"], rec["count"] = PTS_TREE, spec[1], spec[2] - spec[1]
+    if spec[0] in ("node", "tnode"):
+        rec["kind"], rec["first"], rec["count"] = (PTS_TREE if spec[0] == "node" else PTS_TREE_TGT), spec[1], spec[2] - spec[1]
     elif spec[0] == "circle":
         rec["kind"], rec["cx"], rec["cy"], rec["r"], rec["count"] = PTS_CIRCLE, spec[1], spec[2], spec[3], spec[4]
     else:
@@ -127,7 +128,7 @@ class Helm2Problem:
     """Keeps the arrays a BfhipHelm2Problem points to alive."""
 
     def __init__(self, points, wavenumber, recipes=None, workspace_bytes=0, layer_pot="S", normals=None,
-                 col_weights=None, self_value=0.0, kr_order=0, orig_index=None, alpha=0.0, beta=0.0):
+                 col_weights=None, self_value=0.0, kr_order=0, orig_index=None, alpha=0.0, beta=0.0, tgt_points=None, tgt_normals=None):
         self.points = np.ascontiguousarray(points, dtype=np.float64)
         assert self.points.ndim == 2 and self.points.shape[1] == 2
         if recipes is None:
@@ -157,6 +158,11 @@ class Helm2Problem:
         s.krOrder = int(kr_order)
         al, be = complex(alpha), complex(beta)
         s.alpha[0], s.alpha[1], s.beta[0], s.beta[1] = al.real, al.imag, be.real, be.imag
+        self.tgt_points = None if tgt_points is None else np.ascontiguousarray(tgt_points, dtype=np.float64)
+        self.tgt_normals = None if tgt_normals is None else np.ascontiguousarray(tgt_normals, dtype=np.float64)
+        s.tgtPoints = None if self.tgt_points is None else self.tgt_points.ctypes.data
+        s.numTgtPoints = 0 if self.tgt_points is None else len(self.tgt_points)
+        s.tgtNormals = None if self.tgt_normals is None else self.tgt_normals.ctypes.data
 
     def byref(self):
         return C.byref(self.struct)
@@ -167,11 +173,13 @@ class Helm2Layout:
     Exposes numpy copies of the descriptor arrays (`arrays()`, as Desc.arrays()), the recipes
     (RECIPE_DTYPE), the quadtree permutation and the tree-ordered points."""
 
-    def __init__(self, points, wavenumber):
+    def __init__(self, points, wavenumber, tgt_points=None):
         lib = load()
         pts = np.ascontiguousarray(points, dtype=np.float64)
+        tpts = None if tgt_points is None else np.ascontiguousarray(tgt_points, dtype=np.float64)
         h = C.c_void_p()
-        check(lib.bfhipHelm2LayoutCreate(pts.ctypes.data, len(pts), float(wavenumber), C.byref(h)))
+        check(lib.bfhipHelm2LayoutCreate2(pts.ctypes.data, len(pts), None if tpts is None else tpts.ctypes.data,
+                                          0 if tpts is None else len(tpts), float(wavenumber), C.byref(h)))
         try:
             d = lib.bfhipHelm2LayoutGetDesc(h).contents
             n, nch = int(d.numNodes), None
@@ -191,6 +199,10 @@ class Helm2Layout:
             self.recipes = arr(rp, int(cnt.value), RECIPE_DTYPE) if cnt.value else np.zeros(0, dtype=RECIPE_DTYPE)
             self.perm = arr(lib.bfhipHelm2LayoutGetPerm(h), len(pts), np.uint64).astype(np.int64)
             self.tree_points = arr(lib.bfhipHelm2LayoutGetTreePoints(h), 2 * len(pts), np.float64).reshape(-1, 2)
+            self.tgt_perm = self.tgt_tree_points = None
+            if tpts is not None:
+                self.tgt_perm = arr(lib.bfhipHelm2LayoutGetTgtPerm(h), len(tpts), np.uint64).astype(np.int64)
+                self.tgt_tree_points = arr(lib.bfhipHelm2LayoutGetTgtTreePoints(h), 2 * len(tpts), np.float64).reshape(-1, 2)
         finally:
             lib.bfhipHelm2LayoutFree(C.byref(h))
 
@@ -314,6 +326,12 @@ def load():
     lib.bfhipHelm2DenseApply.restype = C.c_int
     lib.bfhipHelm2LayoutCreate.argtypes = [vp, C.c_uint64, C.c_double, C.POINTER(vp)]
     lib.bfhipHelm2LayoutCreate.restype = C.c_int
+    lib.bfhipHelm2LayoutCreate2.argtypes = [vp, C.c_uint64, vp, C.c_uint64, C.c_double, C.POINTER(vp)]
+    lib.bfhipHelm2LayoutCreate2.restype = C.c_int
+    lib.bfhipHelm2LayoutGetTgtPerm.argtypes = [vp]
+    lib.bfhipHelm2LayoutGetTgtPerm.restype = vp
+    lib.bfhipHelm2LayoutGetTgtTreePoints.argtypes = [vp]
+    lib.bfhipHelm2LayoutGetTgtTreePoints.restype = vp
     lib.bfhipHelm2LayoutGetDesc.argtypes = [vp]
     lib.bfhipHelm2LayoutGetDesc.restype = C.POINTER(BfhipDesc)
     lib.bfhipHelm2LayoutGetRecipes.argtypes = [vp, C.POINTER(C.c_uint64)]
@@ -327,6 +345,9 @@ def load():
     lib.bfhipFacHelm2MakeMultilevel.argtypes = [vp, vp, vp, C.c_uint64, C.POINTER(BfhipHelm2Problem), C.POINTER(BfhipOptions), C.POINTER(vp),
                                                 vp, C.POINTER(BfhipBuildStats)]
     lib.bfhipFacHelm2MakeMultilevel.restype = C.c_int
+    lib.bfhipFacHelm2MakeMultilevel2.argtypes = [vp, vp, vp, C.c_uint64, vp, vp, C.c_uint64, C.POINTER(BfhipHelm2Problem), C.POINTER(BfhipOptions),
+                                                 C.POINTER(vp), vp, vp, C.POINTER(BfhipBuildStats)]
+    lib.bfhipFacHelm2MakeMultilevel2.restype = C.c_int
     _lib = lib
     return lib
 

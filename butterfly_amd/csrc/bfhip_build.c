@@ -31,9 +31,12 @@ static BfBuildPts toPts(BfhipPointSet const *p) {
   return q;
 }
 
-static int checkPts(BfhipPointSet const *p, uint64_t numPoints, char const *what, uint64_t idx) {
+static int checkPts(BfhipPointSet const *p, BfhipHelm2Problem const *prob, char const *what, uint64_t idx) {
   if (p->count == 0) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "recipe %llu: empty %s point set", (unsigned long long)idx, what);
-  if (p->kind == BFHIP_PTS_TREE) {
+  if (p->kind == BFHIP_PTS_TREE || p->kind == BFHIP_PTS_TREE_TGT) {
+    if (p->kind == BFHIP_PTS_TREE_TGT && !prob->tgtPoints)
+      return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "recipe %llu: %s points refer to a target tree but tgtPoints is NULL", (unsigned long long)idx, what);
+    uint64_t const numPoints = p->kind == BFHIP_PTS_TREE ? prob->numPoints : prob->numTgtPoints;
     if (p->first + p->count > numPoints)
       return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "recipe %llu: %s points [%llu, %llu) exceed numPoints", (unsigned long long)idx, what,
                        (unsigned long long)p->first, (unsigned long long)(p->first + p->count));
@@ -57,6 +60,8 @@ static int checkProblem(BfhipHelm2Problem const *prob) {
   if (prob->krOrder != 0 && prob->krOrder != 2 && prob->krOrder != 6 && prob->krOrder != 10)
     return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "Kapur-Rokhlin order must be 0, 2, 6 or 10");    /* src/quadrature.c:106 */
   if (prob->krOrder && !prob->origIndex) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "the KR correction needs origIndex");
+  if (prob->tgtPoints && (prob->krOrder || prob->selfValue[0] != 0 || prob->selfValue[1] != 0))
+    return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "selfValue / KR correction apply to square operators (no separate target tree)");
   if (prob->krOrder && prob->numPoints < 2 * (uint64_t)prob->krOrder + 1)
     return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "too few points for the KR correction");          /* src/quadrature.c:115 */
   if (!prob->points || (!prob->recipes && prob->numRecipes)) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "NULL points / recipes");
@@ -67,16 +72,17 @@ static int checkProblem(BfhipHelm2Problem const *prob) {
 static int checkRecipe(BfhipHelm2Problem const *prob, uint64_t i) {
   BfhipHelm2Recipe const *r = &prob->recipes[i];
   int rc;
-  if ((rc = checkPts(&r->src, prob->numPoints, "source", i))) return rc;
-  if ((rc = checkPts(&r->tgt, prob->numPoints, "target", i))) return rc;
+  if ((rc = checkPts(&r->src, prob, "source", i))) return rc;
+  if ((rc = checkPts(&r->tgt, prob, "target", i))) return rc;
   if (r->kind == BFHIP_LEAF_REEXP) {
-    if ((rc = checkPts(&r->equiv, prob->numPoints, "equivalent-source", i))) return rc;
+    if ((rc = checkPts(&r->equiv, prob, "equivalent-source", i))) return rc;
     if (r->tgt.count < r->equiv.count)
       return bfhipFail(BFABI_ERROR_NOT_IMPLEMENTED, "recipe %llu: fewer check points (%u) than equivalent sources (%u)",
                        (unsigned long long)i, r->tgt.count, r->equiv.count);
   } else if (r->kind != BFHIP_LEAF_KERNEL) {
     return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "recipe %llu: unknown kind %u", (unsigned long long)i, r->kind);
-  } else if (prob->layerPot == BFHIP_LAYER_POTENTIAL_PV_NORMAL_DERIV_SINGLE && r->tgt.kind != BFHIP_PTS_TREE) {
+  } else if (prob->layerPot == BFHIP_LAYER_POTENTIAL_PV_NORMAL_DERIV_SINGLE &&
+             (r->tgt.kind == BFHIP_PTS_CIRCLE || (r->tgt.kind == BFHIP_PTS_TREE_TGT && !prob->tgtNormals))) {
     return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "recipe %llu: an S' kernel leaf needs target normals, i.e. tree-point targets", (unsigned long long)i);
   }
   return 0;
@@ -93,9 +99,13 @@ static uint32_t proxyPotCode(uint32_t layerPot) {
 }
 
 /* device copies of what every kernel evaluation reads */
-typedef struct DevEnv { BfEvalEnv env; void *dPoints, *dNormals, *dWeights, *dOrig, *dHits; } DevEnv;
+typedef struct DevEnv { BfEvalEnv env; void *dPoints, *dNormals, *dWeights, *dOrig, *dHits, *dTgtPoints, *dTgtNormals; } DevEnv;
 
-static void envFree(DevEnv *e) { bfdevFree(e->dPoints); bfdevFree(e->dNormals); bfdevFree(e->dWeights); bfdevFree(e->dOrig); bfdevFree(e->dHits); memset(e, 0, sizeof *e); }
+static void envFree(DevEnv *e) {
+  bfdevFree(e->dPoints); bfdevFree(e->dNormals); bfdevFree(e->dWeights); bfdevFree(e->dOrig); bfdevFree(e->dHits);
+  bfdevFree(e->dTgtPoints); bfdevFree(e->dTgtNormals);
+  memset(e, 0, sizeof *e);
+}
 
 static int envUpload(BfhipHelm2Problem const *prob, DevEnv *e) {
   memset(e, 0, sizeof *e);
@@ -110,6 +120,15 @@ static int envUpload(BfhipHelm2Problem const *prob, DevEnv *e) {
     rc = bfdevMalloc(&e->dWeights, n * 8);
     if (!rc) rc = bfdevMemcpyH2D(e->dWeights, prob->colWeights, (size_t)prob->numPoints * 8);
   }
+  if (!rc && prob->tgtPoints) {
+    size_t const m = (size_t)(prob->numTgtPoints ? prob->numTgtPoints : 1);
+    rc = bfdevMalloc(&e->dTgtPoints, m * 16);
+    if (!rc) rc = bfdevMemcpyH2D(e->dTgtPoints, prob->tgtPoints, (size_t)prob->numTgtPoints * 16);
+    if (!rc && prob->tgtNormals) {
+      rc = bfdevMalloc(&e->dTgtNormals, m * 16);
+      if (!rc) rc = bfdevMemcpyH2D(e->dTgtNormals, prob->tgtNormals, (size_t)prob->numTgtPoints * 16);
+    }
+  }
   if (!rc && prob->krOrder) {
     rc = bfdevMalloc(&e->dOrig, n * 8);
     if (!rc) rc = bfdevMemcpyH2D(e->dOrig, prob->origIndex, (size_t)prob->numPoints * 8);
@@ -119,6 +138,7 @@ static int envUpload(BfhipHelm2Problem const *prob, DevEnv *e) {
   if (rc) { envFree(e); return rc; }
   e->env.dOrigIndex = e->dOrig; e->env.numPoints = prob->numPoints; e->env.krOrder = prob->krOrder;
   e->env.dKrHits = (unsigned long long *)e->dHits;
+  e->env.dTgtPoints = e->dTgtPoints; e->env.dTgtNormals = e->dTgtNormals;
   e->env.dPoints = e->dPoints; e->env.dNormals = e->dNormals; e->env.dColWeights = e->dWeights;
   e->env.wavenumber = prob->wavenumber; e->env.selfRe = prob->selfValue[0]; e->env.selfIm = prob->selfValue[1];
   e->env.alphaRe = prob->alpha[0]; e->env.alphaIm = prob->alpha[1]; e->env.betaRe = prob->beta[0]; e->env.betaIm = prob->beta[1];
@@ -346,7 +366,7 @@ static int fillArena(BfPlan const *pl, BfIr const *ir, void *dArena, void *vctx)
   }
   /* every KR pair must have been met exactly once by a dense near-field leaf; a pair inside a
    * butterflied block cannot be corrected through the values */
-  if (!rc && prob->krOrder && pl->numRows == prob->numPoints && pl->numCols == prob->numPoints) {
+  if (!rc && prob->krOrder && !prob->tgtPoints && pl->numRows == prob->numPoints && pl->numCols == prob->numPoints) {
     unsigned long long hits = 0;
     rc = bfdevMemcpyD2H(&hits, dev.dHits, 8);
     if (!rc && hits != 2ull * prob->krOrder * prob->numPoints)
@@ -423,7 +443,9 @@ int bfhipHelm2DenseApplyDevice(BfhipHelm2Problem const *prob, int device, void c
   if ((rc = bfdevSetDevice(device))) return rc;
   DevEnv dev;
   rc = envUpload(prob, &dev);
-  if (!rc) rc = bfdevHelm2Dense(&dev.env, leafPotCode(prob->layerPot), prob->numPoints, dX, dY, stream);
+  if (!rc && prob->tgtPoints && prob->layerPot == BFHIP_LAYER_POTENTIAL_PV_NORMAL_DERIV_SINGLE && !prob->tgtNormals)
+    rc = bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "S' on a separate target tree needs tgtNormals");
+  if (!rc) rc = bfdevHelm2Dense(&dev.env, leafPotCode(prob->layerPot), prob->numPoints, prob->tgtPoints ? prob->numTgtPoints : 0, dX, dY, stream);
   envFree(&dev);
   if (prev >= 0) bfdevSetDevice(prev);
   return rc;
@@ -437,12 +459,12 @@ int bfhipHelm2DenseApply(BfhipHelm2Problem const *prob, int device, void const *
   bfdevGetDevice(&prev);
   if ((rc = bfdevSetDevice(device))) return rc;
   void *dX = NULL, *dY = NULL;
-  size_t const bytes = (size_t)(prob->numPoints ? prob->numPoints : 1) * 16;
-  rc = bfdevMalloc(&dX, bytes);
-  if (!rc) rc = bfdevMalloc(&dY, bytes);
+  uint64_t const m = prob->tgtPoints ? prob->numTgtPoints : prob->numPoints;
+  rc = bfdevMalloc(&dX, (size_t)(prob->numPoints ? prob->numPoints : 1) * 16);
+  if (!rc) rc = bfdevMalloc(&dY, (size_t)(m ? m : 1) * 16);
   if (!rc) rc = bfdevMemcpyH2D(dX, X, (size_t)prob->numPoints * 16);
   if (!rc) rc = bfhipHelm2DenseApplyDevice(prob, -1, dX, dY, NULL);
-  if (!rc) rc = bfdevMemcpyD2H(Y, dY, (size_t)prob->numPoints * 16);
+  if (!rc) rc = bfdevMemcpyD2H(Y, dY, (size_t)m * 16);
   bfdevFree(dX); bfdevFree(dY);
   if (prev >= 0) bfdevSetDevice(prev);
   return rc;

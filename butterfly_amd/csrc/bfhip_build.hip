@@ -43,10 +43,11 @@ template <typename T> static int uploadArrayB(T **d, T const *h, uint64_t count,
 // ---------------------------------------------------------------------------
 // points and the kernel
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ void bfPoint(BfBuildPts const &ps, uint32_t i, double const *pts, double &x, double &y) {
-  if (ps.kind == BFHIP_PTS_TREE) {
-    x = pts[2 * (ps.first + i)];
-    y = pts[2 * (ps.first + i) + 1];
+__device__ __forceinline__ void bfPoint(BfBuildPts const &ps, uint32_t i, double const *pts, double const *tpts, double &x, double &y) {
+  if (ps.kind != BFHIP_PTS_CIRCLE) {
+    double const *base = ps.kind == BFHIP_PTS_TREE ? pts : tpts;
+    x = base[2 * (ps.first + i)];
+    y = base[2 * (ps.first + i) + 1];
   } else {
     // bfCircle2SamplePoints, src/circle.c:12-35
     double const theta = (6.283185307179586 / (double)ps.count) * (double)i;
@@ -84,7 +85,7 @@ __constant__ double bfKrWeights[18] = {
     2.172421547519342, -8.707796087382991, 2.053584266072635, -2.166984103403823};
 
 struct EvalEnvDev {
-  double const *pts, *normals, *colWeights;
+  double const *pts, *normals, *colWeights, *tpts, *tnormals;
   uint64_t const *orig;
   double k, selfRe, selfIm;
   double2 alpha, beta;
@@ -119,9 +120,10 @@ __device__ __forceinline__ double2 bfKernelValue(EvalEnvDev const &E, uint32_t p
 // unit normal at point i of a point set: stored normals for tree points, the radial direction for a
 // sampled circle (bfCircle2SampleUnitNormals, src/circle.c:36-58)
 __device__ __forceinline__ void bfNormal(EvalEnvDev const &E, BfBuildPts const &ps, uint32_t i, double &nx, double &ny) {
-  if (ps.kind == BFHIP_PTS_TREE) {
-    nx = E.normals[2 * (ps.first + i)];
-    ny = E.normals[2 * (ps.first + i) + 1];
+  if (ps.kind != BFHIP_PTS_CIRCLE) {
+    double const *base = ps.kind == BFHIP_PTS_TREE ? E.normals : E.tnormals;
+    nx = base[2 * (ps.first + i)];
+    ny = base[2 * (ps.first + i) + 1];
   } else {
     double const theta = (6.283185307179586 / (double)ps.count) * (double)i;
     nx = cos(theta);
@@ -133,8 +135,8 @@ __device__ __forceinline__ void bfNormal(EvalEnvDev const &E, BfBuildPts const &
 __device__ __forceinline__ double2 bfKernelEntry(EvalEnvDev const &E, BfBuildPts const &src, BfBuildPts const &tgt, uint32_t i, uint32_t j,
                                                   uint32_t pot, uint32_t decorate) {
   double tx, ty, sx, sy;
-  bfPoint(tgt, i, E.pts, tx, ty);
-  bfPoint(src, j, E.pts, sx, sy);
+  bfPoint(tgt, i, E.pts, E.tpts, tx, ty);
+  bfPoint(src, j, E.pts, E.tpts, sx, sy);
   bool const bothTree = src.kind == BFHIP_PTS_TREE && tgt.kind == BFHIP_PTS_TREE;
   if (decorate && bothTree && tgt.first + i == src.first + j) return make_double2(E.selfRe, E.selfIm);
   double snx = 0, sny = 0, tnx = 0, tny = 0;
@@ -178,6 +180,7 @@ __global__ __launch_bounds__(256) void bfEvalKernel(BfEvalMat const *mats, uint6
 static EvalEnvDev toDev(BfEvalEnv const *env) {
   EvalEnvDev E;
   E.pts = (double const *)env->dPoints; E.normals = (double const *)env->dNormals; E.colWeights = (double const *)env->dColWeights;
+  E.tpts = (double const *)env->dTgtPoints; E.tnormals = (double const *)env->dTgtNormals;
   E.k = env->wavenumber; E.selfRe = env->selfRe; E.selfIm = env->selfIm;
   E.alpha = make_double2(env->alphaRe, env->alphaIm); E.beta = make_double2(env->betaRe, env->betaIm);
   E.orig = (uint64_t const *)env->dOrigIndex; E.n = env->numPoints;
@@ -624,8 +627,8 @@ int bfdevBuildPack(void *arena, void const *store, BfPackPiece const *hostPieces
 // targets and one slice of the sources (staged through LDS, 256 at a time);
 // slices are summed afterwards in fixed order.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void bfHelm2DenseKernel(EvalEnvDev const E, uint32_t pot, uint64_t n, double2 const *x, double2 *partial,
-                                                          uint64_t sliceLen) {
+__global__ __launch_bounds__(256) void bfHelm2DenseKernel(EvalEnvDev const E, uint32_t pot, uint64_t n, uint64_t m, bool square,
+                                                          double2 const *x, double2 *partial, uint64_t sliceLen) {
   __shared__ double sx[256], sy[256], sw[256];
   __shared__ double2 xv[256];
   __shared__ uint64_t so[256];
@@ -635,10 +638,12 @@ __global__ __launch_bounds__(256) void bfHelm2DenseKernel(EvalEnvDev const E, ui
   uint64_t const j1 = j0 + sliceLen < n ? j0 + sliceLen : n;
   double tx = 0, ty = 0, nx = 0, ny = 0;
   uint64_t oi = 0;
-  if (i < n) {
-    tx = E.pts[2 * i]; ty = E.pts[2 * i + 1];
-    if (pot == 1) { nx = E.normals[2 * i]; ny = E.normals[2 * i + 1]; }
-    if (E.krOrder) oi = E.orig[i];
+  double const *tp = square ? E.pts : E.tpts, *tn = square ? E.normals : E.tnormals;
+  bool const kr = square && E.krOrder;
+  if (i < m) {
+    tx = tp[2 * i]; ty = tp[2 * i + 1];
+    if (pot == 1) { nx = tn[2 * i]; ny = tn[2 * i + 1]; }
+    if (kr) oi = E.orig[i];
   }
   double ar = 0, ai = 0;
   for (uint64_t jb = j0; jb < j1; jb += 256) {
@@ -647,20 +652,20 @@ __global__ __launch_bounds__(256) void bfHelm2DenseKernel(EvalEnvDev const E, ui
     if (j < j1) {
       sx[threadIdx.x] = E.pts[2 * j]; sy[threadIdx.x] = E.pts[2 * j + 1]; xv[threadIdx.x] = x[j];
       sw[threadIdx.x] = E.colWeights ? E.colWeights[j] : 1.0;
-      so[threadIdx.x] = E.krOrder ? E.orig[j] : 0;
+      so[threadIdx.x] = kr ? E.orig[j] : 0;
       snx[threadIdx.x] = pot >= 2 ? E.normals[2 * j] : 0.0;
       sny[threadIdx.x] = pot >= 2 ? E.normals[2 * j + 1] : 0.0;
     }
     __syncthreads();
     uint32_t const cnt = (uint32_t)(j1 - jb < 256 ? j1 - jb : 256);
-    if (i < n)
+    if (i < m)
       for (uint32_t t = 0; t < cnt; ++t) {
         double2 g;
-        if (jb + t == i) g = make_double2(E.selfRe, E.selfIm);
+        if (square && jb + t == i) g = make_double2(E.selfRe, E.selfIm);
         else {
           g = bfKernelValue(E, pot, tx - sx[t], ty - sy[t], snx[t], sny[t], nx, ny);
           bool hit;
-          double const f = sw[t] * (E.krOrder ? bfKrFactor(E, oi, so[t], hit) : 1.0);
+          double const f = sw[t] * (kr ? bfKrFactor(E, oi, so[t], hit) : 1.0);
           g.x *= f; g.y *= f;
         }
         double2 const v = xv[t];
@@ -668,7 +673,7 @@ __global__ __launch_bounds__(256) void bfHelm2DenseKernel(EvalEnvDev const E, ui
         ai = fma(g.x, v.y, ai); ai = fma(g.y, v.x, ai);
       }
   }
-  if (i < n) partial[(uint64_t)blockIdx.y * n + i] = make_double2(ar, ai);
+  if (i < m) partial[(uint64_t)blockIdx.y * m + i] = make_double2(ar, ai);
 }
 
 __global__ __launch_bounds__(256) void bfSliceSumKernel(double2 const *partial, uint64_t n, uint32_t slices, double2 *y) {
@@ -686,22 +691,24 @@ int bfdevMemFree(uint64_t *freeBytes) {
   return rc;
 }
 
-int bfdevHelm2Dense(BfEvalEnv const *env, uint32_t pot, uint64_t n, void const *dX, void *dY, void *stream) {
+int bfdevHelm2Dense(BfEvalEnv const *env, uint32_t pot, uint64_t n, uint64_t numTgt, void const *dX, void *dY, void *stream) {
   if (!n) return 0;
   hipStream_t const s = (hipStream_t)stream;
-  uint32_t const tb = (uint32_t)((n + 255) / 256);
+  bool const square = numTgt == 0;
+  uint64_t const m = square ? n : numTgt;
+  uint32_t const tb = (uint32_t)((m + 255) / 256);
   // enough workgroups to fill 256 CUs several times over, slices of >= 256 sources
   uint32_t slices = tb >= 4096 ? 1 : (4096 + tb - 1) / tb;
   if ((uint64_t)slices * 256 > n) slices = (uint32_t)((n + 255) / 256);
   uint64_t const sliceLen = ((n + slices - 1) / slices + 255) / 256 * 256;
   slices = (uint32_t)((n + sliceLen - 1) / sliceLen);
   double2 *partial = NULL;
-  int rc = hipFailB(hipMalloc((void **)&partial, (size_t)slices * n * sizeof(double2)), "hipMalloc(dense apply partials)");
+  int rc = hipFailB(hipMalloc((void **)&partial, (size_t)slices * m * sizeof(double2)), "hipMalloc(dense apply partials)");
   if (rc) return rc;
-  hipLaunchKernelGGL(bfHelm2DenseKernel, dim3(tb, slices), dim3(256), 0, s, toDev(env), pot, n, (double2 const *)dX, partial, sliceLen);
+  hipLaunchKernelGGL(bfHelm2DenseKernel, dim3(tb, slices), dim3(256), 0, s, toDev(env), pot, n, m, square, (double2 const *)dX, partial, sliceLen);
   rc = hipFailB(hipGetLastError(), "dense apply launch");
   if (!rc) {
-    hipLaunchKernelGGL(bfSliceSumKernel, dim3(tb), dim3(256), 0, s, partial, n, slices, (double2 *)dY);
+    hipLaunchKernelGGL(bfSliceSumKernel, dim3(tb), dim3(256), 0, s, partial, m, slices, (double2 *)dY);
     rc = hipFailB(hipGetLastError(), "dense apply sum launch");
   }
   if (!rc) rc = hipFailB(hipStreamSynchronize(s), "dense apply");

@@ -245,6 +245,7 @@ typedef struct BfEvalMat {
 /* what every kernel evaluation needs besides the two points */
 typedef struct BfEvalEnv {
   void const *dPoints, *dNormals, *dColWeights;   /* device; normals / weights may be NULL */
+  void const *dTgtPoints, *dTgtNormals;           /* separate target tree (BFHIP_PTS_TREE_TGT) or NULL */
   void const *dOrigIndex;                         /* device uint64[numPoints] or NULL */
   double wavenumber, selfRe, selfIm;
   double alphaRe, alphaIm, betaRe, betaIm;
@@ -287,7 +288,8 @@ int bfdevBuildPack(void *arena, void const *store, BfPackPiece const *hostPieces
 int bfdevMemFree(uint64_t *freeBytes);    /* free device memory right now */
 
 /* y = G x, N x N single-layer kernel evaluated on the fly; scratch is allocated inside */
-int bfdevHelm2Dense(BfEvalEnv const *env, uint32_t pot, uint64_t n, void const *dX, void *dY, void *stream);
+/* numTgt == 0: square (targets = the points); else targets = env->dTgtPoints */
+int bfdevHelm2Dense(BfEvalEnv const *env, uint32_t pot, uint64_t n, uint64_t numTgt, void const *dX, void *dY, void *stream);
 int bfdevMemcpyH2DAsync(void *dst, void const *src, size_t bytes, void *stream);
 int bfdevMemcpyD2DAsync(void *dst, void const *src, size_t bytes, void *stream);
 

@@ -34,6 +34,7 @@ typedef struct QN {
   uint64_t i0, i1;
   uint32_t depth, nch;
   uint32_t ch[4];
+  uint32_t tree;            /* 0: the source tree (or the only one), 1: a separate target tree */
   /* levels of the subtree, built on demand: nodes of level d are lv[lvBegin[d] .. lvBegin[d+1]) */
   uint32_t *lv, *lvBegin;
   uint32_t nlv;
@@ -46,6 +47,10 @@ struct BfhipHelm2Layout {
   uint64_t n;
   uint64_t *perm;
   double *treePoints;
+  /* separate target tree (NULL / 0 when src tree == tgt tree) */
+  uint64_t m;
+  uint64_t *tperm;
+  double *ttreePoints;
   /* descriptor under construction */
   uint8_t *kind, *blockKind;
   uint64_t *rows, *cols, *childBegin;
@@ -107,7 +112,7 @@ static uint64_t descAdd(BfhipHelm2Layout *L, uint8_t kind, uint64_t rows, uint64
 static BfhipPointSet nodePts(QN const *nd) {
   BfhipPointSet p;
   memset(&p, 0, sizeof p);
-  p.kind = BFHIP_PTS_TREE; p.first = nd->i0; p.count = (uint32_t)(nd->i1 - nd->i0);
+  p.kind = nd->tree ? BFHIP_PTS_TREE_TGT : BFHIP_PTS_TREE; p.first = nd->i0; p.count = (uint32_t)(nd->i1 - nd->i0);
   return p;
 }
 static BfhipPointSet circPts(QN const *nd, uint64_t count) {
@@ -134,7 +139,8 @@ static uint64_t addKernelLeaf(BfhipHelm2Layout *L, uint64_t rows, uint64_t cols,
 }
 
 /* ---- quadtree ---------------------------------------------------------------------- */
-static uint32_t newNode(BfhipHelm2Layout *L, double xmin, double ymin, double xmax, double ymax, uint64_t i0, uint64_t i1, uint32_t depth) {
+static uint32_t newNode(BfhipHelm2Layout *L, double xmin, double ymin, double xmax, double ymax, uint64_t i0, uint64_t i1, uint32_t depth,
+                        uint32_t tree) {
   if (L->numNodes == L->capNodes) {
     uint64_t cap = L->capNodes;
     L->nodes = grow(L->nodes, &cap, (uint64_t)L->numNodes + 1, sizeof(QN), &L->oom);
@@ -143,15 +149,14 @@ static uint32_t newNode(BfhipHelm2Layout *L, double xmin, double ymin, double xm
   }
   QN *nd = &L->nodes[L->numNodes];
   memset(nd, 0, sizeof *nd);
-  nd->xmin = xmin; nd->ymin = ymin; nd->xmax = xmax; nd->ymax = ymax; nd->i0 = i0; nd->i1 = i1; nd->depth = depth;
+  nd->xmin = xmin; nd->ymin = ymin; nd->xmax = xmax; nd->ymax = ymax; nd->i0 = i0; nd->i1 = i1; nd->depth = depth; nd->tree = tree;
   nd->r = hypot(xmax - xmin, ymax - ymin) / 2;         /* bounding circle: src/quadtree_node.c:321-330 */
   nd->cx = (xmin + xmax) / 2;
   nd->cy = (ymin + ymax) / 2;
   return L->numNodes++;
 }
 
-static int buildQuadtree(BfhipHelm2Layout *L, double const *pts) {
-  uint64_t const n = L->n;
+static int buildQuadtree(BfhipHelm2Layout *L, double const *pts, uint64_t n, uint64_t *perm, uint32_t tree, uint32_t *rootOut) {
   double xmin = pts[0], xmax = pts[0], ymin = pts[1], ymax = pts[1];
   for (uint64_t i = 1; i < n; ++i) {
     double const x = pts[2 * i], y = pts[2 * i + 1];
@@ -169,14 +174,15 @@ static int buildQuadtree(BfhipHelm2Layout *L, double const *pts) {
     double const c = (xmin + xmax) / 2, lo = h * (xmin - c) / w + c, hi = h * (xmax - c) / w + c;
     xmin = lo; xmax = hi;
   }
-  for (uint64_t i = 0; i < n; ++i) L->perm[i] = i;
+  for (uint64_t i = 0; i < n; ++i) perm[i] = i;
   uint64_t *tmp = malloc((size_t)n * 8);
   uint8_t *quad = malloc((size_t)n);
   uint32_t *stack = NULL;
   uint64_t sp = 0, capStack = 0;
   int rc = 0;
   if (!tmp || !quad) { rc = bfhipFail(BFABI_ERROR_MEMORY_ERROR, "host OOM (quadtree)"); goto done; }
-  uint32_t const root = newNode(L, xmin, ymin, xmax, ymax, 0, n, 0);
+  uint32_t const root = newNode(L, xmin, ymin, xmax, ymax, 0, n, 0, tree);
+  *rootOut = root;
   stack = grow(stack, &capStack, 1, 4, &L->oom);
   if (L->oom) goto done;
   stack[sp++] = root;
@@ -187,7 +193,7 @@ static int buildQuadtree(BfhipHelm2Layout *L, double const *pts) {
     double const sx = nd.cx, sy = nd.cy;                 /* split = box centre (src/quadtree_node.c:237) */
     uint64_t cnt[4] = {0, 0, 0, 0}, off[5];
     for (uint64_t i = nd.i0; i < nd.i1; ++i) {
-      double const x = pts[2 * L->perm[i]], y = pts[2 * L->perm[i] + 1];
+      double const x = pts[2 * perm[i]], y = pts[2 * perm[i] + 1];
       uint8_t const q = x <= sx ? (y <= sy ? 0 : 1) : (y <= sy ? 2 : 3);
       quad[i] = q;
       cnt[q]++;
@@ -195,12 +201,12 @@ static int buildQuadtree(BfhipHelm2Layout *L, double const *pts) {
     off[0] = nd.i0;
     for (int q = 0; q < 4; ++q) off[q + 1] = off[q] + cnt[q];
     uint64_t cur[4] = {off[0], off[1], off[2], off[3]};
-    for (uint64_t i = nd.i0; i < nd.i1; ++i) tmp[cur[quad[i]]++] = L->perm[i];      /* stable */
-    memcpy(L->perm + nd.i0, tmp + nd.i0, (size_t)(nd.i1 - nd.i0) * 8);
+    for (uint64_t i = nd.i0; i < nd.i1; ++i) tmp[cur[quad[i]]++] = perm[i];         /* stable */
+    memcpy(perm + nd.i0, tmp + nd.i0, (size_t)(nd.i1 - nd.i0) * 8);
     double const box[4][4] = {{nd.xmin, nd.ymin, sx, sy}, {nd.xmin, sy, sx, nd.ymax}, {sx, nd.ymin, nd.xmax, sy}, {sx, sy, nd.xmax, nd.ymax}};
     for (int q = 0; q < 4; ++q) {
       if (off[q + 1] == off[q]) continue;
-      uint32_t const c = newNode(L, box[q][0], box[q][1], box[q][2], box[q][3], off[q], off[q + 1], nd.depth + 1);
+      uint32_t const c = newNode(L, box[q][0], box[q][1], box[q][2], box[q][3], off[q], off[q + 1], nd.depth + 1, tree);
       if (L->oom) break;
       QN *par = &L->nodes[id];
       par->ch[par->nch++] = c;
@@ -485,17 +491,19 @@ void bfhipHelm2LayoutFree(BfhipHelm2Layout **pl) {
   if (!pl || !*pl) return;
   BfhipHelm2Layout *L = *pl;
   for (uint32_t i = 0; i < L->numNodes; ++i) { free(L->nodes[i].lv); free(L->nodes[i].lvBegin); }
-  free(L->nodes); free(L->perm); free(L->treePoints);
+  free(L->nodes); free(L->perm); free(L->treePoints); free(L->tperm); free(L->ttreePoints);
   free(L->kind); free(L->blockKind); free(L->rows); free(L->cols); free(L->childBegin);
   free(L->childNode); free(L->childRow0); free(L->childCol0); free(L->topRowBlock); free(L->recipes);
   free(L);
   *pl = NULL;
 }
 
-int bfhipHelm2LayoutCreate(double const *points, uint64_t numPoints, double wavenumber, BfhipHelm2Layout **out) {
+int bfhipHelm2LayoutCreate2(double const *points, uint64_t numPoints, double const *tgtPoints, uint64_t numTgtPoints, double wavenumber,
+                            BfhipHelm2Layout **out) {
   if (!points || !out) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "NULL argument");
   *out = NULL;
-  if (numPoints < 2 || numPoints > 0x7fffffffu) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "numPoints out of range");
+  if (numPoints < 2 || numPoints > 0x7fffffffu || (tgtPoints && (numTgtPoints < 2 || numTgtPoints > 0x7fffffffu)))
+    return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "numPoints out of range");
   if (!(wavenumber > 0)) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "wavenumber must be positive");
   BfhipHelm2Layout *L = calloc(1, sizeof *L);
   if (!L) return bfhipFail(BFABI_ERROR_MEMORY_ERROR, "host OOM");
@@ -503,30 +511,45 @@ int bfhipHelm2LayoutCreate(double const *points, uint64_t numPoints, double wave
   L->perm = malloc((size_t)numPoints * 8);
   L->treePoints = malloc((size_t)numPoints * 16);
   int rc = (!L->perm || !L->treePoints) ? bfhipFail(BFABI_ERROR_MEMORY_ERROR, "host OOM") : 0;
+  if (!rc && tgtPoints) {
+    L->m = numTgtPoints;
+    L->tperm = malloc((size_t)numTgtPoints * 8);
+    L->ttreePoints = malloc((size_t)numTgtPoints * 16);
+    if (!L->tperm || !L->ttreePoints) rc = bfhipFail(BFABI_ERROR_MEMORY_ERROR, "host OOM");
+  }
   Child *ch = NULL;
-  if (!rc) rc = buildQuadtree(L, points);
+  uint32_t sroot = 0, troot = 0;
+  if (!rc) rc = buildQuadtree(L, points, numPoints, L->perm, 0, &sroot);
   if (!rc) {
     for (uint64_t i = 0; i < numPoints; ++i) { L->treePoints[2 * i] = points[2 * L->perm[i]]; L->treePoints[2 * i + 1] = points[2 * L->perm[i] + 1]; }
-    rc = ensureLevels(L, 0);
+    troot = sroot;
+    if (tgtPoints) {
+      rc = buildQuadtree(L, tgtPoints, numTgtPoints, L->tperm, 1, &troot);
+      if (!rc)
+        for (uint64_t i = 0; i < numTgtPoints; ++i) { L->ttreePoints[2 * i] = tgtPoints[2 * L->tperm[i]]; L->ttreePoints[2 * i + 1] = tgtPoints[2 * L->tperm[i] + 1]; }
+    }
   }
-  if (!rc && L->nodes[0].nlv < 3) rc = bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "quadtree has fewer than 3 levels");
+  if (!rc) rc = ensureLevels(L, sroot);
+  if (!rc) rc = ensureLevels(L, troot);
+  if (!rc && (L->nodes[sroot].nlv < 3 || L->nodes[troot].nlv < 3)) rc = bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "quadtree has fewer than 3 levels");
   if (!rc) {
-    /* the top level of the operator is the grid of level-2 nodes (:956-982) */
-    uint32_t cnt;
-    uint32_t const *l2 = levelNodes(L, 0, 2, &cnt);
-    uint32_t *nodes2 = malloc((size_t)cnt * 4);
+    /* the top level of the operator is the grid of level-2 nodes (:956-982): rows = target nodes */
+    uint32_t cntS, cntT;
+    uint32_t const *s2 = levelNodes(L, sroot, 2, &cntS), *t2 = levelNodes(L, troot, 2, &cntT);
+    uint32_t *src2 = malloc((size_t)cntS * 4), *tgt2 = malloc((size_t)cntT * 4);
     uint64_t nc = 0, rr = 0, cc = 0;
-    if (!nodes2) rc = bfhipFail(BFABI_ERROR_MEMORY_ERROR, "host OOM");
+    if (!src2 || !tgt2) rc = bfhipFail(BFABI_ERROR_MEMORY_ERROR, "host OOM");
     if (!rc) {
-      memcpy(nodes2, l2, (size_t)cnt * 4);
-      rc = multilevelRec(L, nodes2, cnt, nodes2, cnt, &ch, &nc, &rr, &cc);
+      memcpy(src2, s2, (size_t)cntS * 4);
+      memcpy(tgt2, t2, (size_t)cntT * 4);
+      rc = multilevelRec(L, src2, cntS, tgt2, cntT, &ch, &nc, &rr, &cc);
     }
     if (!rc) {
       uint64_t const root = descAdd(L, BFHIP_NODE_BLOCK, rr, cc, ch, nc, BFABI_TYPE_MAT_BLOCK_DENSE);
       L->topRowBlock = malloc((size_t)(nc + 1) * 8);
       if (!L->topRowBlock || L->oom) rc = bfhipFail(BFABI_ERROR_MEMORY_ERROR, "host OOM");
       else {
-        for (uint64_t i = 0; i < nc; ++i) L->topRowBlock[i] = i / cnt;
+        for (uint64_t i = 0; i < nc; ++i) L->topRowBlock[i] = i / cntS;
         BfhipDesc *d = &L->desc;
         memset(d, 0, sizeof *d);
         d->structSize = sizeof *d; d->dtype = BFHIP_C128; d->numNodes = L->numDesc; d->root = root;
@@ -535,12 +558,16 @@ int bfhipHelm2LayoutCreate(double const *points, uint64_t numPoints, double wave
         d->topRowBlock = L->topRowBlock; d->blockKind = L->blockKind;
       }
     }
-    free(nodes2);
+    free(src2); free(tgt2);
   }
   free(ch);
   if (rc) { bfhipHelm2LayoutFree(&L); return rc; }
   *out = L;
   return 0;
+}
+
+int bfhipHelm2LayoutCreate(double const *points, uint64_t numPoints, double wavenumber, BfhipHelm2Layout **out) {
+  return bfhipHelm2LayoutCreate2(points, numPoints, NULL, 0, wavenumber, out);
 }
 
 BfhipDesc const *bfhipHelm2LayoutGetDesc(BfhipHelm2Layout const *L) { return L ? &L->desc : NULL; }
@@ -550,19 +577,22 @@ BfhipHelm2Recipe const *bfhipHelm2LayoutGetRecipes(BfhipHelm2Layout const *L, ui
 }
 uint64_t const *bfhipHelm2LayoutGetPerm(BfhipHelm2Layout const *L) { return L ? L->perm : NULL; }
 double const *bfhipHelm2LayoutGetTreePoints(BfhipHelm2Layout const *L) { return L ? L->treePoints : NULL; }
+uint64_t const *bfhipHelm2LayoutGetTgtPerm(BfhipHelm2Layout const *L) { return L ? L->tperm : NULL; }
+double const *bfhipHelm2LayoutGetTgtTreePoints(BfhipHelm2Layout const *L) { return L ? L->ttreePoints : NULL; }
 
 /* points -> device operator in one call: what bfFacHelm2MakeMultilevel (src/fac_helm2.c:943-1002)
  * followed by bfhipCompile gives, without the CPU build */
-int bfhipFacHelm2MakeMultilevel(double const *points, double const *normals, double const *colWeights, uint64_t numPoints,
-                                BfhipHelm2Problem const *params, BfhipOptions const *opts, BfhipOperator **out, uint64_t *permOut,
-                                BfhipBuildStats *stats) {
+int bfhipFacHelm2MakeMultilevel2(double const *points, double const *normals, double const *colWeights, uint64_t numPoints,
+                                 double const *tgtPoints, double const *tgtNormals, uint64_t numTgtPoints,
+                                 BfhipHelm2Problem const *params, BfhipOptions const *opts, BfhipOperator **out, uint64_t *permOut,
+                                 uint64_t *tgtPermOut, BfhipBuildStats *stats) {
   if (!points || !params || !out) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "NULL argument");
   *out = NULL;
   if (params->structSize < sizeof *params) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "BfhipHelm2Problem.structSize too small");
   BfhipHelm2Layout *L = NULL;
-  int rc = bfhipHelm2LayoutCreate(points, numPoints, params->wavenumber, &L);
+  int rc = bfhipHelm2LayoutCreate2(points, numPoints, tgtPoints, tgtPoints ? numTgtPoints : 0, params->wavenumber, &L);
   if (rc) return rc;
-  double *nrm = NULL, *w = NULL;
+  double *nrm = NULL, *w = NULL, *tnrm = NULL;
   if (normals) {
     nrm = malloc((size_t)numPoints * 16);
     if (!nrm) rc = bfhipFail(BFABI_ERROR_MEMORY_ERROR, "host OOM");
@@ -573,15 +603,28 @@ int bfhipFacHelm2MakeMultilevel(double const *points, double const *normals, dou
     if (!w) rc = bfhipFail(BFABI_ERROR_MEMORY_ERROR, "host OOM");
     else for (uint64_t i = 0; i < numPoints; ++i) w[i] = colWeights[L->perm[i]];
   }
+  if (!rc && tgtPoints && tgtNormals) {
+    tnrm = malloc((size_t)numTgtPoints * 16);
+    if (!tnrm) rc = bfhipFail(BFABI_ERROR_MEMORY_ERROR, "host OOM");
+    else for (uint64_t i = 0; i < numTgtPoints; ++i) { tnrm[2 * i] = tgtNormals[2 * L->tperm[i]]; tnrm[2 * i + 1] = tgtNormals[2 * L->tperm[i] + 1]; }
+  }
   if (!rc) {
     BfhipHelm2Problem prob = *params;
     prob.structSize = sizeof prob;
     prob.points = L->treePoints; prob.numPoints = numPoints; prob.recipes = L->recipes; prob.numRecipes = L->numRecipes;
     prob.normals = nrm; prob.colWeights = w; prob.origIndex = L->perm;
+    prob.tgtPoints = tgtPoints ? L->ttreePoints : NULL; prob.numTgtPoints = tgtPoints ? numTgtPoints : 0; prob.tgtNormals = tnrm;
     rc = bfhipBuildHelm2(&L->desc, &prob, opts, out, stats);
   }
   if (!rc && permOut) memcpy(permOut, L->perm, (size_t)numPoints * 8);
-  free(nrm); free(w);
+  if (!rc && tgtPermOut && tgtPoints) memcpy(tgtPermOut, L->tperm, (size_t)numTgtPoints * 8);
+  free(nrm); free(w); free(tnrm);
   bfhipHelm2LayoutFree(&L);
   return rc;
+}
+
+int bfhipFacHelm2MakeMultilevel(double const *points, double const *normals, double const *colWeights, uint64_t numPoints,
+                                BfhipHelm2Problem const *params, BfhipOptions const *opts, BfhipOperator **out, uint64_t *permOut,
+                                BfhipBuildStats *stats) {
+  return bfhipFacHelm2MakeMultilevel2(points, normals, colWeights, numPoints, NULL, NULL, 0, params, opts, out, permOut, NULL, stats);
 }

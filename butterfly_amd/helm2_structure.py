@@ -47,11 +47,12 @@ def circle_points(n: int) -> np.ndarray:
 # --------------------------------------------------------------------------
 class QNode:
     __slots__ = ("xmin", "ymin", "xmax", "ymax", "i0", "i1", "children", "depth",
-                 "cx", "cy", "r", "_levels")
+                 "cx", "cy", "r", "_levels", "tree")
 
-    def __init__(self, xmin, ymin, xmax, ymax, i0, i1, depth):
+    def __init__(self, xmin, ymin, xmax, ymax, i0, i1, depth, tree=0):
         self.xmin, self.ymin, self.xmax, self.ymax = xmin, ymin, xmax, ymax
         self.i0, self.i1, self.depth = i0, i1, depth
+        self.tree = tree      # 0: the source tree (or the only one), 1: a separate target tree
         self.children = []  # non-empty children in quadrant order 0..3
         # bounding circle: src/quadtree_node.c:321-330
         self.r = float(np.hypot(xmax - xmin, ymax - ymin)) / 2
@@ -95,7 +96,7 @@ def _sift_exact(px, py, perm, i0, i1, sx, sy):
     return off
 
 
-def build_quadtree(points: np.ndarray, exact_sift: bool = False):
+def build_quadtree(points: np.ndarray, exact_sift: bool = False, tree: int = 0):
     """Returns (root, perm): perm[i] = index into `points` of the i-th point in
     tree order (BfTree.perm, include/bf/tree.h:30-38)."""
     n = len(points)
@@ -110,7 +111,7 @@ def build_quadtree(points: np.ndarray, exact_sift: bool = False):
     else:
         c = (xmin + xmax) / 2
         xmin, xmax = h * (xmin - c) / w + c, h * (xmax - c) / w + c
-    root = QNode(float(xmin), float(ymin), float(xmax), float(ymax), 0, n, 0)
+    root = QNode(float(xmin), float(ymin), float(xmax), float(ymax), 0, n, 0, tree)
     if exact_sift:
         perm = list(range(n))
         pxl, pyl = px.tolist(), py.tolist()
@@ -140,7 +141,7 @@ def build_quadtree(points: np.ndarray, exact_sift: bool = False):
             if off[q + 1] == off[q]:
                 continue
             b = boxes[q]
-            ch = QNode(b[0], b[1], b[2], b[3], off[q], off[q + 1], nd.depth + 1)
+            ch = QNode(b[0], b[1], b[2], b[3], off[q], off[q + 1], nd.depth + 1, tree)
             nd.children.append(ch)
             if ch.npts > LEAF_SIZE_THRESHOLD:
                 stack.append(ch)
@@ -284,7 +285,8 @@ class Desc:
 
 
 def _node_pts(nd: QNode):
-    return ("node", nd.i0, nd.i1)
+    # "node": a range of the (source) tree's points; "tnode": of a separate target tree's points
+    return ("node" if nd.tree == 0 else "tnode", nd.i0, nd.i1)
 
 
 def _circ_pts(nd: QNode, count):
@@ -411,24 +413,31 @@ def _multilevel_rec(desc: Desc, k, src_nodes, tgt_nodes, recipes, stats):
 
 
 def helm2_multilevel_structure(points: np.ndarray, k: float, recipes: bool = False,
-                               exact_sift: bool = False):
-    """bfFacHelm2MakeMultilevel (src/fac_helm2.c:943-1002) with src tree = tgt
-    tree (examples/simple/bf_all_blocks.c:130).  Returns (Desc, root QNode, perm)."""
+                               exact_sift: bool = False, tgt_points: np.ndarray | None = None):
+    """bfFacHelm2MakeMultilevel (src/fac_helm2.c:943-1002).  With `tgt_points` None the source and
+    target trees are the same quadtree (examples/simple/bf_all_blocks.c:130) and (Desc, root QNode,
+    perm) is returned; with separate target points (the evaluation butterfly of
+    examples/multiple_scattering/multiple_scattering_context.c:998) a second quadtree is built and
+    (Desc, (src root, tgt root), (src perm, tgt perm)) is returned -- rows follow the target tree."""
     root, perm = build_quadtree(points, exact_sift=exact_sift)
-    lv = levels_below(root)
-    if len(lv) < 3:
+    troot, tperm = (root, perm) if tgt_points is None else build_quadtree(tgt_points, exact_sift=exact_sift, tree=1)
+    lv, tlv = levels_below(root), levels_below(troot)
+    if len(lv) < 3 or len(tlv) < 3:
         raise ValueError("quadtree has fewer than 3 levels")
-    nodes2 = lv[2].nodes                                            # level-2 nodes (:956-982)
+    src2, tgt2 = lv[2].nodes, tlv[2].nodes                          # level-2 nodes (:956-982)
     desc = Desc(dtype=0)
     stats = {"dense_leaves": 0, "products": {}, "block_dense": 0}
-    ch, rr, cc = _multilevel_rec(desc, k, nodes2, nodes2, recipes, stats)
+    ch, rr, cc = _multilevel_rec(desc, k, src2, tgt2, recipes, stats)
     stats["block_dense"] += 1
     desc.root = desc.add(NODE_BLOCK, rr, cc, ch, BF_TYPE_BLOCK_DENSE)
     # block-row id of each root child, for row sharding (SURVEY.md section 8(e))
-    ncol = len(nodes2)
+    ncol = len(src2)
     desc.top_row_block = [i // ncol for i in range(len(ch))]
-    desc.meta = dict(stats=stats, n=len(points), k=float(k), top_rows=[t.npts for t in nodes2])
-    return desc, root, perm
+    desc.meta = dict(stats=stats, n=len(points), k=float(k), top_rows=[t.npts for t in tgt2])
+    if tgt_points is None:
+        return desc, root, perm
+    desc.meta["m"] = len(tgt_points)
+    return desc, (root, troot), (perm, tperm)
 
 
 def single_product_structure(points: np.ndarray, k: float, src_path, tgt_path, recipes=True):
@@ -546,11 +555,12 @@ class ArrayDesc:
         return tot
 
 
-def native_multilevel_structure(points: np.ndarray, k: float):
-    """helm2_multilevel_structure through the C layout (bfhipHelm2LayoutCreate): same arrays
-    (tests/test_layout_cpu.py), ~25x faster.  Returns (ArrayDesc, perm)."""
+def native_multilevel_structure(points: np.ndarray, k: float, tgt_points: np.ndarray | None = None):
+    """helm2_multilevel_structure through the C layout (bfhipHelm2LayoutCreate[2]): same arrays
+    (tests/test_layout_cpu.py), ~25x faster.  Returns (ArrayDesc, perm), or (ArrayDesc, (perm,
+    tgt perm)) with a separate target tree."""
     from . import _capi
-    lay = _capi.Helm2Layout(points, k)
+    lay = _capi.Helm2Layout(points, k, tgt_points)
     a = lay.arrays()
     rb, re = int(a["childBegin"][lay.root]), int(a["childBegin"][lay.root + 1])
     ncol = 0
@@ -567,4 +577,7 @@ def native_multilevel_structure(points: np.ndarray, k: float):
              "block_dense": int(((a["kind"] == NODE_BLOCK) & (a["blockKind"] == BF_TYPE_BLOCK_DENSE)).sum())}
     desc = ArrayDesc(a, lay.root, lay.dtype, lay.top_row_block, lay.recipes,
                      dict(stats=stats, n=len(points), k=float(k), top_rows=top_rows))
-    return desc, lay.perm
+    if tgt_points is None:
+        return desc, lay.perm
+    desc.meta["m"] = len(tgt_points)
+    return desc, (lay.perm, lay.tgt_perm)

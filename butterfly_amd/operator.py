@@ -61,7 +61,8 @@ class HipOperator:
 
     @classmethod
     def build_helm2(cls, desc, points, wavenumber, root=None, workspace_bytes=0, layer_pot="S", normals=None,
-                    col_weights=None, self_value=0.0, kr_order=0, orig_index=None, alpha=0.0, beta=0.0, **opts):
+                    col_weights=None, self_value=0.0, kr_order=0, orig_index=None, alpha=0.0, beta=0.0, tgt_points=None,
+                    tgt_normals=None, **opts):
         """bfhipBuildHelm2: lay out `desc` (helm2_structure with recipes=True) and
         compute every leaf on the device from its recipe.  `points` (and
         `normals` for layer_pot="Sp"): [N, 2] in quadtree order.  The operator
@@ -73,7 +74,7 @@ class HipOperator:
         recipes = getattr(desc, "recipe_array", None)
         prob = _capi.Helm2Problem(points, wavenumber, recipes if recipes is not None else desc.recipe, workspace_bytes, layer_pot, normals,
                                   col_weights, self_value,
-                                  kr_order, orig_index, alpha, beta)
+                                  kr_order, orig_index, alpha, beta, tgt_points, tgt_normals)
         st = _capi.BfhipBuildStats()
         st.structSize = C.sizeof(st)
         h = C.c_void_p()
@@ -83,23 +84,26 @@ class HipOperator:
 
     @classmethod
     def fac_helm2_make_multilevel(cls, points, wavenumber, normals=None, col_weights=None, layer_pot="S", self_value=0.0,
-                                  kr_order=0, alpha=0.0, beta=0.0, workspace_bytes=0, **opts):
-        """bfhipFacHelm2MakeMultilevel: points (original order) -> device operator in one native
-        call (C layout + device build).  Returns (operator, perm, build statistics); the operator
-        acts on vectors in quadtree order: x_tree = x[perm]."""
+                                  kr_order=0, alpha=0.0, beta=0.0, workspace_bytes=0, tgt_points=None, tgt_normals=None, **opts):
+        """bfhipFacHelm2MakeMultilevel[2]: points (original order) -> device operator in one native
+        call (C layout + device build).  Returns (operator, perm, build statistics), or with
+        `tgt_points` (operator, (perm, tgt_perm), statistics); the operator maps x[perm] to
+        y[tgt_perm] (quadtree orders)."""
         lib = _capi.load()
-        pts = np.ascontiguousarray(points, dtype=np.float64)
-        nrm = None if normals is None else np.ascontiguousarray(normals, dtype=np.float64)
-        w = None if col_weights is None else np.ascontiguousarray(col_weights, dtype=np.float64)
+        f64 = lambda a: None if a is None else np.ascontiguousarray(a, dtype=np.float64)
+        ptr = lambda a: None if a is None else a.ctypes.data
+        pts, nrm, w, tpts, tnrm = f64(points), f64(normals), f64(col_weights), f64(tgt_points), f64(tgt_normals)
         params = _capi.Helm2Problem(pts, wavenumber, None, workspace_bytes, layer_pot, None, None, self_value, kr_order, None, alpha, beta)
         st = _capi.BfhipBuildStats()
         st.structSize = C.sizeof(st)
         perm = np.empty(len(pts), dtype=np.uint64)
+        tperm = np.empty(0 if tpts is None else len(tpts), dtype=np.uint64)
         h = C.c_void_p()
         o = _options(**opts)
-        check(lib.bfhipFacHelm2MakeMultilevel(pts.ctypes.data, None if nrm is None else nrm.ctypes.data, None if w is None else w.ctypes.data,
-                                              len(pts), params.byref(), C.byref(o), C.byref(h), perm.ctypes.data, C.byref(st)))
-        return cls(h.value), perm.astype(np.int64), st.as_dict()
+        check(lib.bfhipFacHelm2MakeMultilevel2(ptr(pts), ptr(nrm), ptr(w), len(pts), ptr(tpts), ptr(tnrm), len(tperm), params.byref(), C.byref(o),
+                                               C.byref(h), perm.ctypes.data, tperm.ctypes.data if len(tperm) else None, C.byref(st)))
+        perm = perm.astype(np.int64)
+        return cls(h.value), (perm if tpts is None else (perm, tperm.astype(np.int64))), st.as_dict()
 
     @classmethod
     def load(cls, path, **opts):
@@ -284,13 +288,14 @@ def helm2_dense_apply(points, wavenumber, x, device=-1, **problem):
     x: numpy [N] or a CUDA tensor; `problem`: layer_pot, normals, col_weights, self_value."""
     prob = _capi.Helm2Problem(points, wavenumber, None, **problem)
     lib = _capi.load()
+    m = len(prob.tgt_points) if prob.tgt_points is not None else len(prob.points)
     if isinstance(x, np.ndarray):
         xs = np.ascontiguousarray(x, dtype=np.complex128)
-        y = np.empty_like(xs)
+        y = np.empty(m, dtype=np.complex128)
         check(lib.bfhipHelm2DenseApply(prob.byref(), device, xs.ctypes.data, y.ctypes.data))
         return y
     import torch
-    y = torch.empty_like(x)
+    y = torch.empty(m, dtype=x.dtype, device=x.device)
     s = torch.cuda.current_stream(x.device)
     check(lib.bfhipHelm2DenseApplyDevice(prob.byref(), x.device.index, C.c_void_p(x.data_ptr()), C.c_void_p(y.data_ptr()),
                                          C.c_void_p(s.cuda_stream)))

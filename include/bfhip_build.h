@@ -36,7 +36,9 @@ extern "C" {
 
 enum {
   BFHIP_PTS_TREE = 0,    /* points[first .. first+count) of the (quadtree-ordered) point array */
-  BFHIP_PTS_CIRCLE = 1   /* count points (cx + r cos(2 pi i/count), cy + r sin(2 pi i/count)), src/circle.c:12-35 */
+  BFHIP_PTS_CIRCLE = 1,  /* count points (cx + r cos(2 pi i/count), cy + r sin(2 pi i/count)), src/circle.c:12-35 */
+  BFHIP_PTS_TREE_TGT = 2 /* tgtPoints[first .. first+count): a separate target tree (bfFacHelm2MakeMultilevel with
+                            srcTree != tgtTree, e.g. examples/multiple_scattering/multiple_scattering_context.c:998) */
 };
 
 typedef struct BfhipPointSet {
@@ -99,6 +101,11 @@ typedef struct BfhipHelm2Problem {
   uint32_t krOrder;
   uint32_t reserved;
   double alpha[2], beta[2];  /* COMBINED_FIELD: complex coefficients (BfHelm2.alpha, .beta, include/bf/helm2.h:13-14) */
+  /* a separate target tree: rows of the operator follow tgtPoints (quadtree order of THAT tree).
+   * NULL: targets are `points` (square operator).  selfValue / KR apply to square operators only. */
+  const double *tgtPoints;   /* [2 * numTgtPoints] or NULL */
+  uint64_t numTgtPoints;
+  const double *tgtNormals;  /* [2 * numTgtPoints]: S' with a separate target tree; else may be NULL */
 } BfhipHelm2Problem;
 
 typedef struct BfhipBuildStats {
@@ -126,6 +133,11 @@ int bfhipBuildHelm2(const BfhipDesc *desc, const BfhipHelm2Problem *prob, const 
  * quadtree permutation.  All returned pointers belong to the layout. */
 typedef struct BfhipHelm2Layout BfhipHelm2Layout;
 int bfhipHelm2LayoutCreate(const double *points, uint64_t numPoints, double wavenumber, BfhipHelm2Layout **out);
+/* src tree != tgt tree: rows follow the quadtree on tgtPoints, columns the one on points */
+int bfhipHelm2LayoutCreate2(const double *points, uint64_t numPoints, const double *tgtPoints, uint64_t numTgtPoints,
+                            double wavenumber, BfhipHelm2Layout **out);
+const uint64_t *bfhipHelm2LayoutGetTgtPerm(const BfhipHelm2Layout *layout);       /* NULL for a single tree */
+const double *bfhipHelm2LayoutGetTgtTreePoints(const BfhipHelm2Layout *layout);   /* NULL for a single tree */
 const BfhipDesc *bfhipHelm2LayoutGetDesc(const BfhipHelm2Layout *layout);
 const BfhipHelm2Recipe *bfhipHelm2LayoutGetRecipes(const BfhipHelm2Layout *layout, uint64_t *count);
 const uint64_t *bfhipHelm2LayoutGetPerm(const BfhipHelm2Layout *layout);        /* perm[t] = original index of tree position t */
@@ -142,6 +154,14 @@ int bfhipFacHelm2MakeMultilevel(const double *points, const double *normals, con
                                 const BfhipHelm2Problem *params, const BfhipOptions *opts, BfhipOperator **out, uint64_t *permOut,
                                 BfhipBuildStats *stats);
 
+/* The same with a separate target tree (srcTree != tgtTree): tgtPoints / tgtNormals (may be NULL unless
+ * S') in the caller's order; rows of the operator follow the target quadtree, tgtPermOut[t] (may be
+ * NULL) = original index of target position t.  tgtPoints == NULL: as above. */
+int bfhipFacHelm2MakeMultilevel2(const double *points, const double *normals, const double *colWeights, uint64_t numPoints,
+                                 const double *tgtPoints, const double *tgtNormals, uint64_t numTgtPoints,
+                                 const BfhipHelm2Problem *params, const BfhipOptions *opts, BfhipOperator **out, uint64_t *permOut,
+                                 uint64_t *tgtPermOut, BfhipBuildStats *stats);
+
 /* One leaf, computed on the device and returned to the host row-major
  * (rows x cols complex128) -- unit-level parity checks of the builder. */
 int bfhipHelm2BuildLeaf(const BfhipHelm2Problem *prob, uint64_t recipeIndex, int device, void *out);
@@ -150,7 +170,8 @@ int bfhipHelm2BuildLeaf(const BfhipHelm2Problem *prob, uint64_t recipeIndex, int
  * (never stored): the reference examples' acceptance check at sizes where
  * the dense matrix does not fit (examples/simple/bf_all_blocks.c:132-153).
  * Uses points, wavenumber, layerPot, normals, colWeights and selfValue of `prob`
- * (recipes are ignored).  dX, dY: device, numPoints complex128. */
+ * (recipes are ignored).  dX: device, numPoints complex128; dY: numTgtPoints if tgtPoints is
+ * given, else numPoints. */
 int bfhipHelm2DenseApplyDevice(const BfhipHelm2Problem *prob, int device, const void *dX, void *dY, void *stream);
 int bfhipHelm2DenseApply(const BfhipHelm2Problem *prob, int device, const void *X, void *Y);
 

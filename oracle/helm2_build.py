@@ -36,9 +36,11 @@ def sample_circle(cx, cy, r, count):
     return np.stack([r * np.cos(theta) + cx, r * np.sin(theta) + cy], axis=1)
 
 
-def resolve_points(spec, tree_points):
+def resolve_points(spec, tree_points, tgt_tree_points=None):
     if spec[0] == "node":
         return tree_points[spec[1]:spec[2]]
+    if spec[0] == "tnode":                      # a range of a separate target tree's points
+        return tgt_tree_points[spec[1]:spec[2]]
     if spec[0] == "circle":
         return sample_circle(spec[1], spec[2], spec[3], spec[4])
     raise ValueError(spec)
@@ -89,10 +91,10 @@ def resolve_normals(spec, normals):
     return np.stack([np.cos(theta), np.sin(theta)], axis=1)
 
 
-def layer_matrix(layer_pot, k, src_spec, tgt_spec, tree_points, normals, alpha=0.0, beta=0.0):
+def layer_matrix(layer_pot, k, src_spec, tgt_spec, tree_points, normals, alpha=0.0, beta=0.0, tgt_tree_points=None):
     """bfHelm2GetKernelMatrix (src/helm2.c:281-318) for S, D and the combined field alpha S + beta D
     (get_S_plus_D_kernel_matrix, :220-279)."""
-    src, tgt = resolve_points(src_spec, tree_points), resolve_points(tgt_spec, tree_points)
+    src, tgt = resolve_points(src_spec, tree_points), resolve_points(tgt_spec, tree_points, tgt_tree_points)
     if layer_pot == "S":
         return kernel_matrix(k, src, tgt)
     d = kernel_matrix_d(k, src, tgt, resolve_normals(src_spec, normals))
@@ -144,7 +146,7 @@ def kr_factors(order, orig_tgt, orig_src, n):
 
 
 def leaf_values(desc, k, tree_points, layer_pot="S", normals=None, col_weights=None, self_value=0.0, kr_order=0,
-                orig_index=None, alpha=0.0, beta=0.0):
+                orig_index=None, alpha=0.0, beta=0.0, tgt_tree_points=None, tgt_normals=None):
     """Evaluate every dense leaf's recipe -> {node: complex128 array}.
 
     layer_pot "Sp": kernel leaves (evaluation factor src/fac_helm2.c:403-509, dense near field
@@ -160,12 +162,13 @@ def leaf_values(desc, k, tree_points, layer_pot="S", normals=None, col_weights=N
     out = {}
     for node, rc in desc.recipe.items():
         if rc[0] == "kernel":
-            src, tgt = resolve_points(rc[1], tree_points), resolve_points(rc[2], tree_points)
+            src, tgt = resolve_points(rc[1], tree_points), resolve_points(rc[2], tree_points, tgt_tree_points)
             if layer_pot == "Sp":
-                assert rc[2][0] == "node"
-                z = kernel_matrix_sp(k, src, tgt, normals[rc[2][1]:rc[2][2]])
+                assert rc[2][0] in ("node", "tnode")
+                nt = normals if rc[2][0] == "node" else tgt_normals
+                z = kernel_matrix_sp(k, src, tgt, nt[rc[2][1]:rc[2][2]])
             else:
-                z = layer_matrix(layer_pot, k, rc[1], rc[2], tree_points, normals, alpha, beta)
+                z = layer_matrix(layer_pot, k, rc[1], rc[2], tree_points, normals, alpha, beta, tgt_tree_points)
             if kr_order and rc[1][0] == "node" and rc[2][0] == "node":
                 z = z * kr_factors(kr_order, orig_index[rc[2][1]:rc[2][2]], orig_index[rc[1][1]:rc[1][2]], len(tree_points))
             z = scaled(z, rc[1])
@@ -176,8 +179,8 @@ def leaf_values(desc, k, tree_points, layer_pot="S", normals=None, col_weights=N
         elif rc[0] == "reexp":
             # proxy potential: S for S and S', the potential itself for D and the combined field
             proxy = "S" if layer_pot in ("S", "Sp") else layer_pot
-            z_eq = layer_matrix(proxy, k, rc[2], rc[3], tree_points, normals, alpha, beta)
-            z_or = layer_matrix(proxy, k, rc[1], rc[3], tree_points, normals, alpha, beta)
+            z_eq = layer_matrix(proxy, k, rc[2], rc[3], tree_points, normals, alpha, beta, tgt_tree_points)
+            z_or = layer_matrix(proxy, k, rc[1], rc[3], tree_points, normals, alpha, beta, tgt_tree_points)
             z = lstsq_truncated(z_eq, scaled(z_or, rc[1]))
         else:
             raise ValueError(rc)

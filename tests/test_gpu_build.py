@@ -297,6 +297,14 @@ def test_points_to_operator_in_one_native_call():
     y_tree = op.apply_host(x[perm])
     assert rel(y_tree, (dense @ x)[perm]) <= 1e-8
     op.close()
+    # and the evaluation operator G_eval of helm2_bie.c:183 (boundary -> exterior targets, weights folded)
+    m = 1500
+    u = 2 * np.pi * np.arange(m) / m
+    tgt = 2.5 * np.stack([np.cos(u), np.sin(u)], axis=1)
+    ev, (ps, pt), st = HipOperator.fac_helm2_make_multilevel(pts, k, col_weights=w, tgt_points=tgt)
+    assert ev.shape == (m, n)
+    assert rel(ev.apply_host(x[ps]), ((hb.kernel_matrix(k, pts, tgt) * w[None, :]) @ x)[pt]) <= 1e-8
+    ev.close()
 
 
 @pytest.mark.parametrize("n,k", [(16384, 1024.0), (65536, 4096.0), (65536, 100.0)])
@@ -331,4 +339,41 @@ def test_reference_checksums_at_the_survey_sizes(n, k):
     # measured 8e-14, 7e-14, 9e-16: the device-built butterfly reproduces the reference's butterfly, its
     # truncation error included (at k = 100 the dense checksum is 1e-9 away, the butterfly's 9e-16)
     assert abs(got - want) / want <= 1e-12, (got, want)
+    op.close()
+
+
+@pytest.mark.parametrize("pot", ["S", "Sp"])
+def test_separate_target_tree_evaluation_operator(pot):
+    """srcTree != tgtTree (examples/multiple_scattering/multiple_scattering_context.c:998, and the
+    G_eval of examples/simple/helm2_bie.c:183): a rectangular butterfly from boundary sources to
+    off-boundary targets, laid out natively, built and applied on the device."""
+    import torch
+    from butterfly_amd import helm2_structure as hs
+    from butterfly_amd.operator import HipOperator, helm2_dense_apply
+    from oracle import bfref, helm2_build as hb
+    n, m, k = 5000, 3500, 90.0
+    t, u = 2 * np.pi * np.arange(n) / n, 2 * np.pi * np.arange(m) / m
+    src = np.stack([np.cos(t), 0.6 * np.sin(t)], axis=1)
+    tgt = np.stack([1.8 + 0.9 * np.cos(u), 0.4 + 0.7 * np.sin(u)], axis=1)
+    tnrm = np.stack([0.7 * np.cos(u), 0.9 * np.sin(u)], axis=1)
+    tnrm /= np.linalg.norm(tnrm, axis=1)[:, None]
+    w = (2 * np.pi / n) * np.hypot(np.sin(t), 0.6 * np.cos(t))
+    desc, (ps, pt) = hs.native_multilevel_structure(src, k, tgt)
+    sp, tp, wp, tn = src[ps], tgt[pt], w[ps], tnrm[pt]
+    deco = dict(layer_pot=pot, col_weights=wp, tgt_points=tp, tgt_normals=tn if pot == "Sp" else None,
+                normals=sp if pot == "Sp" else None)      # (source normals are not used by S'; any array passes the check)
+    op, st = HipOperator.build_helm2(desc, sp, k, **deco)
+    assert op.shape == (m, n) and st["notConverged"] == 0 and st["reexpLeaves"] > 0
+    x = hb.complex_randn(n, 0)
+    y = op.apply_host(x)
+    K = hb.kernel_matrix(k, sp, tp) if pot == "S" else hb.kernel_matrix_sp(k, sp, tp, tn)
+    want = (K * wp[None, :]) @ x
+    assert rel(y, want) <= 1e-9
+    assert rel(helm2_dense_apply(sp, k, x, **deco), want) <= 1e-13
+    assert rel(helm2_dense_apply(sp, k, torch.from_numpy(x).cuda(), **deco).cpu().numpy(), want) <= 1e-13
+    # the same operand through the Python layout + numpy/LAPACK values + the oracle apply
+    d_py, _, (ps2, pt2) = hs.helm2_multilevel_structure(src, k, recipes=True, tgt_points=tgt)
+    assert np.array_equal(ps2, ps) and np.array_equal(pt2, pt)
+    vals = hb.leaf_values(d_py, k, sp, layer_pot=pot, normals=sp, col_weights=wp, tgt_tree_points=tp, tgt_normals=tn)
+    assert rel(y, bfref.mat_mul(bfref.from_desc(d_py, vals), x)) <= 1e-10
     op.close()

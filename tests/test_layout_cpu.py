@@ -80,3 +80,25 @@ def test_array_backed_descriptor_shards_like_the_python_one():
             op.close()
         stats.append(row)
     assert stats[0] == stats[1]
+
+
+def test_two_tree_layout_equals_the_python_restatement():
+    """bfFacHelm2MakeMultilevel(helm, srcTree, tgtTree) with different trees (the evaluation butterfly of
+    examples/multiple_scattering): rows follow the target quadtree."""
+    n, m, k = 5000, 3500, 90.0
+    t, u = 2 * np.pi * np.arange(n) / n, 2 * np.pi * np.arange(m) / m
+    src = np.stack([np.cos(t), 0.6 * np.sin(t)], axis=1)
+    tgt = np.stack([1.8 + 0.9 * np.cos(u), 0.4 + 0.7 * np.sin(u)], axis=1)
+    desc, _, (ps, pt) = hs.helm2_multilevel_structure(src, k, recipes=True, tgt_points=tgt)
+    lay = _capi.Helm2Layout(src, k, tgt)
+    assert np.array_equal(lay.perm, ps) and np.array_equal(lay.tgt_perm, pt)
+    assert np.array_equal(lay.tree_points, src[ps]) and np.array_equal(lay.tgt_tree_points, tgt[pt])
+    want, got = desc.arrays(), lay.arrays()
+    for key in ("kind", "rows", "cols", "childBegin", "childNode", "childRow0", "childCol0", "blockKind"):
+        assert np.array_equal(got[key], want[key]), key
+    assert int(got["rows"][lay.root]) == m and int(got["cols"][lay.root]) == n and desc.meta["stats"]["products"]
+    ref = _capi.recipe_array(desc.recipe)
+    for ps_ in ("src", "equiv", "tgt"):
+        for f in ("kind", "count", "first", "cx", "cy", "r"):
+            assert np.array_equal(lay.recipes[ps_][f], ref[ps_][f]), (ps_, f)
+    assert set(np.unique(lay.recipes["tgt"]["kind"])) >= {_capi.PTS_TREE_TGT}
