@@ -377,3 +377,19 @@ def test_separate_target_tree_evaluation_operator(pot):
     vals = hb.leaf_values(d_py, k, sp, layer_pot=pot, normals=sp, col_weights=wp, tgt_tree_points=tp, tgt_normals=tn)
     assert rel(y, bfref.mat_mul(bfref.from_desc(d_py, vals), x)) <= 1e-10
     op.close()
+
+
+def test_plain_c_driver_against_the_shared_library(tmp_path):
+    """examples/helm2_bie_device.c: the reference's BIE driver written against include/bfhip*.h only,
+    compiled with gcc and linked to libbfhip.so -- the C-ABI used from C, no Python in the loop.  It
+    exits 0 iff the exterior field of the GMRES solution matches the point source to 1e-6."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(root, "butterfly_amd", "csrc")
+    exe = str(tmp_path / "helm2_bie_device")
+    subprocess.check_call(["gcc", "-O2", "-std=gnu11", "-Wall", "-Werror", "-I", os.path.join(root, "include"),
+                           os.path.join(root, "examples", "helm2_bie_device.c"), "-L", lib, "-lbfhip", "-lm", f"-Wl,-rpath,{lib}", "-o", exe])
+    p = subprocess.run([exe, "8192", "48"], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert "GMRES:" in p.stdout and "exterior field" in p.stdout
