@@ -47,7 +47,7 @@ def test_single_top_level_blocks_match_the_oracle(full):
     picks = [order[0], order[len(order) // 2], order[-1]]          # lightest, median, heaviest (r, c) block
     for i in picks:
         node, r0, c0 = desc.children[desc.root][i]
-        m, n = desc.rows[node], desc.cols[node]
+        m, n = int(desc.rows[node]), int(desc.cols[node])
         xc = (full["rng"].standard_normal(n) + 1j * full["rng"].standard_normal(n)) / np.sqrt(2)
         x = np.zeros(N, dtype=complex)
         x[c0:c0 + n] = xc
