@@ -1,0 +1,115 @@
+/* Host-side code of libbfhip (IR walker, planner, layout, plan inspection) under AddressSanitizer /
+ * UBSan, without a GPU: the device layer is replaced by stubs that fail, and only paths that never
+ * reach it are driven (BFHIP_FLAG_PLAN_ONLY).  Built and run by tests/test_host_asan.py. */
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "bfhip_build.h"
+
+#define CHECK(c) do { int rc_ = (c); if (rc_) { fprintf(stderr, "%s -> %d (%s)\n", #c, rc_, bfhipLastErrorMessage()); return 1; } } while (0)
+
+static int drive(double const *pts, uint64_t n, double const *tgt, uint64_t m, double k) {
+  BfhipHelm2Layout *lay = NULL;
+  CHECK(bfhipHelm2LayoutCreate2(pts, n, tgt, m, k, &lay));
+  BfhipDesc const *d = bfhipHelm2LayoutGetDesc(lay);
+  uint64_t nrec = 0;
+  BfhipHelm2Recipe const *rec = bfhipHelm2LayoutGetRecipes(lay, &nrec);
+  if (!d || !rec || !nrec || !bfhipHelm2LayoutGetPerm(lay) || !bfhipHelm2LayoutGetTreePoints(lay)) return 2;
+  for (unsigned flags = BFHIP_FLAG_PLAN_ONLY; flags <= (BFHIP_FLAG_PLAN_ONLY | BFHIP_FLAG_ADJOINT); flags += BFHIP_FLAG_ADJOINT) {
+    for (unsigned maxRhs = 1; maxRhs <= 64; maxRhs += 63) {
+      BfhipOptions o;
+      memset(&o, 0, sizeof o);
+      o.structSize = sizeof o; o.device = -1; o.flags = flags; o.maxRhs = maxRhs;
+      BfhipOperator *op = NULL;
+      CHECK(bfhipCompileDesc(d, &o, &op));
+      BfhipPlanInfo info;
+      memset(&info, 0, sizeof info);
+      info.structSize = sizeof info;
+      CHECK(bfhipPlanGetInfo(op, &info));
+      uint64_t const stages = info.numStages + info.numStagesT;
+      uint64_t items = 0;
+      for (uint64_t s = 0; s < stages; ++s) {
+        BfhipStageView v;
+        memset(&v, 0, sizeof v);
+        v.structSize = sizeof v;
+        CHECK(bfhipPlanGetStage(op, s, &v));
+        items += v.numItems;
+        for (uint64_t r = 0; r < v.numReduce; ++r) {
+          BfhipReduceView rv;
+          memset(&rv, 0, sizeof rv);
+          rv.structSize = sizeof rv;
+          CHECK(bfhipPlanGetReduce(op, s, r, &rv));
+        }
+      }
+      BfhipStats st;
+      memset(&st, 0, sizeof st);
+      st.structSize = sizeof st;
+      CHECK(bfhipGetStats(op, &st));
+      if (!items || st.numRows != (m ? m : n) || st.numCols != n) return 3;
+      /* a row shard through the options (square operators only carry topRowBlock for it) */
+      bfhipFree(&op);
+      if (!m) {
+        o.rowBlockBegin = 1; o.rowBlockEnd = 3; o.flags = BFHIP_FLAG_PLAN_ONLY;
+        CHECK(bfhipCompileDesc(d, &o, &op));
+        bfhipFree(&op);
+      }
+    }
+  }
+  bfhipHelm2LayoutFree(&lay);
+  return 0;
+}
+
+int main(void) {
+  uint64_t const n = 6000, m = 2500;
+  double *pts = malloc(n * 16), *tgt = malloc(m * 16), *rnd = malloc(3000 * 16);
+  for (uint64_t i = 0; i < n; ++i) { double t = 2 * M_PI * i / n; pts[2 * i] = cos(t); pts[2 * i + 1] = 0.4 * sin(t); }
+  for (uint64_t i = 0; i < m; ++i) { double t = 2 * M_PI * i / m; tgt[2 * i] = 1.9 + 0.8 * cos(t); tgt[2 * i + 1] = 0.3 + 0.6 * sin(t); }
+  unsigned long long s = 88172645463325252ull;
+  for (uint64_t i = 0; i < 6000; ++i) { s ^= s << 13; s ^= s >> 7; s ^= s << 17; rnd[i] = (double)(s >> 11) / 9007199254740992.0; }
+  int rc = drive(pts, n, NULL, 0, 150.0);
+  if (!rc) rc = drive(pts, n, tgt, m, 90.0);
+  if (!rc) rc = drive(rnd, 3000, NULL, 0, 60.0);
+  /* error paths */
+  BfhipHelm2Layout *lay = NULL;
+  double zeros[16] = {0};
+  if (!rc && bfhipHelm2LayoutCreate(zeros, 8, 1.0, &lay) == 0) rc = 4;
+  if (!rc && bfhipHelm2LayoutCreate(pts, 1, 1.0, &lay) == 0) rc = 5;
+  free(pts); free(tgt); free(rnd);
+  printf(rc ? "FAILED %d\n" : "host code clean\n", rc);
+  return rc;
+}
+
+/* ---- device layer stand-ins: plan-only paths must never reach them ------------------------------- */
+#define STUB(name) int name() { fprintf(stderr, "device layer reached: %s\n", #name); abort(); }
+/* releasing nothing is fine (bfhipFree on a plan-only operator); releasing something is not */
+void bfdevFree(void *p) { if (p) { fprintf(stderr, "device layer reached: bfdevFree(non-NULL)\n"); abort(); } }
+void bfdevEventDestroy(void *e) { if (e) { fprintf(stderr, "device layer reached: bfdevEventDestroy(non-NULL)\n"); abort(); } }
+STUB(bfdevBuildEval)
+STUB(bfdevBuildGemm)
+STUB(bfdevBuildJacobi)
+STUB(bfdevBuildPack)
+STUB(bfdevEventCreate)
+STUB(bfdevEventElapsed)
+STUB(bfdevEventRecord)
+STUB(bfdevGetDevice)
+STUB(bfdevGmresDot)
+STUB(bfdevGmresFinish)
+STUB(bfdevGmresMgsStep)
+STUB(bfdevGmresResidual)
+STUB(bfdevGmresUpdate)
+STUB(bfdevHelm2Dense)
+STUB(bfdevLaunchReduce)
+STUB(bfdevLaunchStage)
+STUB(bfdevMalloc)
+STUB(bfdevMemFree)
+STUB(bfdevMemcpyD2DAsync)
+STUB(bfdevMemcpyD2H)
+STUB(bfdevMemcpyD2HAsync)
+STUB(bfdevMemcpyH2D)
+STUB(bfdevMemcpyH2DAsync)
+STUB(bfdevMemset)
+STUB(bfdevSetDevice)
+STUB(bfdevSync)
+STUB(bfdevSynthFill)
