@@ -7,6 +7,7 @@
 #include <string.h>
 
 #include "bfhip_build.h"
+#include "../../oracle/bfref.h"      /* byte-compatible BfMat graphs for the graph walker (bfhipCompile) */
 
 #define CHECK(c) do { int rc_ = (c); if (rc_) { fprintf(stderr, "%s -> %d (%s)\n", #c, rc_, bfhipLastErrorMessage()); return 1; } } while (0)
 
@@ -61,6 +62,58 @@ static int drive(double const *pts, uint64_t n, double const *tgt, uint64_t m, d
   return 0;
 }
 
+/* a small reference-style object graph with every node type the walker accepts */
+static double *randv(size_t count) {
+  double *v = malloc(count * sizeof *v);
+  for (size_t i = 0; i < count; ++i) v[i] = (double)rand() / RAND_MAX - 0.5;
+  return v;
+}
+static BfMat *dense(size_t m, size_t n) { return bfMatDenseComplexNewFromPtr(m, n, randv(2 * m * n), 2); }
+
+static int driveGraph(void) {
+  BfMat *d1[2] = {dense(5, 7), dense(6, 4)};
+  BfMat *f1 = bfMatBlockDiagNewFromBlocks(2, d1);                                   /* 11 x 11 */
+  size_t const ro[3] = {0, 4, 9}, co[3] = {0, 5, 11}, ri[3] = {0, 1, 1}, ci[3] = {0, 0, 1};
+  BfMat *c0[3] = {dense(4, 5), dense(5, 5), dense(5, 6)};
+  BfMat *f0 = bfMatBlockCooNewFromArrays(2, 2, 3, ro, co, ri, ci, c0);              /* 9 x 11 */
+  BfMat *fs[2] = {f0, f1};
+  BfMat *prod = bfMatProductNewFromFactors(2, fs);                                  /* 9 x 11 */
+  size_t const cr[2] = {0, 3}, cc[2] = {1, 5};
+  double const cv[4] = {0.5, -1.0, 2.0, 0.25};
+  BfMat *terms[2] = {dense(6, 6), bfMatCooComplexNewFromArrays(6, 6, 2, cr, cc, cv)};
+  BfMat *sum = bfMatSumNewFromTerms(2, terms);
+  BfMat *grid[4] = {prod, dense(9, 6), dense(6, 11), sum};
+  size_t const gro[3] = {0, 9, 15}, gco[3] = {0, 11, 17};
+  BfMat *A = bfMatBlockDenseNewFromBlocks(2, 2, gro, gco, grid);                    /* 15 x 17 */
+  if (!A) return 10;
+  for (unsigned flags = BFHIP_FLAG_PLAN_ONLY; flags <= (BFHIP_FLAG_PLAN_ONLY | BFHIP_FLAG_ADJOINT); flags += BFHIP_FLAG_ADJOINT) {
+    BfhipOptions o;
+    memset(&o, 0, sizeof o);
+    o.structSize = sizeof o; o.device = -1; o.flags = flags; o.maxRhs = 3;
+    BfhipOperator *op = NULL;
+    CHECK(bfhipCompile(A, &o, &op));
+    if (bfhipGetNumRows(op) != 15 || bfhipGetNumCols(op) != 17) return 11;
+    double *packed = malloc(bfhipNumBytes(op) * 4 + 4096);
+    BfhipPlanInfo info;
+    memset(&info, 0, sizeof info);
+    info.structSize = sizeof info;
+    CHECK(bfhipPlanGetInfo(op, &info));
+    free(packed);
+    packed = malloc((size_t)info.arenaElems * 16 + 16);
+    CHECK(bfhipPlanPackArena(op, packed));
+    free(packed);
+    bfhipFree(&op);
+  }
+  /* refusals: NULL graph, a node with a NULL vtable */
+  BfhipOperator *op = NULL;
+  if (bfhipCompile(NULL, NULL, &op) == 0) return 12;
+  BfAbiMat bogus;
+  memset(&bogus, 0, sizeof bogus);
+  if (bfhipCompile(&bogus, NULL, &op) == 0) return 13;
+  bfMatDelete(&A);
+  return 0;
+}
+
 int main(void) {
   uint64_t const n = 6000, m = 2500;
   double *pts = malloc(n * 16), *tgt = malloc(m * 16), *rnd = malloc(3000 * 16);
@@ -71,6 +124,7 @@ int main(void) {
   int rc = drive(pts, n, NULL, 0, 150.0);
   if (!rc) rc = drive(pts, n, tgt, m, 90.0);
   if (!rc) rc = drive(rnd, 3000, NULL, 0, 60.0);
+  if (!rc) rc = driveGraph();
   /* error paths */
   BfhipHelm2Layout *lay = NULL;
   double zeros[16] = {0};

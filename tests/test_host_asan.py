@@ -1,4 +1,4 @@
-"""The host C code of libbfhip (BfhipDesc walker, planner incl. the transposed plan and row shards,
+"""The host C code of libbfhip (BfMat graph walker on oracle-built graphs, BfhipDesc walker, planner incl. the transposed plan and row shards,
 native layout incl. two trees, plan inspection, error paths) under AddressSanitizer + UBSan +
 LeakSanitizer, on the CPU: tests/native/asan_host.c replaces the device layer by stubs that abort,
 so the run also proves that plan-only paths never touch a device."""
@@ -16,7 +16,8 @@ def test_host_code_is_clean_under_sanitizers(tmp_path):
     exe = str(tmp_path / "asan_host")
     cmd = ["gcc", "-std=gnu11", "-g", "-O1", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
            "-fno-omit-frame-pointer", "-I", os.path.join(ROOT, "include"), "-I", SRC,
-           os.path.join(ROOT, "tests", "native", "asan_host.c")] + [os.path.join(SRC, f) for f in HOST] + ["-lm", "-o", exe]
+           os.path.join(ROOT, "tests", "native", "asan_host.c"), os.path.join(ROOT, "oracle", "bfref.c")] + \
+          [os.path.join(SRC, f) for f in HOST] + ["-lm", "-ldl", "-o", exe]
     b = subprocess.run(cmd, capture_output=True, text=True)
     if b.returncode != 0 and ("asan" in b.stderr.lower() or "sanitize" in b.stderr.lower()):
         pytest.skip("no sanitizer runtime for gcc here")
