@@ -150,3 +150,86 @@ class ShardedApply:
         dst = torch.view_as_real(self.gathered) if self.gathered.is_complex() else self.gathered
         dist.all_gather_into_tensor(dst, src, group=self.group)
         return self.gathered.index_select(0, self.index)
+
+
+# --------------------------------------------------------------------------
+# GMRES over a sharded apply ("with multi-GPU the
+# allgathered iterate is already replicated")
+# --------------------------------------------------------------------------
+def _givens(a, b):
+    """bfVecComplexGetGivensRotation, reference src/vec_complex.c:275-286."""
+    if abs(b) == 0:
+        return 1.0 + 0j, 0.0 + 0j
+    if abs(b) > abs(a):
+        tmp = -a / b
+        sn = 1 / (1 + abs(tmp) ** 2) ** 0.5
+        return tmp * sn, sn + 0j
+    tmp = -b / a
+    cs = 1 / (1 + abs(tmp) ** 2) ** 0.5
+    return cs + 0j, tmp * cs
+
+
+def _rot(col, i, c, s):
+    """mulInplace_givensComplex, src/vec_complex.c:155-168, on entries (i, i + 1) of a Python list."""
+    z0, z1 = col[i], col[i + 1]
+    col[i], col[i + 1] = c.conjugate() * z0 - s * z1, s * z0 + c * z1
+
+
+def sharded_solve_gmres(step, b, x0=None, tol=1e-12, max_num_iter=100):
+    """bfSolveGMRES (reference src/linalg.c:47-317) with the matvec spread over the ranks of a
+    process group: `step(x)` is a ShardedApply (or any callable) returning the FULL product on
+    every rank.  All vectors are replicated -- the apply's closing collective already hands every
+    rank the whole iterate -- so the Krylov recurrences run redundantly and identically on each
+    GPU (O(j N) per iteration, nothing next to the apply) and the only communication of an iteration
+    is the apply's one collective.  Same algorithm and quirks as the single-GPU bfhipSolveGMRES
+    (unrestarted, modified Gram-Schmidt, residual = max_p |s_{j+1,p}| / max_p ||r_p||, a converged
+    solve uses j basis vectors).  b: [n] or [n, nrhs] complex tensor on the apply's device.
+    Returns (x, num_iter, residual)."""
+    import torch
+    one_d = b.dim() == 1
+    B = b[:, None] if one_d else b
+    n, nrhs = B.shape
+    call = (lambda v: step(v[:, 0].contiguous())[:, None]) if one_d else (lambda v: step(v.contiguous()))
+    X0 = torch.zeros_like(B) if x0 is None else (x0[:, None] if one_d else x0)
+    # `step` may return its own reused buffer: clone what is kept
+    R = B - call(X0)
+    rnorm = torch.linalg.vector_norm(R, dim=0)
+    beta = float(rnorm.max())
+    V = [R / rnorm]
+    S = [[complex(rnorm[p]) if i == 0 else 0j for i in range(max_num_iter + 1)] for p in range(nrhs)]
+    H, J = [], {}
+    residual, converged, j = float("inf"), False, 0
+    for j in range(max_num_iter):
+        W = call(V[j]).clone()
+        Hj = [[0j] * (j + 2) for _ in range(nrhs)]
+        for i in range(j + 1):                       # modified Gram-Schmidt, src/linalg.c:174-184
+            hij = torch.sum(V[i].conj() * W, dim=0)
+            W -= V[i] * hij
+            for p, v in enumerate(hij.tolist()):
+                Hj[p][i] = complex(v)
+        wnorm = torch.linalg.vector_norm(W, dim=0)
+        V.append(W / wnorm)
+        for p in range(nrhs):
+            col = Hj[p]
+            col[j + 1] = complex(float(wnorm[p]))
+            for i in range(j):                       # earlier rotations, then the new one (:206-228)
+                _rot(col, i, *J[(i, p)])
+            J[(j, p)] = _givens(col[j], col[j + 1])
+            _rot(col, j, *J[(j, p)])
+            _rot(S[p], j, *J[(j, p)])
+        H.append(Hj)
+        residual = max(abs(S[p][j + 1]) for p in range(nrhs)) / beta
+        if residual < tol:                           # :235-241: breaks before j is incremented
+            converged = True
+            break
+    if not converged:
+        j = max_num_iter
+    X = X0.clone()
+    for p in range(nrhs):                            # back substitution and update (:245-285)
+        y = [0j] * j
+        for r in range(j - 1, -1, -1):
+            acc = S[p][r] - sum(H[c][p][r] * y[c] for c in range(r + 1, j))
+            y[r] = acc / H[r][p][r]
+        for i in range(j):
+            X[:, p] += V[i][:, p] * y[i]
+    return (X[:, 0] if one_d else X), j, residual

@@ -83,3 +83,21 @@ def test_device_gmres_on_resident_tensors(system):
         op.solve_gmres(b[:, 0], max_num_iter=0)
     assert e.value.code == 1
     op.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nrhs", [1, 2])
+def test_replicated_vector_gmres_matches_the_device_solver(system, nrhs):
+    """dist.sharded_solve_gmres (what a multi-GPU solve runs on every rank around the sharded apply),
+    here with world size 1 on the GPU: same iteration count and solution as bfhipSolveGMRESDevice."""
+    import torch
+    from butterfly_amd.dist import sharded_solve_gmres
+    from butterfly_amd.operator import HipOperator
+    desc, root, vals, dense, A, b = system
+    op = HipOperator.from_desc(desc, vals, root=root, max_rhs=nrhs)
+    bd = torch.from_numpy(np.ascontiguousarray(b[:, 0] if nrhs == 1 else b)).cuda()
+    x_dev, it_dev, res_dev = op.solve_gmres_device(bd, tol=1e-10, max_num_iter=80)
+    x, it, res = sharded_solve_gmres(lambda v: op.apply_device(v), bd, tol=1e-10, max_num_iter=80)
+    assert it == it_dev and abs(res - res_dev) <= 1e-6 * res_dev + 1e-16
+    assert rel(x.cpu().numpy(), x_dev.cpu().numpy()) < 1e-10
+    op.close()
