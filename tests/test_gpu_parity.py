@@ -385,3 +385,31 @@ def test_save_load_round_trip(tmp_path, helm2_cases):
     with pytest.raises(_capi.BfhipError) as e:
         HipOperator.load(trunc)
     assert e.value.code == 6
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_deeply_nested_real_graphs_forward_and_transposed(seed):
+    """The survey's fac_streamer sample nests all three block types and Identity leaves up to 9 deep
+    (SURVEY.md section 8(c)): graphs of depth 9 through the BfMat walker, f64 and f32, A x and A^T x."""
+    import randgraph
+    from butterfly_amd import _capi
+    from butterfly_amd.operator import HipOperator
+    from oracle import bfref
+    rng = np.random.default_rng(7000 + seed)
+    for _ in range(50):                                          # draw until the graph is a real zoo
+        desc, vals = randgraph.random_real_operand(rng, depth=9, size_hint=700)
+        kinds = np.asarray(desc.kind)
+        if (kinds == 1).sum() >= 2 and (kinds == 3).sum() >= 3 and len(kinds) > 80:
+            break
+    assert (kinds == 1).sum() >= 2 and len(kinds) > 80          # Identity leaves inside a deep nest
+    m, n = desc.rows[desc.root], desc.cols[desc.root]
+    x, w = rng.standard_normal(n), rng.standard_normal(m)
+    A = bfref.from_desc(desc, vals)
+    want, want_t = bfref.mat_mul_vec(A, x), bfref.mat_rmul_vec(A, w)
+    op = HipOperator.from_bfmat(A.ptr.value, flags=_capi.FLAG_ADJOINT)
+    assert rel(op.apply_host(x) + 1, want + 1) <= TOL
+    assert rel(op.apply_transpose_host(w) + 1, want_t + 1) <= TOL
+    op.close()
+    op32 = HipOperator.from_bfmat(A.ptr.value, demote_to_f32=True)
+    assert rel(op32.apply_host(x) + 1, want + 1) <= 2e-5
+    op32.close()
