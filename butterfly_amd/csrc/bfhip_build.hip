@@ -22,6 +22,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "bfhip_internal.h"
 #include "../../include/bfhip_abi.h"
@@ -243,6 +244,80 @@ __device__ __forceinline__ void bfRoundRobin(uint32_t M, uint32_t s, uint32_t kk
   if (p > q) { uint32_t const t = p; p = q; q = t; }
 }
 
+// singular values, the reference's truncation rule (src/mat_dense_complex.c:1800-1812) and the
+// statistics, once the columns of A are orthogonal
+template <int W>
+__device__ void bfJacobiFinish(BfSvdProb const &P, BfSvdStats *stats, int sweep, bool converged, double *sigMaxShared) {
+  uint32_t const mt = P.mt, me = P.me;
+  double2 const *A = (double2 const *)P.a;
+  uint32_t const nthreads = blockDim.x, tid = threadIdx.x;
+  uint32_t const groups = nthreads / W, g = tid / W, l = tid % W;
+  for (uint32_t j = g; j < me; j += groups) {
+    double2 const *aj = A + (uint64_t)j * mt;
+    double s2 = 0;
+    for (uint32_t r = l; r < mt; r += W) { double2 const a = aj[r]; s2 = fma(a.x, a.x, fma(a.y, a.y, s2)); }
+    s2 = bfGroupSum<W>(s2);
+    if (l == 0) P.scale[j] = s2;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    double mx = 0;
+    for (uint32_t j = 0; j < me; ++j) mx = fmax(mx, P.scale[j]);
+    *sigMaxShared = sqrt(mx);
+  }
+  __syncthreads();
+  double const eps = 2.220446049250313e-16;
+  double const tol = (double)(mt > me ? mt : me) * eps * *sigMaxShared + eps;
+  unsigned long long dropped = 0;
+  for (uint32_t j = tid; j < me; j += nthreads) {
+    double const s2 = P.scale[j];
+    bool const keep = sqrt(s2) >= tol;
+    P.scale[j] = keep ? 1.0 / s2 : 0.0;
+    dropped += keep ? 0 : 1;
+  }
+  // statistics only (not part of any result)
+  if (dropped) atomicAdd(&stats->truncated, dropped);
+  if (tid == 0) {
+    atomicMax(&stats->maxSweeps, (unsigned long long)(sweep + (converged ? 1 : 0)));
+    atomicAdd(&stats->sumSweeps, (unsigned long long)(sweep + (converged ? 1 : 0)));
+    if (!converged) atomicAdd(&stats->notConverged, 1ull);
+  }
+}
+
+// largest squared column norm of A (a lower bound of sigma_max^2), order-independent
+template <int W>
+__device__ double bfJacobiMaxNorm2(BfSvdProb const &P, unsigned long long *maxBitsShared) {
+  uint32_t const mt = P.mt, me = P.me;
+  double2 const *A = (double2 const *)P.a;
+  uint32_t const nthreads = blockDim.x, tid = threadIdx.x;
+  uint32_t const groups = nthreads / W, g = tid / W, l = tid % W;
+  if (tid == 0) *maxBitsShared = 0;
+  __syncthreads();
+  for (uint32_t j = g; j < me; j += groups) {
+    double2 const *aj = A + (uint64_t)j * mt;
+    double s2 = 0;
+    for (uint32_t r = l; r < mt; r += W) { double2 const a = aj[r]; s2 = fma(a.x, a.x, fma(a.y, a.y, s2)); }
+    s2 = bfGroupSum<W>(s2);
+    if (l == 0) atomicMax(maxBitsShared, (unsigned long long)__double_as_longlong(s2));
+  }
+  __syncthreads();
+  return __longlong_as_double((long long)*maxBitsShared);
+}
+
+// rotation of a column pair from its inner products (alpha, beta, gamma); false: below the threshold
+__device__ __forceinline__ bool bfJacobiAngle(double alpha, double beta, double gr, double gi, double tol2, double dead2,
+                                               double &c, double &sn, double &er, double &ei) {
+  double const g2 = gr * gr + gi * gi;
+  if (alpha < dead2 || beta < dead2) return false;
+  if (!(g2 > tol2 * alpha * beta) || g2 == 0.0) return false;
+  double const gabs = sqrt(g2);
+  double const zeta = (beta - alpha) / (2.0 * gabs);
+  double const t = copysign(1.0, zeta) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+  c = 1.0 / sqrt(1.0 + t * t); sn = c * t;
+  er = gr / gabs; ei = -gi / gabs;                // e^{-i phi}
+  return true;
+}
+
 template <int W>
 __global__ __launch_bounds__(1024) void bfJacobiKernel(BfSvdProb const *probs, uint32_t const *list, BfSvdStats *stats, uint32_t ldsBytes) {
   extern __shared__ __attribute__((aligned(16))) unsigned char bfJacobiLds[];
@@ -295,18 +370,8 @@ __global__ __launch_bounds__(1024) void bfJacobiKernel(BfSvdProb const *probs, u
   // Columns below the truncation threshold (relative to the largest column norm, a lower bound of
   // sigma_max) are never rotated: they will be dropped, and what they carry is below the rounding
   // error of the matrix.  Left alone they would keep the sweeps busy orthogonalising noise.
-  if (tid == 0) maxNormBits = 0;
-  __syncthreads();
-  for (uint32_t j = g; j < me; j += groups) {
-    double2 const *aj = A + (uint64_t)j * mt;
-    double s2 = 0;
-    for (uint32_t r = l; r < mt; r += W) { double2 const a = aj[r]; s2 = fma(a.x, a.x, fma(a.y, a.y, s2)); }
-    s2 = bfGroupSum<W>(s2);
-    if (l == 0) atomicMax(&maxNormBits, (unsigned long long)__double_as_longlong(s2));   // order-independent
-  }
-  __syncthreads();
   double const deadRel = (double)(mt > me ? mt : me) * 2.220446049250313e-16;
-  double const dead2 = deadRel * deadRel * __longlong_as_double((long long)maxNormBits);
+  double const dead2 = deadRel * deadRel * bfJacobiMaxNorm2<W>(P, &maxNormBits);
   if (resident) loadPair(0, 1, true);
   else {
     for (uint64_t e = tid; e < (uint64_t)me * me; e += nthreads) V[e] = make_double2((e % me == e / me) ? 1.0 : 0.0, 0.0);
@@ -340,14 +405,8 @@ __global__ __launch_bounds__(1024) void bfJacobiKernel(BfSvdProb const *probs, u
             }
             alpha = bfGroupSum<W>(alpha); beta = bfGroupSum<W>(beta);
             gr = bfGroupSum<W>(gr); gi = bfGroupSum<W>(gi);
-            double const g2 = gr * gr + gi * gi;
-            if (alpha < dead2 || beta < dead2) continue;
-            if (!(g2 > tol2 * alpha * beta) || g2 == 0.0) continue;
-            double const gabs = sqrt(g2);
-            double const zeta = (beta - alpha) / (2.0 * gabs);
-            double const t = copysign(1.0, zeta) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-            double const c = 1.0 / sqrt(1.0 + t * t), sn = c * t;
-            double const er = gr / gabs, ei = -gi / gabs;    // e^{-i phi}
+            double c, sn, er, ei;
+            if (!bfJacobiAngle(alpha, beta, gr, gi, tol2, dead2, c, sn, er, ei)) continue;
             for (uint32_t r = l; r < R; r += W) {
               double2 const x = sp[r], y = sq[r];
               double2 const yt = make_double2(er * y.x - ei * y.y, er * y.y + ei * y.x);
@@ -367,37 +426,68 @@ __global__ __launch_bounds__(1024) void bfJacobiKernel(BfSvdProb const *probs, u
   }
   if (resident) storePair(0, 1);
   __syncthreads();
-  // singular values and the reference's truncation rule (src/mat_dense_complex.c:1800-1812)
-  for (uint32_t j = g; j < me; j += groups) {
-    double2 const *aj = A + (uint64_t)j * mt;
-    double s2 = 0;
-    for (uint32_t r = l; r < mt; r += W) { double2 const a = aj[r]; s2 = fma(a.x, a.x, fma(a.y, a.y, s2)); }
-    s2 = bfGroupSum<W>(s2);
-    if (l == 0) P.scale[j] = s2;
-  }
+  bfJacobiFinish<W>(P, stats, sweep, converged, &sigMax);
+}
+
+// Fallback for problems whose stacked column pair does not fit the LDS tile (check points +
+// equivalent sources > ~4600): the same sweeps straight out of global memory, one column pair per
+// 64-lane group of a 1024-thread workgroup.  Slow (every rotation streams its columns), but total.
+__global__ __launch_bounds__(1024) void bfJacobiGlobalKernel(BfSvdProb const *probs, uint32_t const *list, BfSvdStats *stats) {
+  constexpr int W = 64;
+  __shared__ int rotated;
+  __shared__ double sigMax;
+  __shared__ unsigned long long maxNormBits;
+  BfSvdProb const P = probs[list[blockIdx.x]];
+  uint32_t const mt = P.mt, me = P.me;
+  double2 *A = (double2 *)P.a, *V = (double2 *)P.v;
+  uint32_t const nthreads = blockDim.x, tid = threadIdx.x;
+  uint32_t const groups = nthreads / W, g = tid / W, l = tid % W;
+  double const tol2 = (double)mt * 2.220446049250313e-16 * 2.220446049250313e-16;
+  double const deadRel = (double)(mt > me ? mt : me) * 2.220446049250313e-16;
+  double const dead2 = deadRel * deadRel * bfJacobiMaxNorm2<W>(P, &maxNormBits);
+  for (uint64_t e = tid; e < (uint64_t)me * me; e += nthreads) V[e] = make_double2((e % me == e / me) ? 1.0 : 0.0, 0.0);
+  uint32_t const M = me + (me & 1u);
+  int sweep = 0;
+  bool converged = false;
   __syncthreads();
-  if (tid == 0) {
-    double mx = 0;
-    for (uint32_t j = 0; j < me; ++j) mx = fmax(mx, P.scale[j]);
-    sigMax = sqrt(mx);
+  for (; sweep < BF_JACOBI_MAX_SWEEPS; ++sweep) {
+    if (tid == 0) rotated = 0;
+    __syncthreads();
+    for (uint32_t s = 0; s + 1 < M; ++s) {
+      for (uint32_t kk = g; kk < M / 2; kk += groups) {
+        uint32_t p, q;
+        bfRoundRobin(M, s, kk, p, q);
+        if (q >= me) continue;                       // the dummy column of an odd me
+        double2 *ap = A + (uint64_t)p * mt, *aq = A + (uint64_t)q * mt;
+        double alpha = 0, beta = 0, gr = 0, gi = 0;
+        for (uint32_t r = l; r < mt; r += W) {
+          double2 const x = ap[r], y = aq[r];
+          alpha = fma(x.x, x.x, fma(x.y, x.y, alpha));
+          beta = fma(y.x, y.x, fma(y.y, y.y, beta));
+          gr = fma(x.x, y.x, fma(x.y, y.y, gr));
+          gi = fma(x.x, y.y, fma(-x.y, y.x, gi));
+        }
+        alpha = bfGroupSum<W>(alpha); beta = bfGroupSum<W>(beta);
+        gr = bfGroupSum<W>(gr); gi = bfGroupSum<W>(gi);
+        double c, sn, er, ei;
+        if (!bfJacobiAngle(alpha, beta, gr, gi, tol2, dead2, c, sn, er, ei)) continue;
+        double2 *vp = V + (uint64_t)p * me, *vq = V + (uint64_t)q * me;
+        for (uint32_t r = l; r < mt + me; r += W) {
+          double2 *xp = r < mt ? ap + r : vp + (r - mt), *yp = r < mt ? aq + r : vq + (r - mt);
+          double2 const x = *xp, y = *yp;
+          double2 const yt = make_double2(er * y.x - ei * y.y, er * y.y + ei * y.x);
+          *xp = make_double2(c * x.x - sn * yt.x, c * x.y - sn * yt.y);
+          *yp = make_double2(sn * x.x + c * yt.x, sn * x.y + c * yt.y);
+        }
+        if (l == 0) rotated = 1;
+      }
+      __syncthreads();
+    }
+    converged = rotated == 0;
+    __syncthreads();
+    if (converged) break;
   }
-  __syncthreads();
-  double const eps = 2.220446049250313e-16;
-  double const tol = (double)(mt > me ? mt : me) * eps * sigMax + eps;
-  unsigned long long dropped = 0;
-  for (uint32_t j = tid; j < me; j += nthreads) {
-    double const s2 = P.scale[j];
-    bool const keep = sqrt(s2) >= tol;
-    P.scale[j] = keep ? 1.0 / s2 : 0.0;
-    dropped += keep ? 0 : 1;
-  }
-  // statistics only (not part of any result)
-  if (dropped) atomicAdd(&stats->truncated, dropped);
-  if (tid == 0) {
-    atomicMax(&stats->maxSweeps, (unsigned long long)(sweep + (converged ? 1 : 0)));
-    atomicAdd(&stats->sumSweeps, (unsigned long long)(sweep + (converged ? 1 : 0)));
-    if (!converged) atomicAdd(&stats->notConverged, 1ull);
-  }
+  bfJacobiFinish<W>(P, stats, sweep, converged, &sigMax);
 }
 
 // Launch classes.  Workgroup: 256 threads for <= 64 columns, 1024 above.  LDS: the smallest of
@@ -406,10 +496,9 @@ __global__ __launch_bounds__(1024) void bfJacobiKernel(BfSvdProb const *probs, u
 // gives each of the b column pairs of an inner step its own group, at most the column length.
 static uint32_t const kJacobiLds[4] = {16u << 10, 32u << 10, 64u << 10, BF_JACOBI_LDS_MAX};
 
-static int jacobiClass(BfSvdProb const *p, int *wlog, int *big, int *ldsClass) {
+static int jacobiClass(BfSvdProb const *p, int forceGlobal, int *wlog, int *big, int *ldsClass) {
   uint64_t const R = (uint64_t)p->mt + p->me, Rp = R | 1u;
-  if (2 * Rp * 16 > BF_JACOBI_LDS_MAX)
-    return bfhipFail(BFABI_ERROR_NOT_IMPLEMENTED, "least-squares problem with %u + %u rows does not fit the LDS tile", p->mt, p->me);
+  if (2 * Rp * 16 > BF_JACOBI_LDS_MAX || forceGlobal) { *ldsClass = -1; *big = 1; *wlog = 4; return 0; }   /* global-memory fallback */
   uint64_t const meEven = p->me + (p->me & 1u);
   int lc = 3;
   for (int c = 0; c < 3; ++c)
@@ -443,9 +532,17 @@ int bfdevBuildJacobi(BfSvdProb const *hostProbs, uint64_t numProbs, BfSvdStats *
   uint64_t counts[NCLS] = {0};
   uint8_t *cls = (uint8_t *)malloc(numProbs);
   int rc = cls ? 0 : bfhipFail(BFABI_ERROR_MEMORY_ERROR, "host OOM");
+  // BFHIP_JACOBI_GLOBAL=1 sends every problem through the fallback kernel (test hook for a path that
+  // otherwise needs problems of > 2300 columns)
+  char const *env = getenv("BFHIP_JACOBI_GLOBAL");
+  int const forceGlobal = env && env[0] == '1';
+  uint32_t *globalList = (uint32_t *)malloc(numProbs * sizeof(uint32_t));
+  uint64_t numGlobal = 0;
+  if (!globalList) rc = bfhipFail(BFABI_ERROR_MEMORY_ERROR, "host OOM");
   for (uint64_t i = 0; i < numProbs && !rc; ++i) {
     int wlog, big, lc;
-    rc = jacobiClass(&hostProbs[i], &wlog, &big, &lc);
+    rc = jacobiClass(&hostProbs[i], forceGlobal, &wlog, &big, &lc);
+    if (lc < 0) { cls[i] = 0xff; globalList[numGlobal++] = (uint32_t)i; continue; }
     cls[i] = (uint8_t)((wlog * 2 + big) * NL + lc);
     counts[cls[i]] += 1;
   }
@@ -455,7 +552,8 @@ int bfdevBuildJacobi(BfSvdProb const *hostProbs, uint64_t numProbs, BfSvdStats *
     if (!lists[c]) rc = bfhipFail(BFABI_ERROR_MEMORY_ERROR, "host OOM");
     counts[c] = 0;
   }
-  for (uint64_t i = 0; i < numProbs && !rc; ++i) lists[cls[i]][counts[cls[i]]++] = (uint32_t)i;
+  for (uint64_t i = 0; i < numProbs && !rc; ++i)
+    if (cls[i] != 0xff) lists[cls[i]][counts[cls[i]]++] = (uint32_t)i;
   BfSvdProb *dP = NULL;
   BfSvdStats *dS = NULL;
   if (!rc) rc = uploadArrayB(&dP, hostProbs, numProbs, "svd problems");
@@ -478,7 +576,17 @@ int bfdevBuildJacobi(BfSvdProb const *hostProbs, uint64_t numProbs, BfSvdStats *
         default: rc = jacobiLaunch<64>(n, threads, lds, dP, dL[c], dS); break;
       }
     }
+  uint32_t *dG = NULL;
+  if (!rc && numGlobal) {
+    rc = uploadArrayB(&dG, globalList, numGlobal, "svd fallback list");
+    if (!rc) {
+      hipLaunchKernelGGL(bfJacobiGlobalKernel, dim3((uint32_t)numGlobal), dim3(1024), 0, 0, dP, dG, dS);
+      rc = hipFailB(hipGetLastError(), "Jacobi SVD (global-memory fallback) launch");
+    }
+  }
   if (!rc) rc = hipFailB(hipDeviceSynchronize(), "Jacobi SVD");
+  (void)hipFree(dG);
+  free(globalList);
   for (int c = 0; c < NCLS; ++c) (void)hipFree(dL[c]);
   if (!rc && stats) {
     BfSvdStats got;

@@ -393,3 +393,28 @@ def test_plain_c_driver_against_the_shared_library(tmp_path):
     p = subprocess.run([exe, "8192", "48"], capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stdout + p.stderr
     assert "GMRES:" in p.stdout and "exterior field" in p.stdout
+
+
+def test_global_memory_jacobi_fallback(monkeypatch, helm2_cases):
+    """Least-squares problems too tall for the LDS tile (> ~2300 equivalent sources, first met at
+    N = 1M) go through bfJacobiGlobalKernel; BFHIP_JACOBI_GLOBAL=1 sends small ones that way so the
+    path is covered: same operator as the LDS-blocked kernel to rounding."""
+    from butterfly_amd.operator import HipOperator, helm2_build_leaf
+    from oracle import helm2_build as hb
+    n, k = 4096, 256.0
+    desc, tp, _ = helm2_cases(n, k)
+    x = hb.complex_randn(n, 0)
+    op, st = HipOperator.build_helm2(desc, tp, k)
+    y = op.apply_host(x)
+    op.close()
+    monkeypatch.setenv("BFHIP_JACOBI_GLOBAL", "1")
+    op, st2 = HipOperator.build_helm2(desc, tp, k)
+    assert st2["notConverged"] == 0 and st2["reexpLeaves"] == st["reexpLeaves"]
+    assert rel(op.apply_host(x), y) <= 1e-11
+    op.close()
+    rc = ("reexp", ("circle", 0.55, 0.05, 0.08, 70), ("circle", 0.5, 0.0, 0.16, 45), ("circle", -0.6, 0.1, 0.2, 51))   # mt > me
+    pts = tp[:16]
+    X = helm2_build_leaf(pts, 400.0, rc)
+    src, eq, tgt = (hb.resolve_points(s, pts) for s in rc[1:])
+    z_or, z_eq = hb.kernel_matrix(400.0, src, tgt), hb.kernel_matrix(400.0, eq, tgt)
+    assert rel(z_eq @ X, z_eq @ hb.lstsq_truncated(z_eq, z_or)) <= 1e-10
