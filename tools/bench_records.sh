@@ -1,0 +1,29 @@
+#!/bin/bash
+# Regenerates the bench / builder / ceiling records committed under profiles/ (run on the GPU box):
+#   gpurun --timeout 1200 -- 'bash tools/bench_records.sh r1'
+# PMC and kernel-stats summaries come from tools/profile_round.sh + tools/summarize_profiles.py.
+set -u
+TAG=${1:-r1}
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+O=$R/gpurun_out/records_$TAG
+mkdir -p $O
+cd $R
+B="timeout -k 10 400 python bench.py"
+run() { local name=$1; shift; "$@" > $O/$name.json 2> $O/$name.err; echo "$name exit=$?"; }
+run ${TAG}_bench_n262144                 $B --pcie
+run ${TAG}_bench_n262144_nrhs64          $B --nrhs 64
+run ${TAG}_bench_n65536                  $B --npoints 65536
+run ${TAG}_bench_n65536_nrhs64           $B --npoints 65536 --nrhs 64 --no-cpu-baseline
+run ${TAG}_bench_n262144_real_f64_proxy  $B --dtype f64 --no-cpu-baseline
+run ${TAG}_bench_n262144_real_f32_proxy  $B --dtype f32 --no-cpu-baseline
+run ${TAG}_bench_n262144_adjoint         $B --adjoint --no-cpu-baseline
+for w in 2 4 8; do run ${TAG}_bench_n262144_shard0of${w}_emulated $B --emulate-world $w --no-cpu-baseline; done
+run ${TAG}_bench_n1048576_shard0of8_emulated  $B --npoints 1048576 --emulate-world 8 --no-cpu-baseline --steps 5 --warmup 1
+run ${TAG}_bench_n1048576_real_f32_proxy      $B --npoints 1048576 --dtype f32 --no-cpu-baseline --steps 5 --warmup 1
+run ${TAG}_build_n65536                  timeout -k 10 400 python tools/build_fullsize.py --npoints 65536
+run ${TAG}_bie_device_n65536_k100        timeout -k 10 400 python tools/helm2_bie_device.py --npoints 65536 --wavenumber 100 --max-iter 300
+hipcc -O3 --offload-arch=gfx950 tools/hbm_peak.hip -o /tmp/hbm_peak 2>/dev/null && run ${TAG}_hbm_peak timeout -k 5 120 /tmp/hbm_peak
+hipcc -O3 --offload-arch=gfx950 tools/mfma_peak.hip -o /tmp/mfma_peak 2>/dev/null && run ${TAG}_mfma_peak timeout -k 5 120 /tmp/mfma_peak
+# the 195 s build of the headline operand is not part of the default set:
+#   python tools/build_fullsize.py --npoints 262144 > $O/${TAG}_build_n262144.json
+ls $O
