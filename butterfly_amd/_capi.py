@@ -173,13 +173,19 @@ class Helm2Layout:
     Exposes numpy copies of the descriptor arrays (`arrays()`, as Desc.arrays()), the recipes
     (RECIPE_DTYPE), the quadtree permutation and the tree-ordered points."""
 
-    def __init__(self, points, wavenumber, tgt_points=None):
+    def __init__(self, points, wavenumber, tgt_points=None, single=None):
+        """single = (src_path, tgt_path): the butterfly of one node pair (bfhipHelm2LayoutCreateSingle)."""
         lib = load()
         pts = np.ascontiguousarray(points, dtype=np.float64)
         tpts = None if tgt_points is None else np.ascontiguousarray(tgt_points, dtype=np.float64)
         h = C.c_void_p()
-        check(lib.bfhipHelm2LayoutCreate2(pts.ctypes.data, len(pts), None if tpts is None else tpts.ctypes.data,
-                                          0 if tpts is None else len(tpts), float(wavenumber), C.byref(h)))
+        if single is not None:
+            sp, tp = (np.ascontiguousarray(p, dtype=np.uint32) for p in single)
+            check(lib.bfhipHelm2LayoutCreateSingle(pts.ctypes.data, len(pts), float(wavenumber), sp.ctypes.data, len(sp), tp.ctypes.data, len(tp),
+                                                   C.byref(h)))
+        else:
+            check(lib.bfhipHelm2LayoutCreate2(pts.ctypes.data, len(pts), None if tpts is None else tpts.ctypes.data,
+                                              0 if tpts is None else len(tpts), float(wavenumber), C.byref(h)))
         try:
             d = lib.bfhipHelm2LayoutGetDesc(h).contents
             n, nch = int(d.numNodes), None
@@ -193,7 +199,7 @@ class Helm2Layout:
                                 childCol0=arr(d.childCol0, nch, np.uint64), blockKind=arr(d.blockKind, n, np.uint8))
             self.dtype, self.root, self.num_nodes = int(d.dtype), int(d.root), n
             rb, re = int(begin[self.root]), int(begin[self.root + 1])
-            self.top_row_block = arr(d.topRowBlock, re - rb, np.uint64).astype(np.int64).tolist()
+            self.top_row_block = arr(d.topRowBlock, re - rb, np.uint64).astype(np.int64).tolist() if d.topRowBlock else None
             cnt = C.c_uint64(0)
             rp = lib.bfhipHelm2LayoutGetRecipes(h, C.byref(cnt))
             self.recipes = arr(rp, int(cnt.value), RECIPE_DTYPE) if cnt.value else np.zeros(0, dtype=RECIPE_DTYPE)
@@ -328,6 +334,8 @@ def load():
     lib.bfhipHelm2LayoutCreate.restype = C.c_int
     lib.bfhipHelm2LayoutCreate2.argtypes = [vp, C.c_uint64, vp, C.c_uint64, C.c_double, C.POINTER(vp)]
     lib.bfhipHelm2LayoutCreate2.restype = C.c_int
+    lib.bfhipHelm2LayoutCreateSingle.argtypes = [vp, C.c_uint64, C.c_double, vp, C.c_uint32, vp, C.c_uint32, C.POINTER(vp)]
+    lib.bfhipHelm2LayoutCreateSingle.restype = C.c_int
     lib.bfhipHelm2LayoutGetTgtPerm.argtypes = [vp]
     lib.bfhipHelm2LayoutGetTgtPerm.restype = vp
     lib.bfhipHelm2LayoutGetTgtTreePoints.argtypes = [vp]

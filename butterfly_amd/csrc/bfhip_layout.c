@@ -566,6 +566,56 @@ int bfhipHelm2LayoutCreate2(double const *points, uint64_t numPoints, double con
   return 0;
 }
 
+/* bfFacHelm2MakeSingleLevel (src/fac_helm2.c:706-729; examples/simple/bf_one_block.c:162): the butterfly
+ * of ONE (source node, target node) pair of the quadtree on `points`.  The nodes are named by their
+ * paths from the root: child positions among the NON-EMPTY children, in quadrant order.  The operator
+ * maps the source node's points to the target node's points (tree order); the recipes address the whole
+ * tree-ordered point array. */
+int bfhipHelm2LayoutCreateSingle(double const *points, uint64_t numPoints, double wavenumber, uint32_t const *srcPath, uint32_t srcDepth,
+                                 uint32_t const *tgtPath, uint32_t tgtDepth, BfhipHelm2Layout **out) {
+  if (!points || !out || (srcDepth && !srcPath) || (tgtDepth && !tgtPath)) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "NULL argument");
+  *out = NULL;
+  if (numPoints < 2 || numPoints > 0x7fffffffu) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "numPoints out of range");
+  if (!(wavenumber > 0)) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "wavenumber must be positive");
+  BfhipHelm2Layout *L = calloc(1, sizeof *L);
+  if (!L) return bfhipFail(BFABI_ERROR_MEMORY_ERROR, "host OOM");
+  L->n = numPoints; L->k = wavenumber;
+  L->perm = malloc((size_t)numPoints * 8);
+  L->treePoints = malloc((size_t)numPoints * 16);
+  int rc = (!L->perm || !L->treePoints) ? bfhipFail(BFABI_ERROR_MEMORY_ERROR, "host OOM") : 0;
+  uint32_t root = 0;
+  if (!rc) rc = buildQuadtree(L, points, numPoints, L->perm, 0, &root);
+  uint32_t sn = root, tn = root;
+  for (uint32_t d = 0; d < srcDepth && !rc; ++d) {
+    if (srcPath[d] >= L->nodes[sn].nch) rc = bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "source path leaves the tree at depth %u", d);
+    else sn = L->nodes[sn].ch[srcPath[d]];
+  }
+  for (uint32_t d = 0; d < tgtDepth && !rc; ++d) {
+    if (tgtPath[d] >= L->nodes[tn].nch) rc = bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "target path leaves the tree at depth %u", d);
+    else tn = L->nodes[tn].ch[tgtPath[d]];
+  }
+  if (!rc && srcDepth != tgtDepth) rc = bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "source and target nodes must be on the same level");
+  if (!rc) {
+    for (uint64_t i = 0; i < numPoints; ++i) { L->treePoints[2 * i] = points[2 * L->perm[i]]; L->treePoints[2 * i + 1] = points[2 * L->perm[i] + 1]; }
+    uint32_t nf = 0, lev = 0;
+    if (L->nodes[sn].nch == 0 || L->nodes[tn].nch == 0) rc = bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "a leaf node has no butterfly");
+    if (!rc) rc = prepare(L, sn, tn, &nf, &lev);
+    if (!rc && nf == 0) rc = bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "this node pair is not butterfliable (rank estimates exceed the point counts)");
+    uint64_t prod = 0;
+    if (!rc) rc = makeProduct(L, sn, tn, nf, lev, &prod);
+    if (!rc) {
+      BfhipDesc *d = &L->desc;
+      memset(d, 0, sizeof *d);
+      d->structSize = sizeof *d; d->dtype = BFHIP_C128; d->numNodes = L->numDesc; d->root = prod;
+      d->kind = L->kind; d->rows = L->rows; d->cols = L->cols; d->childBegin = L->childBegin;
+      d->childNode = L->childNode; d->childRow0 = L->childRow0; d->childCol0 = L->childCol0; d->blockKind = L->blockKind;
+    }
+  }
+  if (rc) { bfhipHelm2LayoutFree(&L); return rc; }
+  *out = L;
+  return 0;
+}
+
 int bfhipHelm2LayoutCreate(double const *points, uint64_t numPoints, double wavenumber, BfhipHelm2Layout **out) {
   return bfhipHelm2LayoutCreate2(points, numPoints, NULL, 0, wavenumber, out);
 }

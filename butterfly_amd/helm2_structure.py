@@ -581,3 +581,13 @@ def native_multilevel_structure(points: np.ndarray, k: float, tgt_points: np.nda
         return desc, lay.perm
     desc.meta["m"] = len(tgt_points)
     return desc, (lay.perm, lay.tgt_perm)
+
+
+def native_single_product_structure(points: np.ndarray, k: float, src_path, tgt_path):
+    """single_product_structure through the C layout (bfhipHelm2LayoutCreateSingle).  Returns
+    (ArrayDesc, perm); the operator maps the source node's points to the target node's."""
+    from . import _capi
+    lay = _capi.Helm2Layout(points, k, single=(src_path, tgt_path))
+    desc = ArrayDesc(lay.arrays(), lay.root, lay.dtype, [], lay.recipes, dict(n=len(points), k=float(k)))
+    desc.top_row_block = None
+    return desc, lay.perm

@@ -138,6 +138,12 @@ int bfhipHelm2LayoutCreate2(const double *points, uint64_t numPoints, const doub
                             double wavenumber, BfhipHelm2Layout **out);
 const uint64_t *bfhipHelm2LayoutGetTgtPerm(const BfhipHelm2Layout *layout);       /* NULL for a single tree */
 const double *bfhipHelm2LayoutGetTgtTreePoints(const BfhipHelm2Layout *layout);   /* NULL for a single tree */
+/* bfFacHelm2MakeSingleLevel (src/fac_helm2.c:706-729; examples/simple/bf_one_block.c:162): the butterfly of
+ * ONE (source node, target node) pair; nodes named by their paths from the root (child positions among
+ * the non-empty children, quadrant order; same depth).  Maps the source node's points to the target
+ * node's points; the recipes address the whole tree-ordered point array. */
+int bfhipHelm2LayoutCreateSingle(const double *points, uint64_t numPoints, double wavenumber, const uint32_t *srcPath, uint32_t srcDepth,
+                                 const uint32_t *tgtPath, uint32_t tgtDepth, BfhipHelm2Layout **out);
 const BfhipDesc *bfhipHelm2LayoutGetDesc(const BfhipHelm2Layout *layout);
 const BfhipHelm2Recipe *bfhipHelm2LayoutGetRecipes(const BfhipHelm2Layout *layout, uint64_t *count);
 const uint64_t *bfhipHelm2LayoutGetPerm(const BfhipHelm2Layout *layout);        /* perm[t] = original index of tree position t */

@@ -418,3 +418,23 @@ def test_global_memory_jacobi_fallback(monkeypatch, helm2_cases):
     src, eq, tgt = (hb.resolve_points(s, pts) for s in rc[1:])
     z_or, z_eq = hb.kernel_matrix(400.0, src, tgt), hb.kernel_matrix(400.0, eq, tgt)
     assert rel(z_eq @ X, z_eq @ hb.lstsq_truncated(z_eq, z_or)) <= 1e-10
+
+
+def test_single_pair_butterfly_built_on_the_device_matches_the_golden_vectors():
+    """examples/simple/bf_one_block.c: bfFacHelm2MakeSingleLevel for one node pair -- native layout,
+    device values -- against the committed golden (numpy/LAPACK-built operand, its x and y)."""
+    import os
+    from butterfly_amd import helm2_structure as hs
+    from butterfly_amd.operator import HipOperator
+    from fixtures import load_fixture
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "helm2_one_block_n2048_k128.npz")
+    gdesc, gvals, ex = load_fixture(gold)
+    pts = hs.circle_points(2048)
+    src_path, tgt_path = tuple(int(v) for v in ex["src_path"]), tuple(int(v) for v in ex["tgt_path"])
+    desc, perm = hs.native_single_product_structure(pts, 128.0, src_path, tgt_path)
+    assert desc.num_nodes == gdesc.num_nodes and int(desc.rows[desc.root]) == gdesc.rows[gdesc.root]
+    op, st = HipOperator.build_helm2(desc, pts[perm], 128.0)
+    y = op.apply_host(ex["x"])
+    assert rel(y, ex["y_oracle"]) <= 1e-10
+    assert rel(y, ex["y_dense"]) <= 1e-9
+    op.close()

@@ -102,3 +102,26 @@ def test_two_tree_layout_equals_the_python_restatement():
         for f in ("kind", "count", "first", "cx", "cy", "r"):
             assert np.array_equal(lay.recipes[ps_][f], ref[ps_][f]), (ps_, f)
     assert set(np.unique(lay.recipes["tgt"]["kind"])) >= {_capi.PTS_TREE_TGT}
+
+
+def test_single_pair_layout_equals_the_python_restatement():
+    """bfFacHelm2MakeSingleLevel (examples/simple/bf_one_block.c): one butterfly for a node pair."""
+    import ctypes as C
+    pts, k = hs.circle_points(2048), 128.0
+    src_path, tgt_path = (0, 0), (3, 1)
+    desc, _, perm, sn, tn = hs.single_product_structure(pts, k, src_path, tgt_path)
+    lay = _capi.Helm2Layout(pts, k, single=(src_path, tgt_path))
+    assert np.array_equal(lay.perm, perm) and lay.root == desc.root
+    want, got = desc.arrays(), lay.arrays()
+    for key in ("kind", "rows", "cols", "childBegin", "childNode", "childRow0", "childCol0", "blockKind"):
+        assert np.array_equal(got[key], want[key]), key
+    assert int(got["rows"][lay.root]) == tn.npts and int(got["cols"][lay.root]) == sn.npts
+    ref = _capi.recipe_array(desc.recipe)
+    for ps in ("src", "equiv", "tgt"):
+        for f in ("kind", "count", "first", "cx", "cy", "r"):
+            assert np.array_equal(lay.recipes[ps][f], ref[ps][f]), (ps, f)
+    lib, h = _capi.load(), C.c_void_p()
+    bad = np.array([9, 0], dtype=np.uint32)
+    ok = np.array([0, 0], dtype=np.uint32)
+    assert lib.bfhipHelm2LayoutCreateSingle(pts.ctypes.data, len(pts), k, bad.ctypes.data, 2, ok.ctypes.data, 2, C.byref(h)) == 1
+    assert lib.bfhipHelm2LayoutCreateSingle(pts.ctypes.data, len(pts), k, ok.ctypes.data, 2, ok.ctypes.data, 1, C.byref(h)) == 1
