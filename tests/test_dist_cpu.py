@@ -23,7 +23,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, n, k, nrhs, out_dir, mode):
+def _worker(rank, world, port, n, k, nrhs, out_dir, mode, native=False):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -33,7 +33,10 @@ def _worker(rank, world, port, n, k, nrhs, out_dir, mode):
     from butterfly_amd.dist import ShardLayout, ShardedApply, assign_row_blocks, block_weights, row_block_weights
     from butterfly_amd.operator import HipOperator
     import plan_emulator
-    desc, root, perm = hs.helm2_multilevel_structure(hs.circle_points(n), k)
+    if native:      # the array-backed descriptor of the C layout: what bench.py shards on the GPUs
+        desc, perm = hs.native_multilevel_structure(hs.circle_points(n), k)
+    else:
+        desc, root, perm = hs.helm2_multilevel_structure(hs.circle_points(n), k)
     if mode == "rows":
         weights = row_block_weights(desc)
         owner, loads = assign_row_blocks(weights, world)
@@ -64,12 +67,13 @@ def _worker(rank, world, port, n, k, nrhs, out_dir, mode):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("nrhs,mode", [(1, "rows"), (2, "rows"), (1, "blocks"), (2, "blocks")])
-def test_two_rank_sharded_apply_matches_full_oracle(tmp_path, nrhs, mode):
+@pytest.mark.parametrize("nrhs,mode,native", [(1, "rows", False), (2, "rows", False), (1, "blocks", False), (2, "blocks", False),
+                                              (1, "rows", True), (1, "blocks", True)])
+def test_two_rank_sharded_apply_matches_full_oracle(tmp_path, nrhs, mode, native):
     from butterfly_amd import helm2_structure as hs
     from oracle import bfref
     n, k, world = 2048, 128, 2
-    mp.spawn(_worker, args=(world, _free_port(), n, k, nrhs, str(tmp_path), mode), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), n, k, nrhs, str(tmp_path), mode, native), nprocs=world, join=True)
     x = np.load(tmp_path / "x.npy")
     desc, root, perm = hs.helm2_multilevel_structure(hs.circle_points(n), k)
     y_ref = bfref.mat_mul(bfref.from_desc(desc, None, seed=11), x)
