@@ -61,6 +61,7 @@ struct BfhipOperator {
   uint64_t leafBytesAlgorithmic;
   /* staging for the host-pointer apply */
   void *dX, *dY;
+  void *hX, *hY;              /* pinned host mirrors of dX / dY */
   uint32_t xyRhs;
   /* profiling */
   void **evStart, **evStop;   /* [numStages] */
@@ -72,6 +73,8 @@ struct BfhipOperator {
   BfIr *ir;
   uint64_t seed;
 };
+
+#define BF_ARENA_SLACK 256u
 
 static void freeDevicePlanOf(BfPlan *plan) {
   for (uint64_t s = 0; s < plan->numStages && plan->stages; ++s) {
@@ -105,6 +108,8 @@ void bfhipFree(BfhipOperator **pop) {
   bfdevFree(op->dZero);
   bfdevFree(op->dX);
   bfdevFree(op->dY);
+  bfdevHostFreePinned(op->hX);
+  bfdevHostFreePinned(op->hY);
   bfPlanFree(&op->plan);
   bfPlanFree(&op->tplan);
   if (op->ir) { bfIrFree(op->ir); free(op->ir); }
@@ -323,7 +328,9 @@ int bfhipCompileIrFill(BfIr *ir, BfhipOptions const *opts, BfFillFn fill, void *
     return 0;
   }
 
-  if ((rc = bfdevMalloc(&op->dArena, (size_t)op->plan.arenaElems * op->plan.elemSize))) goto done;
+  /* + 256 B of slack: no kernel reads past the last piece by construction, the slack keeps a
+   * future mistake there off the end of the mapping */
+  if ((rc = bfdevMalloc(&op->dArena, (size_t)op->plan.arenaElems * op->plan.elemSize + BF_ARENA_SLACK))) goto done;
   if ((rc = uploadPlanMeta(op, &op->plan))) goto done;
   if (op->hasTplan && (rc = uploadPlanMeta(op, &op->tplan))) goto done;
   /* leaf values: computed on the device by the caller's builder, or packed / synthesized from the IR */
@@ -410,26 +417,26 @@ static int runPlan(BfhipOperator *op, BfPlan *plan, void const *dX, size_t nrhs,
   if (!op || !dX || !dY) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "NULL argument");
   if (nrhs == 0 || nrhs > 0xffffu) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "nrhs out of range");
   if (op->flags & BFHIP_FLAG_PLAN_ONLY) return bfhipFail(BFABI_ERROR_RUNTIME_ERROR, "operator was compiled with BFHIP_FLAG_PLAN_ONLY: no device operator exists");
-  int rc;
+  int rc = 0;
   int prev = -1;
   bfdevGetDevice(&prev);
   if (prev != op->device && (rc = bfdevSetDevice(op->device))) return rc;
   if (op->tempRhs < nrhs) {
     /* growing the vector arena is not stream-ordered: drain first */
-    if ((rc = bfdevSync(stream))) return rc;
-    if ((rc = ensureTemp(op, (uint32_t)nrhs))) return rc;
+    if ((rc = bfdevSync(stream))) goto out;
+    if ((rc = ensureTemp(op, (uint32_t)nrhs))) goto out;
   }
   int const prof = (op->flags & BFHIP_FLAG_PROFILE) != 0 && plan == &op->plan;
-  if (prof && (rc = harvestEvents(op))) return rc;
+  if (prof && (rc = harvestEvents(op))) goto out;
   for (uint64_t s = 0; s < plan->numStages; ++s) {
     BfStage *st = &plan->stages[s];
     BfLaunchArgs a;
     a.arena = op->dArena; a.items = st->dItems; a.pieces = st->dPieces; a.numItems = st->numItems;
     a.x = dX; a.y = dY; a.temp = op->dTemp; a.zero = op->dZero; a.nrhs = (uint32_t)nrhs; a.dtype = plan->dtype; a.maxRows = st->maxRows;
     a.transposed = plan->transposed;
-    if (prof && (rc = bfdevEventRecord(op->evStart[s], stream))) return rc;
-    if ((rc = bfdevLaunchStage(&a, stream))) return rc;
-    if (prof && (rc = bfdevEventRecord(op->evStop[s], stream))) return rc;
+    if (prof && (rc = bfdevEventRecord(op->evStart[s], stream))) goto out;
+    if ((rc = bfdevLaunchStage(&a, stream))) goto out;
+    if (prof && (rc = bfdevEventRecord(op->evStop[s], stream))) goto out;
     for (uint64_t r0 = 0; r0 < st->numReduce; r0 += 16) {
       BfReduceArgs ra[16];
       uint32_t const cnt = (uint32_t)(st->numReduce - r0 < 16 ? st->numReduce - r0 : 16);
@@ -439,12 +446,14 @@ static int runPlan(BfhipOperator *op, BfPlan *plan, void const *dX, size_t nrhs,
         ra[r].numRows = rd->numRows; ra[r].temp = op->dTemp; ra[r].nrhs = (uint32_t)nrhs; ra[r].dtype = plan->dtype;
         ra[r].dest = rd->destSpace == BF_SPACE_Y ? dY : (void *)((char *)op->dTemp + rd->destOff * nrhs * plan->elemSize);
       }
-      if ((rc = bfdevLaunchReduce(ra, cnt, stream))) return rc;
+      if ((rc = bfdevLaunchReduce(ra, cnt, stream))) goto out;
     }
   }
   if (prof) { op->evPending = 1; op->lastNrhs = (uint32_t)nrhs; }
+out:
+  /* every path hands the caller's device back */
   if (prev >= 0 && prev != op->device) bfdevSetDevice(prev);
-  return 0;
+  return rc;
 }
 
 int bfhipApplyDevice(BfhipOperator *op, void const *dX, size_t nrhs, void *dY, void *stream) {
@@ -471,39 +480,36 @@ static int applyHost(BfhipOperator *op, int transpose, void const *X, size_t ldx
   size_t hostEs = op->srcDtype == BFHIP_C128 ? 16 : 8;      /* host side is always double precision */
   uint64_t n = transpose ? op->plan.numRows : op->plan.numCols, m = transpose ? op->plan.numCols : op->plan.numRows;
   uint64_t big = n > m ? n : m;
-  if (transpose && !op->hasTplan) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "operator was not compiled with BFHIP_FLAG_ADJOINT");
+  void *hx = NULL, *hy = NULL;
   if (op->xyRhs < nrhs) {
     bfdevFree(op->dX); bfdevFree(op->dY); op->dX = op->dY = NULL; op->xyRhs = 0;
-    if ((rc = bfdevMalloc(&op->dX, big * nrhs * es))) return rc;
-    if ((rc = bfdevMalloc(&op->dY, big * nrhs * es))) return rc;
+    bfdevHostFreePinned(op->hX); bfdevHostFreePinned(op->hY); op->hX = op->hY = NULL;
+    if ((rc = bfdevMalloc(&op->dX, big * nrhs * es))) goto out;
+    if ((rc = bfdevMalloc(&op->dY, big * nrhs * es))) goto out;
+    /* pinned staging: the copies run at PCIe rate instead of through the runtime's pageable bounce buffers */
+    if ((rc = bfdevHostAllocPinned(&op->hX, (big * nrhs * es) != 0 ? big * nrhs * es : 16))) goto out;
+    if ((rc = bfdevHostAllocPinned(&op->hY, (big * nrhs * es) != 0 ? big * nrhs * es : 16))) goto out;
     op->xyRhs = (uint32_t)nrhs;
   }
-  /* pack to ld == nrhs (and demote if the operator computes in fp32) */
-  void *hx = NULL, *hy = NULL;
-  int needPackX = ldx != nrhs || es != hostEs, needPackY = ldy != nrhs || es != hostEs;
-  if (needPackX) {
-    hx = malloc(n && nrhs ? n * nrhs * es : 1);
-    if (!hx) return bfhipFail(BFABI_ERROR_MEMORY_ERROR, "host OOM");
-    if (es == hostEs) for (uint64_t i = 0; i < n; ++i) memcpy((char *)hx + i * nrhs * es, (char const *)X + i * ldx * es, nrhs * es);
-    else for (uint64_t i = 0; i < n; ++i) for (size_t q = 0; q < nrhs; ++q) ((float *)hx)[i * nrhs + q] = (float)((double const *)X)[i * ldx + q];
-  }
-  rc = bfdevMemcpyH2D(op->dX, needPackX ? hx : X, n * nrhs * es);
-  free(hx);
-  if (rc) return rc;
-  if ((rc = runPlan(op, transpose ? &op->tplan : &op->plan, op->dX, nrhs, op->dY, NULL))) return rc;
-  if ((rc = bfdevSync(NULL))) return rc;
-  if (needPackY) {
-    hy = malloc(m && nrhs ? m * nrhs * es : 1);
-    if (!hy) return bfhipFail(BFABI_ERROR_MEMORY_ERROR, "host OOM");
-    rc = bfdevMemcpyD2H(hy, op->dY, m * nrhs * es);
-    if (!rc) {
-      if (es == hostEs) for (uint64_t i = 0; i < m; ++i) memcpy((char *)Y + i * ldy * es, (char *)hy + i * nrhs * es, nrhs * es);
-      else for (uint64_t i = 0; i < m; ++i) for (size_t q = 0; q < nrhs; ++q) ((double *)Y)[i * ldy + q] = ((float *)hy)[i * nrhs + q];
-    }
-    free(hy);
+  /* pack to ld == nrhs (and demote if the operator computes in fp32) into the pinned buffer */
+  hx = op->hX; hy = op->hY;
+  if (es == hostEs) {
+    if (ldx == nrhs) memcpy(hx, X, n * nrhs * es);
+    else for (uint64_t i = 0; i < n; ++i) memcpy((char *)hx + i * nrhs * es, (char const *)X + i * ldx * es, nrhs * es);
   } else {
-    rc = bfdevMemcpyD2H(Y, op->dY, m * nrhs * es);
+    for (uint64_t i = 0; i < n; ++i) for (size_t q = 0; q < nrhs; ++q) ((float *)hx)[i * nrhs + q] = (float)((double const *)X)[i * ldx + q];
   }
+  if ((rc = bfdevMemcpyH2DAsync(op->dX, hx, n * nrhs * es, NULL))) goto out;
+  if ((rc = runPlan(op, transpose ? &op->tplan : &op->plan, op->dX, nrhs, op->dY, NULL))) goto out;
+  if ((rc = bfdevMemcpyD2HAsync(hy, op->dY, m * nrhs * es, NULL))) goto out;
+  if ((rc = bfdevSync(NULL))) goto out;
+  if (es == hostEs) {
+    if (ldy == nrhs) memcpy(Y, hy, m * nrhs * es);
+    else for (uint64_t i = 0; i < m; ++i) memcpy((char *)Y + i * ldy * es, (char *)hy + i * nrhs * es, nrhs * es);
+  } else {
+    for (uint64_t i = 0; i < m; ++i) for (size_t q = 0; q < nrhs; ++q) ((double *)Y)[i * ldy + q] = ((float *)hy)[i * nrhs + q];
+  }
+out:
   if (prev >= 0 && prev != op->device) bfdevSetDevice(prev);
   return rc;
 }
@@ -516,6 +522,7 @@ int bfhipApplyTranspose(BfhipOperator *op, void const *X, size_t ldx, size_t nrh
 }
 
 /* ---- introspection ---------------------------------------------------------- */
+int bfhipOperatorDevice(BfhipOperator const *op) { return (!op || (op->flags & BFHIP_FLAG_PLAN_ONLY)) ? -1 : op->device; }
 size_t bfhipGetNumRows(BfhipOperator const *op) { return op ? op->plan.numRows : 0; }
 size_t bfhipGetNumCols(BfhipOperator const *op) { return op ? op->plan.numCols : 0; }
 size_t bfhipNumBytes(BfhipOperator const *op) { return op ? op->plan.leafElems * (op->srcDtype == BFHIP_C128 ? 16 : 8) : 0; }
@@ -630,7 +637,7 @@ static int writeDeviceArray(FILE *fp, void const *d, size_t bytes) {
   return rc;
 }
 static int readDeviceArray(FILE *fp, void **d, size_t bytes, uint64_t *meta) {
-  int rc = bfdevMalloc(d, bytes);
+  int rc = bfdevMalloc(d, bytes + BF_ARENA_SLACK);
   if (rc || !bytes) return rc;
   if (meta) *meta += bytes;
   size_t const chunk = (size_t)64 << 20;
@@ -666,16 +673,78 @@ static int savePlan(FILE *fp, BfPlan const *pl) {
   return rc;
 }
 
+/* index tables are small (0.03 % of the operand): read whole, validate on the host, then upload */
+static int readMetaArray(FILE *fp, void **d, void **h, size_t bytes, uint64_t *meta) {
+  *h = NULL;
+  int rc = bfdevMalloc(d, bytes);
+  if (rc || !bytes) return rc;
+  if (meta) *meta += bytes;
+  *h = malloc(bytes);
+  if (!*h) return bfhipFail(BFABI_ERROR_MEMORY_ERROR, "host OOM");
+  if ((rc = readAll(fp, *h, bytes))) return rc;
+  return bfdevMemcpyH2D(*d, *h, bytes);
+}
+
+/* A file is untrusted input: every offset the kernels will dereference is checked against the
+ * sizes in the header before the operator is accepted (a truncated or corrupt file must not turn
+ * into device out-of-bounds accesses). */
+static int validateStage(BfPlan const *pl, uint64_t arenaElems, BfStage const *st, BfDevItem const *items, BfDevPiece const *pieces) {
+  uint64_t const inX = pl->numCols, outY = pl->numRows, temp = pl->tempElems;
+  for (uint64_t i = 0; i < st->numItems; ++i) {
+    BfDevItem const *it = &items[i];
+    uint32_t const mr = it->mrFlags & 0xffffu;
+    uint64_t const outLen = (it->mrFlags & BF_ITEM_OUT_Y) ? outY : temp;
+    if (!mr || mr > pl->maxItemRows || mr > st->maxRows || (it->mrFlags & ~(0xffffu | BF_ITEM_OUT_Y)) ||
+        (uint64_t)it->outOff + mr > outLen || (uint64_t)it->pieceBegin + it->numPieces > st->numPieces)
+      return bfhipFail(BFABI_ERROR_FILE_ERROR, "corrupt operator file: item %llu out of bounds", (unsigned long long)i);
+    uint32_t const mrPad = (mr + pl->epl - 1) / pl->epl * pl->epl;
+    for (uint32_t k = 0; k < it->numPieces; ++k) {
+      BfDevPiece const *pc = &pieces[it->pieceBegin + k];
+      uint64_t const inLen = (pc->flags & BF_PIECE_IN_X) ? inX : temp;
+      int bad = (pc->flags & ~(BF_PIECE_IN_X | BF_PIECE_IDENTITY)) != 0;
+      if (pc->flags & BF_PIECE_IDENTITY) bad |= (uint64_t)pc->inOff + mr > inLen;
+      else if (pl->transposed)
+        bad |= !pc->ld || pc->ld % pl->epl || pc->ncols > pc->ld || pc->dataOff % pl->epl ||
+               pc->dataOff + (uint64_t)mr * pc->ld > arenaElems || (uint64_t)pc->inOff + pc->ncols > inLen;
+      else
+        bad |= !pc->ncols || pc->ncols > pl->xcap || pc->dataOff % pl->epl ||
+               pc->dataOff + (uint64_t)mrPad * pc->ncols > arenaElems || (uint64_t)pc->inOff + pc->ncols > inLen;
+      if (bad) return bfhipFail(BFABI_ERROR_FILE_ERROR, "corrupt operator file: piece %u of item %llu out of bounds", k, (unsigned long long)i);
+    }
+  }
+  return 0;
+}
+
+static int validateReduce(BfPlan const *pl, BfReduce const *rd, uint32_t const *rowInterval, uint32_t const *ivBegin, int64_t const *srcBias) {
+  uint64_t const destLen = rd->destSpace == BF_SPACE_Y ? pl->numRows : pl->tempElems;
+  if ((rd->destSpace != BF_SPACE_Y && rd->destSpace != BF_SPACE_TEMP) || rd->destOff + rd->numRows > destLen || rd->numIntervals > rd->numRows + 1)
+    return bfhipFail(BFABI_ERROR_FILE_ERROR, "corrupt operator file: reduce destination out of bounds");
+  if (ivBegin[0] != 0 || ivBegin[rd->numIntervals] > rd->numSrc) return bfhipFail(BFABI_ERROR_FILE_ERROR, "corrupt operator file: reduce interval table");
+  for (uint64_t i = 0; i < rd->numIntervals; ++i)
+    if (ivBegin[i + 1] < ivBegin[i]) return bfhipFail(BFABI_ERROR_FILE_ERROR, "corrupt operator file: reduce interval table not monotone");
+  for (uint64_t r = 0; r < rd->numRows; ++r) {
+    uint32_t const iv = rowInterval[r];
+    if (iv >= rd->numIntervals) return bfhipFail(BFABI_ERROR_FILE_ERROR, "corrupt operator file: reduce row %llu", (unsigned long long)r);
+    for (uint32_t k = ivBegin[iv]; k < ivBegin[iv + 1]; ++k) {
+      int64_t const src = srcBias[k] + (int64_t)r;
+      if (src < 0 || (uint64_t)src >= pl->tempElems) return bfhipFail(BFABI_ERROR_FILE_ERROR, "corrupt operator file: reduce source out of bounds");
+    }
+  }
+  return 0;
+}
+
 static int loadPlan(FILE *fp, BfhipOperator *op, BfPlan *pl, FileHeader const *fh) {
   FilePlanHeader ph;
   int rc = readAll(fp, &ph, sizeof ph);
   if (rc) return rc;
-  if (ph.numStages > (1u << 20)) return bfhipFail(BFABI_ERROR_FILE_ERROR, "corrupt plan header");
+  if (ph.numStages > (1u << 20) || ph.tempElems >= 0xffffffffu) return bfhipFail(BFABI_ERROR_FILE_ERROR, "corrupt plan header");
   pl->dtype = fh->dtype; pl->elemSize = fh->elemSize; pl->epl = fh->epl; pl->xcap = fh->xcap;
   pl->maxItemRows = ph.maxItemRows; pl->transposed = (int)ph.transposed;
   pl->numRows = ph.numRows; pl->numCols = ph.numCols; pl->numStages = ph.numStages; pl->tempElems = ph.tempElems;
   pl->arenaElems = pl->transposed ? 0 : fh->arenaElems;
   pl->leafElems = fh->leafElems; pl->numLeaves = fh->numLeaves;
+  if (pl->epl != 16 / pl->elemSize || pl->xcap != 256 || pl->maxItemRows > 64 * pl->epl || (pl->transposed && pl->maxItemRows > 16))
+    return bfhipFail(BFABI_ERROR_FILE_ERROR, "corrupt plan header (lane granule / piece width / item height)");
   pl->stages = calloc(ph.numStages ? ph.numStages : 1, sizeof(BfStage));
   if (!pl->stages) return bfhipFail(BFABI_ERROR_MEMORY_ERROR, "host OOM");
   for (uint64_t s = 0; s < pl->numStages && !rc; ++s) {
@@ -685,8 +754,11 @@ static int loadPlan(FILE *fp, BfhipOperator *op, BfPlan *pl, FileHeader const *f
     if (sh.numItems > 0xffffffffu || sh.numPieces > 0xffffffffu || sh.numReduce > (1u << 20)) { rc = bfhipFail(BFABI_ERROR_FILE_ERROR, "corrupt stage header"); break; }
     st->numItems = sh.numItems; st->numPieces = sh.numPieces; st->leafElems = sh.leafElems; st->vecIn = sh.vecIn; st->vecOut = sh.vecOut;
     st->maxRows = sh.maxRows;
-    rc = readDeviceArray(fp, &st->dItems, st->numItems * sizeof(BfDevItem), &op->metaBytes);
-    if (!rc) rc = readDeviceArray(fp, &st->dPieces, st->numPieces * sizeof(BfDevPiece), &op->metaBytes);
+    void *hItems = NULL, *hPieces = NULL;
+    rc = readMetaArray(fp, &st->dItems, &hItems, st->numItems * sizeof(BfDevItem), &op->metaBytes);
+    if (!rc) rc = readMetaArray(fp, &st->dPieces, &hPieces, st->numPieces * sizeof(BfDevPiece), &op->metaBytes);
+    if (!rc) rc = validateStage(pl, fh->arenaElems, st, hItems, hPieces);
+    free(hItems); free(hPieces);
     if (!rc && sh.numReduce) {
       st->reduce = calloc(sh.numReduce, sizeof(BfReduce));
       if (!st->reduce) rc = bfhipFail(BFABI_ERROR_MEMORY_ERROR, "host OOM");
@@ -697,9 +769,13 @@ static int loadPlan(FILE *fp, BfhipOperator *op, BfPlan *pl, FileHeader const *f
       if ((rc = readAll(fp, &rh, sizeof rh))) break;
       st->numReduce = r + 1;
       rd->destOff = rh.destOff; rd->numRows = rh.numRows; rd->numIntervals = rh.numIntervals; rd->numSrc = rh.numSrc; rd->destSpace = rh.destSpace;
-      rc = readDeviceArray(fp, &rd->dRowInterval, rd->numRows * 4, &op->metaBytes);
-      if (!rc) rc = readDeviceArray(fp, &rd->dIvBegin, (rd->numIntervals + 1) * 4, &op->metaBytes);
-      if (!rc) rc = readDeviceArray(fp, &rd->dSrcBias, rd->numSrc * 8, &op->metaBytes);
+      if (rd->numRows >= 0xffffffffu || rd->numIntervals >= 0xffffffffu || rd->numSrc >= 0xffffffffu) { rc = bfhipFail(BFABI_ERROR_FILE_ERROR, "corrupt reduce header"); break; }
+      void *hRow = NULL, *hIv = NULL, *hBias = NULL;
+      rc = readMetaArray(fp, &rd->dRowInterval, &hRow, rd->numRows * 4, &op->metaBytes);
+      if (!rc) rc = readMetaArray(fp, &rd->dIvBegin, &hIv, (rd->numIntervals + 1) * 4, &op->metaBytes);
+      if (!rc) rc = readMetaArray(fp, &rd->dSrcBias, &hBias, rd->numSrc * 8, &op->metaBytes);
+      if (!rc) rc = validateReduce(pl, rd, hRow, hIv, hBias);
+      free(hRow); free(hIv); free(hBias);
     }
   }
   return rc;
@@ -793,6 +869,25 @@ typedef struct BfhipMat {
   int ownsOperator;
 } BfhipMat;
 
+/* Failures surface the way the reference's own Mul failures do: the global error code is set
+ * (bfSetError, src/error.c:20-24) and NULL is returned (the RAISE_ERROR / BF_ERROR_END idiom, e.g.
+ * src/mat_product.c:404-405).  libbfhip does not link the reference; when the host process has
+ * it loaded its bfSetError is found at run time.  Note that bfSetError asserts on a non-zero code
+ * (src/error.c:21), so in a reference build with assertions a failed Mul is as fatal as the
+ * reference's own BF_DIE() paths; bfhipSetErrorForwarding(0) keeps failures to NULL +
+ * bfhipLastErrorMessage(). */
+#include <dlfcn.h>
+static int forwardErrors = 1;
+void bfhipSetErrorForwarding(int on) { forwardErrors = on; }
+static void shimRaise(int code) {
+  if (!forwardErrors || !code) return;
+  static void (*setError)(int);
+  static int looked;
+  if (!looked) { looked = 1; setError = (void (*)(int))dlsym(RTLD_DEFAULT, "bfSetError"); }
+  if (setError) setError(code);
+}
+#define SHIM_FAIL(code, ...) do { shimRaise(bfhipFail((code), __VA_ARGS__)); return NULL; } while (0)
+
 static size_t shimGetNumRows(BfAbiMat const *m) { return bfhipGetNumRows(((BfhipMat const *)m)->op); }
 static size_t shimGetNumCols(BfAbiMat const *m) { return bfhipGetNumCols(((BfhipMat const *)m)->op); }
 static int shimGetType(BfAbiMat const *m) { (void)m; return BFABI_TYPE_MAT_FUNC; }
@@ -800,9 +895,22 @@ static size_t shimNumBytes(BfAbiMat const *m) { return bfhipNumBytes(((BfhipMat 
 static void shimDelete(BfAbiMat **m) {
   if (!m || !*m) return;
   BfhipMat *s = (BfhipMat *)*m;
-  if (s->ownsOperator) bfhipFree(&s->op);
+  /* a view never owns the operator (bfMatDenseRealDeinit skips the payload of a view the same way,
+   * src/mat_dense_real.c:1667-1672) */
+  if (s->ownsOperator && !(s->super.props & BFABI_MAT_PROPS_VIEW)) bfhipFree(&s->op);
   free(s);
   *m = NULL;
+}
+/* GetView: a shallow copy flagged VIEW, what every reference type returns (e.g.
+ * bfMatDenseRealGetView, src/mat_dense_real.c:67-85).  bfMatBlockDenseGetBlockConst calls it on
+ * every sub-block of a BlockDense on each Mul (src/mat_block_dense.c:1043-1061, via bfMatGet
+ * with BF_POLICY_VIEW), so a shim placed INSIDE a reference container needs it. */
+static BfAbiMat *shimGetView(BfAbiMat *m) {
+  BfhipMat *v = malloc(sizeof *v);
+  if (!v) SHIM_FAIL(BFABI_ERROR_MEMORY_ERROR, "host OOM");
+  *v = *(BfhipMat *)m;
+  v->super.props |= BFABI_MAT_PROPS_VIEW;
+  return &v->super;
 }
 
 /* Y = A X for a reference dense RHS; the result is allocated through the
@@ -811,26 +919,26 @@ static void shimDelete(BfAbiMat **m) {
 void *bfhipMatMulFunc(void const *rhsV, void *opV) {
   BfhipOperator *op = opV;
   BfAbiMat const *rhs = rhsV;
-  if (!op || !rhs || !rhs->vtbl) { bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "NULL operand"); return NULL; }
+  if (!op || !rhs || !rhs->vtbl) SHIM_FAIL(BFABI_ERROR_INVALID_ARGUMENTS, "NULL operand");
   BfAbiGetTypeFn getType = (BfAbiGetTypeFn)rhs->vtbl->slot[BFABI_SLOT_GetType];
-  if (!getType || getType(rhs) != BFABI_TYPE_MAT_DENSE_COMPLEX || op->srcDtype != BFHIP_C128) {
+  if (!getType || getType(rhs) != BFABI_TYPE_MAT_DENSE_COMPLEX || op->srcDtype != BFHIP_C128)
     /* same restriction as bfMatDenseComplexMul's switch (mat_dense_complex.c:1036-1047) */
-    bfhipFail(BFABI_ERROR_NOT_IMPLEMENTED, "Mul needs a complex operator and a BfMatDenseComplex right-hand side");
-    return NULL;
-  }
-  if (rhs->props & (BFABI_MAT_PROPS_TRANS | BFABI_MAT_PROPS_CONJ)) { bfhipFail(BFABI_ERROR_NOT_IMPLEMENTED, "transposed right-hand side"); return NULL; }
+    SHIM_FAIL(BFABI_ERROR_NOT_IMPLEMENTED, "Mul needs a complex operator and a BfMatDenseComplex right-hand side");
+  if (rhs->props & (BFABI_MAT_PROPS_TRANS | BFABI_MAT_PROPS_CONJ)) SHIM_FAIL(BFABI_ERROR_NOT_IMPLEMENTED, "transposed right-hand side");
   BfAbiMatDenseComplex const *x = (BfAbiMatDenseComplex const *)rhs;
-  if (rhs->numRows != op->plan.numCols) { bfhipFail(BFABI_ERROR_INCOMPATIBLE_SHAPES, "operator has %llu columns, right-hand side %llu rows", (unsigned long long)op->plan.numCols, (unsigned long long)rhs->numRows); return NULL; }
-  if (x->colStride != 1) { bfhipFail(BFABI_ERROR_NOT_IMPLEMENTED, "right-hand side with colStride != 1"); return NULL; }
+  if (rhs->numRows != op->plan.numCols)
+    SHIM_FAIL(BFABI_ERROR_INCOMPATIBLE_SHAPES, "operator has %llu columns, right-hand side %llu rows", (unsigned long long)op->plan.numCols, (unsigned long long)rhs->numRows);
+  if (x->colStride != 1) SHIM_FAIL(BFABI_ERROR_NOT_IMPLEMENTED, "right-hand side with colStride != 1");
   BfAbiLikeFn emptyLike = (BfAbiLikeFn)rhs->vtbl->slot[BFABI_SLOT_EmptyLike];
-  if (!emptyLike) { bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "right-hand side has no EmptyLike"); return NULL; }
+  if (!emptyLike) SHIM_FAIL(BFABI_ERROR_INVALID_ARGUMENTS, "right-hand side has no EmptyLike");
   BfAbiMat *res = emptyLike(rhs, op->plan.numRows, rhs->numCols);
-  if (!res) { bfhipFail(BFABI_ERROR_MEMORY_ERROR, "EmptyLike failed"); return NULL; }
+  if (!res) SHIM_FAIL(BFABI_ERROR_MEMORY_ERROR, "EmptyLike failed");
   BfAbiMatDenseComplex *y = (BfAbiMatDenseComplex *)res;
   int rc = bfhipApply(op, x->data, x->rowStride, rhs->numCols, y->data, y->rowStride);
   if (rc) {
     BfAbiDeleteFn del = (BfAbiDeleteFn)res->vtbl->slot[BFABI_SLOT_Delete];
     if (del) del(&res);
+    shimRaise(rc);
     return NULL;
   }
   return res;
@@ -840,62 +948,44 @@ static BfAbiMat *shimMul(BfAbiMat const *lhs, BfAbiMat const *rhs) {
   return bfhipMatMulFunc(rhs, ((BfhipMat const *)lhs)->op);
 }
 
-/* y = A x for a reference BfVecReal (real operators only: the block types
- * reject complex vectors, mat_block_coo.c:438-444).  The result is a Copy of
- * the argument when sizes agree, so it carries the reference's own vtable. */
-static BfAbiVec *shimMulVec(BfAbiMat const *lhs, BfAbiVec const *vec) {
+/* y = A x (transpose == 0) or z = x^T A as a vector (bfMatRmulVec) for a reference BfVecReal; real
+ * operators only: the block types reject complex vectors (mat_block_coo.c:438-444).  The result
+ * is sized by the operator, as the reference's containers size theirs (bfVecRealNewWithValue(m, 0)
+ * in src/mat_block_dense.c:574-590 and src/mat_block_coo.c:427-444; n for RmulVec, :696-712):
+ * a malloc'd BfVecReal {vtbl, props NONE, size, stride 1, malloc'd data} carrying the ARGUMENT's
+ * vtable, so that the reference's bfVecDelete -> bfVecRealDeinitAndDealloc frees data and struct with
+ * free() (src/vec_real.c:661-676, src/mem.c:65-67).  Rectangular operators are the normal case:
+ * cov_matvec applies the N x m operator Phi both ways (examples/covariance/lbo_cov.c:48-60). */
+static BfAbiVec *shimApplyVec(BfAbiMat const *lhs, BfAbiVec const *vec, int transpose) {
   BfhipOperator *op = ((BfhipMat const *)lhs)->op;
-  if (!vec || !vec->vtbl) { bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "NULL vector"); return NULL; }
+  char const *const what = transpose ? "RmulVec" : "MulVec";
+  if (!vec || !vec->vtbl) SHIM_FAIL(BFABI_ERROR_INVALID_ARGUMENTS, "%s: NULL vector", what);
   BfAbiVecGetTypeFn getType = (BfAbiVecGetTypeFn)vec->vtbl->slot[BFABI_VSLOT_GetType];
-  if (!getType || getType(vec) != BFABI_TYPE_VEC_REAL || op->srcDtype != BFHIP_F64) {
-    bfhipFail(BFABI_ERROR_NOT_IMPLEMENTED, "MulVec needs a real operator and a BfVecReal");
-    return NULL;
-  }
-  if (vec->size != op->plan.numCols) { bfhipFail(BFABI_ERROR_NOT_IMPLEMENTED, "vector size mismatch"); return NULL; }
-  if (op->plan.numRows != op->plan.numCols) { bfhipFail(BFABI_ERROR_NOT_IMPLEMENTED, "MulVec shim needs a square operator (result is a Copy of the argument)"); return NULL; }
+  if (!getType || getType(vec) != BFABI_TYPE_VEC_REAL || op->srcDtype != BFHIP_F64)
+    SHIM_FAIL(BFABI_ERROR_NOT_IMPLEMENTED, "%s needs a real operator and a BfVecReal", what);
+  if (transpose && !op->hasTplan) SHIM_FAIL(BFABI_ERROR_NOT_IMPLEMENTED, "RmulVec needs an operator compiled with BFHIP_FLAG_ADJOINT");
+  uint64_t const inLen = transpose ? op->plan.numRows : op->plan.numCols;
+  uint64_t const outLen = transpose ? op->plan.numCols : op->plan.numRows;
+  if (vec->size != inLen)
+    SHIM_FAIL(BFABI_ERROR_INCOMPATIBLE_SHAPES, "%s: operator expects %llu entries, vector has %llu", what, (unsigned long long)inLen, (unsigned long long)vec->size);
   BfAbiVecReal const *x = (BfAbiVecReal const *)vec;
-  BfAbiVecCopyFn copy = (BfAbiVecCopyFn)vec->vtbl->slot[BFABI_VSLOT_Copy];
-  if (!copy) { bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "vector has no Copy"); return NULL; }
-  BfAbiVec *res = copy(vec);
-  if (!res) { bfhipFail(BFABI_ERROR_MEMORY_ERROR, "vector Copy failed"); return NULL; }
-  BfAbiVecReal *y = (BfAbiVecReal *)res;
-  int rc = bfhipApply(op, x->data, x->stride, 1, y->data, y->stride);
-  if (rc) {
-    BfAbiVecDeleteFn del = (BfAbiVecDeleteFn)res->vtbl->slot[BFABI_VSLOT_Delete];
-    if (del) del(&res);
-    return NULL;
-  }
-  return res;
+  BfAbiVecReal *y = malloc(sizeof *y);
+  double *data = malloc((outLen ? outLen : 1) * sizeof(double));
+  if (!y || !data) { free(y); free(data); SHIM_FAIL(BFABI_ERROR_MEMORY_ERROR, "host OOM"); }
+  y->super.vtbl = vec->vtbl;
+  y->super.props = BFABI_VEC_PROPS_NONE;
+  y->super.size = outLen;
+  y->stride = 1;
+  y->data = data;
+  int rc = applyHost(op, transpose, x->data, x->stride, 1, y->data, 1);
+  if (rc) { free(data); free(y); shimRaise(rc); return NULL; }
+  return &y->super;
 }
-
-/* z = x^T A as a vector (bfMatRmulVec): real operators, square (the result is a
- * Copy of the argument), compiled with BFHIP_FLAG_ADJOINT */
-static BfAbiVec *shimRmulVec(BfAbiMat const *lhs, BfAbiVec const *vec) {
-  BfhipOperator *op = ((BfhipMat const *)lhs)->op;
-  if (!vec || !vec->vtbl) { bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "NULL vector"); return NULL; }
-  BfAbiVecGetTypeFn getType = (BfAbiVecGetTypeFn)vec->vtbl->slot[BFABI_VSLOT_GetType];
-  if (!getType || getType(vec) != BFABI_TYPE_VEC_REAL || op->srcDtype != BFHIP_F64) {
-    bfhipFail(BFABI_ERROR_NOT_IMPLEMENTED, "RmulVec needs a real operator and a BfVecReal");
-    return NULL;
-  }
-  if (vec->size != op->plan.numRows) { bfhipFail(BFABI_ERROR_NOT_IMPLEMENTED, "vector size mismatch"); return NULL; }
-  if (op->plan.numRows != op->plan.numCols) { bfhipFail(BFABI_ERROR_NOT_IMPLEMENTED, "RmulVec shim needs a square operator (result is a Copy of the argument)"); return NULL; }
-  BfAbiVecReal const *x = (BfAbiVecReal const *)vec;
-  BfAbiVecCopyFn copy = (BfAbiVecCopyFn)vec->vtbl->slot[BFABI_VSLOT_Copy];
-  if (!copy) { bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "vector has no Copy"); return NULL; }
-  BfAbiVec *res = copy(vec);
-  if (!res) { bfhipFail(BFABI_ERROR_MEMORY_ERROR, "vector Copy failed"); return NULL; }
-  BfAbiVecReal *y = (BfAbiVecReal *)res;
-  int rc = bfhipApplyTranspose(op, x->data, x->stride, 1, y->data, y->stride);
-  if (rc) {
-    BfAbiVecDeleteFn del = (BfAbiVecDeleteFn)res->vtbl->slot[BFABI_VSLOT_Delete];
-    if (del) del(&res);
-    return NULL;
-  }
-  return res;
-}
+static BfAbiVec *shimMulVec(BfAbiMat const *lhs, BfAbiVec const *vec) { return shimApplyVec(lhs, vec, 0); }
+static BfAbiVec *shimRmulVec(BfAbiMat const *lhs, BfAbiVec const *vec) { return shimApplyVec(lhs, vec, 1); }
 
 static BfAbiMatVtable ShimVtable = {.slot = {
+  [BFABI_SLOT_GetView] = (void *)shimGetView,
   [BFABI_SLOT_RmulVec] = (void *)shimRmulVec,
   [BFABI_SLOT_Delete] = (void *)shimDelete,
   [BFABI_SLOT_GetType] = (void *)shimGetType,

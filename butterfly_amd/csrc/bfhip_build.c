@@ -396,9 +396,14 @@ int bfhipBuildHelm2(BfhipDesc const *desc, BfhipHelm2Problem const *prob, BfhipO
   double const t0 = nowSeconds();
   rc = bfhipCompileIrFill(&ir, opts, fillArena, &ctx, out);
   local.seconds = nowSeconds() - t0;
-  if (!rc && stats) {
-    if (stats->structSize < sizeof local) { bfhipFree(out); return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "BfhipBuildStats.structSize too small"); }
-    *stats = local;
+  if (stats && stats->structSize >= sizeof local) *stats = local;     /* also on failure: the counts say why */
+  if (!rc && stats && stats->structSize < sizeof local) { bfhipFree(out); return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "BfhipBuildStats.structSize too small"); }
+  if (!rc && local.notConverged && !getenv("BFHIP_ALLOW_UNCONVERGED_SVD")) {
+    /* a least-squares leaf from an SVD that hit the sweep cap is a silently wrong operator: refuse
+     * it (BFHIP_ALLOW_UNCONVERGED_SVD=1 in the environment keeps the operator, for diagnosis) */
+    bfhipFree(out);
+    return bfhipFail(BFABI_ERROR_RUNTIME_ERROR, "%llu Jacobi SVD problem(s) did not converge within the sweep cap; operator discarded",
+                     (unsigned long long)local.notConverged);
   }
   return rc;
 }

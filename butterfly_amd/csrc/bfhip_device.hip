@@ -502,13 +502,16 @@ __global__ __launch_bounds__(BF_WAVES_PER_WG * 64) void bfStageKernelT(StagePara
           }
           continue;
         }
-        uint32_t const units = pc.ld / EPL;          // 16-byte units per column (multiple of 16)
+        uint32_t const units = pc.ld / EPL;          // 16-byte units per column (forward mrPad / EPL: any value >= 1)
         uint32_t const n = pc.ncols;                 // rows of the forward piece
-        U const *src = arena + pc.dataOff / EPL + r;
+        U const *src = arena + pc.dataOff / EPL;
         for (uint32_t rb = 0; rb < units; rb += 16) {
+          // the last 16-unit block of a column may be short: clamp the unit index into the column
+          // (the rows it stands for are >= n, so their x is zero below) -- never read past the piece
+          uint32_t const ru = rb + r < units ? rb + r : units - 1;
           U a[4];
 #pragma unroll
-          for (int cq = 0; cq < 4; ++cq) a[cq] = bfLoadStreamV(src + jcol[cq] * units + rb);
+          for (int cq = 0; cq < 4; ++cq) a[cq] = bfLoadStreamV(src + jcol[cq] * units + ru);
           S xv[UNIT];
 #pragma unroll
           for (int e = 0; e < EPL; ++e) {

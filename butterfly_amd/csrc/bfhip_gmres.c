@@ -36,8 +36,26 @@ static void applyGivens(cplx *z0p, cplx *z1p, cplx c, cplx s) {
   *z1p = s * z0 + c * z1;
 }
 
+static int solveDevice(BfhipOperator *op, void const *dB, size_t nrhs, void const *dX0, double tol,
+                       size_t maxNumIter, size_t *numIter, double *residual, void *dX, void *stream);
+
+/* the Krylov basis and every staging buffer live on the OPERATOR's device, whatever device is
+ * current in the caller; the caller's device is restored on every path */
 int bfhipSolveGMRESDevice(BfhipOperator *op, void const *dB, size_t nrhs, void const *dX0, double tol,
                           size_t maxNumIter, size_t *numIter, double *residual, void *dX, void *stream) {
+  if (!op) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "NULL argument");
+  int prev = -1, dev = bfhipOperatorDevice(op);
+  if (dev < 0) return bfhipFail(BFABI_ERROR_RUNTIME_ERROR, "operator has no device (compiled with BFHIP_FLAG_PLAN_ONLY)");
+  bfdevGetDevice(&prev);
+  int rc = prev != dev ? bfdevSetDevice(dev) : 0;
+  if (rc) return rc;
+  rc = solveDevice(op, dB, nrhs, dX0, tol, maxNumIter, numIter, residual, dX, stream);
+  if (prev >= 0 && prev != dev) bfdevSetDevice(prev);
+  return rc;
+}
+
+static int solveDevice(BfhipOperator *op, void const *dB, size_t nrhs, void const *dX0, double tol,
+                       size_t maxNumIter, size_t *numIter, double *residual, void *dX, void *stream) {
   if (!op || !dB || !dX) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "NULL argument");
   if (maxNumIter == 0) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "maxNumIter must be positive (linalg.c:81-82)");
   if (nrhs == 0 || nrhs > 0xffffu) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "nrhs out of range");
@@ -161,9 +179,13 @@ int bfhipSolveGMRES(BfhipOperator *op, void const *B, size_t ldb, size_t nrhs, v
   uint64_t n = bfhipGetNumRows(op);
   size_t const vecBytes = (size_t)n * nrhs * 16;
   void *dB = NULL, *dX0 = NULL, *dX = NULL;
+  int prev = -1, dev = bfhipOperatorDevice(op);
+  if (dev < 0) return bfhipFail(BFABI_ERROR_RUNTIME_ERROR, "operator has no device (compiled with BFHIP_FLAG_PLAN_ONLY)");
   char *pack = malloc(vecBytes ? vecBytes : 1);
   int rc = 0;
   if (!pack) return bfhipFail(BFABI_ERROR_MEMORY_ERROR, "host OOM");
+  bfdevGetDevice(&prev);
+  if (prev != dev && (rc = bfdevSetDevice(dev))) { free(pack); return rc; }
   if ((rc = bfdevMalloc(&dB, vecBytes))) goto done;
   if ((rc = bfdevMalloc(&dX, vecBytes))) goto done;
   for (uint64_t i = 0; i < n; ++i) memcpy(pack + i * nrhs * 16, (char const *)B + i * ldb * 16, nrhs * 16);
@@ -179,5 +201,6 @@ int bfhipSolveGMRES(BfhipOperator *op, void const *B, size_t ldb, size_t nrhs, v
 done:
   bfdevFree(dB); bfdevFree(dX0); bfdevFree(dX);
   free(pack);
+  if (prev >= 0 && prev != dev) bfdevSetDevice(prev);
   return rc;
 }

@@ -156,6 +156,8 @@ typedef int (*BfFillFn)(BfPlan const *plan, BfIr const *ir, void *dArena, void *
 struct BfhipOptions;
 struct BfhipOperator;
 int bfhipCompileIrFill(BfIr *ir, struct BfhipOptions const *opts, BfFillFn fill, void *fillCtx, struct BfhipOperator **out);
+/* HIP ordinal the operator lives on; -1 for a plan-only operator */
+int bfhipOperatorDevice(struct BfhipOperator const *op);
 
 /* ------------------------------------------------------------------------
  * Device layer (implemented in bfhip_device.hip)

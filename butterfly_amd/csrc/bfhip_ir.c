@@ -40,6 +40,11 @@ int bfIrFromDesc(BfhipDesc const *d, BfIr *ir) {
   if (!d->numNodes || d->root >= d->numNodes) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "bad root / empty descriptor");
   if (!d->kind || !d->rows || !d->cols || !d->childBegin) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "descriptor arrays missing");
   uint64_t n = d->numNodes, nc = d->childBegin[n];
+  /* the CSR must be well formed before anything indexes the child arrays through it */
+  if (d->childBegin[0] != 0) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "childBegin[0] must be 0");
+  for (uint64_t i = 0; i < n; ++i)
+    if (d->childBegin[i + 1] < d->childBegin[i] || d->childBegin[i + 1] > nc)
+      return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "childBegin is not a non-decreasing prefix array (node %llu)", (unsigned long long)i);
   if (nc && (!d->childNode || !d->childRow0 || !d->childCol0)) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "descriptor child arrays missing");
   ir->dtype = d->dtype;
   ir->numNodes = n;
@@ -404,7 +409,10 @@ int bfIrFinalize(BfIr *ir) {
   }
   /* depth by iterative post-order (children may have any ids) */
   uint8_t *state = calloc(n, 1);
-  uint64_t *stack = malloc((n + 1) * 8);
+  /* a node is pushed once per parent entry that lists it (a block may list one child many
+   * times, a descriptor may share sub-expressions), so the stack holds up to one entry per child
+   * edge plus the root */
+  uint64_t *stack = malloc((ir->numChildren + 2) * 8);
   if (!state || !stack) { free(state); free(stack); bfIrFree(ir); return bfhipFail(BFABI_ERROR_MEMORY_ERROR, "host OOM"); }
   uint64_t sp = 0;
   stack[sp++] = ir->root;

@@ -261,12 +261,16 @@ class HipOperator:
         return ms, launches, nbytes
 
     # ---- reference-vtable shim ---------------------------------------------
-    def as_bfmat(self):
-        """A BfMat* whose Mul/MulVec run on the device (bfhipMatNew).  The shim
-        does not own the operator; keep this object alive while it is used."""
-        p = self._lib.bfhipMatNew(self._h, 0)
+    def as_bfmat(self, owns=False):
+        """A BfMat* whose Mul / MulVec / RmulVec run on the device (bfhipMatNew).  With
+        owns=False the shim does not own the operator (keep this object alive while it is
+        used); with owns=True the operator is handed over to the shim -- its Delete slot frees
+        it -- and this object is left closed."""
+        p = self._lib.bfhipMatNew(self._h, 1 if owns else 0)
         if not p:
             raise _capi.BfhipError(1, self._lib.bfhipLastErrorMessage().decode())
+        if owns:
+            self._h = C.c_void_p(None)
         return p
 
 

@@ -234,14 +234,25 @@ void bfhipFree(BfhipOperator **op);
 
 /* ---- reference-vtable shim ----------------------------------------------- */
 
-/* A `BfMat *` whose vtable implements Mul, MulVec, GetNumRows, GetNumCols,
- * GetType (-> BF_TYPE_MAT_FUNC), NumBytes and Delete on top of `op`, so that
- * unmodified reference code (bfSolveGMRES src/linalg.c:125,155; the example
- * drivers) can call bfMatMul on it.  Results are allocated through the
- * RHS's own vtable (`EmptyLike`, slot 8) so that the reference's bfMatDelete
- * frees them (mat_dense_complex.c:2164-2187).  Delete releases the shim and,
- * if `ownsOperator`, the operator. */
+/* A `BfMat *` whose vtable implements Mul, MulVec, RmulVec, GetView, GetNumRows,
+ * GetNumCols, GetType (-> BF_TYPE_MAT_FUNC), NumBytes and Delete on top of
+ * `op`, so that unmodified reference code (bfSolveGMRES src/linalg.c:125,155;
+ * cov_matvec examples/covariance/lbo_cov.c:48-60; an enclosing BfMatBlockDense,
+ * src/mat_block_dense.c:541-563) can call bfMatMul / bfMatMulVec / bfMatRmulVec
+ * on it.  Mul results are allocated through the RHS's own vtable (`EmptyLike`,
+ * slot 8) so that the reference's bfMatDelete frees them
+ * (mat_dense_complex.c:2164-2187); MulVec / RmulVec results are malloc'd
+ * BfVecReal of the operator's row / column count carrying the argument's
+ * vtable (rectangular operators are fine).  Delete releases the shim and, if
+ * `ownsOperator`, the operator; a GetView copy never owns it. */
 void *bfhipMatNew(BfhipOperator *op, int ownsOperator);
+
+/* Failures of the shim's Mul / MulVec / RmulVec / GetView return NULL and, by default, also raise
+ * the reference's global error state: `bfSetError(code)` (src/error.c:20-24) is looked up in the
+ * host process at run time (libbfhip does not link the reference).  bfSetError asserts on a
+ * non-zero code, so in a reference build with assertions this is as fatal as the reference's own
+ * BF_DIE() paths; pass 0 to keep failures to NULL + bfhipLastErrorMessage(). */
+void bfhipSetErrorForwarding(int on);
 
 /* `MatMulFunc` for the reference's own callback operator
  * (include/bf/mat_func.h:5): bfMatFuncInit(f, m, n, bfhipMatMulFunc, op). */

@@ -75,6 +75,12 @@ enum {
   BFABI_MAT_PROPS_CONJ = 1 << 2
 };
 
+/* ---- BfVecProps bits (vec.h:10-13) ---------------------------------------- */
+enum {
+  BFABI_VEC_PROPS_NONE = 0,
+  BFABI_VEC_PROPS_VIEW = 1 << 0
+};
+
 /* ---- BfError values (error.h:3-16) ---------------------------------------- */
 enum {
   BFABI_ERROR_NONE = 0,

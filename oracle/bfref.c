@@ -28,6 +28,9 @@ static int currentError = 0;
 int bfGetError(void) { return currentError; }
 void bfClearError(void) { currentError = 0; }
 static void setError(int e) { if (!currentError) currentError = e; }
+/* src/error.c:20-24 under its own name (the assertion is dropped with the rest of the fatal
+ * behaviour): what a foreign operator behind the vtable calls to raise the reference's error state */
+void bfSetError(int error) { setError(error); }
 
 static BfrefCounters counters;
 void bfrefResetCounters(void) { memset(&counters, 0, sizeof counters); }
@@ -785,10 +788,14 @@ static void blockDenseDelete(BfMat **mat) {
   *mat = NULL;
 }
 /* src/mat_block_dense.c:512-572.  bfMatBlockDenseGetBlockConst (:1043-1061)
- * hands out a *view* of the block (GetView slot); children here expose no
- * GetView for container types, so the block pointer is used directly -- the
- * arithmetic is identical, only one malloc/free pair per block is not
- * re-enacted (counted below so the cpu_baseline report can state it). */
+ * hands out a *view* of the block: bfMatGet(block, BF_POLICY_VIEW) ->
+ * block->vtbl->GetView(block), deleted after the product (:559).  A block
+ * whose vtable fills GetView (dense leaves here; a foreign operator such as
+ * the device shim) goes through exactly that; this file's own container
+ * types expose no GetView, so their pointer is used directly -- the
+ * arithmetic is identical, one malloc/free pair per block is re-enacted by
+ * the stand-in below (counted so the cpu_baseline report can state it). */
+typedef BfMat *(*GetViewFn)(BfMat *);
 static BfMat *blockDenseMul(BfMat const *mat, BfMat const *otherMat) {
   BfAbiMatBlock const *matBlock = (BfAbiMatBlock const *)mat;
   if (bfMatGetNumCols(mat) != bfMatGetNumRows(otherMat)) { setError(BFABI_ERROR_INCOMPATIBLE_SHAPES); return NULL; }
@@ -809,12 +816,17 @@ static BfMat *blockDenseMul(BfMat const *mat, BfMat const *otherMat) {
       j1 = matBlock->colOffset[j + 1];
       BfMat *op2Rows = bfMatGetRowRange((BfMat *)otherMat, j0, j1);
       BfMat const *block = matBlock->block[i * numColBlocks + j];
-      void *viewStandIn = xmalloc(64); /* the block view the reference mallocs here */
+      GetViewFn getView = (GetViewFn)block->vtbl->slot[BFABI_SLOT_GetView];
+      BfMat *blockView = getView ? getView((BfMat *)block) : NULL;
+      void *viewStandIn = blockView ? NULL : xmalloc(64); /* the block view the reference mallocs here */
+      if (getView && !blockView) setError(BFABI_ERROR_MEMORY_ERROR);
+      if (blockView) block = blockView;
       if (bfMatGetNumRows(block) != i1 - i0 || bfMatGetNumCols(block) != j1 - j0) setError(BFABI_ERROR_INCOMPATIBLE_SHAPES);
       BfMat *tmp = (op2Rows && !currentError) ? bfMatMul(block, op2Rows) : NULL;
       if (tmp) bfMatAddInplace(resultRows, tmp);
       bfMatDelete(&tmp);
       bfMatDelete(&op2Rows);
+      bfMatDelete(&blockView);
       free(viewStandIn);
       if (currentError) { bfMatDelete(&resultRows); bfMatDelete(&result); return NULL; }
     }

@@ -76,6 +76,7 @@ double *bfMatDenseData(BfMat *mat);   /* complex or real dense */
 /* global error code, as src/error.c:7-24 but non-fatal */
 int bfGetError(void);
 void bfClearError(void);
+void bfSetError(int error);             /* src/error.c:20-24 (non-fatal here) */
 
 /* counters for the cpu_baseline report */
 typedef struct BfrefCounters {

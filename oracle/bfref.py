@@ -32,7 +32,9 @@ def load():
         return _lib
     if not os.path.exists(LIB_PATH):
         build()
-    lib = C.CDLL(LIB_PATH)
+    # RTLD_GLOBAL: a foreign operator behind the vtable (the device shim) finds the oracle's
+    # bfSetError the way it would find the reference's in a host process that links libbf
+    lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
     vp = C.c_void_p
     sz = C.c_size_t
     lib.bfMatMul.argtypes = [vp, vp]; lib.bfMatMul.restype = vp

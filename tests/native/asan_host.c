@@ -114,6 +114,42 @@ static int driveGraph(void) {
   return 0;
 }
 
+/* malformed public descriptors must be refused, not walked (DFS stack sized by nodes
+ * while a child can be listed many times; childBegin never validated) */
+static int driveBadDescs(void) {
+  BfhipOptions o;
+  memset(&o, 0, sizeof o);
+  o.structSize = sizeof o; o.device = -1; o.flags = BFHIP_FLAG_PLAN_ONLY;
+  BfhipOperator *op = NULL;
+  /* (1) legal but nasty: a BLOCK root listing the same 1 x 1 leaf 40 times */
+  {
+    enum { K = 40 };
+    uint8_t kind[2] = {BFHIP_NODE_BLOCK, BFHIP_NODE_DENSE};
+    uint64_t rows[2] = {K, 1}, cols[2] = {K, 1}, cb[3] = {0, K, K}, cn[K], r0[K], c0[K];
+    for (int i = 0; i < K; ++i) { cn[i] = 1; r0[i] = (uint64_t)i; c0[i] = (uint64_t)i; }
+    BfhipDesc d;
+    memset(&d, 0, sizeof d);
+    d.structSize = sizeof d; d.dtype = BFHIP_F64; d.numNodes = 2; d.root = 0;
+    d.kind = kind; d.rows = rows; d.cols = cols; d.childBegin = cb; d.childNode = cn; d.childRow0 = r0; d.childCol0 = c0;
+    CHECK(bfhipCompileDesc(&d, &o, &op));
+    if (bfhipGetNumRows(op) != K) return 20;
+    bfhipFree(&op);
+    /* (2) childBegin not monotone */
+    uint64_t cbBad[3] = {0, K, 3};
+    d.childBegin = cbBad;
+    if (bfhipCompileDesc(&d, &o, &op) != 1 /* BF_ERROR_INVALID_ARGUMENTS */) return 21;
+    /* (3) childBegin[0] != 0 */
+    uint64_t cbBad2[3] = {2, K, K};
+    d.childBegin = cbBad2;
+    if (bfhipCompileDesc(&d, &o, &op) != 1) return 22;
+    /* (4) an interior entry beyond the child arrays */
+    uint64_t cbBad3[3] = {0, K + 5, K};
+    d.childBegin = cbBad3;
+    if (bfhipCompileDesc(&d, &o, &op) != 1) return 23;
+  }
+  return 0;
+}
+
 int main(void) {
   uint64_t const n = 6000, m = 2500;
   double *pts = malloc(n * 16), *tgt = malloc(m * 16), *rnd = malloc(3000 * 16);
@@ -125,6 +161,7 @@ int main(void) {
   if (!rc) rc = drive(pts, n, tgt, m, 90.0);
   if (!rc) rc = drive(rnd, 3000, NULL, 0, 60.0);
   if (!rc) rc = driveGraph();
+  if (!rc) rc = driveBadDescs();
   /* error paths */
   BfhipHelm2Layout *lay = NULL;
   double zeros[16] = {0};
@@ -148,6 +185,8 @@ STUB(bfdevEventCreate)
 STUB(bfdevEventElapsed)
 STUB(bfdevEventRecord)
 STUB(bfdevGetDevice)
+STUB(bfdevHostAllocPinned)
+void bfdevHostFreePinned(void *p) { if (p) { fprintf(stderr, "device layer reached: bfdevHostFreePinned(non-NULL)\n"); abort(); } }
 STUB(bfdevGmresDot)
 STUB(bfdevGmresFinish)
 STUB(bfdevGmresMgsStep)

@@ -69,6 +69,8 @@ def run_plan(op, x, transpose=False):
                     # lanes j < mr on the columns of a forward piece: element (step s, lane j) = arena[d0 + j*ld + s]
                     ld = int(pc["ld"])
                     assert ld >= n and mr <= 64
+                    # what bfStageKernelT may touch: columns j < mr, units clamped into the column
+                    assert d0 + mr * ld <= len(arena), "transposed piece reaches past the leaf arena"
                     idx = d0 + np.arange(mr)[:, None] * ld + np.arange(n)[None, :]
                     acc += arena[idx] @ src[io:io + n]
                     continue

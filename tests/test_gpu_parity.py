@@ -413,3 +413,98 @@ def test_deeply_nested_real_graphs_forward_and_transposed(seed):
     op32 = HipOperator.from_bfmat(A.ptr.value, demote_to_f32=True)
     assert rel(op32.apply_host(x) + 1, want + 1) <= 2e-5
     op32.close()
+
+
+def _handle(ptr, shape):
+    """What oracle.bfref.mat_mul_vec / mat_rmul_vec need of an operand: .ptr and .shape."""
+    return type("H", (), {"ptr": ptr, "shape": shape})()
+
+
+@pytest.mark.parametrize("m,n", [(300, 70), (64, 211)])
+def test_rectangular_cov_matvec_through_the_shim(m, n):
+    """cov_matvec's sequence on a RECTANGULAR real operator Phi (N x m eigenvector band):
+    tmp = bfMatRmulVec(Phi, v); z = bfMatMulVec(Phi, Gamma^2 tmp)
+    (examples/covariance/lbo_cov.c:48-60), dispatched by the oracle's own bfMatRmulVec / bfMatMulVec
+    on the shim.  The results are sized by the operator (src/mat_block_dense.c:574-590,
+    src/mat_block_coo.c:427-444) and freed by the oracle's bfVecDelete."""
+    import randgraph
+    from butterfly_amd import _capi
+    from butterfly_amd.operator import HipOperator
+    from oracle import bfref
+    rng = np.random.default_rng(1000 + m)
+    desc, vals = randgraph.random_operand(rng, depth=4, size_hint=120, cplx=False, m=m, n=n)
+    A = bfref.from_desc(desc, vals)
+    gamma2 = rng.random(n) ** 2
+    v = rng.standard_normal(m)
+    t_ref = bfref.mat_rmul_vec(A, v)
+    z_ref = bfref.mat_mul_vec(A, gamma2 * t_ref)
+    op = HipOperator.from_bfmat(A.ptr.value, flags=_capi.FLAG_ADJOINT)
+    a_hip = C.c_void_p(op.as_bfmat())
+    h = _handle(a_hip, (m, n))
+    t = bfref.mat_rmul_vec(h, v)
+    assert t.shape == (n,) and rel(t, t_ref) <= TOL
+    z = bfref.mat_mul_vec(h, gamma2 * t)
+    assert z.shape == (m,) and rel(z, z_ref) <= TOL
+    # shape errors surface as NULL + the reference's error state (bfSetError), not as a crash
+    lib = bfref.load()
+    lib.bfClearError()
+    with pytest.raises(RuntimeError, match="BfError 8"):     # BF_ERROR_INCOMPATIBLE_SHAPES
+        bfref.mat_mul_vec(h, np.zeros(n + 1))
+    lib.bfMatDelete(C.byref(a_hip))
+    op.close()
+
+
+def test_shim_nested_inside_an_oracle_block_dense(helm2_cases):
+    """The device operator as ONE block of a reference container: bfMatBlockDenseMul takes every
+    block through bfMatGet(block, BF_POLICY_VIEW) = the block's GetView slot, multiplies, and
+    deletes the view (src/mat_block_dense.c:541-563, :1043-1061)."""
+    from butterfly_amd.operator import HipOperator
+    from oracle import bfref, helm2_build as hb
+    n, k = 1024, 100
+    desc, tp, vals = helm2_cases(n, k)
+    A = bfref.from_desc(desc, vals)
+    op = HipOperator.from_bfmat(A.ptr.value)
+    rng = np.random.default_rng(5)
+    m2 = 37
+    d01 = rng.standard_normal((n, m2)) + 1j * rng.standard_normal((n, m2))
+    d10 = rng.standard_normal((m2, n)) + 1j * rng.standard_normal((m2, n))
+    d11 = rng.standard_normal((m2, m2)) + 1j * rng.standard_normal((m2, m2))
+    x = rng.standard_normal((n + m2, 2)) + 1j * rng.standard_normal((n + m2, 2))
+    y0 = bfref.mat_mul(A, x[:n]) + d01 @ x[n:]
+    y1 = d10 @ x[:n] + d11 @ x[n:]
+    want = np.vstack([y0, y1])
+
+    class Borrowed(bfref.Mat):           # the container steals the pointer like any other block
+        pass
+    shim = Borrowed(op.as_bfmat(owns=True))
+    grid = bfref.block_dense([0, n, n + m2], [0, n, n + m2],
+                             [shim, bfref.dense_complex(d01), bfref.dense_complex(d10), bfref.dense_complex(d11)])
+    got = bfref.mat_mul(grid, x)
+    assert rel(got, want) <= TOL
+    del grid                              # bfMatDelete on the container deletes the shim (and with it the operator)
+
+
+def test_adjoint_never_reads_past_a_short_column_block():
+    """with a leaf height that is not a multiple of 16 the transposed kernel's last
+    16-unit block used to read into whatever follows the piece (times x = 0: NaN if those bits are
+    NaN).  Poisoned neighbour: a second leaf full of NaN is packed right behind the first."""
+    from butterfly_amd import _capi
+    from butterfly_amd.helm2_structure import BF_TYPE_BLOCK_DIAG, Desc, NODE_BLOCK, NODE_DENSE
+    from butterfly_amd.operator import HipOperator
+    rng = np.random.default_rng(3)
+    for dtype, cplx in ((0, True), (1, False)):
+        d = Desc(dtype=dtype)
+        a = d.add(NODE_DENSE, 37, 19)
+        b = d.add(NODE_DENSE, 5, 5)
+        d.root = d.add(NODE_BLOCK, 42, 24, [(a, 0, 0), (b, 37, 19)], BF_TYPE_BLOCK_DIAG)
+        va = rng.standard_normal((37, 19)) + (1j * rng.standard_normal((37, 19)) if cplx else 0)
+        vb = np.full((5, 5), np.nan) + (1j * np.nan if cplx else 0)
+        for demote in ((False,) if cplx else (False, True)):
+            op = HipOperator.from_desc(d, {a: va, b: vb}, flags=_capi.FLAG_ADJOINT, demote_to_f32=demote)
+            x = rng.standard_normal(42) + (1j * rng.standard_normal(42) if cplx else 0)
+            y = op.apply_transpose_host(x)
+            want = va.T @ x[:37]
+            assert np.all(np.isfinite(y[:19])), "adjoint picked up the poisoned neighbour"
+            assert rel(y[:19], want) <= (2e-5 if demote else TOL)
+            assert np.all(np.isnan(y[19:]))       # the NaN leaf's own outputs
+            op.close()
