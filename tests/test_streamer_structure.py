@@ -1,0 +1,228 @@
+"""BASELINE config 5's operand: the streamed real butterfly (`fac_streamer`).
+
+CPU: the restatement of the streamer's merge-and-split recursion (butterfly_amd/streamer_structure.py +
+the numpy SVD of oracle/streamer_values.py) against the numbers the survey recorded from a run of the
+REAL reference on the same input (tests/golden/survey_probe_stats.json), the flat
+descriptor it emits against the C oracle and the plan emulator, and the value-free rank model against
+SVD-driven structures.  GPU: the HIP path on that operand, forward and transposed, f64 and f32."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def rel(a, b):
+    return float(np.linalg.norm(np.ravel(a) - np.ravel(b)) / np.linalg.norm(np.ravel(b)))
+
+
+_CACHE = {}
+
+
+def probe_case():
+    """The survey's streamer probe: N = 4096 Fibonacci-sphere points, 1024 lattice plane waves, tol 1e-3,
+    minNumRows = minNumCols = 20, frequency tree of depth 3 (8 feeds)."""
+    if "probe" not in _CACHE:
+        from butterfly_amd import streamer_structure as ss
+        from oracle import streamer_values as sv
+        st, phi = sv.stream_probe_case(4096, 1024, 1e-3, 3)
+        A = st.get_mat()
+        desc, vals = ss.to_desc(A)
+        _CACHE["probe"] = (st, phi, A, desc, vals)
+    return _CACHE["probe"]
+
+
+def lbo_case():
+    """Laplace-Beltrami eigenvectors of the sphere, N = 4096 >> J = 256 (the regime of the covariance
+    example), streamed with real SVDs."""
+    if "lbo" not in _CACHE:
+        from butterfly_amd import streamer_structure as ss
+        from oracle import streamer_values as sv
+        pts, phi, freqs = sv.sphere_lbo_problem(4096, 15)
+        st, a_phi = sv.stream_columns(pts, phi, freqs, float(np.sqrt(15 * 16.0) * 1.0001), 3)
+        A = st.get_mat()
+        desc, vals = ss.to_desc(A)
+        _CACHE["lbo"] = (st, a_phi, A, desc, vals)
+    return _CACHE["lbo"]
+
+
+def test_streamer_restatement_reproduces_the_survey_probe():
+    """Every count the survey's walk of the reference's object graph printed:
+    3656 DenseReal / 2454 Identity leaves in 5332 BlockDense / 2558 BlockCoo / 1834 BlockDiag nodes nested 9
+    deep, 42.6 MB of leaves with m in [1, 154] and n in [61, 207], one product with numW = 4 and 794 row
+    nodes, bfMatNumBytes 43.6 MB, and the example's own accuracy check (5.1e-4 vs the dense matrix)."""
+    from butterfly_amd import streamer_structure as ss
+    from oracle import streamer_values as sv
+    st, phi, A, desc, vals = probe_case()
+    gold = json.load(open(os.path.join(HERE, "golden", "survey_probe_stats.json")))["fac_streamer_n4096_j1024"]
+    gs = ss.graph_stats(A)
+    for key in ("product", "blockCoo", "blockDense", "blockDiag", "denseReal", "identity", "maxNest", "minM", "maxM", "minN", "maxN"):
+        assert gs[key] == gold[key], (key, gs[key], gold[key])
+    assert abs(gs["leafBytes"] / 1e6 - gold["leafMB"]) < 0.05
+    assert abs(A.num_bytes() / 1e6 - gold["numBytesMB"]) < 0.05
+    assert [len(f.W) for f in st.partial] == [gold["numW"]] and [len(f.row_nodes) for f in st.partial] == [gold["rowNodes"]]
+    x = np.random.default_rng(0).standard_normal(1024)
+    err = rel(sv.apply(A, x), phi @ x)
+    assert 3e-4 < err < 8e-4, err              # the survey measured 5.1e-4 with its own x
+
+
+def test_streamed_operand_through_the_c_oracle_and_the_planner():
+    """The flat descriptor of that operand: oracle/bfref.c's bfMatMulVec / bfMatRmulVec on it equal the
+    numpy recursion over the block algebra, and the engine's flattened plan (run by the numpy plan
+    emulator: no GPU) equals the oracle, forward and transposed."""
+    import plan_emulator
+    from butterfly_amd import _capi
+    from butterfly_amd.operator import HipOperator
+    from oracle import bfref, streamer_values as sv
+    for st, phi, A, desc, vals in (probe_case(), lbo_case()):
+        n, J = phi.shape
+        rng = np.random.default_rng(4)
+        x, v = rng.standard_normal(J), rng.standard_normal(n)
+        M = bfref.from_desc(desc, vals)
+        assert M.shape == (n, J) and M.num_bytes() == sum(8 * a.size for a in vals.values())
+        y = bfref.mat_mul_vec(M, x)
+        z = bfref.mat_rmul_vec(M, v)
+        assert rel(y, sv.apply(A, x)) <= 1e-13
+        assert rel(z, sv.densify(A).T @ v) <= 1e-12
+        op = HipOperator.from_desc(desc, vals, flags=_capi.FLAG_PLAN_ONLY | _capi.FLAG_ADJOINT)
+        assert op.stats()["numStages"] == 1 + len(st.partial[0].W)
+        assert rel(plan_emulator.run_plan(op, x), y) <= 1e-13
+        assert rel(plan_emulator.run_plan(op, v, transpose=True), z) <= 1e-13
+        op.close()
+
+
+def test_partial_stream_is_a_row_of_products():
+    """lbo_cov.c stops streaming once `numEigs` columns went in (examples/covariance/lbo_cov.c:139-143): the
+    operand is then a 1 x numFacs BlockDense row of products of different depths (src/fac_span.c:126-155)."""
+    from butterfly_amd import streamer_structure as ss
+    from oracle import bfref, streamer_values as sv
+    pts, phi, freqs = sv.sphere_lbo_problem(2048, 15)
+    st, a_phi = sv.stream_columns(pts, phi, freqs, float(np.sqrt(15 * 16.0) * 1.0001), 3, max_cols=150)
+    assert not st.is_done() and len(st.partial) >= 2
+    A = st.get_mat()
+    assert isinstance(A, ss.BlockDense) and A.nbr == 1 and A.nbc == len(st.partial)
+    assert len({len(f.W) for f in st.partial}) > 1            # products of different depths side by side
+    desc, vals = ss.to_desc(A)
+    x = np.random.default_rng(1).standard_normal(a_phi.shape[1])
+    y = bfref.mat_mul_vec(bfref.from_desc(desc, vals), x)
+    assert rel(y, a_phi @ x) < 2e-3
+
+
+def test_rank_model_structure_tracks_the_svd_structure():
+    """The value-free rank model (what lays out the N = 1M bench operand) against structures found with
+    real SVDs (tests/golden/streamer_lbo_stats.json, generated by make_streamer_golden.py): same row cut,
+    node counts and leaf bytes within 35 % in the regime N >> J."""
+    from butterfly_amd import streamer_structure as ss
+    from oracle import streamer_values as sv
+    gold = json.load(open(os.path.join(HERE, "golden", "streamer_lbo_stats.json")))["n16384_lmax31_fd4"]
+    tree = ss.Octree(sv.fibonacci_sphere(gold["n"]), 1)
+    counts, lmax = ss.sphere_band_columns(gold["wmax"], gold["freq_depth"])
+    assert lmax == gold["lmax"] and sum(counts) == (lmax + 1) ** 2
+    st = ss.stream_structure(tree, gold["wmax"], gold["freq_depth"], counts)
+    gs = ss.graph_stats(st.get_mat())
+    assert [len(f.row_nodes) for f in st.partial] == gold["row_nodes"] and [len(f.W) for f in st.partial] == gold["num_w"]
+    for key in ("denseReal", "identity", "blockCoo", "blockDense", "leafBytes"):
+        assert abs(gs[key] / gold["stats"][key] - 1) < 0.35, (key, gs[key], gold["stats"][key])
+    # a value-free graph compiles (values synthesized) and keeps every shape
+    desc, vals = ss.to_desc(st.get_mat())
+    assert not vals and desc.leaf_elems() * 8 == gs["leafBytes"]
+
+
+def test_octree_matches_reference_conventions():
+    """bfOctreeInit(points, maxLeafSize = 1): one point per leaf, children in octant order with `<=` going
+    low (src/octree_node.c:105-140), index ranges nested and contiguous."""
+    from butterfly_amd import streamer_structure as ss
+    from oracle import streamer_values as sv
+    pts = sv.fibonacci_sphere(500)
+    t = ss.Octree(pts, 1)
+    assert sorted(t.perm.tolist()) == list(range(500))
+    leaves = [v for v in range(len(t.first)) if not t.children(v)]
+    assert all(t.rows(v) == 1 for v in leaves) and len(leaves) == 500
+    for v in range(len(t.first)):
+        ch = t.children(v)
+        if ch:
+            assert t.first[ch[0]] == t.first[v] and t.last[ch[-1]] == t.last[v]
+            assert all(t.last[a] == t.first[b] for a, b in zip(ch[:-1], ch[1:]))
+    lo, hi = t.bbox
+    c = (lo + hi) / 2
+    x = pts[t.perm]
+    for slot, v in enumerate(t.child[0]):
+        if v < 0:
+            continue
+        gt = x[t.first[v]:t.last[v]] > c
+        assert np.all(gt[:, 0] * 4 + gt[:, 1] * 2 + gt[:, 2] == slot)
+
+
+# ---------------------------------------------------------------------------------------------------
+# GPU
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["probe", "lbo"])
+def test_streamed_operand_on_gpu_forward_and_transposed(case):
+    """HIP vs the C oracle on the fac_streamer-shaped operand: f64 <= 1e-12, f32 (build extension) <= 1e-5,
+    y = Phi x and z = Phi^T v; and against the dense matrix within the factorization's own tolerance."""
+    from butterfly_amd import _capi
+    from butterfly_amd.operator import HipOperator
+    from oracle import bfref
+    st, phi, A, desc, vals = probe_case() if case == "probe" else lbo_case()
+    n, J = phi.shape
+    rng = np.random.default_rng(9)
+    x, v = rng.standard_normal(J), rng.standard_normal(n)
+    M = bfref.from_desc(desc, vals)
+    y_ref, z_ref = bfref.mat_mul_vec(M, x), bfref.mat_rmul_vec(M, v)
+    for demote, tol in ((False, 1e-12), (True, 1e-5)):
+        op = HipOperator.from_desc(desc, vals, flags=_capi.FLAG_ADJOINT, demote_to_f32=demote)
+        y = op.apply_host(x)
+        z = op.apply_transpose_host(v)
+        assert rel(y, y_ref) <= tol and rel(z, z_ref) <= tol, (demote, rel(y, y_ref), rel(z, z_ref))
+        assert rel(y, phi @ x) < 2e-3 and rel(z, phi.T @ v) < 2e-3
+        op.close()
+
+
+@pytest.mark.gpu
+def test_cov_matvec_on_the_streamed_operand_through_the_shim():
+    """cov_matvec (examples/covariance/lbo_cov.c:48-60) on the real operand shape -- a rectangular N x J
+    product of nested block factors -- with the oracle's dispatch calling the device shim."""
+    from butterfly_amd import _capi
+    from butterfly_amd.operator import HipOperator
+    from oracle import bfref
+    st, phi, A, desc, vals = lbo_case()
+    n, J = phi.shape
+    M = bfref.from_desc(desc, vals)
+    op = HipOperator.from_bfmat(M.ptr.value, flags=_capi.FLAG_ADJOINT)      # walks the BfMat graph itself
+    a_hip = C.c_void_p(op.as_bfmat())
+    h = type("H", (), {"ptr": a_hip, "shape": (n, J)})()
+    rng = np.random.default_rng(11)
+    gamma = np.exp(-0.01 * np.arange(J))
+    v = rng.standard_normal(n)
+    want = bfref.mat_mul_vec(M, gamma * gamma * bfref.mat_rmul_vec(M, v))
+    got = bfref.mat_mul_vec(h, gamma * gamma * bfref.mat_rmul_vec(h, v))
+    assert rel(got, want) <= 1e-12
+    bfref.load().bfMatDelete(C.byref(a_hip))
+    op.close()
+
+
+@pytest.mark.gpu
+def test_rank_model_operand_synthetic_values_on_gpu():
+    """The bench operand's smaller sibling: structure from the rank model, values synthesized in HBM,
+    checked against the oracle building the same values on the host."""
+    from butterfly_amd import _capi, streamer_structure as ss
+    from butterfly_amd.operator import HipOperator
+    from oracle import bfref, streamer_values as sv
+    n, lmax, fd = 32768, 31, 4
+    tree = ss.Octree(sv.fibonacci_sphere(n), 1)
+    wmax = float(np.sqrt(lmax * (lmax + 1.0)) * 1.0001)
+    counts, _ = ss.sphere_band_columns(wmax, fd)
+    A = ss.stream_structure(tree, wmax, fd, counts).get_mat()
+    desc, _ = ss.to_desc(A)
+    M = bfref.from_desc(desc, None, seed=7)
+    rng = np.random.default_rng(2)
+    x, v = rng.standard_normal(A.n), rng.standard_normal(n)
+    y_ref, z_ref = bfref.mat_mul_vec(M, x), bfref.mat_rmul_vec(M, v)
+    for demote, tol in ((False, 1e-12), (True, 2e-5)):
+        op = HipOperator.from_desc(desc, None, seed=7, flags=_capi.FLAG_ADJOINT, demote_to_f32=demote)
+        assert rel(op.apply_host(x), y_ref) <= tol and rel(op.apply_transpose_host(v), z_ref) <= tol
+        op.close()
