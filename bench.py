@@ -1,49 +1,108 @@
 #!/usr/bin/env python3
 """bench.py -- butterfly matvecs/sec + achieved HBM GB/s on MI355X.
 
-Workload (BASELINE.json `metric`): 2D Helmholtz single-layer operator on N
-equispaced points of the unit circle, k = N/16 (16 points per wavelength),
-fac_helm2-style multilevel butterfly (HODBF), complex128, one right-hand side.
-The operand is *structure-exact, value-synthetic* (SURVEY.md section 8(d)): every
-block shape is what the reference's builder would produce (checked against the
-survey's probe statistics in tests/test_structure.py); values are a seeded
-counter-based stream generated directly in HBM.  Apply cost does not depend on
-the values.
+Headline workload (BASELINE.json `metric`, --workload helm2): 2D Helmholtz single-layer operator on N
+equispaced points of the unit circle, k = N/16 (16 points per wavelength), fac_helm2-style multilevel
+butterfly (HODBF), complex128, one right-hand side.  The operand is *structure-exact, value-synthetic*
+(SURVEY.md section 8(d)): every block shape is what the reference's builder would produce (checked against
+the survey's probe statistics in tests/test_structure.py); values are a seeded counter-based stream
+generated directly in HBM.  Apply cost does not depend on the values.
 
-A "step" is one full apply y = A x with x, y resident in HBM.  With N GPUs the
-top-level row blocks are dealt to ranks (strong scaling: the operator is fixed);
-each step then ends with one RCCL all-gather of y over xGMI.
+--workload streamer (BASELINE configs[4]): the streamed real butterfly of examples/covariance --
+Laplace-Beltrami eigenvectors of a sphere with N vertices, octree rows, binary frequency tree, tol 1e-3,
+minNumRows = minNumCols = 20 -- laid out by the reference's merge-and-split recursion
+(butterfly_amd/streamer_structure.py) under the fitted rank model, values synthetic, fp32 by default.
 
-Prints ONE JSON line on rank 0 (contract in the round prompt): metric, value,
-roofline{...} for the stage kernel from hipEvents inside the library, and
-cpu_baseline{...} = the CPU oracle (oracle/bfref.c, a port of the reference's
-bfMatMul) timed on a bounded sample of the same operand on this box.
+A "step" is one full apply y = A x with x, y resident in HBM.  With N GPUs (`--gpus N`: this script starts
+the N rank processes itself when it was not started by torch.distributed.run) the top-level blocks are
+dealt to ranks (strong scaling: the operator is fixed); each step then ends with ONE RCCL collective on y
+over xGMI, issued by libbfhip.so on the apply stream.
+
+Prints ONE JSON line on rank 0 (contract in the round prompt): metric, value, roofline{...} for the stage
+kernel from hipEvents inside the library, and cpu_baseline{...} = the CPU oracle (oracle/bfref.c, a port of
+the reference's bfMatMul / bfMatMulVec) timed on a bounded sample of the same operand on this box.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable copy)
 FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X dense FP64 matrix peak = FP64 vector peak = 1/2 of the 157.3 TFLOP/s FP32 rate
+PROFILE_ROUND = "r2"      # which committed rocprofv3 summaries the `traffic` figure is read from
 
 
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def cpu_baseline(desc, seed, total_leaf_elems, weights, budget_bytes, nrhs, x, y_gpu_full, row_offsets):
-    """Oracle (port of the reference bfMatMul) on a bounded sample: the top-level
-    block rows, smallest first, that fit in `budget_bytes` of leaf data."""
-    from butterfly_amd import helm2_structure as hs
+def parse_args(argv):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", choices=["helm2", "streamer"], default="helm2")
+    ap.add_argument("--npoints", "--n", dest="n", type=int, default=None, help="points (default 262144 helm2, 1048576 streamer)")
+    ap.add_argument("--wavenumber", "--k", dest="k", type=float, default=None, help="helm2: wavenumber (default N/16)")
+    ap.add_argument("--lmax", type=int, default=255, help="streamer: highest spherical-harmonic degree streamed (J = (lmax + 1)^2 columns)")
+    ap.add_argument("--freq-depth", type=int, default=None, help="streamer: depth of the frequency tree (default: row-tree depth - 3, lbo_cov.c:97-98)")
+    ap.add_argument("--nrhs", type=int, default=1)
+    ap.add_argument("--seed", type=int, default=1234)
+    ap.add_argument("--cpu-budget-gb", type=float, default=4.0, help="leaf bytes of the cpu_baseline sample")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the 64-RHS measurement appended to the default line")
+    ap.add_argument("--dtype", choices=["c128", "f64", "f32"], default=None,
+                    help="helm2: c128 (headline); f64 / f32 = the same block layout with real values (a kernel proxy).  "
+                         "streamer: f32 (default; the build's extension, configs[4]) or f64 (the reference's type)")
+    ap.add_argument("--adjoint", action="store_true", help="also time y = A^T x (RmulVec path) and report it next to the headline")
+    ap.add_argument("--pcie", action="store_true", help="also time the host-buffer path (H2D + apply + D2H)")
+    ap.add_argument("--emulate-world", type=int, default=0,
+                    help="diagnostic: on ONE GPU, time the shard that rank --emulate-rank of an N-rank job would own (no collective); "
+                         "--emulate-rank -1 times every rank's shard one after another")
+    ap.add_argument("--emulate-rank", type=int, default=0)
+    ap.add_argument("--python-layout", action="store_true", help="lay the operand out with butterfly_amd/helm2_structure.py instead of the C layout")
+    ap.add_argument("--force-collective", action="store_true", help="rehearsal: run the sharded C-ABI path (RCCL communicator + collective) even with one rank")
+    ap.add_argument("--shard", choices=["auto", "rows", "blocks"], default="auto",
+                    help="multi-GPU: top-level block rows + all-gather, or (row, col) blocks + all-reduce")
+    return ap.parse_args(argv)
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(args, argv):
+    """--gpus N without a launcher: start N rank processes (torch.distributed.run on 127.0.0.1) BEFORE this
+    process touches a GPU, relay rank 0's JSON line, and fail if any rank fails."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__)] + argv
+    log("bench.py: starting", args.gpus, "ranks:", " ".join(cmd))
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, text=True)
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    if p.returncode != 0 or not lines:
+        log(f"bench.py: rank processes failed (exit code {p.returncode}, {len(lines)} JSON line(s))")
+        sys.stdout.write(p.stdout)
+        sys.exit(p.returncode or 1)
+    print(lines[-1], flush=True)
+    sys.exit(0)
+
+
+# ---------------------------------------------------------------------------------------------------
+# CPU baselines (the oracle as the checker and as the stated baseline; never the thing shipped)
+# ---------------------------------------------------------------------------------------------------
+def _blas_one_thread():
     from oracle import bfref
     blas = bfref.try_use_openblas()
     if blas:
@@ -52,6 +111,16 @@ def cpu_baseline(desc, seed, total_leaf_elems, weights, budget_bytes, nrhs, x, y
             ctypes.CDLL(blas).scipy_openblas_set_num_threads(1)
         except Exception:
             pass
+    return blas
+
+
+def cpu_baseline_helm2(desc, seed, total_leaf_elems, weights, budget_bytes, nrhs, x, y_gpu_full, row_offsets):
+    """Oracle (port of the reference bfMatMul) on a bounded sample: the top-level block rows, smallest
+    first, that fit in `budget_bytes` of leaf data; extrapolated to the whole operand by leaf bytes."""
+    import numpy as np
+    from butterfly_amd import helm2_structure as hs
+    from oracle import bfref
+    blas = _blas_one_thread()
     order = np.argsort(weights)
     chosen, acc = [], 0
     for rb in order:
@@ -67,10 +136,8 @@ def cpu_baseline(desc, seed, total_leaf_elems, weights, budget_bytes, nrhs, x, y
     A = bfref.from_desc(desc, None, seed=seed, root=root)
     t_build = time.time() - t0
     xs = x if nrhs > 1 else x[:, None]
-    best = None
-    reps = 0
+    best, reps, y = None, 0, None
     t_start = time.time()
-    y = None
     while reps < 5 and (reps < 2 or time.time() - t_start < 20):
         bfref.reset_counters()
         t0 = time.perf_counter()
@@ -110,50 +177,77 @@ def cpu_baseline(desc, seed, total_leaf_elems, weights, budget_bytes, nrhs, x, y
         extra["all_cores"] = {"value": nrhs / (multi[1] / frac), "unit": "matvec/s", "cores": multi[0],
                               "note": "same port, OpenBLAS threads = host cores available to this process"}
     return dict(value=full_equiv, unit="matvec/s", cores=1, kind="port", **extra,
-                sample=(f"top-level block rows {chosen} of {len(weights)} ({sample_elems * 16 / 1e9:.2f} GB of "
-                        f"{total_leaf_elems * 16 / 1e9:.2f} GB leaf data, {frac * 100:.1f}%), best of {reps} in "
+                sample=(f"EXTRAPOLATED from a {frac * 100:.1f}% sample: top-level block rows {chosen} of {len(weights)} "
+                        f"({sample_elems * 16 / 1e9:.2f} GB of {total_leaf_elems * 16 / 1e9:.2f} GB leaf data), best of {reps} in "
                         f"{best * 1e3:.1f} ms, scaled by leaf bytes; blas={os.path.basename(blas) if blas else 'builtin-c'}; "
-                        f"{cnt['gemmCalls']} leaf gemm calls, {cnt['mallocs']} mallocs per apply; graph build {t_build:.1f}s"),
+                        f"{cnt['gemmCalls']} leaf gemm calls, {cnt['mallocs']} mallocs per sample apply; graph build {t_build:.1f}s"),
                 sample_seconds=best, parity_rel_l2=err)
 
 
+def cpu_baseline_streamer(graph, seed, budget_bytes):
+    """Oracle bfMatMulVec on a bounded sample of the streamed operand: of every factor of the (first)
+    product a prefix of its top-level blocks, `budget_bytes` of leaves in total, each timed as its own
+    sub-operator; extrapolated to the whole operand by leaf bytes (fp64, the reference's only type)."""
+    import numpy as np
+    from butterfly_amd import streamer_structure as ss
+    from oracle import bfref
+    blas = _blas_one_thread()
+    prods = [b for b in graph.blocks if isinstance(b, ss.Product)] if isinstance(graph, ss.BlockDense) else [graph]
+    factors = [f for p in prods for f in p.factors]
+    total = sum(ss.graph_stats(f)["leafBytes"] for f in factors)
+    per = budget_bytes / max(len(factors), 1)
+    rng = np.random.default_rng(seed)
+    t_sum, b_sum, pieces = 0.0, 0, []
+    for f in factors:
+        kids, acc = [], 0
+        for b in f.blocks:
+            kids.append(b)
+            acc += ss.graph_stats(b)["leafBytes"]
+            if acc >= per:
+                break
+        sub = ss.BlockDiag(kids) if isinstance(f, ss.BlockDiag) else ss.BlockDense.col(kids) if (isinstance(f, ss.BlockDense) and f.nbc == 1) else f
+        acc = ss.graph_stats(sub)["leafBytes"]
+        if acc == 0:
+            continue
+        desc, _ = ss.to_desc(sub, with_values=False)
+        M = bfref.from_desc(desc, None, seed=seed)
+        x = rng.standard_normal(sub.n)
+        best = None
+        for _ in range(3):
+            t0 = time.perf_counter()
+            bfref.mat_mul_vec(M, x)
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+        t_sum += best
+        b_sum += acc
+        pieces.append(f"{type(f).__name__}[{len(kids)}/{len(f.blocks)}]")
+    frac = b_sum / total
+    return dict(value=1.0 / (t_sum / frac), unit="matvec/s", cores=1, kind="port",
+                sample=(f"EXTRAPOLATED from a {frac * 100:.2f}% sample: a prefix of the top-level blocks of each of the {len(factors)} factors "
+                        f"({', '.join(pieces)}; {b_sum / 1e9:.2f} GB of {total / 1e9:.2f} GB fp64 leaf data), each sub-operator's bfMatMulVec best of 3, "
+                        f"{t_sum * 1e3:.1f} ms in total, scaled by leaf bytes; fp64 (the reference has no fp32); blas={os.path.basename(blas) if blas else 'builtin-c'}"),
+                sample_seconds=t_sum)
+
+
+# ---------------------------------------------------------------------------------------------------
 def main():
-    # Exactly one line may reach stdout (the JSON).  Native libraries (RCCL prints a
-    # version banner at communicator creation) write to fd 1 directly, so fd 1 is
-    # pointed at stderr for the whole run and the JSON goes to the saved descriptor.
+    argv = sys.argv[1:]
+    args = parse_args(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        launch_ranks(args, argv)          # never returns
+
+    # Exactly one line may reach stdout (the JSON).  Native libraries (RCCL prints a version banner at
+    # communicator creation) write to fd 1 directly, so fd 1 is pointed at stderr for the whole run and the
+    # JSON goes to the saved descriptor.
     sys.stdout.flush()
     real_stdout = os.fdopen(os.dup(1), "w")
     os.dup2(2, 1)
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--npoints", "--n", dest="n", type=int, default=262144,
-                    help="(use --npoints under torch.distributed.run: its parser treats a bare --n as ambiguous)")
-    ap.add_argument("--wavenumber", "--k", dest="k", type=float, default=None, help="wavenumber (default N/16)")
-    ap.add_argument("--nrhs", type=int, default=1)
-    ap.add_argument("--seed", type=int, default=1234)
-    ap.add_argument("--cpu-budget-gb", type=float, default=4.0, help="leaf bytes of the cpu_baseline sample")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--dtype", choices=["c128", "f64", "f32"], default="c128",
-                    help="c128: the fac_helm2 operand (headline).  f64 / f32: the SAME block layout with real values, a proxy "
-                         "for the real BfMatDenseReal path (BASELINE.json configs[4]); fp32 is the build's extension")
-    ap.add_argument("--adjoint", action="store_true", help="also time y = A^T x (RmulVec path) and report it next to the headline")
-    ap.add_argument("--pcie", action="store_true", help="also time the host-buffer path (H2D + apply + D2H)")
-    ap.add_argument("--emulate-world", type=int, default=0,
-                    help="diagnostic: on ONE GPU, time the shard that rank --emulate-rank of an N-rank job would own (no collective)")
-    ap.add_argument("--emulate-rank", type=int, default=0)
-    ap.add_argument("--python-layout", action="store_true", help="lay the operand out with butterfly_amd/helm2_structure.py instead of the C layout")
-    ap.add_argument("--force-collective", action="store_true",
-                    help="rehearsal: initialise RCCL and run the step's collective even with one rank")
-    ap.add_argument("--shard", choices=["auto", "rows", "blocks"], default="auto",
-                    help="multi-GPU: top-level block rows + all-gather, or (row, col) blocks + all-reduce")
-    args = ap.parse_args()
 
+    import numpy as np
     import torch
     import torch.distributed as dist
     from butterfly_amd import _capi, helm2_structure as hs
-    from butterfly_amd.dist import (ShardLayout, ShardedApply, assign_row_blocks, block_weights, choose_mode,
+    from butterfly_amd.dist import (RcclShardedApply, ShardLayout, assign_row_blocks, block_weights, choose_mode,
                                     row_block_weights)
     from butterfly_amd.operator import HipOperator
 
@@ -162,58 +256,101 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    use_pg = world > 1 or args.force_collective
+    use_pg = world > 1
     if use_pg:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29511")
-        os.environ.setdefault("RANK", "0")
-        os.environ.setdefault("WORLD_SIZE", "1")
+        os.environ.setdefault("MASTER_PORT", str(29500 + os.getpid() % 1000))
         dist.init_process_group("nccl", device_id=dev)
+        world = dist.get_world_size()
     if world != args.gpus and rank == 0:
-        log(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE")
+        log(f"note: --gpus {args.gpus} but the launcher started {world} rank(s); reporting n_gpus = {world}")
 
-    n = args.n
-    k = args.k if args.k is not None else n / 16.0
+    streamer = args.workload == "streamer"
+    dtype = args.dtype or ("f32" if streamer else "c128")
+    if streamer and dtype == "c128":
+        raise SystemExit("the streamed operand is real: --dtype f32 or f64")
+    if streamer and (world > 1 or args.emulate_world > 1):
+        raise SystemExit("configs[4] is a one-GPU workload: the streamed operand is one product, it has no top-level row blocks to deal out")
+    real = dtype != "c128"
+    esz = {"c128": 16, "f64": 8, "f32": 4}[dtype]
+    tdtype = {"c128": torch.complex128, "f64": torch.float64, "f32": torch.float32}[dtype]
+    flags = _capi.FLAG_PROFILE | (_capi.FLAG_ADJOINT if args.adjoint else 0)
+
+    # ---- the operand's block layout -------------------------------------------------------------------
     t0 = time.time()
-    # block layout of the operand: the native layout (bfhip_layout.c) unless the Python restatement is asked for
-    if args.python_layout:
-        desc, _, perm = hs.helm2_multilevel_structure(hs.circle_points(n), k)
+    graph = None
+    if streamer:
+        from butterfly_amd import streamer_structure as ss
+        n = args.n or 1048576
+        tree = ss.Octree(ss.fibonacci_sphere(n), 1)
+        fd = args.freq_depth if args.freq_depth is not None else tree.max_depth - 3
+        wmax = float(np.sqrt(args.lmax * (args.lmax + 1.0)) * 1.0001)
+        counts, _ = ss.sphere_band_columns(wmax, fd)
+        st_run = ss.stream_structure(tree, wmax, fd, counts)
+        graph = st_run.get_mat()
+        gstats = ss.graph_stats(graph)
+        desc, _ = ss.to_desc(graph, with_values=False)
+        ncols = graph.n
+        total_leaf = gstats["leafBytes"] // 8
+        workload = (f"fac_streamer butterfly of the N x J Laplace-Beltrami eigenvector matrix of a sphere (examples/covariance): N={n} octree rows, "
+                    f"J={ncols} columns (lmax={args.lmax}), frequency tree depth {fd}, tol=1e-3 rank model, minNumRows=minNumCols=20, nrhs={args.nrhs}")
+        config = {"workload": workload, "n": n, "num_cols": ncols, "lmax": args.lmax, "freq_depth": fd, "nrhs": args.nrhs,
+                  "leaf_bytes": total_leaf * esz, "num_w": [len(f.W) for f in st_run.partial],
+                  "graph": {k: gstats[k] for k in ("denseReal", "identity", "blockCoo", "blockDense", "blockDiag", "maxNest")},
+                  "dense_bytes": n * ncols * esz, "sharding": "none"}
+        data = "synthetic (block structure laid out by the fac_streamer merge-and-split recursion under the fitted rank model; seeded values generated in HBM)"
+        metric = "butterfly matvecs/sec (streamed real butterfly apply, examples/covariance)"
+        top_rows, weights, row_offsets = [n], [total_leaf], np.array([0, n])
+        sworld, srank, mode, mine, owner, loads = 1, 0, "rows", [0], [0], [total_leaf]
     else:
-        desc, perm = hs.native_multilevel_structure(hs.circle_points(n), k)
+        n = args.n or 262144
+        ncols = n
+        k = args.k if args.k is not None else n / 16.0
+        # the native layout (bfhip_layout.c) unless the Python restatement is asked for
+        if args.python_layout:
+            desc, _, perm = hs.helm2_multilevel_structure(hs.circle_points(n), k)
+        else:
+            desc, perm = hs.native_multilevel_structure(hs.circle_points(n), k)
+        if real:
+            desc.dtype = 1          # BFHIP_F64 leaves; --dtype f32 demotes them on upload
+        weights = row_block_weights(desc)
+        total_leaf = int(sum(weights))
+        top_rows = desc.meta["top_rows"]
+        row_offsets = np.concatenate([[0], np.cumsum(top_rows)]).astype(np.int64)
+        sworld, srank = (args.emulate_world, max(args.emulate_rank, 0)) if args.emulate_world > 1 else (world, rank)
+        mode = choose_mode(desc, sworld, args.shard)
+        if mode == "rows":
+            owner, loads = assign_row_blocks(weights, sworld)
+        else:
+            bw = block_weights(desc)
+            bowner, loads = assign_row_blocks(bw, sworld)
+            owner = [0] * len(weights)
+        workload = (f"fac_helm2 multilevel butterfly, unit circle, N={n}, k={k:g} (16 ppw), nrhs={args.nrhs}"
+                    + ("" if not real else f" [real-valued {dtype} proxy on the same block layout]"))
+        config = {"workload": workload, "n": n, "k": k, "nrhs": args.nrhs, "leaf_bytes": total_leaf * esz}
+        data = "synthetic (structure-exact fac_helm2 layout, seeded values generated in HBM)"
+        metric = "butterfly matvecs/sec (2D Helmholtz HODBF apply)"
     t_struct = time.time() - t0
-    real = args.dtype != "c128"
-    if real:
-        desc.dtype = 1          # BFHIP_F64 leaves; --dtype f32 demotes them on upload
-    esz = {"c128": 16, "f64": 8, "f32": 4}[args.dtype]
-    tdtype = {"c128": torch.complex128, "f64": torch.float64, "f32": torch.float32}[args.dtype]
-    weights = row_block_weights(desc)
-    total_leaf = int(sum(weights))
-    top_rows = desc.meta["top_rows"]
-    row_offsets = np.concatenate([[0], np.cumsum(top_rows)]).astype(np.int64)
-    sworld, srank = (args.emulate_world, args.emulate_rank) if args.emulate_world > 1 else (world, rank)
-    mode = choose_mode(desc, sworld, args.shard)
-    if mode == "rows":
-        owner, loads = assign_row_blocks(weights, sworld)
-        mine = [rb for rb in range(len(weights)) if owner[rb] == srank]
-    else:
-        bw = block_weights(desc)
-        bowner, loads = assign_row_blocks(bw, sworld)
-        mine = [i for i in range(len(bw)) if bowner[i] == srank]
-        owner = [0] * len(weights)
     if rank == 0:
-        log(f"structure: N={n} k={k:g} nodes={desc.num_nodes} leafGB={total_leaf * 16 / 1e9:.2f} "
-            f"products={desc.meta['stats']['products']} [{t_struct:.1f}s]; shard mode={mode}; rank loads GB="
-            f"{[round(l * 16 / 1e9, 2) for l in loads]}")
+        log(f"structure: {workload}; nodes={desc.num_nodes} leafGB={total_leaf * esz / 1e9:.2f} [{t_struct:.1f}s]; "
+            f"shard mode={mode}; rank loads GB={[round(l * esz / 1e9, 2) for l in loads]}")
+
+    def compile_shard(r, max_rhs):
+        """The operator rank r of an `sworld`-rank job holds."""
+        if sworld == 1:
+            root, rows = desc.root, n
+        elif mode == "rows":
+            mine_r = [rb for rb in range(len(weights)) if owner[rb] == r]
+            root, rows = hs.shard_desc(desc, mine_r)
+        else:
+            mine_r = [i for i in range(len(bowner)) if bowner[i] == r]
+            root, rows = hs.shard_desc_blocks(desc, mine_r), n
+        o = HipOperator.from_desc(desc, None, root=root, device=local_rank, flags=flags, seed=args.seed, max_rhs=max_rhs,
+                                  demote_to_f32=(dtype == "f32"))
+        return o, rows
 
     t0 = time.time()
-    if sworld == 1:
-        root, local_rows = desc.root, n
-    elif mode == "rows":
-        root, local_rows = hs.shard_desc(desc, mine)
-    else:
-        root, local_rows = hs.shard_desc_blocks(desc, mine), n
-    op = HipOperator.from_desc(desc, None, root=root, device=local_rank, flags=_capi.FLAG_PROFILE | (_capi.FLAG_ADJOINT if args.adjoint else 0),
-                               seed=args.seed, max_rhs=args.nrhs, demote_to_f32=(args.dtype == "f32"))
+    op, local_rows = compile_shard(srank, args.nrhs)
     torch.cuda.synchronize()
     t_compile = time.time() - t0
     st = op.stats()
@@ -221,20 +358,30 @@ def main():
         log(f"compile+synthesize: {t_compile:.1f}s stages={st['numStages']} items={st['numItems']} pieces={st['numPieces']} "
             f"arenaGB={st['arenaBytes'] / 1e9:.2f} metaMB={st['metaBytes'] / 1e6:.1f} tempElems={st['tempElems']}")
 
-    # x: seeded complex normal, identical on every rank (replicated input)
+    # x: seeded normal, identical on every rank (replicated input)
     rng = np.random.default_rng(args.seed)
-    shape = (n,) if args.nrhs == 1 else (n, args.nrhs)
+    shape = (ncols,) if args.nrhs == 1 else (ncols, args.nrhs)
     if real:
         x_host = rng.standard_normal(shape)
     else:
         x_host = (rng.standard_normal(shape) + 1j * rng.standard_normal(shape)) / np.sqrt(2)
     x = torch.from_numpy(x_host).to(dev).to(tdtype)
-    layout = ShardLayout(top_rows, owner, sworld)
-    if args.emulate_world > 1:
-        layout.world = 1        # one process: run this shard's local apply only
-    assert mode == "blocks" or layout.rows_of[srank] == local_rows
-    step = ShardedApply(layout, srank, lambda xin, out: op.apply_device(xin, out), dev, tdtype, nrhs=args.nrhs,
-                        mode=mode, force_collective=args.force_collective)
+
+    sharded = None
+    if (world > 1 or args.force_collective) and args.emulate_world <= 1:
+        layout = ShardLayout(top_rows, owner, world)
+
+        def bcast(payload):
+            box = [payload]
+            dist.broadcast_object_list(box, src=0)
+            return box[0]
+        sharded = RcclShardedApply(layout, rank, op, local_rank, nrhs=args.nrhs, mode=mode, bcast=bcast if world > 1 else None)
+        step = sharded
+    else:
+        y_buf = torch.empty((local_rows,) + shape[1:], dtype=tdtype, device=dev)
+
+        def step(xin):
+            return op.apply_device(xin, y_buf)
 
     for _ in range(args.warmup):
         y_full = step(x)
@@ -254,8 +401,29 @@ def main():
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-
     ms, launches, sbytes = op.stage_profile()
+
+    # multi-GPU: per-rank leaf bytes, the slowest rank's local stages, and the collective, separately
+    # (a few extra steps outside the timed region: reading the events synchronizes the host)
+    multi = None
+    if sharded is not None:
+        loc, coll = [], []
+        for _ in range(5):
+            step(x)
+            a, b = sharded.last_times()
+            loc.append(a); coll.append(b)
+        v = torch.tensor([float(np.median(loc)), float(np.median(coll)), st["leafBytes"] / 1e9], dtype=torch.float64, device=dev)
+        if use_pg:
+            allv = [torch.zeros_like(v) for _ in range(world)]
+            dist.all_gather(allv, v)
+        else:
+            allv = [v]
+        allv = torch.stack(allv).cpu().numpy()
+        multi = {"mode": mode, "collective": "ncclAllGather (in place) + segment reorder" if mode == "rows" else "ncclAllReduce (sum)",
+                 "rank_leaf_gb": [round(float(r[2]), 3) for r in allv], "rank_local_ms": [round(float(r[0]), 4) for r in allv],
+                 "max_local_ms": float(allv[:, 0].max()), "collective_ms_per_rank": [round(float(r[1]), 4) for r in allv],
+                 "max_collective_ms": float(allv[:, 1].max()), "collective_bytes": int(n * args.nrhs * esz)}
+
     if rank == 0:
         kern_ms = float(ms.sum())
         n_launch = int(launches.sum())
@@ -277,19 +445,25 @@ def main():
         else:
             roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                        "kernel": "bfStageKernelC128" if not real else f"bfStageKernelReal<{args.dtype}>", "launches_per_apply": len(ms),
-                        "avg_launch_ms": avg_launch_ms, "algorithmic_bytes_per_apply": bytes_per_apply,
-                        "kernel_ms_per_apply": kern_ms / max(launches.max(), 1)}
-        # HBM traffic per launch from the committed PMC profile of this very command (rocprofv3 --pmc
-        # FETCH_SIZE / WRITE_SIZE in separate passes, gfx950 x2 FETCH correction); PMC counters cannot be
-        # read from inside the process, so other configurations report null.
-        prof = os.path.join(ROOT, "profiles", "r1_pmc_summary.json")
-        if world == 1 and n == 262144 and abs(k - 16384) < 1e-9 and args.nrhs in (1, 64) and not real and os.path.exists(prof):
+                        "kernel": "bfStageKernelC128" if not real else f"bfStageKernelReal<{dtype}>", "launches_per_apply": len(ms),
+                        "avg_launch_ms": avg_launch_ms, "algorithmic_bytes_per_launch": bytes_per_apply / len(ms),
+                        "algorithmic_bytes_per_apply": bytes_per_apply, "kernel_ms_per_apply": kern_ms / max(launches.max(), 1)}
+        # `traffic` = HBM bytes PER LAUNCH (like `achieved`), from the COMMITTED rocprofv3 --pmc profile of this
+        # very command (FETCH_SIZE / WRITE_SIZE in separate passes, gfx950 x2 FETCH correction): counters cannot
+        # be read from inside the process, so it is not measured in this run and other configurations report null.
+        for rnd in (PROFILE_ROUND, "r1"):
+            prof = os.path.join(ROOT, "profiles", f"{rnd}_pmc_summary.json")
+            if not (world == 1 and not streamer and n == 262144 and abs(k - 16384) < 1e-9 and args.nrhs in (1, 64) and not real
+                    and args.emulate_world <= 1 and os.path.exists(prof)):
+                continue
             try:
                 key = "bfStageKernelC128_per_launch" if args.nrhs == 1 else "bfStageKernelC128Mfma_per_launch"
                 pm = json.load(open(prof))[key]
                 roofline["traffic"] = pm["hbm_bytes"]
-                roofline["traffic_source"] = f"profiles/r1_pmc_summary.json [{key}]: HBM bytes per launch of this command under rocprofv3 --pmc"
+                roofline["traffic_per_apply"] = pm["hbm_bytes"] * len(ms)
+                roofline["traffic_source"] = (f"profiles/{rnd}_pmc_summary.json [{key}]: from the committed profile of this command "
+                                              "(rocprofv3 --pmc, separate passes), NOT measured in this run; per launch, as `achieved`")
+                break
             except Exception:
                 pass
         # context for `frac` (informational; `peak` stays the guide's figure): what a pure stream of
@@ -307,8 +481,12 @@ def main():
             for _ in range(reps):
                 op.apply_host(x_host)
             pcie_ms = (time.perf_counter() - t1) / reps * 1e3
+        config["stages"] = st["numStages"]
+        if not streamer:
+            config["sharding"] = ("none" if sworld == 1 else "top-level row blocks (LPT by leaf bytes) + one all-gather" if mode == "rows"
+                                  else "top-level (row, col) blocks (LPT by leaf bytes) + one all-reduce")
         out = {
-            "metric": "butterfly matvecs/sec (2D Helmholtz HODBF apply)",
+            "metric": metric,
             "value": args.steps * args.nrhs / elapsed,
             "unit": "matvec/s",
             "n_gpus": world,
@@ -316,20 +494,19 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "strong",
+            "scaling": "strong" if not streamer else "weak",
             "vs_baseline": None,
-            "dtype": args.dtype,
-            "data": "synthetic (structure-exact fac_helm2 layout, seeded values generated in HBM)",
-            "config": {"workload": f"fac_helm2 multilevel butterfly, unit circle, N={n}, k={k:g} (16 ppw), nrhs={args.nrhs}"
-                                   + ("" if not real else f" [real-valued {args.dtype} proxy on the same block layout]"),
-                       "n": n, "k": k, "nrhs": args.nrhs, "leaf_bytes": total_leaf * esz,
-                       "stages": st["numStages"], "sharding": ("none" if world == 1 else "top-level row blocks (LPT by leaf bytes) + one all-gather" if mode == "rows"
-                                    else "top-level (row, col) blocks (LPT by leaf bytes) + one all-reduce")},
+            "dtype": dtype,
+            "data": data,
+            "config": config,
             "roofline": roofline,
-            "hbm_gbs_whole_step": (total_leaf * esz / 1e9) / (elapsed / args.steps),
+            # leaf bytes this process streamed per step / step time (one rank's share in a multi-GPU or emulated run)
+            "hbm_gbs_whole_step": (st["leafBytes"] / 1e9) / (elapsed / args.steps),
         }
+        if multi:
+            out["multi_gpu"] = multi
         if args.adjoint and world == 1:
-            xt = torch.from_numpy(x_host).to(dev).to(tdtype)
+            xt = torch.from_numpy(rng.standard_normal((local_rows,) + shape[1:]) if real else x_host).to(dev).to(tdtype)
             for _ in range(2):
                 yt = op.apply_transpose_device(xt)
             torch.cuda.synchronize()
@@ -339,23 +516,87 @@ def main():
             torch.cuda.synchronize()
             adj_ms = (time.perf_counter() - t1) / args.steps * 1e3
             out["adjoint"] = {"ms_per_apply": adj_ms, "matvec_per_s": args.nrhs / (adj_ms / 1e3),
-                              "hbm_gbs": total_leaf * esz / 1e9 / (adj_ms / 1e3)}
+                              "hbm_gbs": st["leafBytes"] / 1e9 / (adj_ms / 1e3)}
+            # <A x, v> = <x, A^T v>: ties the two plans together on the full-size operand
+            yx = op.apply_device(x)
+            lhs = torch.sum(yx.to(torch.complex128 if not real else torch.float64) * xt.to(torch.complex128 if not real else torch.float64))
+            rhs = torch.sum(x.to(lhs.dtype) * yt.to(lhs.dtype))
+            out["adjoint"]["transpose_identity_rel"] = float(abs(lhs - rhs) / max(abs(lhs), 1e-300))
         if args.pcie:
             out["pcie_inclusive"] = {"ms_per_apply": pcie_ms, "matvec_per_s": args.nrhs / (pcie_ms / 1e3),
-                                     "note": "bfhipApply on pageable host buffers: H2D x + apply + D2H y"}
+                                     "note": "bfhipApply: pack into pinned staging + H2D x + apply + D2H y + unpack"}
         if args.emulate_world > 1:
-            out["emulated_shard"] = {"world": args.emulate_world, "rank": args.emulate_rank, "mode": mode,
-                                     "shard_leaf_bytes": st["leafBytes"]}
-        if world == 1 and not args.no_cpu_baseline and not real and args.emulate_world <= 1:
+            out["emulated_shard"] = {"world": args.emulate_world, "rank": srank, "mode": mode, "shard_leaf_bytes": st["leafBytes"]}
+        if world == 1 and not args.no_cpu_baseline and args.emulate_world <= 1:
             try:
-                y_host = y_full.cpu().numpy()
-                out["cpu_baseline"] = cpu_baseline(desc, args.seed, total_leaf, weights, args.cpu_budget_gb * 1e9,
-                                                   args.nrhs, x_host, y_host, row_offsets)
+                if streamer:
+                    out["cpu_baseline"] = cpu_baseline_streamer(graph, args.seed, args.cpu_budget_gb * 1e9)
+                elif not real:
+                    out["cpu_baseline"] = cpu_baseline_helm2(desc, args.seed, total_leaf, weights, args.cpu_budget_gb * 1e9, args.nrhs, x_host,
+                                                             y_full.cpu().numpy(), row_offsets)
             except Exception as e:  # the baseline must never take the measurement down
                 out["cpu_baseline"] = {"value": None, "unit": "matvec/s", "cores": 1, "kind": "port", "sample": f"failed: {e!r}"}
+
+    # every rank's shard of an N-rank job, one after another on this GPU (the slowest bounds the job)
+    if args.emulate_world > 1 and args.emulate_rank < 0 and rank == 0:
+        times = []
+        op.close()
+        for r in range(args.emulate_world):
+            o, rows = compile_shard(r, args.nrhs)
+            yb = torch.empty((rows,) + shape[1:], dtype=tdtype, device=dev)
+            for _ in range(2):
+                o.apply_device(x, yb)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                o.apply_device(x, yb)
+            torch.cuda.synchronize()
+            times.append({"rank": r, "leaf_gb": o.stats()["leafBytes"] / 1e9, "ms_per_apply": (time.perf_counter() - t1) / args.steps * 1e3})
+            o.close()
+            del yb
+        out["emulated_shard"]["all_ranks"] = times
+        out["emulated_shard"]["slowest_ms"] = max(t["ms_per_apply"] for t in times)
+        op = None
+
+    # BASELINE configs[2] rides along on the default line: the same operand applied to 64 right-hand sides
+    # (FP64 MFMA kernel), timed after the headline loop so that the driver's run carries it
+    if (rank == 0 and world == 1 and not streamer and not real and args.nrhs == 1 and not args.no_extra and args.emulate_world <= 1
+            and n == 262144):
+        try:
+            op.close()
+            op = None
+            nr = 64
+            o64, _ = compile_shard(0, nr)
+            x64 = torch.from_numpy((rng.standard_normal((n, nr)) + 1j * rng.standard_normal((n, nr))) / np.sqrt(2)).to(dev)
+            y64 = torch.empty((n, nr), dtype=tdtype, device=dev)
+            o64.apply_device(x64, y64)
+            torch.cuda.synchronize()
+            o64.stage_profile(reset=True)
+            reps = 5
+            t1 = time.perf_counter()
+            for _ in range(reps):
+                o64.apply_device(x64, y64)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t1) / reps
+            ms64, l64, _ = o64.stage_profile()
+            flops = 8.0 * nr * o64.stats()["leafElems"]
+            tf = flops * reps / 1e12 / (float(ms64.sum()) / 1e3)
+            out["nrhs64"] = {"config": "BASELINE configs[2]: the same operand, 64 right-hand sides (bfStageKernelC128Mfma)", "steps": reps,
+                             "matvec_per_s": nr / dt, "ms_per_apply": dt * 1e3,
+                             "roofline": {"bound": "mfma", "achieved": tf, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP64_MFMA_PEAK_TFLOPS,
+                                          "kernel": "bfStageKernelC128Mfma", "kernel_ms_per_apply": float(ms64.sum()) / reps,
+                                          "algorithmic_flops_per_apply": flops}}
+            o64.close()
+        except Exception as e:
+            out["nrhs64"] = {"error": repr(e)}
+
+    if rank == 0:
         real_stdout.write(json.dumps(out) + "\n")
         real_stdout.flush()
-    op.close()
+    if sharded is not None:
+        sharded.close()
+    if op is not None:
+        op.close()
     if use_pg:
         dist.destroy_process_group()
 

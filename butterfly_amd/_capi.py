@@ -44,6 +44,14 @@ class BfhipStats(C.Structure):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}
 
 
+SHARD_ROWS, SHARD_BLOCKS = 0, 1
+
+
+class BfhipShardSpec(C.Structure):
+    _fields_ = [("structSize", C.c_uint32), ("mode", C.c_uint32), ("numRowsGlobal", C.c_uint64),
+                ("numSegments", C.c_uint32), ("reserved", C.c_uint32), ("segRows", C.c_void_p), ("segOwner", C.c_void_p)]
+
+
 class BfhipPlanInfo(C.Structure):
     _fields_ = [(n, C.c_uint32) for n in ("structSize", "dtype", "elemSize", "epl", "xcap", "reserved")] + [
         (n, C.c_uint64) for n in ("numRows", "numCols", "numStages", "arenaElems", "tempElems", "numStagesT", "tempElemsT")]
@@ -313,6 +321,22 @@ def load():
     lib.bfhipMatNew.restype = vp
     lib.bfhipMatMulFunc.argtypes = [vp, vp]
     lib.bfhipMatMulFunc.restype = vp
+    lib.bfhipSetErrorForwarding.argtypes = [C.c_int]
+    lib.bfhipSetErrorForwarding.restype = None
+    lib.bfhipCommGetUniqueId.argtypes = [vp]
+    lib.bfhipCommGetUniqueId.restype = C.c_int
+    lib.bfhipCommInitRank.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
+    lib.bfhipCommInitRank.restype = C.c_int
+    lib.bfhipCommDestroy.argtypes = [C.POINTER(vp)]
+    lib.bfhipCommDestroy.restype = None
+    lib.bfhipShardedCreate.argtypes = [vp, vp, C.POINTER(BfhipShardSpec), C.c_uint32, C.POINTER(vp)]
+    lib.bfhipShardedCreate.restype = C.c_int
+    lib.bfhipShardedApplyDevice.argtypes = [vp, vp, C.c_size_t, vp, vp]
+    lib.bfhipShardedApplyDevice.restype = C.c_int
+    lib.bfhipShardedLastTimes.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    lib.bfhipShardedLastTimes.restype = C.c_int
+    lib.bfhipShardedFree.argtypes = [C.POINTER(vp)]
+    lib.bfhipShardedFree.restype = None
     lib.bfhipErrorString.argtypes = [C.c_int]
     lib.bfhipErrorString.restype = C.c_char_p
     lib.bfhipLastErrorMessage.argtypes = []

@@ -705,7 +705,8 @@ static int validateStage(BfPlan const *pl, uint64_t arenaElems, BfStage const *s
       if (pc->flags & BF_PIECE_IDENTITY) bad |= (uint64_t)pc->inOff + mr > inLen;
       else if (pl->transposed)
         bad |= !pc->ld || pc->ld % pl->epl || pc->ncols > pc->ld || pc->dataOff % pl->epl ||
-               pc->dataOff + (uint64_t)mr * pc->ld > arenaElems || (uint64_t)pc->inOff + pc->ncols > inLen;
+               pc->dataOff + (uint64_t)(mr - 1) * pc->ld + (pc->ncols + pl->epl - 1) / pl->epl * pl->epl > arenaElems ||
+               (uint64_t)pc->inOff + pc->ncols > inLen;
       else
         bad |= !pc->ncols || pc->ncols > pl->xcap || pc->dataOff % pl->epl ||
                pc->dataOff + (uint64_t)mrPad * pc->ncols > arenaElems || (uint64_t)pc->inOff + pc->ncols > inLen;

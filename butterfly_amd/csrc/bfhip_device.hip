@@ -502,8 +502,9 @@ __global__ __launch_bounds__(BF_WAVES_PER_WG * 64) void bfStageKernelT(StagePara
           }
           continue;
         }
-        uint32_t const units = pc.ld / EPL;          // 16-byte units per column (forward mrPad / EPL: any value >= 1)
-        uint32_t const n = pc.ncols;                 // rows of the forward piece
+        uint32_t const stride = pc.ld / EPL;         // 16-byte units between columns (forward mrPad / EPL)
+        uint32_t const n = pc.ncols;                 // rows of the forward piece taken (a piece may be entered part-way)
+        uint32_t const units = (n + EPL - 1) / EPL;  // 16-byte units per column that hold them
         U const *src = arena + pc.dataOff / EPL;
         for (uint32_t rb = 0; rb < units; rb += 16) {
           // the last 16-unit block of a column may be short: clamp the unit index into the column
@@ -511,7 +512,7 @@ __global__ __launch_bounds__(BF_WAVES_PER_WG * 64) void bfStageKernelT(StagePara
           uint32_t const ru = rb + r < units ? rb + r : units - 1;
           U a[4];
 #pragma unroll
-          for (int cq = 0; cq < 4; ++cq) a[cq] = bfLoadStreamV(src + jcol[cq] * units + ru);
+          for (int cq = 0; cq < 4; ++cq) a[cq] = bfLoadStreamV(src + jcol[cq] * stride + ru);
           S xv[UNIT];
 #pragma unroll
           for (int e = 0; e < EPL; ++e) {

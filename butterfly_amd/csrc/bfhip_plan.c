@@ -45,8 +45,14 @@ typedef struct Task {
   uint64_t leaf;
   uint64_t outOff, inOff;
   uint64_t rows, cols;
+  uint64_t sub0;       /* offset of this task inside its leaf along the contracted dimension (long leaves are cut) */
   uint64_t seq;        /* emission order: fixes the summation order */
 } Task;
+
+/* A leaf is contracted in sub-tasks of at most this many columns (forward) / rows (transposed):
+ * granularity for splitting one row group over several items when a single item would stream too
+ * much.  Forward: a multiple of the piece width (xcap), so the pieces are what they would have been. */
+#define BF_TASK_SPAN 1024u
 
 typedef struct Buf {
   uint64_t len;
@@ -97,9 +103,15 @@ static int emit(Builder *b, uint64_t node, uint32_t inBuf, uint64_t inOff, uint3
     Task t;
     memset(&t, 0, sizeof t);
     t.stage = (uint32_t)stageEnd; t.leaf = node;
-    t.inBuf = inBuf; t.inOff = inOff; t.outBuf = outBuf; t.outOff = outOff;
-    t.rows = ir->rows[node]; t.cols = ir->cols[node];
-    return pushTask(b, &t);
+    t.inBuf = inBuf; t.outBuf = outBuf; t.outOff = outOff;
+    t.rows = ir->rows[node];
+    uint64_t const span = ir->kind[node] == BFHIP_NODE_IDENTITY ? ir->cols[node] : BF_TASK_SPAN;
+    for (uint64_t c0 = 0; c0 < ir->cols[node]; c0 += span) {
+      t.sub0 = c0; t.inOff = inOff + c0;
+      t.cols = ir->cols[node] - c0 < span ? ir->cols[node] - c0 : span;
+      if ((rc = pushTask(b, &t))) return rc;
+    }
+    return 0;
   }
   case BFHIP_NODE_BLOCK:
     for (uint64_t c = ir->childBegin[node]; c < ir->childBegin[node + 1]; ++c)
@@ -139,9 +151,15 @@ static int emitT(Builder *b, uint64_t node, uint32_t inBuf, uint64_t inOff, uint
     Task t;
     memset(&t, 0, sizeof t);
     t.stage = (uint32_t)stageEnd; t.leaf = node;
-    t.inBuf = inBuf; t.inOff = inOff; t.outBuf = outBuf; t.outOff = outOff;
-    t.rows = ir->cols[node]; t.cols = ir->rows[node];
-    return pushTask(b, &t);
+    t.inBuf = inBuf; t.outBuf = outBuf; t.outOff = outOff;
+    t.rows = ir->cols[node];
+    uint64_t const span = ir->kind[node] == BFHIP_NODE_IDENTITY ? ir->rows[node] : BF_TASK_SPAN;
+    for (uint64_t r0 = 0; r0 < ir->rows[node]; r0 += span) {      /* contracted dimension of A^T = rows of A */
+      t.sub0 = r0; t.inOff = inOff + r0;
+      t.cols = ir->rows[node] - r0 < span ? ir->rows[node] - r0 : span;
+      if ((rc = pushTask(b, &t))) return rc;
+    }
+    return 0;
   }
   case BFHIP_NODE_BLOCK:
     for (uint64_t c = ir->childBegin[node]; c < ir->childBegin[node + 1]; ++c)
@@ -384,9 +402,25 @@ int bfPlanBuild(BfIr const *ir, BfPlanOptions const *po, BfPlan *plan) {
     uint64_t numGroups = 0, capGroups = 1024;
     Group *groups = malloc(capGroups * sizeof(Group));
     if (!groups) { rc = bfhipFail(BFABI_ERROR_MEMORY_ERROR, "host OOM"); free(bufRead); goto fail; }
+    /* One item (one wavefront) streams chunkRows x (sum of its group's contraction lengths) elements.
+     * Row groups whose sum is long -- tall leaves in a transposed plan, a block column of hundreds of
+     * leaves (fac_streamer's W factors), very wide leaves -- are cut into several groups over the same
+     * output rows; the planner's overlap machinery below then gives each a private slot and one
+     * deterministic reduce.  The cap is 1 MiB per item, less when the stage is too small to fill the GPU
+     * otherwise (>= ~4096 items wanted), never below the regular item size. */
+    uint64_t stageElems = 0;
+    for (uint64_t t = tBegin; t < tEnd; ++t) stageElems += b.tasks[t].rows * b.tasks[t].cols;
+    uint64_t capBytes = 1u << 20;
+    if (stageElems * plan->elemSize / 4096 < capBytes) capBytes = stageElems * plan->elemSize / 4096;
+    if (capBytes < BF_ITEM_BYTES) capBytes = BF_ITEM_BYTES;
+    uint64_t const floorRowsCap = T ? 16 : (uint64_t)(po->minChunkRows ? po->minChunkRows : 16) * plan->epl;
+    uint64_t capCols = capBytes / (floorRowsCap * plan->elemSize);
+    if (capCols < BF_TASK_SPAN) capCols = BF_TASK_SPAN;
     for (uint64_t t = tBegin; t < tEnd;) {
       uint64_t u = t + 1;
-      while (u < tEnd && b.tasks[u].outBuf == b.tasks[t].outBuf && b.tasks[u].outOff == b.tasks[t].outOff && b.tasks[u].rows == b.tasks[t].rows) ++u;
+      uint64_t span = b.tasks[t].cols;
+      while (u < tEnd && b.tasks[u].outBuf == b.tasks[t].outBuf && b.tasks[u].outOff == b.tasks[t].outOff && b.tasks[u].rows == b.tasks[t].rows &&
+             span + b.tasks[u].cols <= capCols) { span += b.tasks[u].cols; ++u; }
       if (numGroups == capGroups) {
         capGroups *= 2;
         Group *p = realloc(groups, capGroups * sizeof(Group));
@@ -519,7 +553,7 @@ int bfPlanBuild(BfIr const *ir, BfPlanOptions const *po, BfPlan *plan) {
       for (uint64_t t = gr->taskBegin; t < gr->taskEnd; ++t) {
         Task const *tk = &b.tasks[t];
         if (ir->kind[tk->leaf] == BFHIP_NODE_IDENTITY) { gr->piecesPerChunk += 1; gr->colsSum += 1; }
-        else if (T) { gr->piecesPerChunk += (tk->cols + 15) / 16 + 1; gr->colsSum += tk->cols; }   /* upper bound: forward row chunks have >= 16 rows */
+        else if (T) { gr->piecesPerChunk += (tk->cols + 15) / 16 + 2; gr->colsSum += tk->cols; }   /* upper bound: forward row chunks have >= 16 rows, one may straddle each end */
         else { gr->piecesPerChunk += (tk->cols + plan->xcap - 1) / plan->xcap; gr->colsSum += tk->cols; }
       }
       uint64_t chunk = itemRows;
@@ -591,17 +625,24 @@ int bfPlanBuild(BfIr const *ir, BfPlanOptions const *po, BfPlan *plan) {
           uint32_t colPiece0 = r0 / plan->xcap * plan->xcap;
           uint64_t k = findFwd(po->fwdPieces, po->numFwdPieces, tk->leaf, colPiece0);
           uint64_t found = 0;
+          /* this task contracts rows [sub0, sub0 + cols) of A; inBase already points at row sub0 of the input */
+          uint64_t const ta = tk->sub0, tb = tk->sub0 + tk->cols;
           for (; k < po->numFwdPieces && po->fwdPieces[k].node == tk->leaf && po->fwdPieces[k].col0 == colPiece0; ++k) {
             BfFwdPiece const *fp = &po->fwdPieces[k];
+            uint64_t const lo = fp->row0 > ta ? fp->row0 : ta, hi = (uint64_t)fp->row0 + fp->mr < tb ? (uint64_t)fp->row0 + fp->mr : tb;
+            if (lo >= hi) continue;                          /* forward piece outside this task's rows */
             if (np >= numPieces) { free(tmp); rc = bfhipFail(BFABI_ERROR_RUNTIME_ERROR, "internal: transposed piece count"); goto stage_fail; }
             BfDevPiece *pc = &st->pieces[np];
-            if (inBase + fp->row0 >= 0xffffffffu) { free(tmp); rc = bfhipFail(BFABI_ERROR_RUNTIME_ERROR, "vector arena exceeds 32-bit offsets"); goto stage_fail; }
-            pc->dataOff = fp->dataOff + (uint64_t)(r0 - fp->col0) * fp->mrPad;
-            pc->inOff = (uint32_t)(inBase + fp->row0);
-            pc->ncols = fp->mr;            /* steps = rows of the forward piece */
+            if (inBase + (lo - ta) >= 0xffffffffu) { free(tmp); rc = bfhipFail(BFABI_ERROR_RUNTIME_ERROR, "vector arena exceeds 32-bit offsets"); goto stage_fail; }
+            /* a forward piece that straddles the task boundary is entered at row lo: a multiple of the lane
+             * granule, since task boundaries (multiples of BF_TASK_SPAN) and forward row chunks both are */
+            if ((lo - fp->row0) % plan->epl) { free(tmp); rc = bfhipFail(BFABI_ERROR_RUNTIME_ERROR, "internal: transposed piece not on a lane boundary"); goto stage_fail; }
+            pc->dataOff = fp->dataOff + (uint64_t)(r0 - fp->col0) * fp->mrPad + (lo - fp->row0);
+            pc->inOff = (uint32_t)(inBase + (lo - ta));
+            pc->ncols = (uint32_t)(hi - lo);   /* steps = rows of the forward piece taken */
             pc->flags = inFlag;
             pc->ld = fp->mrPad;
-            st->pieceSrc[np].node = tk->leaf; st->pieceSrc[np].row0 = fp->row0; st->pieceSrc[np].col0 = r0;
+            st->pieceSrc[np].node = tk->leaf; st->pieceSrc[np].row0 = (uint32_t)lo; st->pieceSrc[np].col0 = r0;
             ++np; ++found;
           }
           if (!found) { free(tmp); rc = bfhipFail(BFABI_ERROR_RUNTIME_ERROR, "internal: leaf missing from the forward plan"); goto stage_fail; }
@@ -612,7 +653,7 @@ int bfPlanBuild(BfIr const *ir, BfPlanOptions const *po, BfPlan *plan) {
           BfDevPiece *pc = &st->pieces[np];
           if (inBase + c0 >= 0xffffffffu) { free(tmp); rc = bfhipFail(BFABI_ERROR_RUNTIME_ERROR, "vector arena exceeds 32-bit offsets"); goto stage_fail; }
           pc->dataOff = arenaTop; pc->inOff = (uint32_t)(inBase + c0); pc->ncols = (uint32_t)nc; pc->flags = inFlag; pc->ld = 0;
-          st->pieceSrc[np].node = tk->leaf; st->pieceSrc[np].row0 = r0; st->pieceSrc[np].col0 = (uint32_t)c0;
+          st->pieceSrc[np].node = tk->leaf; st->pieceSrc[np].row0 = r0; st->pieceSrc[np].col0 = (uint32_t)(tk->sub0 + c0);
           arenaTop += (uint64_t)mrPad * nc;
           ++np;
         }
@@ -637,7 +678,7 @@ int bfPlanBuild(BfIr const *ir, BfPlanOptions const *po, BfPlan *plan) {
     st->numPieces = np;
     /* algorithmic counts */
     for (uint64_t t = tBegin; t < tEnd; ++t)
-      if (ir->kind[b.tasks[t].leaf] == BFHIP_NODE_DENSE) { st->leafElems += b.tasks[t].rows * b.tasks[t].cols; ++plan->numLeaves; }
+      if (ir->kind[b.tasks[t].leaf] == BFHIP_NODE_DENSE) { st->leafElems += b.tasks[t].rows * b.tasks[t].cols; plan->numLeaves += b.tasks[t].sub0 == 0; }
     for (uint64_t bi = 1; bi < b.numBufs; ++bi) if (b.bufs[bi].stage == s) st->vecOut += b.bufs[bi].len;
     plan->leafElems += st->leafElems;
     memset(bufRead, 0, b.numBufs);

@@ -1,0 +1,264 @@
+// bfhip_shard.hip -- the multi-GPU step behind the C-ABI: one process per GPU,
+// each holding the operator of its share of the top-level blocks, and ONE RCCL collective per apply.
+//
+// The reference computes every top-level block row independently from the full x
+// (bfMatBlockDenseMul, src/mat_block_dense.c:534-566), so
+//   "rows"   : a rank owns whole block rows; its operator writes their rows, compacted, straight into
+//              its slot of a rank-major gather buffer; ONE in-place ncclAllGather over xGMI; one
+//              tiny kernel puts the <= 16 row segments into global row order in the caller's y.
+//   "blocks" : a rank owns (row, col) blocks at their original offsets (finer balance: 144 blocks
+//              instead of 12 rows on a circle); its operator writes a full-length partial y; ONE
+//              in-place ncclAllReduce (sum).
+// Both are enqueued on the caller's stream right behind the stage kernels: no host synchronisation.
+//
+// RCCL is resolved at run time (dlopen of the copy already in the process -- PyTorch ships one --
+// else the system one): plain C hosts without RCCL still load libbfhip.so; the sharded entry points
+// then fail with RUNTIME_ERROR instead of the library failing to load.
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+#include <dlfcn.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "bfhip_internal.h"
+#include "../../include/bfhip_abi.h"
+
+namespace {
+
+struct Rccl {
+  void *lib;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId *);
+  ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int);
+  ncclResult_t (*CommDestroy)(ncclComm_t);
+  ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t);
+  ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t);
+  const char *(*GetErrorString)(ncclResult_t);
+};
+Rccl g;
+
+int loadRccl() {
+  if (g.lib) return 0;
+  char const *names[] = {"librccl.so.1", "librccl.so"};
+  void *lib = NULL;
+  for (int pass = 0; pass < 2 && !lib; ++pass)         // pass 0: a copy already mapped (torch's); pass 1: load one
+    for (int i = 0; i < 2 && !lib; ++i) lib = dlopen(names[i], RTLD_NOW | RTLD_GLOBAL | (pass == 0 ? RTLD_NOLOAD : 0));
+  if (!lib) return bfhipFail(BFABI_ERROR_RUNTIME_ERROR, "RCCL not found (librccl.so.1): %s", dlerror());
+#define SYM(field, name) do { *(void **)&g.field = dlsym(lib, name); if (!g.field) return bfhipFail(BFABI_ERROR_RUNTIME_ERROR, "RCCL lacks %s", name); } while (0)
+  SYM(GetUniqueId, "ncclGetUniqueId"); SYM(CommInitRank, "ncclCommInitRank"); SYM(CommDestroy, "ncclCommDestroy");
+  SYM(AllGather, "ncclAllGather"); SYM(AllReduce, "ncclAllReduce"); SYM(GetErrorString, "ncclGetErrorString");
+#undef SYM
+  g.lib = lib;
+  return 0;
+}
+
+int ncclFail(ncclResult_t r, char const *what) {
+  if (r == ncclSuccess) return 0;
+  return bfhipFail(BFABI_ERROR_RUNTIME_ERROR, "%s: %s", what, g.GetErrorString ? g.GetErrorString(r) : "RCCL error");
+}
+int hipFailS(hipError_t e, char const *what) {
+  if (e == hipSuccess) return 0;
+  return bfhipFail(e == hipErrorOutOfMemory ? BFABI_ERROR_MEMORY_ERROR : BFABI_ERROR_RUNTIME_ERROR, "%s: %s", what, hipGetErrorString(e));
+}
+
+struct Seg { uint64_t globalOff, srcOff, rows; };    // rows [globalOff, +rows) of y come from gather-buffer rows [srcOff, +rows)
+
+// y[row][:] = gathered[srcOff(seg) + row - globalOff(seg)][:], one thread per unit of the row
+// (unit = 16 bytes when the row size allows, else 8 or 4); segments are sorted by globalOff
+template <typename U>
+__global__ __launch_bounds__(256) void bfScatterSegmentsKernel(Seg const *segs, uint32_t numSegs, uint64_t numRows,
+                                                               U const *gathered, U *y, uint64_t unitsPerRow) {
+  uint64_t u = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (u >= numRows * unitsPerRow) return;
+  uint64_t const row = u / unitsPerRow, k = u - row * unitsPerRow;
+  uint32_t lo = 0, hi = numSegs;                       // last segment with globalOff <= row
+  while (hi - lo > 1) { uint32_t mid = (lo + hi) / 2; if (segs[mid].globalOff <= row) lo = mid; else hi = mid; }
+  y[u] = gathered[(segs[lo].srcOff + (row - segs[lo].globalOff)) * unitsPerRow + k];
+}
+
+}  // namespace
+
+struct BfhipComm { ncclComm_t comm; int nranks, rank, device; };
+
+struct BfhipSharded {
+  BfhipOperator *op;
+  BfhipComm *comm;
+  uint32_t mode, dtype, elemSize, maxRhs, numSegs;
+  uint64_t numRowsGlobal, myRows, maxRows;
+  void *dGather;                 // rows mode: nranks * maxRows * maxRhs elements
+  Seg *dSegs;
+  Seg *hSegs;
+  hipEvent_t e0, e1, e2;
+  int timed;
+};
+
+extern "C" {
+
+int bfhipCommGetUniqueId(void *id128) {
+  if (!id128) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "NULL id buffer");
+  int rc = loadRccl();
+  if (rc) return rc;
+  static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+  return ncclFail(g.GetUniqueId((ncclUniqueId *)id128), "ncclGetUniqueId");
+}
+
+int bfhipCommInitRank(void const *id128, int nranks, int rank, int device, BfhipComm **out) {
+  if (!id128 || !out || nranks < 1 || rank < 0 || rank >= nranks) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "bad communicator arguments");
+  *out = NULL;
+  int rc = loadRccl();
+  if (rc) return rc;
+  int prev = -1;
+  (void)hipGetDevice(&prev);
+  if (device >= 0 && (rc = hipFailS(hipSetDevice(device), "hipSetDevice"))) return rc;
+  BfhipComm *c = (BfhipComm *)calloc(1, sizeof *c);
+  if (!c) return bfhipFail(BFABI_ERROR_MEMORY_ERROR, "host OOM");
+  ncclUniqueId id;
+  memcpy(&id, id128, sizeof id);
+  rc = ncclFail(g.CommInitRank(&c->comm, nranks, id, rank), "ncclCommInitRank");
+  if (!rc) rc = hipFailS(hipGetDevice(&c->device), "hipGetDevice");
+  if (device >= 0 && prev >= 0 && prev != device) (void)hipSetDevice(prev);
+  if (rc) { free(c); return rc; }
+  c->nranks = nranks; c->rank = rank;
+  *out = c;
+  return 0;
+}
+
+void bfhipCommDestroy(BfhipComm **pc) {
+  if (!pc || !*pc) return;
+  if ((*pc)->comm && g.CommDestroy) (void)g.CommDestroy((*pc)->comm);
+  free(*pc);
+  *pc = NULL;
+}
+
+void bfhipShardedFree(BfhipSharded **ps) {
+  if (!ps || !*ps) return;
+  BfhipSharded *s = *ps;
+  int prev = -1;
+  (void)hipGetDevice(&prev);
+  (void)hipSetDevice(s->comm->device);
+  (void)hipFree(s->dGather); (void)hipFree(s->dSegs);
+  if (s->e0) (void)hipEventDestroy(s->e0);
+  if (s->e1) (void)hipEventDestroy(s->e1);
+  if (s->e2) (void)hipEventDestroy(s->e2);
+  free(s->hSegs);
+  free(s);
+  *ps = NULL;
+  if (prev >= 0) (void)hipSetDevice(prev);
+}
+
+int bfhipShardedCreate(BfhipOperator *op, BfhipComm *comm, BfhipShardSpec const *spec, uint32_t maxRhs, BfhipSharded **out) {
+  if (!op || !comm || !spec || !out || spec->structSize < sizeof(BfhipShardSpec)) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "bad sharded-apply arguments");
+  *out = NULL;
+  if (spec->mode != BFHIP_SHARD_ROWS && spec->mode != BFHIP_SHARD_BLOCKS) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "unknown shard mode");
+  BfhipStats st;
+  memset(&st, 0, sizeof st);
+  st.structSize = sizeof st;
+  int rc = bfhipGetStats(op, &st);
+  if (rc) return rc;
+  if (bfhipOperatorDevice(op) != comm->device) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "operator lives on device %d, communicator on %d", bfhipOperatorDevice(op), comm->device);
+  BfhipSharded *s = (BfhipSharded *)calloc(1, sizeof *s);
+  if (!s) return bfhipFail(BFABI_ERROR_MEMORY_ERROR, "host OOM");
+  s->op = op; s->comm = comm; s->mode = spec->mode; s->dtype = st.dtype;
+  s->elemSize = st.dtype == BFHIP_C128 ? 16 : st.dtype == BFHIP_F64 ? 8 : 4;
+  s->maxRhs = maxRhs ? maxRhs : 1;
+  s->numRowsGlobal = spec->numRowsGlobal;
+  int prev = -1;
+  (void)hipGetDevice(&prev);
+  if ((rc = hipFailS(hipSetDevice(comm->device), "hipSetDevice"))) { free(s); return rc; }
+  if (spec->mode == BFHIP_SHARD_BLOCKS) {
+    if (st.numRows != spec->numRowsGlobal) rc = bfhipFail(BFABI_ERROR_INCOMPATIBLE_SHAPES, "blocks mode: the local operator must produce all %llu rows", (unsigned long long)spec->numRowsGlobal);
+  } else {
+    // segments in global row order; a rank's compact local order is its segments in that same order
+    uint64_t *rowsOf = (uint64_t *)calloc((size_t)comm->nranks, 8), pos = 0;
+    s->hSegs = (Seg *)malloc((spec->numSegments ? spec->numSegments : 1) * sizeof(Seg));
+    if (!rowsOf || !s->hSegs) rc = bfhipFail(BFABI_ERROR_MEMORY_ERROR, "host OOM");
+    for (uint32_t i = 0; i < spec->numSegments && !rc; ++i) {
+      if (!spec->segRows || !spec->segOwner || spec->segOwner[i] >= (uint32_t)comm->nranks) { rc = bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "segment %u: bad owner", i); break; }
+      rowsOf[spec->segOwner[i]] += spec->segRows[i];
+      pos += spec->segRows[i];
+    }
+    if (!rc && pos != spec->numRowsGlobal) rc = bfhipFail(BFABI_ERROR_INCOMPATIBLE_SHAPES, "segments cover %llu rows, operator has %llu", (unsigned long long)pos, (unsigned long long)spec->numRowsGlobal);
+    if (!rc) {
+      for (int r = 0; r < comm->nranks; ++r) if (rowsOf[r] > s->maxRows) s->maxRows = rowsOf[r];
+      s->myRows = rowsOf[comm->rank];
+      if (st.numRows != s->myRows) rc = bfhipFail(BFABI_ERROR_INCOMPATIBLE_SHAPES, "rows mode: the local operator produces %llu rows, this rank's segments hold %llu", (unsigned long long)st.numRows, (unsigned long long)s->myRows);
+    }
+    if (!rc) {
+      memset(rowsOf, 0, (size_t)comm->nranks * 8);
+      uint64_t g0 = 0;
+      for (uint32_t i = 0; i < spec->numSegments; ++i) {
+        uint32_t o = spec->segOwner[i];
+        s->hSegs[i].globalOff = g0; s->hSegs[i].srcOff = (uint64_t)o * s->maxRows + rowsOf[o]; s->hSegs[i].rows = spec->segRows[i];
+        rowsOf[o] += spec->segRows[i]; g0 += spec->segRows[i];
+      }
+      s->numSegs = spec->numSegments;
+      if (!rc) rc = hipFailS(hipMalloc(&s->dGather, (size_t)comm->nranks * s->maxRows * s->maxRhs * s->elemSize + 16), "hipMalloc(gather buffer)");
+      if (!rc) rc = hipFailS(hipMalloc((void **)&s->dSegs, (s->numSegs ? s->numSegs : 1) * sizeof(Seg)), "hipMalloc(segments)");
+      if (!rc) rc = hipFailS(hipMemcpy(s->dSegs, s->hSegs, s->numSegs * sizeof(Seg), hipMemcpyHostToDevice), "hipMemcpy(segments)");
+    }
+    free(rowsOf);
+  }
+  if (!rc) rc = hipFailS(hipEventCreate(&s->e0), "hipEventCreate");
+  if (!rc) rc = hipFailS(hipEventCreate(&s->e1), "hipEventCreate");
+  if (!rc) rc = hipFailS(hipEventCreate(&s->e2), "hipEventCreate");
+  if (prev >= 0) (void)hipSetDevice(prev);
+  if (rc) { bfhipShardedFree(&s); return rc; }
+  *out = s;
+  return 0;
+}
+
+int bfhipShardedApplyDevice(BfhipSharded *s, void const *dX, size_t nrhs, void *dY, void *streamV) {
+  if (!s || !dX || !dY) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "NULL argument");
+  if (!nrhs || nrhs > s->maxRhs) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "nrhs %zu exceeds the %u this sharded apply was created for", nrhs, s->maxRhs);
+  hipStream_t stream = (hipStream_t)streamV;
+  int prev = -1;
+  (void)hipGetDevice(&prev);
+  int rc = prev != s->comm->device ? hipFailS(hipSetDevice(s->comm->device), "hipSetDevice") : 0;
+  if (rc) return rc;
+  ncclDataType_t const dt = s->dtype == BFHIP_F32 ? ncclFloat32 : ncclFloat64;
+  size_t const scalarsPerElem = s->dtype == BFHIP_C128 ? 2 : 1;
+  (void)hipEventRecord(s->e0, stream);
+  if (s->mode == BFHIP_SHARD_BLOCKS) {
+    rc = bfhipApplyDevice(s->op, dX, nrhs, dY, stream);
+    (void)hipEventRecord(s->e1, stream);
+    // partial results add up; disjoint supports make the sum exact in any order
+    if (!rc) rc = ncclFail(g.AllReduce(dY, dY, (size_t)s->numRowsGlobal * nrhs * scalarsPerElem, dt, ncclSum, s->comm->comm, stream), "ncclAllReduce");
+  } else {
+    size_t const rowBytes = nrhs * s->elemSize;
+    char *slot = (char *)s->dGather + (size_t)s->comm->rank * s->maxRows * rowBytes;
+    rc = bfhipApplyDevice(s->op, dX, nrhs, slot, stream);
+    (void)hipEventRecord(s->e1, stream);
+    if (!rc) rc = ncclFail(g.AllGather(slot, s->dGather, (size_t)s->maxRows * nrhs * scalarsPerElem, dt, s->comm->comm, stream), "ncclAllGather");
+    if (!rc && s->numSegs) {
+      // unit = the largest power of two <= 16 bytes dividing a row; buffers are 16-byte aligned
+      size_t unit = 16;
+      while (rowBytes % unit) unit /= 2;
+      uint64_t const unitsPerRow = rowBytes / unit;
+      uint64_t const total = s->numRowsGlobal * unitsPerRow;
+      uint32_t const grid = (uint32_t)((total + 255) / 256);
+      if (grid) {
+        if (unit == 16) hipLaunchKernelGGL(bfScatterSegmentsKernel<uint4>, dim3(grid), dim3(256), 0, stream, s->dSegs, s->numSegs, s->numRowsGlobal, (uint4 const *)s->dGather, (uint4 *)dY, unitsPerRow);
+        else if (unit == 8) hipLaunchKernelGGL(bfScatterSegmentsKernel<uint2>, dim3(grid), dim3(256), 0, stream, s->dSegs, s->numSegs, s->numRowsGlobal, (uint2 const *)s->dGather, (uint2 *)dY, unitsPerRow);
+        else hipLaunchKernelGGL(bfScatterSegmentsKernel<uint32_t>, dim3(grid), dim3(256), 0, stream, s->dSegs, s->numSegs, s->numRowsGlobal, (uint32_t const *)s->dGather, (uint32_t *)dY, unitsPerRow);
+        rc = hipFailS(hipGetLastError(), "segment scatter launch");
+      }
+    }
+  }
+  (void)hipEventRecord(s->e2, stream);
+  s->timed = !rc;
+  if (prev >= 0 && prev != s->comm->device) (void)hipSetDevice(prev);
+  return rc;
+}
+
+int bfhipShardedLastTimes(BfhipSharded *s, double *localMs, double *collectiveMs) {
+  if (!s || !s->timed) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "no sharded apply has run yet");
+  int rc = hipFailS(hipEventSynchronize(s->e2), "hipEventSynchronize");
+  float a = 0, b = 0;
+  if (!rc) rc = hipFailS(hipEventElapsedTime(&a, s->e0, s->e1), "hipEventElapsedTime");
+  if (!rc) rc = hipFailS(hipEventElapsedTime(&b, s->e1, s->e2), "hipEventElapsedTime");
+  if (localMs) *localMs = a;
+  if (collectiveMs) *collectiveMs = b;
+  return rc;
+}
+
+}  // extern "C"

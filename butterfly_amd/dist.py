@@ -152,6 +152,74 @@ class ShardedApply:
         return self.gathered.index_select(0, self.index)
 
 
+class RcclShardedApply:
+    """The same step through the C-ABI (include/bfhip.h "multi-GPU"): the local stages and the ONE RCCL
+    collective -- in-place ncclAllGather + segment reordering for "rows", ncclAllReduce for "blocks" --
+    are enqueued by libbfhip.so on the caller's stream; Python only ships the 128-byte communicator id
+    from rank 0 to the others (through `bcast`, e.g. a torch.distributed object broadcast).  This is what
+    bench.py runs on GPUs; `ShardedApply` above is the torch.distributed rendition the CPU (gloo) tests
+    drive with a stand-in local apply."""
+
+    def __init__(self, layout: ShardLayout, rank, op, device_index, nrhs=1, mode="rows", bcast=None):
+        import ctypes as C
+
+        from . import _capi
+        self._lib = lib = _capi.load()
+        self.layout, self.rank, self.op, self.mode, self.nrhs = layout, rank, op, mode, nrhs
+        ident = C.create_string_buffer(128)
+        if rank == 0:
+            _capi.check(lib.bfhipCommGetUniqueId(ident))
+        if layout.world > 1:
+            if bcast is None:
+                raise ValueError("more than one rank needs a way to ship the communicator id")
+            ident = C.create_string_buffer(bcast(ident.raw if rank == 0 else None), 128)
+        self._comm = C.c_void_p()
+        _capi.check(lib.bfhipCommInitRank(ident, layout.world, rank, device_index, C.byref(self._comm)))
+        spec = _capi.BfhipShardSpec()
+        spec.structSize = C.sizeof(spec)
+        spec.mode = _capi.SHARD_ROWS if mode == "rows" else _capi.SHARD_BLOCKS
+        spec.numRowsGlobal = layout.n
+        self._seg_rows = np.ascontiguousarray(layout.top_rows, dtype=np.uint64)
+        self._seg_owner = np.ascontiguousarray(layout.owner, dtype=np.uint32)
+        if mode == "rows":
+            spec.numSegments = len(self._seg_rows)
+            spec.segRows, spec.segOwner = self._seg_rows.ctypes.data, self._seg_owner.ctypes.data
+        self._sh = C.c_void_p()
+        _capi.check(lib.bfhipShardedCreate(op.handle, self._comm, C.byref(spec), nrhs, C.byref(self._sh)))
+        self._y = None
+
+    def __call__(self, x):
+        import ctypes as C
+
+        import torch
+
+        from . import _capi
+        if self._y is None:
+            shape = (self.layout.n,) if x.dim() == 1 else (self.layout.n, x.shape[1])
+            self._y = torch.empty(shape, dtype=x.dtype, device=x.device)
+        nrhs = 1 if x.dim() == 1 else x.shape[1]
+        s = torch.cuda.current_stream(x.device)
+        _capi.check(self._lib.bfhipShardedApplyDevice(self._sh, C.c_void_p(x.data_ptr()), nrhs, C.c_void_p(self._y.data_ptr()),
+                                                      C.c_void_p(s.cuda_stream)))
+        return self._y
+
+    def last_times(self):
+        """(local stage ms, collective ms) of the most recent step, from hipEvents on its stream."""
+        import ctypes as C
+
+        from . import _capi
+        a, b = C.c_double(), C.c_double()
+        _capi.check(self._lib.bfhipShardedLastTimes(self._sh, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def close(self):
+        import ctypes as C
+        if self._sh:
+            self._lib.bfhipShardedFree(C.byref(self._sh))
+        if self._comm:
+            self._lib.bfhipCommDestroy(C.byref(self._comm))
+
+
 # --------------------------------------------------------------------------
 # GMRES over a sharded apply (SURVEY.md section 8(f) row 1: "with multi-GPU the
 # allgathered iterate is already replicated")

@@ -647,6 +647,16 @@ def nonzero_cols(mat):
     raise TypeError(type(mat))
 
 
+def fibonacci_sphere(n):
+    """n quasi-uniform points on the unit sphere (the point set of the survey's streamer probe and of
+    tests/generate_data_for_test_linalg.py:29-32 in the reference)."""
+    i = np.arange(n, dtype=np.float64)
+    x = 1 - 2.0 * (i + 0.5) / n
+    r = np.sqrt(1 - x * x)
+    th = np.pi * (np.sqrt(5.0) - 1) * i
+    return np.stack([x, r * np.cos(th), r * np.sin(th)], axis=1)
+
+
 def sphere_band_columns(wmax, col_depth):
     """Number of Laplace-Beltrami eigenfunctions of the unit sphere per leaf band of the frequency tree
     over [0, wmax]: degree l has 2l + 1 of them at frequency sqrt(l (l + 1)); the leftmost / rightmost

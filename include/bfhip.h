@@ -169,6 +169,46 @@ int bfhipSolveGMRES(BfhipOperator *op, const void *B, size_t ldb, size_t nrhs, c
 int bfhipSolveGMRESDevice(BfhipOperator *op, const void *dB, size_t nrhs, const void *dX0, double tol,
                           size_t maxNumIter, size_t *numIter, double *residual, void *dX, void *stream);
 
+/* ---- multi-GPU: one process per GPU, one RCCL collective per apply -------- */
+/* The top-level block rows of a factorization are independent (bfMatBlockDenseMul computes each from the
+ * full x, src/mat_block_dense.c:534-566), so they shard across the GPUs of a node with no data-path
+ * exchange except the closing collective on y.  Each rank compiles the operator of
+ * ITS share (BfhipOptions.rowBlockBegin/End, or a descriptor restricted to its blocks) and then:
+ *
+ *   char id[128]; if (rank == 0) bfhipCommGetUniqueId(id);  ... ship `id` to every rank (MPI, a file, ...)
+ *   bfhipCommInitRank(id, nranks, rank, device, &comm);      // ncclCommInitRank
+ *   bfhipShardedCreate(op, comm, &spec, maxRhs, &sh);
+ *   bfhipShardedApplyDevice(sh, dX, nrhs, dY, stream);       // every rank: x replicated in, FULL y out
+ *
+ * BFHIP_SHARD_ROWS:   this rank's operator yields the rows of the segments it owns, in global order,
+ *                     compacted; the step ends with ONE in-place ncclAllGather (xGMI) and a small kernel
+ *                     that puts the segments into global row order in dY.
+ * BFHIP_SHARD_BLOCKS: this rank's operator yields a full-length partial y (its (row, col) blocks at
+ *                     their original offsets, zeros elsewhere); the step ends with ONE ncclAllReduce.
+ * Everything is enqueued on `stream` behind the stage kernels; nothing synchronizes the host.  RCCL is
+ * looked up at run time (the copy already in the process, else librccl.so.1); without it these entry
+ * points return RUNTIME_ERROR and the rest of the library works. */
+typedef struct BfhipComm BfhipComm;
+typedef struct BfhipSharded BfhipSharded;
+enum { BFHIP_SHARD_ROWS = 0, BFHIP_SHARD_BLOCKS = 1 };
+typedef struct BfhipShardSpec {
+  uint32_t structSize;      /* = sizeof(BfhipShardSpec) */
+  uint32_t mode;            /* BFHIP_SHARD_* */
+  uint64_t numRowsGlobal;   /* rows of the whole operator = length of y */
+  uint32_t numSegments;     /* ROWS: consecutive row segments of y, in global order (top-level block rows) */
+  uint32_t reserved;
+  const uint64_t *segRows;  /* [numSegments] rows of each segment */
+  const uint32_t *segOwner; /* [numSegments] rank that computes it */
+} BfhipShardSpec;
+int bfhipCommGetUniqueId(void *id128);                                       /* ncclGetUniqueId: 128 bytes */
+int bfhipCommInitRank(const void *id128, int nranks, int rank, int device, BfhipComm **out);
+void bfhipCommDestroy(BfhipComm **comm);
+int bfhipShardedCreate(BfhipOperator *op, BfhipComm *comm, const BfhipShardSpec *spec, uint32_t maxRhs, BfhipSharded **out);
+int bfhipShardedApplyDevice(BfhipSharded *sh, const void *dX, size_t nrhs, void *dY, void *stream);
+/* hipEvent times of the most recent apply: stage kernels, and collective (+ reordering).  Synchronizes. */
+int bfhipShardedLastTimes(BfhipSharded *sh, double *localMs, double *collectiveMs);
+void bfhipShardedFree(BfhipSharded **sh);     /* neither the operator nor the communicator is released */
+
 /* ---- introspection ------------------------------------------------------- */
 int bfhipGetStats(const BfhipOperator *op, BfhipStats *stats);
 size_t bfhipGetNumRows(const BfhipOperator *op);

@@ -122,12 +122,7 @@ class SvdFactorizer:
 # ---------------------------------------------------------------------------------------------------
 # the survey's synthetic eigenband input
 # ---------------------------------------------------------------------------------------------------
-def fibonacci_sphere(n):
-    i = np.arange(n, dtype=np.float64)
-    x = 1 - 2.0 * (i + 0.5) / n
-    r = np.sqrt(1 - x * x)
-    th = np.pi * (np.sqrt(5.0) - 1) * i
-    return np.stack([x, r * np.cos(th), r * np.sin(th)], axis=1)
+fibonacci_sphere = ss.fibonacci_sphere
 
 
 def half_space_lattice(num):

@@ -70,7 +70,7 @@ def run_plan(op, x, transpose=False):
                     ld = int(pc["ld"])
                     assert ld >= n and mr <= 64
                     # what bfStageKernelT may touch: columns j < mr, units clamped into the column
-                    assert d0 + mr * ld <= len(arena), "transposed piece reaches past the leaf arena"
+                    assert d0 + (mr - 1) * ld + (n + epl - 1) // epl * epl <= len(arena), "transposed piece reaches past the leaf arena"
                     idx = d0 + np.arange(mr)[:, None] * ld + np.arange(n)[None, :]
                     acc += arena[idx] @ src[io:io + n]
                     continue

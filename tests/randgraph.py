@@ -85,3 +85,33 @@ def densify(d, vals, node):
         a = densify(d, vals, c)
         out[r0:r0 + a.shape[0], c0:c0 + a.shape[1]] += a
     return out
+
+
+def long_contraction_operand(rng, dtype):
+    """BlockDiag(wide 40 x 40000 leaf, tall 37000 x 21 leaf, block column of 90 leaves over 33 columns): every
+    way a row group's contraction gets long, forward or transposed.  Returns (desc, vals, dense-transpose fn)."""
+    from butterfly_amd import helm2_structure as hs
+    cplx = dtype == 0
+
+    def val(m, n):
+        return rng.standard_normal((m, n)) + (1j * rng.standard_normal((m, n)) if cplx else 0)
+    d = hs.Desc(dtype=dtype)
+    vals = {}
+    wide = d.add(hs.NODE_DENSE, 40, 40000); vals[wide] = val(40, 40000)
+    tall = d.add(hs.NODE_DENSE, 37000, 21); vals[tall] = val(37000, 21)
+    col, ch, r0 = [], [], 0
+    for i in range(90):
+        b = d.add(hs.NODE_DENSE, 500 + (i % 7), 33); vals[b] = val(500 + (i % 7), 33)
+        col.append(b); ch.append((b, r0, 0)); r0 += d.rows[b]
+    colnode = d.add(hs.NODE_BLOCK, r0, 33, ch, hs.BF_TYPE_BLOCK_DENSE)
+    d.root = d.add(hs.NODE_BLOCK, 40 + 37000 + r0, 40000 + 21 + 33, [(wide, 0, 0), (tall, 40, 40000), (colnode, 37040, 40021)], hs.BF_TYPE_BLOCK_DIAG)
+
+    def apply_t(v):
+        out = np.zeros(d.cols[d.root], dtype=np.result_type(v.dtype, vals[wide].dtype))
+        out[:40000] = vals[wide].T @ v[:40]
+        out[40000:40021] = vals[tall].T @ v[40:37040]
+        p = 37040
+        for b in col:
+            out[40021:] += vals[b].T @ v[p:p + d.rows[b]]; p += d.rows[b]
+        return out
+    return d, vals, apply_t, val

@@ -508,3 +508,69 @@ def test_adjoint_never_reads_past_a_short_column_block():
             assert rel(y[:19], want) <= (2e-5 if demote else TOL)
             assert np.all(np.isnan(y[19:]))       # the NaN leaf's own outputs
             op.close()
+
+
+def test_sharded_apply_from_plain_c(tmp_path):
+    """examples/sharded_apply.c: the multi-GPU step of include/bfhip.h (RCCL communicator, local stages,
+    in-place ncclAllGather + segment reordering / ncclAllReduce) driven from plain C with a 1-rank
+    communicator; exits 0 iff both shard modes reproduce the unsharded apply bit for bit."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(root, "butterfly_amd", "csrc")
+    exe = str(tmp_path / "sharded_apply")
+    subprocess.check_call(["gcc", "-O2", "-std=gnu11", "-Wall", "-Werror", "-I", os.path.join(root, "include"),
+                           os.path.join(root, "examples", "sharded_apply.c"), "-L", lib, "-lbfhip", "-L/opt/rocm/lib", "-lamdhip64", "-lm",
+                           f"-Wl,-rpath,{lib}", "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
+    p = subprocess.run([exe, "1", "0"], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert p.stdout.count("bit-identical") == 2, p.stdout
+
+
+@pytest.mark.parametrize("mode", ["rows", "blocks"])
+def test_rccl_sharded_apply_one_rank_matches_plain_apply(helm2_cases, mode):
+    """dist.RcclShardedApply (the C-ABI's sharded step as bench.py drives it) with a 1-rank communicator:
+    identical to the plain device apply, for 1 and 3 right-hand sides."""
+    import torch
+    from butterfly_amd import helm2_structure as hs
+    from butterfly_amd.dist import RcclShardedApply, ShardLayout
+    from butterfly_amd.operator import HipOperator
+    from oracle import helm2_build as hb
+    n, k = 4096, 100
+    desc, tp, vals = helm2_cases(n, k)
+    op = HipOperator.from_desc(desc, vals, max_rhs=3)
+    top_rows = desc.meta["top_rows"]
+    layout = ShardLayout(top_rows, [0] * len(top_rows), 1)
+    for nrhs in (1, 3):
+        x = hb.complex_randn(n * nrhs, 3).reshape(n, nrhs) if nrhs > 1 else hb.complex_randn(n, 3)
+        xd = torch.from_numpy(np.ascontiguousarray(x)).to("cuda:0")
+        want = op.apply_device(xd).cpu().numpy()
+        step = RcclShardedApply(layout, 0, op, 0, nrhs=nrhs, mode=mode)
+        got = step(xd)
+        torch.cuda.synchronize()
+        assert np.array_equal(got.cpu().numpy(), want)
+        loc, coll = step.last_times()
+        assert loc > 0 and coll >= 0
+        step.close()
+    op.close()
+
+
+@pytest.mark.parametrize("dtype,demote", [(0, False), (1, False), (1, True)])
+def test_long_contractions_on_gpu(dtype, demote):
+    """Row groups cut into several groups (private slots + reduce) because their contraction is long: a
+    40 x 40000 leaf, a 37000 x 21 leaf and a block column of 90 leaves, forward and transposed."""
+    import randgraph
+    from butterfly_amd import _capi
+    from butterfly_amd.operator import HipOperator
+    from oracle import bfref
+    rng = np.random.default_rng(23 + dtype)
+    d, vals, apply_t, val = randgraph.long_contraction_operand(rng, dtype)
+    m, n = d.rows[d.root], d.cols[d.root]
+    x, v = val(n, 1)[:, 0], val(m, 1)[:, 0]
+    A = bfref.from_desc(d, vals)
+    y_ref = bfref.mat_mul(A, x) if dtype == 0 else bfref.mat_mul_vec(A, x)
+    op = HipOperator.from_desc(d, vals, flags=_capi.FLAG_ADJOINT, demote_to_f32=demote)
+    tol = 3e-5 if demote else TOL
+    assert rel(op.apply_host(x), y_ref) <= tol
+    assert rel(op.apply_transpose_host(v), apply_t(v)) <= tol
+    op.close()

@@ -110,6 +110,32 @@ def test_wide_and_tall_leaves_are_split():
     assert rel(plan_emulator.run_plan(op, x), vals[a] @ (vals[b] @ x)) < 1e-13
 
 
+@pytest.mark.parametrize("dtype", [0, 1])
+def test_long_contractions_are_cut_into_several_groups(dtype):
+    """A row group whose contraction is long -- a very wide leaf, a tall leaf under the transposed plan, a
+    block column of many leaves (fac_streamer's W factors) -- is cut into several groups over the same
+    output rows: private slots + one deterministic reduce, forward and transposed."""
+    rng = np.random.default_rng(17 + dtype)
+    cplx = dtype == 0
+    d, vals, apply_t, val = randgraph.long_contraction_operand(rng, dtype)
+    m, n = d.rows[d.root], d.cols[d.root]
+    x = val(n, 1)[:, 0]
+    v = val(m, 1)[:, 0]
+    A = bfref.from_desc(d, vals)
+    y_ref = bfref.mat_mul(A, x) if cplx else bfref.mat_mul_vec(A, x)
+    op = HipOperator.from_desc(d, vals, flags=_capi.FLAG_PLAN_ONLY | _capi.FLAG_ADJOINT)
+    lib = _capi.load()
+    sv = _capi.BfhipStageView(); sv.structSize = C.sizeof(sv)
+    _capi.check(lib.bfhipPlanGetStage(op.handle, 0, C.byref(sv)))
+    assert sv.numReduce == 1                                  # the wide leaf's 40 rows are summed from several slots
+    _capi.check(lib.bfhipPlanGetStage(op.handle, 1, C.byref(sv)))
+    assert sv.numReduce == 1                                  # transposed: the tall leaf's and the block column's columns
+    assert rel(plan_emulator.run_plan(op, x), y_ref) < 1e-12
+    dense_t = apply_t(v)
+    assert rel(plan_emulator.run_plan(op, v, transpose=True), dense_t) < 1e-12
+    op.close()
+
+
 def test_row_sharding_union_equals_full(helm2_cases):
     n, k = 2048, 128
     desc, tp, vals = helm2_cases(n, k)
