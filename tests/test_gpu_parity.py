@@ -177,9 +177,13 @@ def test_random_nested_complex_graphs_on_gpu_multi_rhs(seed):
     n = desc.cols[desc.root]
     x = rng.standard_normal((n, 5)) + 1j * rng.standard_normal((n, 5))
     want = randgraph.densify(desc, vals, desc.root) @ x
-    op = HipOperator.from_desc(desc, vals)
-    assert rel(op.apply_host(x) + 1, want + 1) <= TOL
-    op.close()
+    # compiled for 1 RHS: items of <= 64 rows, one wave each (GEMV / one-wave matrix-core kernels);
+    # compiled for a block of RHS: items of <= 128 rows on the workgroup-cooperative kernel (any nrhs)
+    for max_rhs in (1, 5):
+        op = HipOperator.from_desc(desc, vals, max_rhs=max_rhs)
+        assert rel(op.apply_host(x) + 1, want + 1) <= TOL
+        assert rel(op.apply_host(np.ascontiguousarray(x[:, 2])) + 1, want[:, 2] + 1) <= TOL
+        op.close()
 
 
 def test_mulvec_shim_real_operator():
