@@ -157,6 +157,19 @@ static void packPiece(BfPlan const *pl, BfIr const *ir, BfDevPiece const *pc, Bf
       else ((float *)dst)[e] = (float)re;
     }
   }
+  /* sparse decorations folded into this leaf (bfhip_ir.c: tryFold): patches are sorted by (leaf, row, col) */
+  if (ir->numPatches && data) {
+    uint64_t lo = 0, hi = ir->numPatches;
+    while (lo < hi) { uint64_t mid = (lo + hi) / 2; if (ir->patches[mid].leaf < node || (ir->patches[mid].leaf == node && ir->patches[mid].row < src->row0)) lo = mid + 1; else hi = mid; }
+    for (; lo < ir->numPatches && ir->patches[lo].leaf == node && ir->patches[lo].row < src->row0 + mr; ++lo) {
+      BfIrPatch const *pt = &ir->patches[lo];
+      if (pt->col < src->col0 || pt->col >= src->col0 + pc->ncols) continue;
+      uint64_t e = (uint64_t)(pt->col - src->col0) * mrPad + (pt->row - src->row0);
+      if (cplx) { ((double *)dst)[2 * e] += pt->re; ((double *)dst)[2 * e + 1] += pt->im; }
+      else if (pl->dtype == BFHIP_F64) ((double *)dst)[e] += pt->re;
+      else ((float *)dst)[e] = (float)((double)((float *)dst)[e] + pt->re);
+    }
+  }
 }
 
 /* pack leaves into the arena, stage by stage, in arena order.  hostDst != NULL:

@@ -746,6 +746,95 @@ __global__ __launch_bounds__(BF_GM_THREADS) void bfGmresUpdateKernel(double2 con
   X[e] = x;
 }
 
+// ---- batched Gram-Schmidt (CGS2): all projections of an iteration in one launch --------------------
+// The reference orthogonalises W against V_0..V_j one vector at a time (modified Gram-Schmidt,
+// src/linalg.c:174-184): j + 1 dependent BLAS-1 passes, each a few microseconds of work behind a launch.
+// Here one pass is three launches whatever j is -- all dots h_i = V_i^H W (W read once per group of 8
+// basis vectors), their reduction over row blocks, and W -= sum_i h_i V_i -- and the pass is run twice
+// (classical Gram-Schmidt with reorthogonalisation, as stable as MGS); H[:, j] = h(pass 1) + h(pass 2).
+#define BF_GM_GROUP 8
+
+__device__ __forceinline__ double bfWaveSum(double v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);      // fixed butterfly: deterministic
+  return v;
+}
+
+// partial[((q * numVec + i) * nb) + bx] = sum over the block's rows of conj(V_i) * W   (i in this group of 8)
+__global__ __launch_bounds__(BF_GM_THREADS) void bfGmresDotsKernel(double2 const *V, double2 const *W, double2 *partial, uint64_t n,
+                                                                  uint32_t nrhs, uint32_t nb, uint32_t numVec) {
+  __shared__ double2 sh[BF_GM_THREADS / 64][BF_GM_GROUP];
+  uint32_t const q = blockIdx.y, i0 = blockIdx.z * BF_GM_GROUP;
+  uint32_t const cnt = numVec - i0 < BF_GM_GROUP ? numVec - i0 : BF_GM_GROUP;
+  uint64_t const vecLen = n * nrhs;
+  uint64_t r0, r1;
+  bfRowRange(n, nb, r0, r1);
+  double ar[BF_GM_GROUP], ai[BF_GM_GROUP];
+#pragma unroll
+  for (int k = 0; k < BF_GM_GROUP; ++k) ar[k] = ai[k] = 0.0;
+  for (uint64_t r = r0 + threadIdx.x; r < r1; r += BF_GM_THREADS) {
+    double2 const w = W[r * nrhs + q];
+#pragma unroll
+    for (int k = 0; k < BF_GM_GROUP; ++k)
+      if ((uint32_t)k < cnt) {
+        double2 const v = V[(uint64_t)(i0 + k) * vecLen + r * nrhs + q];
+        ar[k] += v.x * w.x + v.y * w.y;
+        ai[k] += v.x * w.y - v.y * w.x;
+      }
+  }
+  int const wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+  for (int k = 0; k < BF_GM_GROUP; ++k) {
+    double const sr = bfWaveSum(ar[k]), si = bfWaveSum(ai[k]);
+    if (lane == 0) sh[wave][k] = make_double2(sr, si);
+  }
+  __syncthreads();
+  if (threadIdx.x < cnt) {
+    double2 t = sh[0][threadIdx.x];
+    for (int w2 = 1; w2 < BF_GM_THREADS / 64; ++w2) { t.x += sh[w2][threadIdx.x].x; t.y += sh[w2][threadIdx.x].y; }
+    partial[((uint64_t)q * numVec + i0 + threadIdx.x) * nb + blockIdx.x] = t;
+  }
+}
+
+// h[i * nrhs + q] = sum_b partial; hSum[i * nrhs + q] = h + (hPrev ? hPrev[i * nrhs + q] : 0)
+__global__ __launch_bounds__(BF_GM_THREADS) void bfGmresDotsFinishKernel(double2 const *partial, double2 const *hPrev, double2 *h, double2 *hSum,
+                                                                        uint32_t nrhs, uint32_t nb, uint32_t numVec) {
+  __shared__ double2 sh[BF_GM_THREADS];
+  uint32_t const i = blockIdx.x, q = blockIdx.y;
+  double2 a = make_double2(0.0, 0.0);
+  for (uint32_t b = threadIdx.x; b < nb; b += BF_GM_THREADS) { double2 v = partial[((uint64_t)q * numVec + i) * nb + b]; a.x += v.x; a.y += v.y; }
+  double2 const t = bfBlockReduce2(a, sh);
+  if (threadIdx.x == 0) {
+    h[(uint64_t)i * nrhs + q] = t;
+    if (hSum) { double2 p = hPrev ? hPrev[(uint64_t)i * nrhs + q] : make_double2(0.0, 0.0); hSum[(uint64_t)i * nrhs + q] = make_double2(t.x + p.x, t.y + p.y); }
+  }
+}
+
+// W -= sum_i h_i V_i; partialOut (optional) = per-block sum |W|^2 of the result
+__global__ __launch_bounds__(BF_GM_THREADS) void bfGmresProjectKernel(double2 const *V, double2 *W, double2 const *h, double2 *partialOut, uint64_t n,
+                                                                     uint32_t nrhs, uint32_t nb, uint32_t numVec) {
+  __shared__ double2 sh[BF_GM_THREADS];
+  uint32_t const q = blockIdx.y;
+  uint64_t const vecLen = n * nrhs;
+  uint64_t r0, r1;
+  bfRowRange(n, nb, r0, r1);
+  double acc = 0.0;
+  for (uint64_t r = r0 + threadIdx.x; r < r1; r += BF_GM_THREADS) {
+    double2 w = W[r * nrhs + q];
+    for (uint32_t i = 0; i < numVec; ++i) {
+      double2 const v = V[(uint64_t)i * vecLen + r * nrhs + q], c = h[(uint64_t)i * nrhs + q];   // h: uniform, cached
+      w.x -= c.x * v.x - c.y * v.y;
+      w.y -= c.x * v.y + c.y * v.x;
+    }
+    W[r * nrhs + q] = w;
+    acc += w.x * w.x + w.y * w.y;
+  }
+  if (partialOut) {
+    double2 const t = bfBlockReduce2(make_double2(acc, 0.0), sh);
+    if (threadIdx.x == 0) partialOut[(uint64_t)q * nb + blockIdx.x] = t;
+  }
+}
+
 // ---------------------------------------------------------------------------
 // host-callable wrappers
 // ---------------------------------------------------------------------------
@@ -864,6 +953,21 @@ int bfdevGmresFinish(void const *W, void const *partialIn, void *Vout, void *hOu
   hipLaunchKernelGGL(bfGmresFinishKernel, dim3(nb, nrhs), dim3(BF_GM_THREADS), 0, (hipStream_t)stream, (double2 const *)W, (double2 const *)partialIn, (double2 *)Vout, (double2 *)hOut, n, nrhs, nb);
   return hipFail(hipGetLastError(), "gmres finish launch");
 }
+int bfdevGmresDots(void const *V, void const *W, void *partial, uint64_t n, uint32_t nrhs, uint32_t nb, uint32_t numVec, void *stream) {
+  hipLaunchKernelGGL(bfGmresDotsKernel, dim3(nb, nrhs, (numVec + BF_GM_GROUP - 1) / BF_GM_GROUP), dim3(BF_GM_THREADS), 0, (hipStream_t)stream,
+                     (double2 const *)V, (double2 const *)W, (double2 *)partial, n, nrhs, nb, numVec);
+  return hipFail(hipGetLastError(), "gmres dots launch");
+}
+int bfdevGmresDotsFinish(void const *partial, void const *hPrev, void *h, void *hSum, uint32_t nrhs, uint32_t nb, uint32_t numVec, void *stream) {
+  hipLaunchKernelGGL(bfGmresDotsFinishKernel, dim3(numVec, nrhs), dim3(BF_GM_THREADS), 0, (hipStream_t)stream, (double2 const *)partial,
+                     (double2 const *)hPrev, (double2 *)h, (double2 *)hSum, nrhs, nb, numVec);
+  return hipFail(hipGetLastError(), "gmres dots-finish launch");
+}
+int bfdevGmresProject(void const *V, void *W, void const *h, void *partialOut, uint64_t n, uint32_t nrhs, uint32_t nb, uint32_t numVec, void *stream) {
+  hipLaunchKernelGGL(bfGmresProjectKernel, dim3(nb, nrhs), dim3(BF_GM_THREADS), 0, (hipStream_t)stream, (double2 const *)V, (double2 *)W,
+                     (double2 const *)h, (double2 *)partialOut, n, nrhs, nb, numVec);
+  return hipFail(hipGetLastError(), "gmres project launch");
+}
 int bfdevGmresUpdate(void const *X0, void const *V, void const *y, uint32_t j, void *X, uint64_t n, uint32_t nrhs, void *stream) {
   uint64_t total = n * nrhs;
   hipLaunchKernelGGL(bfGmresUpdateKernel, dim3((uint32_t)((total + BF_GM_THREADS - 1) / BF_GM_THREADS)), dim3(BF_GM_THREADS), 0, (hipStream_t)stream, (double2 const *)X0, (double2 const *)V, (double2 const *)y, j, (double2 *)X, n, nrhs);
@@ -876,6 +980,7 @@ int bfdevMemcpyD2DAsync(void *dst, void const *src, size_t bytes, void *stream) 
 int bfdevEventCreate(void **ev) { return hipFail(hipEventCreate((hipEvent_t *)ev), "hipEventCreate"); }
 void bfdevEventDestroy(void *ev) { if (ev) (void)hipEventDestroy((hipEvent_t)ev); }
 int bfdevEventRecord(void *ev, void *stream) { return hipFail(hipEventRecord((hipEvent_t)ev, (hipStream_t)stream), "hipEventRecord"); }
+int bfdevEventSync(void *ev) { return hipFail(hipEventSynchronize((hipEvent_t)ev), "hipEventSynchronize"); }
 int bfdevEventElapsed(void *start, void *stop, float *ms) {
   hipError_t e = hipEventSynchronize((hipEvent_t)stop);
   if (e != hipSuccess) return hipFail(e, "hipEventSynchronize");

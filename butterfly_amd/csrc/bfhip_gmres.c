@@ -4,10 +4,19 @@
  * one Givens rotation per column and right-hand side, convergence on
  * max_p |s_{j+1,p}| / max_p ||r_p|| -- but keeps x0, b, the Krylov basis V and
  * the work vector on the GPU: per iteration the host receives only the new
- * Hessenberg column ((j+2) * nrhs complex numbers).  What the reference does
- * with one heap allocation per BLAS-1 call (`bfMatCopy`, `bfMatScaleCols`,
- * `bfMatSubInplace`, src/linalg.c:174-184) is one fused kernel per basis
- * vector here (subtract the projection on V_i and start the dot with V_{i+1}).
+ * Hessenberg column ((j+2) * nrhs complex numbers, into pinned memory).
+ *
+ * Orthogonalisation: the reference runs modified Gram-Schmidt, one basis vector at
+ * a time with a heap allocation per BLAS-1 call (`bfMatCopy`, `bfMatScaleCols`,
+ * `bfMatSubInplace`, src/linalg.c:174-184): j + 1 dependent passes per iteration.  On a
+ * GPU that is j + 1 launches of a few microseconds of work each; by default this solver
+ * runs classical Gram-Schmidt twice (CGS2) instead -- all j + 1 dots in one launch, one
+ * reduction launch, one projection launch, then the same again -- 7 launches per iteration
+ * whatever j is.  CGS2 is as stable as MGS; H[:, j] is the sum of the two passes'
+ * coefficients, and iteration counts stay within +-1 of the reference's order
+ * (tests/test_gmres.py).  BFHIP_GMRES_MGS=1 in the environment selects the reference's
+ * own order (one fused kernel per basis vector), which follows oracle/linalg_ref.py
+ * iteration for iteration.
  *
  * Reference quirk kept for parity: when the residual test passes at iteration
  * j the loop breaks before j is incremented, so the solution uses j (not j+1)
@@ -68,11 +77,17 @@ static int solveDevice(BfhipOperator *op, void const *dB, size_t nrhs, void cons
   uint64_t const n = st.numRows;
   size_t const m = maxNumIter;
   size_t const vecBytes = (size_t)n * nrhs * 16;
-  uint32_t nb = (uint32_t)((n + 2047) / 2048);
+  uint32_t nb = (uint32_t)((n + 255) / 256);          /* row blocks = partial sums per RHS and dot */
   if (nb > 1024) nb = 1024;
   if (nb == 0) nb = 1;
+  char const *mgsEnv = getenv("BFHIP_GMRES_MGS");
+  int const useMgs = mgsEnv && mgsEnv[0] == '1';
 
   void *dV = NULL, *dW = NULL, *dPartA = NULL, *dPartB = NULL, *dH = NULL, *dY = NULL, *dAX0 = NULL;
+  void *dPartAll = NULL, *dH1 = NULL, *dH2 = NULL;     /* CGS2: partials of all dots, coefficients of the two passes */
+  void *hHpinned = NULL;
+  void *evCol[2] = {NULL, NULL};      /* "column j is in host memory", two in flight */
+  cplx *hHslot[2] = {NULL, NULL};
   cplx *hH = NULL, *H = NULL, *S = NULL, *Jc = NULL, *Js = NULL, *y = NULL;
   double *rnorm = NULL;
   size_t j = 0;
@@ -86,14 +101,23 @@ static int solveDevice(BfhipOperator *op, void const *dB, size_t nrhs, void cons
   CHECK(bfdevMalloc(&dPartB, (size_t)nb * nrhs * 16));
   CHECK(bfdevMalloc(&dH, (m + 2) * nrhs * 16));
   CHECK(bfdevMalloc(&dY, (m + 1) * nrhs * 16));
-  hH = malloc((m + 2) * nrhs * sizeof(cplx));
+  if (!useMgs) {
+    CHECK(bfdevMalloc(&dPartAll, (size_t)nb * nrhs * (m + 1) * 16));
+    CHECK(bfdevMalloc(&dH1, (m + 1) * nrhs * 16));
+    CHECK(bfdevMalloc(&dH2, (m + 1) * nrhs * 16));
+  }
+  CHECK(bfdevHostAllocPinned(&hHpinned, 2 * (m + 2) * nrhs * sizeof(cplx)));
+  hH = hHpinned;
+  hHslot[0] = hH; hHslot[1] = hH + (m + 2) * nrhs;
+  CHECK(bfdevEventCreate(&evCol[0]));
+  CHECK(bfdevEventCreate(&evCol[1]));
   H = calloc((m + 2) * m * nrhs, sizeof(cplx));       /* H[(j*(m+2) + i)*nrhs + p] */
   S = calloc((m + 1) * nrhs, sizeof(cplx));
   Jc = malloc(m * nrhs * sizeof(cplx));
   Js = malloc(m * nrhs * sizeof(cplx));
   y = malloc((m + 1) * nrhs * sizeof(cplx));
   rnorm = malloc(nrhs * sizeof(double));
-  if (!hH || !H || !S || !Jc || !Js || !y || !rnorm) { rc = bfhipFail(BFABI_ERROR_MEMORY_ERROR, "host OOM"); goto done; }
+  if (!H || !S || !Jc || !Js || !y || !rnorm) { rc = bfhipFail(BFABI_ERROR_MEMORY_ERROR, "host OOM"); goto done; }
 
   /* R = B - A X0 (linalg.c:127-131); X0 == NULL means zeros (:120-123) */
   if (dX0) {
@@ -116,27 +140,50 @@ static int solveDevice(BfhipOperator *op, void const *dB, size_t nrhs, void cons
     goto finish;
   }
 
+  /* One iteration's device work is enqueued by enqueueIteration(); the host needs its Hessenberg column only
+   * for the Givens rotations and the convergence test, so iteration jj + 1 is enqueued BEFORE the host waits
+   * for column jj (V[jj+1] is already on the device): the GPU never idles on the host round trip.  At most
+   * one speculative iteration is thrown away when the test passes. */
+#define ENQUEUE(J) do { \
+    size_t const j_ = (J); \
+    char *Vj = (char *)dV + j_ * vecBytes; \
+    CHECK(bfhipApplyDevice(op, Vj, nrhs, dW, stream));                       /* W = A V[j]  (:157) */ \
+    void *pin = dPartA, *pout = dPartB; \
+    if (useMgs) { \
+      /* modified Gram-Schmidt (:174-184): dot with V_0, then for each i subtract and start the next dot */ \
+      CHECK(bfdevGmresDot(dV, dW, dPartA, n, (uint32_t)nrhs, nb, stream)); \
+      for (size_t i = 0; i <= j_; ++i) { \
+        char *Vi = (char *)dV + i * vecBytes; \
+        char *Vn = i < j_ ? (char *)dV + (i + 1) * vecBytes : NULL; \
+        CHECK(bfdevGmresMgsStep(Vi, Vn, dW, pin, pout, (char *)dH + i * nrhs * 16, n, (uint32_t)nrhs, nb, stream)); \
+        void *t = pin; pin = pout; pout = t; \
+      } \
+    } else { \
+      /* CGS2: h1 = V^H W, W -= V h1; h2 = V^H W, W -= V h2 (its |W|^2 partials feed the normalisation); H[:, j] = h1 + h2 */ \
+      uint32_t const nv = (uint32_t)(j_ + 1); \
+      CHECK(bfdevGmresDots(dV, dW, dPartAll, n, (uint32_t)nrhs, nb, nv, stream)); \
+      CHECK(bfdevGmresDotsFinish(dPartAll, NULL, dH1, NULL, (uint32_t)nrhs, nb, nv, stream)); \
+      CHECK(bfdevGmresProject(dV, dW, dH1, NULL, n, (uint32_t)nrhs, nb, nv, stream)); \
+      CHECK(bfdevGmresDots(dV, dW, dPartAll, n, (uint32_t)nrhs, nb, nv, stream)); \
+      CHECK(bfdevGmresDotsFinish(dPartAll, dH1, dH2, dH, (uint32_t)nrhs, nb, nv, stream)); \
+      CHECK(bfdevGmresProject(dV, dW, dH2, dPartA, n, (uint32_t)nrhs, nb, nv, stream)); \
+    } \
+    /* H[j][j+1] = ||W||, V[j+1] = W / ||W||  (:186-198) */ \
+    CHECK(bfdevGmresFinish(dW, pin, (char *)dV + (j_ + 1) * vecBytes, (char *)dH + (j_ + 1) * nrhs * 16, n, (uint32_t)nrhs, nb, stream)); \
+    CHECK(bfdevMemcpyD2HAsync(hHslot[j_ & 1], dH, (j_ + 2) * nrhs * 16, stream)); \
+    CHECK(bfdevEventRecord(evCol[j_ & 1], stream)); \
+  } while (0)
+
+  ENQUEUE(0);
   for (j = 0; j < m; ++j) {
-    char *Vj = (char *)dV + j * vecBytes;
-    CHECK(bfhipApplyDevice(op, Vj, nrhs, dW, stream));                       /* W = A V[j]  (:157) */
-    /* modified Gram-Schmidt (:174-184): dot with V_0, then for each i subtract and start the next dot */
-    CHECK(bfdevGmresDot(dV, dW, dPartA, n, (uint32_t)nrhs, nb, stream));
-    void *pin = dPartA, *pout = dPartB;
-    for (size_t i = 0; i <= j; ++i) {
-      char *Vi = (char *)dV + i * vecBytes;
-      char *Vn = i < j ? (char *)dV + (i + 1) * vecBytes : NULL;
-      CHECK(bfdevGmresMgsStep(Vi, Vn, dW, pin, pout, (char *)dH + i * nrhs * 16, n, (uint32_t)nrhs, nb, stream));
-      void *t = pin; pin = pout; pout = t;
-    }
-    /* H[j][j+1] = ||W||, V[j+1] = W / ||W||  (:186-198) */
-    CHECK(bfdevGmresFinish(dW, pin, (char *)dV + (j + 1) * vecBytes, (char *)dH + (j + 1) * nrhs * 16, n, (uint32_t)nrhs, nb, stream));
-    CHECK(bfdevMemcpyD2HAsync(hH, dH, (j + 2) * nrhs * 16, stream));
-    CHECK(bfdevSync(stream));
+    if (j + 1 < m) ENQUEUE(j + 1);
+    CHECK(bfdevEventSync(evCol[j & 1]));
+    cplx const *hCol = hHslot[j & 1];
 
     double resmax = 0;
     for (size_t p = 0; p < nrhs; ++p) {
       cplx *col = H + (j * (m + 2)) * nrhs;        /* column j, entries i = 0..j+1 at col[i*nrhs + p] */
-      for (size_t i = 0; i < j + 2; ++i) col[i * nrhs + p] = hH[i * nrhs + p];
+      for (size_t i = 0; i < j + 2; ++i) col[i * nrhs + p] = hCol[i * nrhs + p];
       for (size_t i = 0; i < j; ++i)               /* earlier rotations (:206-212) */
         applyGivens(&col[i * nrhs + p], &col[(i + 1) * nrhs + p], Jc[i * nrhs + p], Js[i * nrhs + p]);
       givens(col[j * nrhs + p], col[(j + 1) * nrhs + p], &Jc[j * nrhs + p], &Js[j * nrhs + p]);   /* (:214-219) */
@@ -148,6 +195,7 @@ static int solveDevice(BfhipOperator *op, void const *dB, size_t nrhs, void cons
     lastResidual = resmax / beta;                  /* (:230-231) */
     if (lastResidual < tol) { converged = 1; break; }   /* j is NOT incremented (:235-241) */
   }
+#undef ENQUEUE
   if (!converged) j = m;
 
   /* back substitution per RHS on the j x j triangle (:245-285) */
@@ -166,8 +214,12 @@ finish:
   if (numIter) *numIter = j;
   if (residual) *residual = lastResidual;
 done:
+  (void)bfdevSync(stream);   /* a speculative iteration may still be in flight: drain before its buffers go */
   bfdevFree(dV); bfdevFree(dW); bfdevFree(dPartA); bfdevFree(dPartB); bfdevFree(dH); bfdevFree(dY); bfdevFree(dAX0);
-  free(hH); free(H); free(S); free(Jc); free(Js); free(y); free(rnorm);
+  bfdevFree(dPartAll); bfdevFree(dH1); bfdevFree(dH2);
+  bfdevEventDestroy(evCol[0]); bfdevEventDestroy(evCol[1]);
+  bfdevHostFreePinned(hHpinned);
+  free(H); free(S); free(Jc); free(Js); free(y); free(rnorm);
   return rc;
 #undef CHECK
 }

@@ -35,10 +35,15 @@ typedef struct BfIr {
   uint64_t *synthBase;         /* per node: base index in the synthetic stream */
   uint64_t *topRowBlock;       /* per child of root, or NULL */
   uint32_t *depth;             /* stages needed by the subtree */
+  /* sparse decorations folded into host-valued dense leaves: value added to leaf element (row, col) when the
+   * arena is packed (sorted by leaf, row, col once finalized) */
+  struct BfIrPatch *patches;
+  uint64_t numPatches, capPatches;
   /* growable capacity (walker) */
   uint64_t capNodes, capChildren;
 } BfIr;
 
+typedef struct BfIrPatch { uint64_t leaf; uint32_t row, col; double re, im; } BfIrPatch;
 void bfIrFree(BfIr *ir);
 int bfIrFromDesc(BfhipDesc const *desc, BfIr *ir);
 int bfIrFromBfMat(void const *bfMat, BfIr *ir);
@@ -220,6 +225,12 @@ int bfdevGmresDot(void const *Vi, void const *W, void *partialOut, uint64_t n, u
 /* h = sum(partialIn); hOut[q] = h; W -= h * Vi; then partialOut = conj(Vnext).W (Vnext != NULL) or |W|^2 */
 int bfdevGmresMgsStep(void const *Vi, void const *Vnext, void *W, void const *partialIn, void *partialOut, void *hOut,
                       uint64_t n, uint32_t nrhs, uint32_t nb, void *stream);
+/* batched Gram-Schmidt pass over V_0..V_{numVec-1} (vectors n*nrhs apart): partial[(q*numVec + i)*nb + b] */
+int bfdevGmresDots(void const *V, void const *W, void *partial, uint64_t n, uint32_t nrhs, uint32_t nb, uint32_t numVec, void *stream);
+/* h[i*nrhs + q] = sum_b partial; hSum = h + hPrev (hSum / hPrev may be NULL) */
+int bfdevGmresDotsFinish(void const *partial, void const *hPrev, void *h, void *hSum, uint32_t nrhs, uint32_t nb, uint32_t numVec, void *stream);
+/* W -= sum_i h_i V_i; partialOut (may be NULL) = per-block |W|^2 */
+int bfdevGmresProject(void const *V, void *W, void const *h, void *partialOut, uint64_t n, uint32_t nrhs, uint32_t nb, uint32_t numVec, void *stream);
 /* nrm = sqrt(sum(partialIn)); hOut[q] = nrm; Vout = W / nrm */
 int bfdevGmresFinish(void const *W, void const *partialIn, void *Vout, void *hOut, uint64_t n, uint32_t nrhs, uint32_t nb, void *stream);
 /* X = X0 + sum_{i<j} V_i * y[i] ; V = (j) vectors of n*nrhs, y = [j][nrhs] */
@@ -300,6 +311,7 @@ int bfdevEventCreate(void **ev);
 void bfdevEventDestroy(void *ev);
 int bfdevEventRecord(void *ev, void *stream);
 int bfdevEventElapsed(void *start, void *stop, float *ms);
+int bfdevEventSync(void *ev);
 
 #ifdef __cplusplus
 }

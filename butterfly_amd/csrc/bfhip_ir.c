@@ -23,7 +23,7 @@ void bfIrFree(BfIr *ir) {
   free(ir->kind); free(ir->rows); free(ir->cols); free(ir->childBegin);
   free(ir->childNode); free(ir->childRow0); free(ir->childCol0);
   free(ir->leafData); free(ir->leafRowStride); free(ir->leafColStride); free(ir->leafReal);
-  free(ir->synthBase); free(ir->topRowBlock); free(ir->depth);
+  free(ir->synthBase); free(ir->topRowBlock); free(ir->depth); free(ir->patches);
   memset(ir, 0, sizeof *ir);
 }
 
@@ -188,6 +188,36 @@ static int walkBlockChildren(Walk *w, BfAbiMatBlock const *blk, uint64_t id, siz
   return 0;
 }
 
+/* Try to add `value` at (i, j) of `node` into a host-valued dense leaf that covers the position and is reached
+ * through block nodes only (then the entry simply adds to that leaf's element: nothing else multiplies it).
+ * Returns 1 when folded, 0 when no such leaf exists (products, identities, synthetic leaves), < 0 on error. */
+static int tryFold(Walk *w, uint64_t node, uint64_t i, uint64_t j, double re, double im, int level) {
+  BfIr *ir = w->ir;
+  if (level > 64) return 0;
+  if (ir->kind[node] == BFHIP_NODE_DENSE) {
+    if (!ir->leafData[node] || ir->leafReal[node] || ir->rows[node] * ir->cols[node] == 1) return 0;
+    if (ir->numPatches == ir->capPatches) {
+      uint64_t cap = ir->capPatches ? ir->capPatches * 2 : 4096;
+      BfIrPatch *p = realloc(ir->patches, cap * sizeof *p);
+      if (!p) return -1;
+      ir->patches = p; ir->capPatches = cap;
+    }
+    BfIrPatch *pt = &ir->patches[ir->numPatches++];
+    pt->leaf = node; pt->row = (uint32_t)i; pt->col = (uint32_t)j; pt->re = re; pt->im = im;
+    return 1;
+  }
+  if (ir->kind[node] != BFHIP_NODE_BLOCK) return 0;
+  for (uint64_t c = 0; c < w->counts[node]; ++c) {
+    WalkChild const *ch = &w->lists[node][c];
+    if (i < ch->r0 || j < ch->c0 || i - ch->r0 >= ir->rows[ch->node] || j - ch->c0 >= ir->cols[ch->node]) continue;
+    int rc = tryFold(w, ch->node, i - ch->r0, j - ch->c0, re, im, level + 1);
+    if (rc) return rc;
+  }
+  return 0;
+}
+
+static int walkSparseTerm(Walk *w, BfAbiMat const *mat, int type, uint64_t const *foldInto, size_t numFoldInto, uint64_t *outId);
+
 static int walkMat(Walk *w, BfAbiMat const *mat, uint64_t *outId, int level) {
   if (level > 256) return bfhipFail(BFABI_ERROR_RUNTIME_ERROR, "BfMat graph nested deeper than 256");
   if (!mat || !mat->vtbl) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "BfMat or its vtable is NULL");
@@ -285,17 +315,30 @@ static int walkMat(Walk *w, BfAbiMat const *mat, uint64_t *outId, int level) {
     uint64_t id;
     if ((rc = walkNewNode(w, BFHIP_NODE_BLOCK, 0, 0, &id))) return rc;
     WalkChild *list = malloc(nt * sizeof(WalkChild));
-    if (!list) return bfhipFail(BFABI_ERROR_MEMORY_ERROR, "host OOM while walking BfMat graph");
-    for (size_t i = 0; i < nt; ++i) {
-      uint64_t cid;
-      rc = walkMat(w, (BfAbiMat const *)sum->termArr.data[i], &cid, level + 1);
-      if (rc) { free(list); return rc; }
-      list[i].node = cid; list[i].r0 = 0; list[i].c0 = 0;
-      if (i && (w->ir->rows[cid] != w->ir->rows[list[0].node] || w->ir->cols[cid] != w->ir->cols[list[0].node])) {
+    uint64_t *plain = malloc(nt * sizeof(uint64_t));
+    if (!list || !plain) { free(list); free(plain); return bfhipFail(BFABI_ERROR_MEMORY_ERROR, "host OOM while walking BfMat graph"); }
+    /* ordinary terms first; the sparse corrections (Kapur-Rokhlin entries, c I) are then added into whatever
+     * dense leaf of those terms covers each entry, and only the entries over butterflied blocks stay terms */
+    size_t numPlain = 0;
+    for (int pass = 0; pass < 2; ++pass)
+      for (size_t i = 0; i < nt; ++i) {
+        BfAbiMat const *term = (BfAbiMat const *)sum->termArr.data[i];
+        if (!term || !term->vtbl || !term->vtbl->slot[BFABI_SLOT_GetType]) { free(list); free(plain); return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "sum term or its vtable is NULL"); }
+        int const ttype = ((BfAbiGetTypeFn)term->vtbl->slot[BFABI_SLOT_GetType])(term);
+        int const sparse = ttype == BFABI_TYPE_MAT_COO_COMPLEX || ttype == BFABI_TYPE_MAT_DIAG_REAL;
+        if (sparse != pass) continue;
+        uint64_t cid;
+        rc = sparse ? walkSparseTerm(w, term, ttype, plain, numPlain, &cid) : walkMat(w, term, &cid, level + 1);
+        if (rc) { free(list); free(plain); return rc; }
+        list[i].node = cid; list[i].r0 = 0; list[i].c0 = 0;
+        if (!sparse) plain[numPlain++] = cid;
+      }
+    free(plain);
+    for (size_t i = 1; i < nt; ++i)
+      if (w->ir->rows[list[i].node] != w->ir->rows[list[0].node] || w->ir->cols[list[i].node] != w->ir->cols[list[0].node]) {
         free(list);
         return bfhipFail(BFABI_ERROR_INCOMPATIBLE_SHAPES, "terms of a sum differ in shape");
       }
-    }
     w->ir->rows[id] = w->ir->rows[list[0].node];
     w->ir->cols[id] = w->ir->cols[list[0].node];
     w->lists[id] = list;
@@ -304,40 +347,52 @@ static int walkMat(Walk *w, BfAbiMat const *mat, uint64_t *outId, int level) {
     return 0;
   }
   case BFABI_TYPE_MAT_COO_COMPLEX:
-  case BFABI_TYPE_MAT_DIAG_REAL: {
-    /* sparse corrections (Kapur-Rokhlin entries, 1/2 I): each stored entry becomes a 1 x 1
-     * leaf, entries of one row add up.  (The reference's own bfMatCooComplexMul *assigns*
-     * z * x_j to the result row, src/mat_coo_complex.c:248-251, so its last entry of a row
-     * wins; that is not reproduced.) */
-    size_t ne;
-    size_t const *ri = NULL, *ci = NULL;
-    double const *val;
-    int const isDiag = type == BFABI_TYPE_MAT_DIAG_REAL;
-    if (isDiag) { BfAbiMatDiagReal const *d = (BfAbiMatDiagReal const *)mat; ne = d->numElts; val = d->data; }
-    else { BfAbiMatCooComplex const *c = (BfAbiMatCooComplex const *)mat; ne = c->numElts; ri = c->rowInd; ci = c->colInd; val = c->value; w->sawComplex = 1; }
-    if (ne && (!val || (!isDiag && (!ri || !ci)))) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "sparse matrix arrays are NULL");
-    if (mat->props & (BFABI_MAT_PROPS_TRANS | BFABI_MAT_PROPS_CONJ)) return bfhipFail(BFABI_ERROR_NOT_IMPLEMENTED, "transposed sparse term");
-    uint64_t id;
-    if ((rc = walkNewNode(w, BFHIP_NODE_BLOCK, mat->numRows, mat->numCols, &id))) return rc;
-    WalkChild *list = malloc((ne ? ne : 1) * sizeof(WalkChild));
-    if (!list) return bfhipFail(BFABI_ERROR_MEMORY_ERROR, "host OOM while walking BfMat graph");
-    for (size_t k = 0; k < ne; ++k) {
-      size_t i = isDiag ? k : ri[k], j = isDiag ? k : ci[k];
-      if (i >= mat->numRows || j >= mat->numCols) { free(list); return bfhipFail(BFABI_ERROR_OUT_OF_RANGE, "sparse entry (%zu,%zu) out of range", i, j); }
-      uint64_t cid;
-      if ((rc = walkNewNode(w, BFHIP_NODE_DENSE, 1, 1, &cid))) { free(list); return rc; }
-      w->ir->leafData[cid] = isDiag ? (void const *)(val + k) : (void const *)(val + 2 * k);
-      w->ir->leafReal[cid] = (uint8_t)isDiag;
-      list[k].node = cid; list[k].r0 = i; list[k].c0 = j;
-    }
-    w->lists[id] = list;
-    w->counts[id] = ne;
-    *outId = id;
-    return 0;
-  }
+  case BFABI_TYPE_MAT_DIAG_REAL:
+    return walkSparseTerm(w, mat, type, NULL, 0, outId);
   default:
     return bfhipFail(BFABI_ERROR_TYPE_ERROR, "unsupported BfType %d in factorization graph", type);
   }
+}
+
+/* sparse corrections (Kapur-Rokhlin entries, 1/2 I): an entry is folded into a covering dense leaf of one of
+ * the `foldInto` nodes when there is one; what is left becomes 1 x 1 leaves, entries of one row add up.
+ * (The reference's own bfMatCooComplexMul *assigns* z * x_j to the result row, src/mat_coo_complex.c:248-251,
+ * so its last entry of a row wins; that is not reproduced.) */
+static int walkSparseTerm(Walk *w, BfAbiMat const *mat, int type, uint64_t const *foldInto, size_t numFoldInto, uint64_t *outId) {
+  size_t ne;
+  size_t const *ri = NULL, *ci = NULL;
+  double const *val;
+  int const isDiag = type == BFABI_TYPE_MAT_DIAG_REAL;
+  int rc;
+  if (isDiag) { BfAbiMatDiagReal const *d = (BfAbiMatDiagReal const *)mat; ne = d->numElts; val = d->data; }
+  else { BfAbiMatCooComplex const *c = (BfAbiMatCooComplex const *)mat; ne = c->numElts; ri = c->rowInd; ci = c->colInd; val = c->value; w->sawComplex = 1; }
+  if (ne && (!val || (!isDiag && (!ri || !ci)))) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "sparse matrix arrays are NULL");
+  if (mat->props & (BFABI_MAT_PROPS_TRANS | BFABI_MAT_PROPS_CONJ)) return bfhipFail(BFABI_ERROR_NOT_IMPLEMENTED, "transposed sparse term");
+  uint64_t id;
+  if ((rc = walkNewNode(w, BFHIP_NODE_BLOCK, mat->numRows, mat->numCols, &id))) return rc;
+  WalkChild *list = malloc((ne ? ne : 1) * sizeof(WalkChild));
+  if (!list) return bfhipFail(BFABI_ERROR_MEMORY_ERROR, "host OOM while walking BfMat graph");
+  uint64_t kept = 0;
+  for (size_t k = 0; k < ne; ++k) {
+    size_t i = isDiag ? k : ri[k], j = isDiag ? k : ci[k];
+    if (i >= mat->numRows || j >= mat->numCols) { free(list); return bfhipFail(BFABI_ERROR_OUT_OF_RANGE, "sparse entry (%zu,%zu) out of range", i, j); }
+    int folded = 0;
+    for (size_t t = 0; t < numFoldInto && !folded; ++t) {
+      folded = tryFold(w, foldInto[t], i, j, isDiag ? val[k] : val[2 * k], isDiag ? 0.0 : val[2 * k + 1], 0);
+      if (folded < 0) { free(list); return bfhipFail(BFABI_ERROR_MEMORY_ERROR, "host OOM while walking BfMat graph"); }
+    }
+    if (folded) continue;
+    uint64_t cid;
+    if ((rc = walkNewNode(w, BFHIP_NODE_DENSE, 1, 1, &cid))) { free(list); return rc; }
+    w->ir->leafData[cid] = isDiag ? (void const *)(val + k) : (void const *)(val + 2 * k);
+    w->ir->leafReal[cid] = (uint8_t)isDiag;
+    list[kept].node = cid; list[kept].r0 = i; list[kept].c0 = j;
+    ++kept;
+  }
+  w->lists[id] = list;
+  w->counts[id] = kept;
+  *outId = id;
+  return 0;
 }
 
 int bfIrFromBfMat(void const *bfMat, BfIr *ir) {
@@ -395,9 +450,17 @@ int bfIrFromBfMat(void const *bfMat, BfIr *ir) {
   return bfIrFinalize(ir);
 }
 
+static int cmpPatch(void const *pa, void const *pb) {
+  BfIrPatch const *a = pa, *b = pb;
+  if (a->leaf != b->leaf) return a->leaf < b->leaf ? -1 : 1;
+  if (a->row != b->row) return a->row < b->row ? -1 : 1;
+  return a->col < b->col ? -1 : (a->col > b->col);
+}
+
 /* validation + derived fields */
 int bfIrFinalize(BfIr *ir) {
   uint64_t n = ir->numNodes;
+  if (ir->numPatches) qsort(ir->patches, ir->numPatches, sizeof(BfIrPatch), cmpPatch);
   ir->depth = calloc(n, sizeof(uint32_t));
   ir->synthBase = malloc(n * 8);
   if (!ir->depth || !ir->synthBase) { bfIrFree(ir); return bfhipFail(BFABI_ERROR_MEMORY_ERROR, "host OOM"); }

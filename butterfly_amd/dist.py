@@ -250,8 +250,8 @@ def sharded_solve_gmres(step, b, x0=None, tol=1e-12, max_num_iter=100):
     rank the whole iterate -- so the Krylov recurrences run redundantly and identically on each
     GPU (O(j N) per iteration, nothing next to the apply) and the only communication of an iteration
     is the apply's one collective.  Same algorithm and quirks as the single-GPU bfhipSolveGMRES
-    (unrestarted, modified Gram-Schmidt, residual = max_p |s_{j+1,p}| / max_p ||r_p||, a converged
-    solve uses j basis vectors).  b: [n] or [n, nrhs] complex tensor on the apply's device.
+    (unrestarted, Gram-Schmidt as two batched classical passes, residual = max_p |s_{j+1,p}| / max_p ||r_p||,
+    a converged solve uses j basis vectors).  b: [n] or [n, nrhs] complex tensor on the apply's device.
     Returns (x, num_iter, residual)."""
     import torch
     one_d = b.dim() == 1
@@ -263,23 +263,28 @@ def sharded_solve_gmres(step, b, x0=None, tol=1e-12, max_num_iter=100):
     R = B - call(X0)
     rnorm = torch.linalg.vector_norm(R, dim=0)
     beta = float(rnorm.max())
-    V = [R / rnorm]
+    # the Krylov basis as ONE tensor [max_num_iter + 1, n, nrhs]: an iteration's projections are two batched
+    # contractions per Gram-Schmidt pass (CGS2: classical Gram-Schmidt, run twice -- as stable as the
+    # reference's modified Gram-Schmidt, src/linalg.c:174-184, but one host synchronisation per iteration
+    # instead of one per basis vector)
+    V = torch.empty((max_num_iter + 1, n, nrhs), dtype=B.dtype, device=B.device)
+    V[0] = R / rnorm
     S = [[complex(rnorm[p]) if i == 0 else 0j for i in range(max_num_iter + 1)] for p in range(nrhs)]
     H, J = [], {}
     residual, converged, j = float("inf"), False, 0
     for j in range(max_num_iter):
         W = call(V[j]).clone()
-        Hj = [[0j] * (j + 2) for _ in range(nrhs)]
-        for i in range(j + 1):                       # modified Gram-Schmidt, src/linalg.c:174-184
-            hij = torch.sum(V[i].conj() * W, dim=0)
-            W -= V[i] * hij
-            for p, v in enumerate(hij.tolist()):
-                Hj[p][i] = complex(v)
+        Vj = V[:j + 1]
+        h1 = torch.einsum("inp,np->ip", Vj.conj(), W)
+        W -= torch.einsum("inp,ip->np", Vj, h1)
+        h2 = torch.einsum("inp,np->ip", Vj.conj(), W)
+        W -= torch.einsum("inp,ip->np", Vj, h2)
         wnorm = torch.linalg.vector_norm(W, dim=0)
-        V.append(W / wnorm)
+        V[j + 1] = W / wnorm
+        hcol = torch.cat([h1 + h2, wnorm[None].to(h1.dtype)], dim=0).tolist()     # the iteration's one host sync
+        Hj = [[complex(hcol[i][p]) for i in range(j + 2)] for p in range(nrhs)]
         for p in range(nrhs):
             col = Hj[p]
-            col[j + 1] = complex(float(wnorm[p]))
             for i in range(j):                       # earlier rotations, then the new one (:206-228)
                 _rot(col, i, *J[(i, p)])
             J[(j, p)] = _givens(col[j], col[j + 1])

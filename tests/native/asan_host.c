@@ -184,10 +184,14 @@ STUB(bfdevBuildPack)
 STUB(bfdevEventCreate)
 STUB(bfdevEventElapsed)
 STUB(bfdevEventRecord)
+STUB(bfdevEventSync)
 STUB(bfdevGetDevice)
 STUB(bfdevHostAllocPinned)
 void bfdevHostFreePinned(void *p) { if (p) { fprintf(stderr, "device layer reached: bfdevHostFreePinned(non-NULL)\n"); abort(); } }
 STUB(bfdevGmresDot)
+STUB(bfdevGmresDots)
+STUB(bfdevGmresDotsFinish)
+STUB(bfdevGmresProject)
 STUB(bfdevGmresFinish)
 STUB(bfdevGmresMgsStep)
 STUB(bfdevGmresResidual)

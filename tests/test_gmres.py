@@ -47,16 +47,23 @@ def test_plan_of_decorated_operator_matches_oracle(system):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("nrhs", [1, 2])
-def test_device_gmres_follows_the_restatement(system, nrhs):
+def test_device_gmres_follows_the_restatement(system, nrhs, monkeypatch):
     from butterfly_amd.operator import HipOperator
     desc, root, vals, dense, A, b = system
     bb = b[:, 0] if nrhs == 1 else b
     op = HipOperator.from_desc(desc, vals, root=root, max_rhs=nrhs)
     x_ref, it_ref, hist = linalg_ref.solve_gmres(lambda v: bfref.mat_mul(A, v), bb, tol=1e-10, max_num_iter=80)
+    # the reference's own order (modified Gram-Schmidt, one basis vector at a time): iteration for iteration
+    monkeypatch.setenv("BFHIP_GMRES_MGS", "1")
     x, it, res = op.solve_gmres(bb, tol=1e-10, max_num_iter=80)
     assert it == it_ref
     assert abs(res - hist[-1]) <= 1e-6 * hist[-1] + 1e-16
     assert rel(x, x_ref) < 1e-9
+    # default: batched CGS2 (7 launches per iteration whatever j): same Krylov space, the count may move by one
+    monkeypatch.delenv("BFHIP_GMRES_MGS")
+    x, it, res = op.solve_gmres(bb, tol=1e-10, max_num_iter=80)
+    assert abs(it - it_ref) <= 1 and res < 1e-10
+    assert rel(x, x_ref) < 1e-8
     assert rel(x, np.linalg.solve(dense, bb)) < 1e-8
     # warm start and an iteration cap: the not-converged path uses all maxNumIter vectors
     x0 = 0.5 * x_ref
