@@ -306,6 +306,7 @@ int bfPlanBuild(BfIr const *ir, BfPlanOptions const *po, BfPlan *plan) {
   plan->epl = 16 / plan->elemSize;
   plan->maxItemRows = 64 * plan->epl;
   int const T = po->fwdPieces != NULL;
+  plan->transposed = T;
   uint32_t itemRows = po->itemRows ? po->itemRows : plan->maxItemRows;
   if (itemRows > plan->maxItemRows) itemRows = plan->maxItemRows;
   itemRows = (uint32_t)roundUp(itemRows, plan->epl);
