@@ -326,6 +326,17 @@ int bfhipCompileIrFill(BfIr *ir, BfhipOptions const *opts, BfFillFn fill, void *
     BfPlanOptions pt = po;
     pt.fwdPieces = fwd;
     pt.numFwdPieces = nf;
+    /* The transposed kernel tiles a piece as (R row lanes x 64 / R columns) per load: R = 16 (16-column items) is
+     * exact for pieces whose height is a multiple of 16 lane units (fac_helm2: 16 - 64 rows of complex128); pieces
+     * of 5 - 15 units (fac_streamer: 20 - 60 rows of fp32 / fp64) leave a third of 16 row lanes idle, and R = 4
+     * (64-column items) wastes only the last 4-unit step.  Pick by the lane slots each tiling would spend. */
+    uint64_t slots16 = 0, slots4 = 0;
+    for (uint64_t k = 0; k < nf; ++k) {
+      uint64_t const u = (fwd[k].mr + op->plan.epl - 1) / op->plan.epl, w = fwd[k].ncols;
+      slots16 += (u + 15) / 16 * 16 * w;
+      slots4 += (u + 3) / 4 * 4 * w;
+    }
+    pt.tCols = (10 * slots4 < 8 * slots16) ? 64 : 16;
     rc = bfPlanBuild(ir, &pt, &op->tplan);
     free(fwd);
     if (rc) goto done;
@@ -757,7 +768,7 @@ static int loadPlan(FILE *fp, BfhipOperator *op, BfPlan *pl, FileHeader const *f
   pl->numRows = ph.numRows; pl->numCols = ph.numCols; pl->numStages = ph.numStages; pl->tempElems = ph.tempElems;
   pl->arenaElems = pl->transposed ? 0 : fh->arenaElems;
   pl->leafElems = fh->leafElems; pl->numLeaves = fh->numLeaves;
-  if (pl->epl != 16 / pl->elemSize || pl->xcap != 256 || pl->maxItemRows > 64 * pl->epl || (pl->transposed && pl->maxItemRows > 16))
+  if (pl->epl != 16 / pl->elemSize || pl->xcap != 256 || pl->maxItemRows > 64 * pl->epl || (pl->transposed && pl->maxItemRows > 64))
     return bfhipFail(BFABI_ERROR_FILE_ERROR, "corrupt plan header (lane granule / piece width / item height)");
   pl->stages = calloc(ph.numStages ? ph.numStages : 1, sizeof(BfStage));
   if (!pl->stages) return bfhipFail(BFABI_ERROR_MEMORY_ERROR, "host OOM");

@@ -457,10 +457,16 @@ __global__ __launch_bounds__(BF_WAVES_PER_WG * 64) void bfStageKernelReal(StageP
 // ---------------------------------------------------------------------------
 #define BF_T_COLS 16
 
-template <typename S> __device__ __forceinline__ S bfRowXor(S v, int mask) { return __shfl_xor(v, mask, 16); }
-
-template <int DT>
+// R = row lanes per column, C = 64 / R columns per load instruction, NQ loads in flight per block: an
+// item is up to NQ * C columns of A.
+//   R = 16, NQ = 4 (16-column items): tall pieces (fac_helm2: 16 - 64 row chunks of complex128 = 1 - 4 blocks).
+//   R = 4, NQ = 4 (64-column items): operands made of short leaves (fac_streamer: 20 - 60 rows = 5 - 15
+//     16-byte units): with 16 row lanes a 10-unit piece keeps 10 of 16 row lanes busy and a 36-column
+//     remainder 9 of 16 quads; with 4 row lanes a block covers 4 units x 16 columns, the row waste drops
+//     to the last 4-unit step and items are 4x larger.
+template <int DT, int R, int NQ>
 __global__ __launch_bounds__(BF_WAVES_PER_WG * 64) void bfStageKernelT(StageParams p) {
+  constexpr int C = 64 / R;                          // columns per load instruction
   using S = typename Traits<DT>::S;
   constexpr int EPL = Traits<DT>::EPL;              // rows per 16-byte unit (complex: 1)
   constexpr int NC = Traits<DT>::CPLX ? 2 : 1;      // scalars per element
@@ -471,19 +477,19 @@ __global__ __launch_bounds__(BF_WAVES_PER_WG * 64) void bfStageKernelT(StagePara
   uint32_t item = __builtin_amdgcn_readfirstlane(blockIdx.x * BF_WAVES_PER_WG + wave);
   if (item >= p.numItems) return;
   BfDevItem const it = p.items[item];
-  uint32_t const mr = it.mrFlags & 0xffffu;          // columns of A in this item (<= 16)
-  uint32_t const c4 = lane >> 4, r = lane & 15;
-  uint32_t jcol[4];                                  // this lane's 4 columns, clamped into the item:
+  uint32_t const mr = it.mrFlags & 0xffffu;          // columns of A in this item (<= NQ * C)
+  uint32_t const c4 = lane / R, r = lane % R;
+  uint32_t jcol[NQ];                                 // this lane's NQ columns, clamped into the item:
 #pragma unroll                                       // the duplicates are summed but never stored
-  for (int cq = 0; cq < 4; ++cq) jcol[cq] = c4 + 4 * cq < mr ? c4 + 4 * cq : mr - 1;
+  for (int cq = 0; cq < NQ; ++cq) jcol[cq] = c4 + C * cq < mr ? c4 + C * cq : mr - 1;
   U const *arena = (U const *)p.arena;               // 16-byte units
   uint32_t const nrhs = p.nrhs;
   S *out = (it.mrFlags & BF_ITEM_OUT_Y) ? (S *)p.y : (S *)p.temp;
 
   for (uint32_t q = 0; q < nrhs; ++q) {
-    S acc[4][NC];
+    S acc[NQ][NC];
 #pragma unroll
-    for (int cq = 0; cq < 4; ++cq)
+    for (int cq = 0; cq < NQ; ++cq)
 #pragma unroll
       for (int k = 0; k < NC; ++k) acc[cq][k] = 0;
     for (uint32_t wbase = 0; wbase < it.numPieces; wbase += 64) {
@@ -496,7 +502,7 @@ __global__ __launch_bounds__(BF_WAVES_PER_WG * 64) void bfStageKernelT(StagePara
         if (pc.flags & BF_PIECE_IDENTITY) {
           if (r == 0) {
 #pragma unroll
-            for (int cq = 0; cq < 4; ++cq)
+            for (int cq = 0; cq < NQ; ++cq)
 #pragma unroll
               for (int k = 0; k < NC; ++k) acc[cq][k] += xin[(uint64_t)jcol[cq] * nrhs * NC + k];
           }
@@ -506,22 +512,28 @@ __global__ __launch_bounds__(BF_WAVES_PER_WG * 64) void bfStageKernelT(StagePara
         uint32_t const n = pc.ncols;                 // rows of the forward piece taken (a piece may be entered part-way)
         uint32_t const units = (n + EPL - 1) / EPL;  // 16-byte units per column that hold them
         U const *src = arena + pc.dataOff / EPL;
-        for (uint32_t rb = 0; rb < units; rb += 16) {
-          // the last 16-unit block of a column may be short: clamp the unit index into the column
+        for (uint32_t rb = 0; rb < units; rb += R) {
+          // the last R-unit block of a column may be short: clamp the unit index into the column
           // (the rows it stands for are >= n, so their x is zero below) -- never read past the piece
           uint32_t const ru = rb + r < units ? rb + r : units - 1;
-          U a[4];
+          U a[NQ];
 #pragma unroll
-          for (int cq = 0; cq < 4; ++cq) a[cq] = bfLoadStreamV(src + jcol[cq] * stride + ru);
+          for (int cq = 0; cq < NQ; ++cq) a[cq] = bfLoadStreamV(src + jcol[cq] * stride + ru);
           S xv[UNIT];
 #pragma unroll
           for (int e = 0; e < EPL; ++e) {
+            // unconditional loads at a clamped row, zeroed by a select: a load under `row < n ? ... : 0`
+            // becomes a branch with its own wait, and the 2 - 4 x loads of a block then run one after another
             uint32_t const row = (rb + r) * EPL + e;
+            uint32_t const rowc = row < n ? row : n - 1;
 #pragma unroll
-            for (int k = 0; k < NC; ++k) xv[e * NC + k] = row < n ? xin[(uint64_t)row * nrhs * NC + k] : (S)0;
+            for (int k = 0; k < NC; ++k) {
+              S const v = xin[(uint64_t)rowc * nrhs * NC + k];
+              xv[e * NC + k] = row < n ? v : (S)0;
+            }
           }
 #pragma unroll
-          for (int cq = 0; cq < 4; ++cq) {
+          for (int cq = 0; cq < NQ; ++cq) {
             if (Traits<DT>::CPLX) {
               acc[cq][0] = fma(a[cq].v[0], xv[0], acc[cq][0]); acc[cq][0] = fma(-a[cq].v[1], xv[NC - 1], acc[cq][0]);
               acc[cq][NC - 1] = fma(a[cq].v[0], xv[NC - 1], acc[cq][NC - 1]); acc[cq][NC - 1] = fma(a[cq].v[1], xv[0], acc[cq][NC - 1]);
@@ -533,19 +545,19 @@ __global__ __launch_bounds__(BF_WAVES_PER_WG * 64) void bfStageKernelT(StagePara
         }
       }
     }
-    // combine the 16 row lanes of every column (fixed butterfly order) and store
+    // combine the R row lanes of every column (fixed butterfly order) and store
 #pragma unroll
-    for (int m = 1; m < 16; m <<= 1)
+    for (int m = 1; m < R; m <<= 1)
 #pragma unroll
-      for (int cq = 0; cq < 4; ++cq)
+      for (int cq = 0; cq < NQ; ++cq)
 #pragma unroll
-        for (int k = 0; k < NC; ++k) acc[cq][k] += bfRowXor(acc[cq][k], m);
+        for (int k = 0; k < NC; ++k) acc[cq][k] += __shfl_xor(acc[cq][k], m, R);
     if (r == 0) {
 #pragma unroll
-      for (int cq = 0; cq < 4; ++cq)
-        if (c4 + 4 * cq < mr)
+      for (int cq = 0; cq < NQ; ++cq)
+        if (c4 + C * cq < mr)
 #pragma unroll
-          for (int k = 0; k < NC; ++k) out[(((uint64_t)it.outOff + c4 + 4 * cq) * nrhs + q) * NC + k] = acc[cq][k];
+          for (int k = 0; k < NC; ++k) out[(((uint64_t)it.outOff + c4 + C * cq) * nrhs + q) * NC + k] = acc[cq][k];
     }
   }
 }
@@ -896,10 +908,14 @@ int bfdevLaunchStage(BfLaunchArgs const *a, void *stream) {
   uint32_t grid = (uint32_t)((a->numItems + BF_WAVES_PER_WG - 1) / BF_WAVES_PER_WG);
   hipStream_t s = (hipStream_t)stream;
   if (a->transposed) {
-    if (a->dtype == BFHIP_C128) hipLaunchKernelGGL(bfStageKernelT<BFHIP_C128>, dim3(grid), dim3(BF_WAVES_PER_WG * 64), 0, s, p);
-    else if (a->dtype == BFHIP_F64) hipLaunchKernelGGL(bfStageKernelT<BFHIP_F64>, dim3(grid), dim3(BF_WAVES_PER_WG * 64), 0, s, p);
-    else if (a->dtype == BFHIP_F32) hipLaunchKernelGGL(bfStageKernelT<BFHIP_F32>, dim3(grid), dim3(BF_WAVES_PER_WG * 64), 0, s, p);
+    bool const wide = a->maxRows > 16;          // items of up to 64 columns of A (plans of short-leaf operands)
+#define BF_LAUNCH_T(DT) do { if (wide) hipLaunchKernelGGL((bfStageKernelT<DT, 4, 4>), dim3(grid), dim3(BF_WAVES_PER_WG * 64), 0, s, p); \
+                             else hipLaunchKernelGGL((bfStageKernelT<DT, 16, 4>), dim3(grid), dim3(BF_WAVES_PER_WG * 64), 0, s, p); } while (0)
+    if (a->dtype == BFHIP_C128) BF_LAUNCH_T(BFHIP_C128);
+    else if (a->dtype == BFHIP_F64) BF_LAUNCH_T(BFHIP_F64);
+    else if (a->dtype == BFHIP_F32) BF_LAUNCH_T(BFHIP_F32);
     else return bfhipFail(BFABI_ERROR_TYPE_ERROR, "unknown dtype %u", a->dtype);
+#undef BF_LAUNCH_T
     return hipFail(hipGetLastError(), "transposed stage launch");
   }
   if (a->dtype == BFHIP_C128 && a->nrhs >= BF_MFMA_MIN_RHS) hipLaunchKernelGGL(bfStageKernelC128Mfma, dim3(grid), dim3(BF_WAVES_PER_WG * 64), 0, s, p);

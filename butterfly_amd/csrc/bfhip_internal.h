@@ -146,6 +146,7 @@ typedef struct BfPlanOptions {
   /* transposed plan (A^T x): pieces are located in the forward plan's arena */
   BfFwdPiece const *fwdPieces;   /* sorted by (node, col0, row0); NULL -> forward plan */
   uint64_t numFwdPieces;
+  uint32_t tCols;            /* transposed plan: columns of A per item, 16 (default) or 64 */
 } BfPlanOptions;
 
 int bfPlanBuild(BfIr const *ir, BfPlanOptions const *po, BfPlan *plan);

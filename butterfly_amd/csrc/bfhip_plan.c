@@ -312,10 +312,10 @@ int bfPlanBuild(BfIr const *ir, BfPlanOptions const *po, BfPlan *plan) {
   itemRows = (uint32_t)roundUp(itemRows, plan->epl);
   plan->xcap = po->xcap ? po->xcap : 256;
   if (T) {
-    /* an item is BF_T_COLS columns of A (one output each), whatever the element
-     * size: the transposed kernel tiles a forward piece as 16 columns x 4 row groups */
-    itemRows = 16;
-    plan->maxItemRows = 16;
+    /* an item is 16 (or, for operands made of short leaves, 64) columns of A (one output each), whatever
+     * the element size: the transposed kernel tiles a forward piece as 4 columns x 16 row units per load */
+    itemRows = po->tCols == 64 ? 64 : 16;
+    plan->maxItemRows = itemRows;
     if (po->rowBlockEnd > 0) return bfhipFail(BFABI_ERROR_NOT_IMPLEMENTED, "transposed plan of a row-sharded operator");
   }
 
@@ -413,7 +413,7 @@ int bfPlanBuild(BfIr const *ir, BfPlanOptions const *po, BfPlan *plan) {
     uint64_t capBytes = 1u << 20;
     if (stageElems * plan->elemSize / 4096 < capBytes) capBytes = stageElems * plan->elemSize / 4096;
     if (capBytes < BF_ITEM_BYTES) capBytes = BF_ITEM_BYTES;
-    uint64_t const floorRowsCap = T ? 16 : (uint64_t)(po->minChunkRows ? po->minChunkRows : 16) * plan->epl;
+    uint64_t const floorRowsCap = T ? itemRows : (uint64_t)(po->minChunkRows ? po->minChunkRows : 16) * plan->epl;
     uint64_t capCols = capBytes / (floorRowsCap * plan->elemSize);
     if (capCols < BF_TASK_SPAN) capCols = BF_TASK_SPAN;
     for (uint64_t t = tBegin; t < tEnd;) {
