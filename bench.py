@@ -453,11 +453,13 @@ def main():
         # be read from inside the process, so it is not measured in this run and other configurations report null.
         for rnd in (PROFILE_ROUND, "r1"):
             prof = os.path.join(ROOT, "profiles", f"{rnd}_pmc_summary.json")
-            if not (world == 1 and not streamer and n == 262144 and abs(k - 16384) < 1e-9 and args.nrhs in (1, 64) and not real
-                    and args.emulate_world <= 1 and os.path.exists(prof)):
+            helm_cfg = (not streamer and n == 262144 and abs(k - 16384) < 1e-9 and args.nrhs in (1, 64) and not real)
+            strm_cfg = (streamer and n == 1048576 and args.lmax == 255 and dtype == "f32" and args.nrhs == 1 and args.freq_depth is None)
+            if not (world == 1 and (helm_cfg or strm_cfg) and args.emulate_world <= 1 and os.path.exists(prof)):
                 continue
             try:
-                key = "bfStageKernelC128_per_launch" if args.nrhs == 1 else "bfStageKernelC128Mfma_per_launch"
+                key = ("bfStageKernelReal_f32_streamer_per_launch" if strm_cfg else
+                       "bfStageKernelC128_per_launch" if args.nrhs == 1 else "bfStageKernelC128Mfma_per_launch")
                 pm = json.load(open(prof))[key]
                 roofline["traffic"] = pm["hbm_bytes"]
                 roofline["traffic_per_apply"] = pm["hbm_bytes"] * len(ms)

@@ -14,12 +14,16 @@ run ${TAG}_bench_n262144                 $B --pcie
 run ${TAG}_bench_n262144_nrhs64          $B --nrhs 64
 run ${TAG}_bench_n65536                  $B --npoints 65536
 run ${TAG}_bench_n65536_nrhs64           $B --npoints 65536 --nrhs 64 --no-cpu-baseline
-run ${TAG}_bench_n262144_real_f64_proxy  $B --dtype f64 --no-cpu-baseline
-run ${TAG}_bench_n262144_real_f32_proxy  $B --dtype f32 --no-cpu-baseline
-run ${TAG}_bench_n262144_adjoint         $B --adjoint --no-cpu-baseline
-for w in 2 4 8; do run ${TAG}_bench_n262144_shard0of${w}_emulated $B --emulate-world $w --no-cpu-baseline; done
-run ${TAG}_bench_n1048576_shard0of8_emulated  $B --npoints 1048576 --emulate-world 8 --no-cpu-baseline --steps 5 --warmup 1
-run ${TAG}_bench_n1048576_real_f32_proxy      $B --npoints 1048576 --dtype f32 --no-cpu-baseline --steps 5 --warmup 1
+run ${TAG}_bench_n262144_adjoint         $B --adjoint --no-cpu-baseline --no-extra
+run ${TAG}_bench_n262144_rccl_1rank      $B --force-collective --no-cpu-baseline --no-extra
+# every rank's shard of a 2 / 4 / 8-GPU job, one after another on this GPU (the slowest bounds the job)
+for w in 2 4 8; do run ${TAG}_bench_n262144_shards${w}_emulated $B --emulate-world $w --emulate-rank -1 --steps 10; done
+run ${TAG}_bench_n1048576_shards8_emulated    $B --npoints 1048576 --emulate-world 8 --emulate-rank -1 --steps 10
+# BASELINE configs[4]: the streamed real butterfly (fac_streamer structure, rank model), fp32 and fp64
+S="timeout -k 10 900 python bench.py --workload streamer"
+run ${TAG}_bench_streamer_n1048576_f32   $S --adjoint --steps 10
+run ${TAG}_bench_streamer_n1048576_f64   $S --dtype f64 --adjoint --steps 10 --no-cpu-baseline
+run ${TAG}_bench_streamer_n262144_f32    $S --npoints 262144 --lmax 127 --adjoint --steps 10
 run ${TAG}_build_n65536                  timeout -k 10 400 python tools/build_fullsize.py --npoints 65536
 run ${TAG}_bie_device_n65536_k100        timeout -k 10 400 python tools/helm2_bie_device.py --npoints 65536 --wavenumber 100 --max-iter 300
 hipcc -O3 --offload-arch=gfx950 tools/hbm_peak.hip -o /tmp/hbm_peak 2>/dev/null && run ${TAG}_hbm_peak timeout -k 5 120 /tmp/hbm_peak

@@ -11,7 +11,7 @@ cd /tmp && export TMPDIR=/tmp
 run() { # name, rocprof args..., -- bench args
   local name=$1; shift
   local rp=(); while [ "$1" != "--" ]; do rp+=("$1"); shift; done; shift
-  rocprofv3 "${rp[@]}" --output-format csv -d $OUT/$name -- python3 $R/bench.py "$@" --no-cpu-baseline > $OUT/$name.json 2> $OUT/$name.log
+  rocprofv3 "${rp[@]}" --output-format csv -d $OUT/$name -- python3 $R/bench.py "$@" --no-cpu-baseline --no-extra > $OUT/$name.json 2> $OUT/$name.log
   echo "$name exit=$?"
 }
 # headline: N=262144, nrhs=1
@@ -24,4 +24,8 @@ run stats_r64  --kernel-trace --stats -- --nrhs 64 --steps 3 --warmup 1
 run mfma_r64   --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -- --nrhs 64 --steps 2 --warmup 1
 run fetch_r64  --kernel-trace --pmc FETCH_SIZE -- --nrhs 64 --steps 2 --warmup 1
 run write_r64  --kernel-trace --pmc WRITE_SIZE -- --nrhs 64 --steps 2 --warmup 1
+# BASELINE configs[4]: streamed real butterfly, N = 1M fp32 (bfStageKernelReal<f32>); each pass lays the operand out again (~3 min)
+run stats_st   --kernel-trace --stats -- --workload streamer --steps 5 --warmup 1
+run fetch_st   --kernel-trace --pmc FETCH_SIZE -- --workload streamer --steps 2 --warmup 1
+run write_st   --kernel-trace --pmc WRITE_SIZE -- --workload streamer --steps 2 --warmup 1
 ls $OUT

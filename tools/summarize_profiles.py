@@ -26,12 +26,12 @@ def counters(name):
 
 out = {"tag": tag, "note": "FETCH_SIZE/WRITE_SIZE in KiB; on gfx950 FETCH_SIZE counts half the bytes of a 16-B/lane streaming read "
        "(MI355X_MICROARCH.md, HBM): fetch bytes = FETCH_SIZE*1024*2; WRITE_SIZE exact.  SQ_* are summed over SEs/XCDs as rocprofv3 reports them."}
-for name in ("stats_r1", "stats_r64"):
+for name in ("stats_r1", "stats_r64", "stats_st"):
     for f in glob.glob(f"{src}/{name}/*/*_kernel_stats.csv"):
         shutil.copy(f, f"profiles/{tag}_{name}_kernel_stats.csv")
     if os.path.exists(f"{src}/{name}.json"):
         shutil.copy(f"{src}/{name}.json", f"profiles/{tag}_{name}_bench_under_rocprof.json")
-for name in ("fetch_r1", "write_r1", "lds_r1", "mfma_r64", "fetch_r64", "write_r64"):
+for name in ("fetch_r1", "write_r1", "lds_r1", "mfma_r64", "fetch_r64", "write_r64", "fetch_st", "write_st"):
     out[name] = counters(name)
 
 
@@ -46,7 +46,8 @@ def per_launch(fetch, write, kern):
 
 out["bfStageKernelC128_per_launch"] = per_launch("fetch_r1", "write_r1", "bfStageKernelC128")
 out["bfStageKernelC128Mfma_per_launch"] = per_launch("fetch_r64", "write_r64", "bfStageKernelC128Mfma")
-for nm, key in (("stats_r1", "bfStageKernelC128_per_launch"), ("stats_r64", "bfStageKernelC128Mfma_per_launch")):
+out["bfStageKernelReal_f32_streamer_per_launch"] = next((v for v in (per_launch("fetch_st", "write_st", k) for k in list(out.get("fetch_st", {})) if "bfStageKernelReal" in k) if v), None)
+for nm, key in (("stats_r1", "bfStageKernelC128_per_launch"), ("stats_r64", "bfStageKernelC128Mfma_per_launch"), ("stats_st", "bfStageKernelReal_f32_streamer_per_launch")):
     p = f"{src}/{nm}.json"
     if os.path.exists(p) and out.get(key):
         b = json.load(open(p))
