@@ -393,6 +393,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         y_full = step(x)
+    enqueue_s = time.perf_counter() - t0          # host time to enqueue all steps (launches are asynchronous)
     torch.cuda.synchronize()
     if use_pg:
         dist.barrier()
@@ -504,6 +505,8 @@ def main():
             "roofline": roofline,
             # leaf bytes this process streamed per step / step time (one rank's share in a multi-GPU or emulated run)
             "hbm_gbs_whole_step": (st["leafBytes"] / 1e9) / (elapsed / args.steps),
+            # what a hipGraph could remove at most: the host's share of a step (it runs ahead of the GPU)
+            "host_enqueue_ms_per_step": enqueue_s / args.steps * 1e3,
         }
         if multi:
             out["multi_gpu"] = multi

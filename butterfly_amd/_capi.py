@@ -293,6 +293,9 @@ def load():
     lib.bfhipSolveGMRESDevice.argtypes = [vp, vp, C.c_size_t, vp, C.c_double, C.c_size_t, C.POINTER(C.c_size_t),
                                           C.POINTER(C.c_double), vp, vp]
     lib.bfhipSolveGMRESDevice.restype = C.c_int
+    lib.bfhipSolveGMRESPrecondDevice.argtypes = [vp, vp, vp, C.c_size_t, vp, C.c_double, C.c_size_t, C.POINTER(C.c_size_t),
+                                                 C.POINTER(C.c_double), vp, vp]
+    lib.bfhipSolveGMRESPrecondDevice.restype = C.c_int
     lib.bfhipGetStats.argtypes = [vp, C.POINTER(BfhipStats)]
     lib.bfhipGetStats.restype = C.c_int
     lib.bfhipGetNumRows.argtypes = [vp]

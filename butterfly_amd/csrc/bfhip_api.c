@@ -64,17 +64,18 @@ struct BfhipOperator {
   void *hX, *hY;              /* pinned host mirrors of dX / dY */
   uint32_t xyRhs;
   /* profiling */
-  void **evStart, **evStop;   /* [numStages] */
+  void **evStart, **evStop;   /* [BF_EV_POOL][numStages]: one set per apply in flight, so timing an apply never waits for the one before */
   double *stageMs;
   uint64_t *stageLaunches;
   uint32_t lastNrhs;
-  int evPending;
+  uint64_t evIssued, evHarvested;   /* applies whose events were recorded / read back */
   /* BFHIP_FLAG_PLAN_ONLY: the IR is kept (borrowed leaf pointers!) for bfhipPlanPackArena */
   BfIr *ir;
   uint64_t seed;
 };
 
 #define BF_ARENA_SLACK 256u
+#define BF_EV_POOL 64u
 
 static void freeDevicePlanOf(BfPlan *plan) {
   for (uint64_t s = 0; s < plan->numStages && plan->stages; ++s) {
@@ -100,7 +101,7 @@ void bfhipFree(BfhipOperator **pop) {
     bfdevGetDevice(&prev);
     bfdevSetDevice(op->device);
   }
-  if (op->evStart) for (uint64_t s = 0; s < op->plan.numStages; ++s) { bfdevEventDestroy(op->evStart[s]); bfdevEventDestroy(op->evStop[s]); }
+  if (op->evStart && op->evStop) for (uint64_t s = 0; s < BF_EV_POOL * op->plan.numStages; ++s) { bfdevEventDestroy(op->evStart[s]); bfdevEventDestroy(op->evStop[s]); }
   free(op->evStart); free(op->evStop); free(op->stageMs); free(op->stageLaunches);
   freeDevicePlan(op);
   bfdevFree(op->dArena);
@@ -367,12 +368,12 @@ int bfhipCompileIrFill(BfIr *ir, BfhipOptions const *opts, BfFillFn fill, void *
   if ((rc = bfdevMemset(op->dZero, 0, 4096))) goto done;
   if (op->flags & BFHIP_FLAG_PROFILE) {
     uint64_t S = op->plan.numStages;
-    op->evStart = calloc(S, sizeof(void *));
-    op->evStop = calloc(S, sizeof(void *));
+    op->evStart = calloc(BF_EV_POOL * S, sizeof(void *));
+    op->evStop = calloc(BF_EV_POOL * S, sizeof(void *));
     op->stageMs = calloc(S, sizeof(double));
     op->stageLaunches = calloc(S, sizeof(uint64_t));
     if (!op->evStart || !op->evStop || !op->stageMs || !op->stageLaunches) { rc = bfhipFail(BFABI_ERROR_MEMORY_ERROR, "host OOM"); goto done; }
-    for (uint64_t s = 0; s < S && !rc; ++s) {
+    for (uint64_t s = 0; s < BF_EV_POOL * S && !rc; ++s) {
       rc = bfdevEventCreate(&op->evStart[s]);
       if (!rc) rc = bfdevEventCreate(&op->evStop[s]);
     }
@@ -404,16 +405,19 @@ int bfhipCompileDesc(BfhipDesc const *desc, BfhipOptions const *opts, BfhipOpera
 }
 
 /* ---- profiling helpers ------------------------------------------------------ */
-static int harvestEvents(BfhipOperator *op) {
-  if (!op->evPending) return 0;
-  for (uint64_t s = 0; s < op->plan.numStages; ++s) {
-    float ms = 0;
-    int rc = bfdevEventElapsed(op->evStart[s], op->evStop[s], &ms);
-    if (rc) return rc;
-    op->stageMs[s] += ms;
-    op->stageLaunches[s] += 1;
+/* read back the events of applies [evHarvested, upTo): synchronizes on each (they complete in order) */
+static int harvestEvents(BfhipOperator *op, uint64_t upTo) {
+  uint64_t const S = op->plan.numStages;
+  for (; op->evHarvested < upTo; ++op->evHarvested) {
+    uint64_t const slot = op->evHarvested % BF_EV_POOL;
+    for (uint64_t s = 0; s < S; ++s) {
+      float ms = 0;
+      int rc = bfdevEventElapsed(op->evStart[slot * S + s], op->evStop[slot * S + s], &ms);
+      if (rc) return rc;
+      op->stageMs[s] += ms;
+      op->stageLaunches[s] += 1;
+    }
   }
-  op->evPending = 0;
   return 0;
 }
 
@@ -425,7 +429,7 @@ static uint64_t stageBytes(BfhipOperator const *op, uint64_t s, uint32_t nrhs) {
 int bfhipGetStageProfile(BfhipOperator *op, double *ms, uint64_t *launches, uint64_t *bytes, int reset) {
   if (!op) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "NULL operator");
   if (!(op->flags & BFHIP_FLAG_PROFILE)) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "operator was not compiled with BFHIP_FLAG_PROFILE");
-  int rc = harvestEvents(op);
+  int rc = harvestEvents(op, op->evIssued);
   if (rc) return rc;
   for (uint64_t s = 0; s < op->plan.numStages; ++s) {
     if (ms) ms[s] = op->stageMs[s];
@@ -451,16 +455,18 @@ static int runPlan(BfhipOperator *op, BfPlan *plan, void const *dX, size_t nrhs,
     if ((rc = ensureTemp(op, (uint32_t)nrhs))) goto out;
   }
   int const prof = (op->flags & BFHIP_FLAG_PROFILE) != 0 && plan == &op->plan;
-  if (prof && (rc = harvestEvents(op))) goto out;
+  /* timing never makes an apply wait for the previous one: only when all BF_EV_POOL event sets are in flight is the oldest read back */
+  if (prof && op->evIssued - op->evHarvested >= BF_EV_POOL && (rc = harvestEvents(op, op->evIssued - BF_EV_POOL + 1))) goto out;
+  uint64_t const evBase = prof ? (op->evIssued % BF_EV_POOL) * plan->numStages : 0;
   for (uint64_t s = 0; s < plan->numStages; ++s) {
     BfStage *st = &plan->stages[s];
     BfLaunchArgs a;
     a.arena = op->dArena; a.items = st->dItems; a.pieces = st->dPieces; a.numItems = st->numItems;
     a.x = dX; a.y = dY; a.temp = op->dTemp; a.zero = op->dZero; a.nrhs = (uint32_t)nrhs; a.dtype = plan->dtype; a.maxRows = st->maxRows;
     a.transposed = plan->transposed;
-    if (prof && (rc = bfdevEventRecord(op->evStart[s], stream))) goto out;
+    if (prof && (rc = bfdevEventRecord(op->evStart[evBase + s], stream))) goto out;
     if ((rc = bfdevLaunchStage(&a, stream))) goto out;
-    if (prof && (rc = bfdevEventRecord(op->evStop[s], stream))) goto out;
+    if (prof && (rc = bfdevEventRecord(op->evStop[evBase + s], stream))) goto out;
     for (uint64_t r0 = 0; r0 < st->numReduce; r0 += 16) {
       BfReduceArgs ra[16];
       uint32_t const cnt = (uint32_t)(st->numReduce - r0 < 16 ? st->numReduce - r0 : 16);
@@ -473,7 +479,7 @@ static int runPlan(BfhipOperator *op, BfPlan *plan, void const *dX, size_t nrhs,
       if ((rc = bfdevLaunchReduce(ra, cnt, stream))) goto out;
     }
   }
-  if (prof) { op->evPending = 1; op->lastNrhs = (uint32_t)nrhs; }
+  if (prof) { ++op->evIssued; op->lastNrhs = (uint32_t)nrhs; }
 out:
   /* every path hands the caller's device back */
   if (prev >= 0 && prev != op->device) bfdevSetDevice(prev);
@@ -872,10 +878,10 @@ int bfhipLoad(char const *path, BfhipOptions const *opts, BfhipOperator **out) {
   if ((rc = bfdevMemset(op->dZero, 0, 4096))) goto done;
   if (op->flags & BFHIP_FLAG_PROFILE) {
     uint64_t S = op->plan.numStages;
-    op->evStart = calloc(S, sizeof(void *)); op->evStop = calloc(S, sizeof(void *));
+    op->evStart = calloc(BF_EV_POOL * S, sizeof(void *)); op->evStop = calloc(BF_EV_POOL * S, sizeof(void *));
     op->stageMs = calloc(S, sizeof(double)); op->stageLaunches = calloc(S, sizeof(uint64_t));
     if (!op->evStart || !op->evStop || !op->stageMs || !op->stageLaunches) { rc = bfhipFail(BFABI_ERROR_MEMORY_ERROR, "host OOM"); goto done; }
-    for (uint64_t s = 0; s < S && !rc; ++s) { rc = bfdevEventCreate(&op->evStart[s]); if (!rc) rc = bfdevEventCreate(&op->evStop[s]); }
+    for (uint64_t s = 0; s < BF_EV_POOL * S && !rc; ++s) { rc = bfdevEventCreate(&op->evStart[s]); if (!rc) rc = bfdevEventCreate(&op->evStop[s]); }
   }
 done:
   fclose(fp);

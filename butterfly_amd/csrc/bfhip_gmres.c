@@ -45,25 +45,37 @@ static void applyGivens(cplx *z0p, cplx *z1p, cplx c, cplx s) {
   *z1p = s * z0 + c * z1;
 }
 
-static int solveDevice(BfhipOperator *op, void const *dB, size_t nrhs, void const *dX0, double tol,
+static int solveDevice(BfhipOperator *op, BfhipOperator *precond, void const *dB, size_t nrhs, void const *dX0, double tol,
                        size_t maxNumIter, size_t *numIter, double *residual, void *dX, void *stream);
 
 /* the Krylov basis and every staging buffer live on the OPERATOR's device, whatever device is
  * current in the caller; the caller's device is restored on every path */
 int bfhipSolveGMRESDevice(BfhipOperator *op, void const *dB, size_t nrhs, void const *dX0, double tol,
                           size_t maxNumIter, size_t *numIter, double *residual, void *dX, void *stream) {
+  return bfhipSolveGMRESPrecondDevice(op, NULL, dB, nrhs, dX0, tol, maxNumIter, numIter, residual, dX, stream);
+}
+
+/* Left-preconditioned GMRES (the reference's M argument, src/linalg.c:90-97,131,159): `solveM` applies what
+ * bfMatSolve(M, .) computes -- the action of M^{-1} -- as a device operator of its own (an approximate
+ * inverse: block-diagonal, a coarser butterfly, ...).  The residual is then the PRECONDITIONED residual, as in
+ * the reference ("the residual will be determined from the preconditioned residual vectors", :41-43). */
+int bfhipSolveGMRESPrecondDevice(BfhipOperator *op, BfhipOperator *solveM, void const *dB, size_t nrhs, void const *dX0, double tol,
+                                 size_t maxNumIter, size_t *numIter, double *residual, void *dX, void *stream) {
   if (!op) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "NULL argument");
+  if (solveM && (bfhipOperatorDevice(solveM) != bfhipOperatorDevice(op) || bfhipGetNumRows(solveM) != bfhipGetNumRows(op) ||
+                 bfhipGetNumCols(solveM) != bfhipGetNumRows(op)))
+    return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "the preconditioner must be an n x n operator on the operator's device (linalg.c:92-97)");
   int prev = -1, dev = bfhipOperatorDevice(op);
   if (dev < 0) return bfhipFail(BFABI_ERROR_RUNTIME_ERROR, "operator has no device (compiled with BFHIP_FLAG_PLAN_ONLY)");
   bfdevGetDevice(&prev);
   int rc = prev != dev ? bfdevSetDevice(dev) : 0;
   if (rc) return rc;
-  rc = solveDevice(op, dB, nrhs, dX0, tol, maxNumIter, numIter, residual, dX, stream);
+  rc = solveDevice(op, solveM, dB, nrhs, dX0, tol, maxNumIter, numIter, residual, dX, stream);
   if (prev >= 0 && prev != dev) bfdevSetDevice(prev);
   return rc;
 }
 
-static int solveDevice(BfhipOperator *op, void const *dB, size_t nrhs, void const *dX0, double tol,
+static int solveDevice(BfhipOperator *op, BfhipOperator *precond, void const *dB, size_t nrhs, void const *dX0, double tol,
                        size_t maxNumIter, size_t *numIter, double *residual, void *dX, void *stream) {
   if (!op || !dB || !dX) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "NULL argument");
   if (maxNumIter == 0) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "maxNumIter must be positive (linalg.c:81-82)");
@@ -85,6 +97,7 @@ static int solveDevice(BfhipOperator *op, void const *dB, size_t nrhs, void cons
 
   void *dV = NULL, *dW = NULL, *dPartA = NULL, *dPartB = NULL, *dH = NULL, *dY = NULL, *dAX0 = NULL;
   void *dPartAll = NULL, *dH1 = NULL, *dH2 = NULL;     /* CGS2: partials of all dots, coefficients of the two passes */
+  void *dPre = NULL;                                   /* left preconditioner: the vector it is applied to */
   void *hHpinned = NULL;
   void *evCol[2] = {NULL, NULL};      /* "column j is in host memory", two in flight */
   cplx *hHslot[2] = {NULL, NULL};
@@ -124,6 +137,14 @@ static int solveDevice(BfhipOperator *op, void const *dB, size_t nrhs, void cons
     CHECK(bfdevMalloc(&dAX0, vecBytes));
     CHECK(bfhipApplyDevice(op, dX0, nrhs, dAX0, stream));
   }
+  if (precond) {
+    /* R = M^{-1} (B - A X0) (:127-135): the difference goes to a scratch vector, the preconditioner writes W,
+     * and the norm partials are taken from W */
+    CHECK(bfdevMalloc(&dPre, vecBytes));
+    CHECK(bfdevGmresResidual(dB, dAX0, dPre, dPartA, n, (uint32_t)nrhs, nb, stream));
+    CHECK(bfhipApplyDevice(precond, dPre, nrhs, dW, stream));
+    CHECK(bfdevGmresResidual(dW, NULL, dW, dPartA, n, (uint32_t)nrhs, nb, stream));
+  } else
   CHECK(bfdevGmresResidual(dB, dAX0, dW, dPartA, n, (uint32_t)nrhs, nb, stream));
   /* V[0] = R / ||R|| per column; S[0] = ||R|| (:139-151) */
   CHECK(bfdevGmresFinish(dW, dPartA, dV, dH, n, (uint32_t)nrhs, nb, stream));
@@ -147,6 +168,10 @@ static int solveDevice(BfhipOperator *op, void const *dB, size_t nrhs, void cons
 #define ENQUEUE(J) do { \
     size_t const j_ = (J); \
     char *Vj = (char *)dV + j_ * vecBytes; \
+    if (precond) { \
+      CHECK(bfhipApplyDevice(op, Vj, nrhs, dPre, stream));                   /* W = M^{-1} (A V[j])  (:155-163) */ \
+      CHECK(bfhipApplyDevice(precond, dPre, nrhs, dW, stream)); \
+    } else \
     CHECK(bfhipApplyDevice(op, Vj, nrhs, dW, stream));                       /* W = A V[j]  (:157) */ \
     void *pin = dPartA, *pout = dPartB; \
     if (useMgs) { \
@@ -216,7 +241,7 @@ finish:
 done:
   (void)bfdevSync(stream);   /* a speculative iteration may still be in flight: drain before its buffers go */
   bfdevFree(dV); bfdevFree(dW); bfdevFree(dPartA); bfdevFree(dPartB); bfdevFree(dH); bfdevFree(dY); bfdevFree(dAX0);
-  bfdevFree(dPartAll); bfdevFree(dH1); bfdevFree(dH2);
+  bfdevFree(dPartAll); bfdevFree(dH1); bfdevFree(dH2); bfdevFree(dPre);
   bfdevEventDestroy(evCol[0]); bfdevEventDestroy(evCol[1]);
   bfdevHostFreePinned(hHpinned);
   free(H); free(S); free(Jc); free(Js); free(y); free(rnorm);

@@ -159,8 +159,8 @@ int bfhipApplyTransposeDevice(BfhipOperator *op, const void *dX, size_t nrhs, vo
  * Hessenberg column crosses PCIe per iteration.  X0 may be NULL (zeros).
  * `numIter` receives the reference's iteration count (the number of basis
  * vectors the solution is built from), `residual` the last relative residual;
- * either may be NULL.  Complex square operators only; a left preconditioner
- * (the reference's M) is NOT_IMPLEMENTED.  Host-pointer form: B, X0, X are
+ * either may be NULL.  Complex square operators only; the left preconditioner
+ * (the reference's M) is the *Precond* entry below.  Host-pointer form: B, X0, X are
  * row-major n x nrhs with leading dimensions in elements. */
 int bfhipSolveGMRES(BfhipOperator *op, const void *B, size_t ldb, size_t nrhs, const void *X0, size_t ldx0,
                     double tol, size_t maxNumIter, size_t *numIter, double *residual, void *X, size_t ldx);
@@ -208,6 +208,12 @@ int bfhipShardedApplyDevice(BfhipSharded *sh, const void *dX, size_t nrhs, void 
 /* hipEvent times of the most recent apply: stage kernels, and collective (+ reordering).  Synchronizes. */
 int bfhipShardedLastTimes(BfhipSharded *sh, double *localMs, double *collectiveMs);
 void bfhipShardedFree(BfhipSharded **sh);     /* neither the operator nor the communicator is released */
+
+/* Left-preconditioned form: the reference's M argument (src/linalg.c:47-49,90-97,131,159).  `solveM` is a device
+ * operator that applies what bfMatSolve(M, .) computes, i.e. the action of M^{-1} (n x n, same device and dtype
+ * as `op`); NULL = no preconditioner.  As in the reference the residual is then the preconditioned one. */
+int bfhipSolveGMRESPrecondDevice(BfhipOperator *op, BfhipOperator *solveM, const void *dB, size_t nrhs, const void *dX0, double tol,
+                                 size_t maxNumIter, size_t *numIter, double *residual, void *dX, void *stream);
 
 /* ---- introspection ------------------------------------------------------- */
 int bfhipGetStats(const BfhipOperator *op, BfhipStats *stats);

@@ -44,16 +44,20 @@ def apply_givens(vec, i0, i1, c, s):
     vec[i1] = s * z0 + c * z1
 
 
-def solve_gmres(matmul, B, X0=None, tol=1e-12, max_num_iter=100):
+def solve_gmres(matmul, B, X0=None, tol=1e-12, max_num_iter=100, msolve=None):
     """Returns (X, num_iter, residual_history).  `matmul(X)` is bfMatMul(A, X)
-    for an n x nrhs complex array."""
+    for an n x nrhs complex array; `msolve(X)` is bfMatSolve(M, X) for the left
+    preconditioner M (src/linalg.c:90-97,131-135,157-163), None without one."""
+    if msolve is not None:
+        plain = matmul
+        matmul = lambda X: msolve(plain(X))                 # W = M^{-1} (A V[j])  :157-163
     B = np.asarray(B, dtype=np.complex128)
     one_d = B.ndim == 1
     if one_d:
         B = B[:, None]
     n, nrhs = B.shape
     X0 = np.zeros_like(B) if X0 is None else np.asarray(X0, dtype=np.complex128).reshape(n, nrhs)
-    R = B - matmul(X0)                                   # :127-131
+    R = B - matmul(X0) if msolve is None else msolve(B - plain(X0))   # :127-135
     rnorm = np.linalg.norm(R, axis=0)                    # :139
     beta = rnorm.max()                                   # :142
     V = [R / rnorm]                                      # :145-146

@@ -108,3 +108,46 @@ def test_replicated_vector_gmres_matches_the_device_solver(system, nrhs):
     assert it == it_dev and abs(res - res_dev) <= 1e-6 * res_dev + 1e-16
     assert rel(x.cpu().numpy(), x_dev.cpu().numpy()) < 1e-10
     op.close()
+
+
+@pytest.mark.gpu
+def test_left_preconditioned_gmres(system, monkeypatch):
+    """bfSolveGMRES(A, B, X0, tol, maxNumIter, &numIter, M) with a left preconditioner (src/linalg.c:90-97,131,159):
+    M^{-1} = block-Jacobi inverse of the dense system, applied as a device operator of its own."""
+    import torch
+    from butterfly_amd import helm2_structure as hs
+    from butterfly_amd.operator import HipOperator
+    desc, root, vals, dense, A, b = system
+    n = dense.shape[0]
+    nb = 16
+    d = hs.Desc(dtype=0)
+    pv, ch = {}, []
+    minv = np.zeros_like(dense)
+    for i in range(nb):
+        sl = slice(i * n // nb, (i + 1) * n // nb)
+        blk = np.linalg.inv(dense[sl, sl])
+        leaf = d.add(hs.NODE_DENSE, blk.shape[0], blk.shape[1])
+        pv[leaf] = blk
+        ch.append((leaf, sl.start, sl.start))
+        minv[sl, sl] = blk
+    d.root = d.add(hs.NODE_BLOCK, n, n, ch, hs.BF_TYPE_BLOCK_DIAG)
+    op = HipOperator.from_desc(desc, vals, root=root)
+    pre = HipOperator.from_desc(d, pv)
+    bb = b[:, 0]
+    x_ref, it_ref, hist = linalg_ref.solve_gmres(lambda v: bfref.mat_mul(A, v), bb, tol=1e-10, max_num_iter=80, msolve=lambda v: minv @ v)
+    _, it_plain, _ = linalg_ref.solve_gmres(lambda v: bfref.mat_mul(A, v), bb, tol=1e-10, max_num_iter=80)
+    assert it_ref <= it_plain
+    bd = torch.from_numpy(np.ascontiguousarray(bb)).cuda()
+    monkeypatch.setenv("BFHIP_GMRES_MGS", "1")
+    x, it, res = op.solve_gmres_device(bd, tol=1e-10, max_num_iter=80, precond=pre)
+    assert it == it_ref and abs(res - hist[-1]) <= 1e-6 * hist[-1] + 1e-16
+    assert rel(x.cpu().numpy(), x_ref) < 1e-9
+    monkeypatch.delenv("BFHIP_GMRES_MGS")
+    x, it, res = op.solve_gmres_device(bd, tol=1e-10, max_num_iter=80, precond=pre)
+    assert abs(it - it_ref) <= 1
+    assert rel(x.cpu().numpy(), np.linalg.solve(dense, bb)) < 1e-8
+    # shape / device mismatches are refused like linalg.c:92-97
+    small = HipOperator.from_desc(d, pv, root=ch[0][0])
+    with pytest.raises(Exception):
+        op.solve_gmres_device(bd, precond=small)
+    small.close(); pre.close(); op.close()
