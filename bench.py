@@ -233,7 +233,8 @@ def cpu_baseline_streamer(graph, seed, budget_bytes):
 def main():
     argv = sys.argv[1:]
     args = parse_args(argv)
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+    # BENCH_FORCE_LAUNCH=1 (tests): go through the launcher path with a single rank as well
+    if (args.gpus > 1 or os.environ.get("BENCH_FORCE_LAUNCH") == "1") and "WORLD_SIZE" not in os.environ:
         launch_ranks(args, argv)          # never returns
 
     # Exactly one line may reach stdout (the JSON).  Native libraries (RCCL prints a version banner at

@@ -41,3 +41,43 @@ def test_rhs_block_reports_mfma_roofline():
     d = run_bench("--nrhs", "64", "--no-cpu-baseline")
     r = d["roofline"]
     assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 78.6 and 0 < r["frac"] < 1
+
+
+def test_bench_starts_its_own_ranks(monkeypatch):
+    """`bench.py --gpus N` without a launcher starts the rank processes itself (torch.distributed.run on
+    127.0.0.1) and relays rank 0's JSON line; here with one rank (a one-GPU box) through the same code path,
+    plus the sharded C-ABI step (RCCL communicator + collective) inside it."""
+    monkeypatch.setenv("BENCH_FORCE_LAUNCH", "1")
+    d = run_bench("--no-cpu-baseline", "--force-collective")
+    assert d["n_gpus"] == 1 and d["value"] > 0
+    m = d["multi_gpu"]
+    assert m["mode"] == "rows" and len(m["rank_local_ms"]) == 1 and m["max_local_ms"] > 0 and m["max_collective_ms"] >= 0
+
+
+def test_bench_fails_loudly_when_a_rank_fails():
+    """More ranks than GPUs on the box: a rank cannot get its device; the parent must exit non-zero, no JSON."""
+    import torch
+    n = torch.cuda.device_count() + 1
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "1", "--warmup", "0", "--npoints", "8192",
+           "--no-cpu-baseline"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert p.returncode != 0
+    assert not [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_streamer_workload_contract():
+    d = run_streamer()
+    assert d["dtype"] == "f32" and d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"] < 1
+    assert d["config"]["num_cols"] == 32 * 32 and d["config"]["graph"]["identity"] > 0
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["value"] > 0
+    assert d["adjoint"]["transpose_identity_rel"] < 1e-4
+
+
+def run_streamer():
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "streamer", "--npoints", "16384", "--lmax", "31", "--steps", "3",
+           "--warmup", "1", "--adjoint", "--cpu-budget-gb", "0.05"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, p.stdout
+    return json.loads(lines[0])

@@ -389,6 +389,18 @@ def test_save_load_round_trip(tmp_path, helm2_cases):
     with pytest.raises(_capi.BfhipError) as e:
         HipOperator.load(trunc)
     assert e.value.code == 6
+    # a file is untrusted input: an index table that points outside the arena / the vectors is refused before
+    # any kernel could dereference it.  Layout: 88-byte file header, 40-byte plan header, 56-byte stage
+    # header, then stage 0's items {u32 pieceBegin, numPieces, outOff, mrFlags}
+    raw = bytearray(path.read_bytes())
+    for off, what in ((184 + 8, "item.outOff"), (184 + 0, "item.pieceBegin"), (184 + 12, "item.mrFlags")):
+        bad_bytes = bytearray(raw)
+        bad_bytes[off:off + 4] = (0xFFFFFFF0).to_bytes(4, "little")
+        corrupt = tmp_path / "corrupt.bfhip"
+        corrupt.write_bytes(bytes(bad_bytes))
+        with pytest.raises(_capi.BfhipError) as e:
+            HipOperator.load(corrupt)
+        assert e.value.code == 6, what
 
 
 @pytest.mark.parametrize("seed", range(3))

@@ -1,9 +1,11 @@
 #!/bin/bash
 # Collects the rocprofv3 evidence committed under profiles/ (run on the GPU box via gpurun).
-#   usage: tools/profile_round.sh <round-tag>      e.g. r1
+#   usage: tools/profile_round.sh <round-tag> [helm2|streamer|all]      e.g. r2 helm2
+# (the streamed operand is laid out again in every pass, ~3 min each: run the two parts in separate gpurun calls)
 # Each PMC set is its own pass with --kernel-trace only (no --stats / sys-trace with --pmc).
 set -u
 TAG=${1:-r1}
+PART=${2:-all}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
@@ -14,6 +16,7 @@ run() { # name, rocprof args..., -- bench args
   rocprofv3 "${rp[@]}" --output-format csv -d $OUT/$name -- python3 $R/bench.py "$@" --no-cpu-baseline --no-extra > $OUT/$name.json 2> $OUT/$name.log
   echo "$name exit=$?"
 }
+if [ "$PART" != "streamer" ]; then
 # headline: N=262144, nrhs=1
 run stats_r1   --kernel-trace --stats -- --steps 10 --warmup 2
 run fetch_r1   --kernel-trace --pmc FETCH_SIZE -- --steps 3 --warmup 1
@@ -24,8 +27,11 @@ run stats_r64  --kernel-trace --stats -- --nrhs 64 --steps 3 --warmup 1
 run mfma_r64   --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -- --nrhs 64 --steps 2 --warmup 1
 run fetch_r64  --kernel-trace --pmc FETCH_SIZE -- --nrhs 64 --steps 2 --warmup 1
 run write_r64  --kernel-trace --pmc WRITE_SIZE -- --nrhs 64 --steps 2 --warmup 1
+fi
+if [ "$PART" != "helm2" ]; then
 # BASELINE configs[4]: streamed real butterfly, N = 1M fp32 (bfStageKernelReal<f32>); each pass lays the operand out again (~3 min)
 run stats_st   --kernel-trace --stats -- --workload streamer --steps 5 --warmup 1
 run fetch_st   --kernel-trace --pmc FETCH_SIZE -- --workload streamer --steps 2 --warmup 1
 run write_st   --kernel-trace --pmc WRITE_SIZE -- --workload streamer --steps 2 --warmup 1
+fi
 ls $OUT
