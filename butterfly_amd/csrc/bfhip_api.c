@@ -139,8 +139,10 @@ static void packPiece(BfPlan const *pl, BfIr const *ir, BfDevPiece const *pc, Bf
   double scale = 0;
   uint64_t vbase = ir->synthBase[node], n = ir->cols[node];
   if (!data) scale = cplx ? sqrt(3.0 / (2.0 * (double)n)) : sqrt(3.0 / (double)n);
+  int const rowMajor = (pc->flags & BF_PIECE_ROWMAJOR) != 0;      /* real dtypes only */
+  uint32_t const rowsStored = rowMajor ? mr : mrPad;
   for (uint32_t c = 0; c < pc->ncols; ++c) {
-    for (uint32_t r = 0; r < mrPad; ++r) {
+    for (uint32_t r = 0; r < rowsStored; ++r) {
       double re = 0, im = 0;
       if (r < mr) {
         uint64_t i = src->row0 + r, j = src->col0 + c;
@@ -152,12 +154,18 @@ static void packPiece(BfPlan const *pl, BfIr const *ir, BfDevPiece const *pc, Bf
           if (cplx) im = bfhip_synth_value(seed, vbase + i * n + j, 1) * scale;
         }
       }
-      uint64_t e = (uint64_t)c * mrPad + r;
+      uint64_t e = rowMajor ? (uint64_t)r * pc->ld + c : (uint64_t)c * mrPad + r;
       if (cplx) { ((double *)dst)[2 * e] = re; ((double *)dst)[2 * e + 1] = im; }
       else if (pl->dtype == BFHIP_F64) ((double *)dst)[e] = re;
       else ((float *)dst)[e] = (float)re;
     }
   }
+  if (rowMajor)      /* the row ends are padded to the lane granule with zeros */
+    for (uint32_t r = 0; r < mr; ++r)
+      for (uint32_t c = pc->ncols; c < pc->ld; ++c) {
+        uint64_t e = (uint64_t)r * pc->ld + c;
+        if (pl->dtype == BFHIP_F64) ((double *)dst)[e] = 0; else ((float *)dst)[e] = 0;
+      }
   /* sparse decorations folded into this leaf (bfhip_ir.c: tryFold): patches are sorted by (leaf, row, col) */
   if (ir->numPatches && data) {
     uint64_t lo = 0, hi = ir->numPatches;
@@ -165,7 +173,7 @@ static void packPiece(BfPlan const *pl, BfIr const *ir, BfDevPiece const *pc, Bf
     for (; lo < ir->numPatches && ir->patches[lo].leaf == node && ir->patches[lo].row < src->row0 + mr; ++lo) {
       BfIrPatch const *pt = &ir->patches[lo];
       if (pt->col < src->col0 || pt->col >= src->col0 + pc->ncols) continue;
-      uint64_t e = (uint64_t)(pt->col - src->col0) * mrPad + (pt->row - src->row0);
+      uint64_t e = rowMajor ? (uint64_t)(pt->row - src->row0) * pc->ld + (pt->col - src->col0) : (uint64_t)(pt->col - src->col0) * mrPad + (pt->row - src->row0);
       if (cplx) { ((double *)dst)[2 * e] += pt->re; ((double *)dst)[2 * e + 1] += pt->im; }
       else if (pl->dtype == BFHIP_F64) ((double *)dst)[e] += pt->re;
       else ((float *)dst)[e] = (float)((double)((float *)dst)[e] + pt->re);
@@ -199,7 +207,7 @@ static int packLeaves(BfhipOperator const *op, BfIr const *ir, uint64_t seed, vo
         BfPieceSrc const *src = &st->pieceSrc[it->pieceBegin + k];
         if (pc->flags & BF_PIECE_IDENTITY) continue;
         uint64_t node = src->node;
-        size_t bytes = (size_t)mrPad * pc->ncols * es;
+        size_t bytes = ((pc->flags & BF_PIECE_ROWMAJOR) ? (size_t)mr * pc->ld : (size_t)mrPad * pc->ncols) * es;
         if (hostDst) {
           packPiece(pl, ir, pc, src, mr, mrPad, (unsigned char *)hostDst + pc->dataOff * es, seed);
           continue;
@@ -217,6 +225,7 @@ static int packLeaves(BfhipOperator const *op, BfIr const *ir, uint64_t seed, vo
           sp->leafCols = (uint32_t)ir->cols[node];
           sp->row0 = src->row0; sp->col0 = src->col0;
           sp->mr = mr; sp->mrPad = mrPad; sp->ncols = pc->ncols;
+          sp->rowMajor = (pc->flags & BF_PIECE_ROWMAJOR) != 0; sp->ldr = pc->ld;
           sp->scale = cplx ? sqrt(3.0 / (2.0 * (double)ir->cols[node])) : sqrt(3.0 / (double)ir->cols[node]);
           continue;
         }
@@ -724,15 +733,25 @@ static int validateStage(BfPlan const *pl, uint64_t arenaElems, BfStage const *s
     BfDevItem const *it = &items[i];
     uint32_t const mr = it->mrFlags & 0xffffu;
     uint64_t const outLen = (it->mrFlags & BF_ITEM_OUT_Y) ? outY : temp;
-    if (!mr || mr > pl->maxItemRows || mr > st->maxRows || (it->mrFlags & ~(0xffffu | BF_ITEM_OUT_Y)) ||
+    if (!mr || mr > pl->maxItemRows || mr > st->maxRows || (it->mrFlags & ~(0xffffu | BF_ITEM_OUT_Y | BF_ITEM_ROWMAJOR)) ||
+        ((it->mrFlags & BF_ITEM_ROWMAJOR) && (pl->transposed || pl->dtype == BFHIP_C128 || mr > 2 * pl->epl)) ||
         (uint64_t)it->outOff + mr > outLen || (uint64_t)it->pieceBegin + it->numPieces > st->numPieces)
       return bfhipFail(BFABI_ERROR_FILE_ERROR, "corrupt operator file: item %llu out of bounds", (unsigned long long)i);
     uint32_t const mrPad = (mr + pl->epl - 1) / pl->epl * pl->epl;
     for (uint32_t k = 0; k < it->numPieces; ++k) {
       BfDevPiece const *pc = &pieces[it->pieceBegin + k];
       uint64_t const inLen = (pc->flags & BF_PIECE_IN_X) ? inX : temp;
-      int bad = (pc->flags & ~(BF_PIECE_IN_X | BF_PIECE_IDENTITY)) != 0;
+      int bad = (pc->flags & ~(BF_PIECE_IN_X | BF_PIECE_IDENTITY | BF_PIECE_ROWMAJOR)) != 0;
+      int const rm = (pc->flags & BF_PIECE_ROWMAJOR) != 0;
+      if (!(pc->flags & BF_PIECE_IDENTITY) && !pl->transposed && rm != ((it->mrFlags & BF_ITEM_ROWMAJOR) != 0)) bad = 1;
       if (pc->flags & BF_PIECE_IDENTITY) bad |= (uint64_t)pc->inOff + mr > inLen;
+      else if (pl->transposed && rm)      /* rows of a row-major forward piece: ncols rows, mr columns from dataOff */
+        bad |= !pc->ld || pc->ld % pl->epl || pc->dataOff % pl->epl || pl->dtype == BFHIP_C128 || !pc->ncols ||
+               pc->dataOff + (uint64_t)(pc->ncols - 1) * pc->ld + (mr + pl->epl - 1) / pl->epl * pl->epl > arenaElems ||
+               (uint64_t)pc->inOff + pc->ncols > inLen;
+      else if (rm)
+        bad |= !pc->ncols || pc->ncols > pl->xcap || pc->ld % pl->epl || pc->ld < pc->ncols || pc->dataOff % pl->epl ||
+               pc->dataOff + (uint64_t)mr * pc->ld > arenaElems || (uint64_t)pc->inOff + pc->ncols > inLen;
       else if (pl->transposed)
         bad |= !pc->ld || pc->ld % pl->epl || pc->ncols > pc->ld || pc->dataOff % pl->epl ||
                pc->dataOff + (uint64_t)(mr - 1) * pc->ld + (pc->ncols + pl->epl - 1) / pl->epl * pl->epl > arenaElems ||

@@ -71,12 +71,14 @@ typedef struct BfDevPiece {
   uint32_t inOff;      /* element offset of column 0 in the input space */
   uint32_t ncols;
   uint32_t flags;      /* bit 0: input space is X (else vector arena); bit 1: identity piece */
-  uint32_t ld;         /* transposed plans: element stride between the lanes' columns (forward mrPad); else 0 */
+  uint32_t ld;         /* transposed plans: element stride between the lanes' columns (forward mrPad); row-major pieces: row stride; else 0 */
 } BfDevPiece;
 
 #define BF_ITEM_OUT_Y (1u << 16)
+#define BF_ITEM_ROWMAJOR (1u << 17)   /* all dense pieces of the item are stored row-major (few-row leaves of real operands) */
 #define BF_PIECE_IN_X 1u
 #define BF_PIECE_IDENTITY 2u
+#define BF_PIECE_ROWMAJOR 4u          /* element (r, c) at dataOff + r * ld + c, ld = columns padded to the lane granule */
 
 /* host-only: where each piece's values come from (for packing / synthesis) */
 typedef struct BfPieceSrc {
@@ -135,6 +137,7 @@ typedef struct BfFwdPiece {
   uint64_t node;
   uint64_t dataOff;
   uint32_t row0, mr, mrPad, col0, ncols;
+  uint32_t rowMajor, ldr;      /* row-major forward piece and its row stride */
 } BfFwdPiece;
 
 typedef struct BfPlanOptions {
@@ -186,6 +189,7 @@ typedef struct BfSynthPiece {
   uint32_t leafCols;    /* leaf row length n (row-major virtual index = i*n + j) */
   uint32_t row0, col0;
   uint32_t mr, mrPad, ncols;
+  uint32_t rowMajor, ldr;      /* row-major piece: element (r, c) at dataOff + r * ldr + c */
   double scale;
 } BfSynthPiece;
 int bfdevSynthFill(void *arena, uint32_t dtype, BfSynthPiece const *hostPieces, uint64_t count, uint64_t seed);

@@ -211,6 +211,7 @@ int bfPlanFwdPieces(BfPlan const *plan, BfFwdPiece **out, uint64_t *count) {
         BfPieceSrc const *src = &st->pieceSrc[it->pieceBegin + p];
         t[k].node = src->node; t[k].dataOff = pc->dataOff; t[k].row0 = src->row0; t[k].mr = mr;
         t[k].mrPad = (mr + plan->epl - 1) / plan->epl * plan->epl; t[k].col0 = src->col0; t[k].ncols = pc->ncols;
+        t[k].rowMajor = (pc->flags & BF_PIECE_ROWMAJOR) != 0; t[k].ldr = pc->ld;
         ++k;
       }
     }
@@ -601,8 +602,14 @@ int bfPlanBuild(BfIr const *ir, BfPlanOptions const *po, BfPlan *plan) {
       it->pieceBegin = (uint32_t)np;
       uint64_t outOff;
       uint32_t flags = 0;
+      /* Few-row wide leaves of real operands (a streamed butterfly ends in row nodes of ~5 rows with leaves thousands
+       * of columns wide) are stored ROW-major: column-major they pad 5 rows to the 4- (fp32) or 2-row (fp64) lane
+       * granule (+60 % bytes) and give the transposed kernel 2 of its 16 row lanes; row-major every lane owns
+       * 16 bytes of consecutive columns, forward and transposed, and nothing is padded but the row ends. */
+      int const rowMajor = !T && plan->dtype != BFHIP_C128 && mr <= 2 * plan->epl && g->colsSum >= 128;
+      if (rowMajor) flags |= BF_ITEM_ROWMAJOR;
       if (g->reduced) outOff = g->slotOff + r0;
-      else if (g->outBuf == by) { outOff = g->outOff + r0; flags = BF_ITEM_OUT_Y; }
+      else if (g->outBuf == by) { outOff = g->outOff + r0; flags |= BF_ITEM_OUT_Y; }
       else outOff = b.bufs[g->outBuf].arenaOff + g->outOff + r0;
       if (outOff >= 0xffffffffu) { free(tmp); rc = bfhipFail(BFABI_ERROR_RUNTIME_ERROR, "vector arena exceeds 32-bit offsets"); goto stage_fail; }
       it->outOff = (uint32_t)outOff;
@@ -636,12 +643,18 @@ int bfPlanBuild(BfIr const *ir, BfPlanOptions const *po, BfPlan *plan) {
             if (inBase + (lo - ta) >= 0xffffffffu) { free(tmp); rc = bfhipFail(BFABI_ERROR_RUNTIME_ERROR, "vector arena exceeds 32-bit offsets"); goto stage_fail; }
             /* a forward piece that straddles the task boundary is entered at row lo: a multiple of the lane
              * granule, since task boundaries (multiples of BF_TASK_SPAN) and forward row chunks both are */
-            if ((lo - fp->row0) % plan->epl) { free(tmp); rc = bfhipFail(BFABI_ERROR_RUNTIME_ERROR, "internal: transposed piece not on a lane boundary"); goto stage_fail; }
-            pc->dataOff = fp->dataOff + (uint64_t)(r0 - fp->col0) * fp->mrPad + (lo - fp->row0);
+            if (!fp->rowMajor && (lo - fp->row0) % plan->epl) { free(tmp); rc = bfhipFail(BFABI_ERROR_RUNTIME_ERROR, "internal: transposed piece not on a lane boundary"); goto stage_fail; }
             pc->inOff = (uint32_t)(inBase + (lo - ta));
             pc->ncols = (uint32_t)(hi - lo);   /* steps = rows of the forward piece taken */
             pc->flags = inFlag;
-            pc->ld = fp->mrPad;
+            if (fp->rowMajor) {                /* element (row s, column j) = arena[dataOff + s * ld + j] */
+              pc->flags |= BF_PIECE_ROWMAJOR;
+              pc->dataOff = fp->dataOff + (lo - fp->row0) * fp->ldr + (r0 - fp->col0);
+              pc->ld = fp->ldr;
+            } else {
+              pc->dataOff = fp->dataOff + (uint64_t)(r0 - fp->col0) * fp->mrPad + (lo - fp->row0);
+              pc->ld = fp->mrPad;
+            }
             st->pieceSrc[np].node = tk->leaf; st->pieceSrc[np].row0 = (uint32_t)lo; st->pieceSrc[np].col0 = r0;
             ++np; ++found;
           }
@@ -654,6 +667,11 @@ int bfPlanBuild(BfIr const *ir, BfPlanOptions const *po, BfPlan *plan) {
           if (inBase + c0 >= 0xffffffffu) { free(tmp); rc = bfhipFail(BFABI_ERROR_RUNTIME_ERROR, "vector arena exceeds 32-bit offsets"); goto stage_fail; }
           pc->dataOff = arenaTop; pc->inOff = (uint32_t)(inBase + c0); pc->ncols = (uint32_t)nc; pc->flags = inFlag; pc->ld = 0;
           st->pieceSrc[np].node = tk->leaf; st->pieceSrc[np].row0 = r0; st->pieceSrc[np].col0 = (uint32_t)(tk->sub0 + c0);
+          if (rowMajor) {
+            pc->flags |= BF_PIECE_ROWMAJOR;
+            pc->ld = (uint32_t)roundUp(nc, plan->epl);
+            arenaTop += (uint64_t)mr * pc->ld;
+          } else
           arenaTop += (uint64_t)mrPad * nc;
           ++np;
         }

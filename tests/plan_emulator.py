@@ -17,6 +17,8 @@ from butterfly_amd import _capi
 BF_ITEM_OUT_Y = 1 << 16
 BF_PIECE_IN_X = 1
 BF_PIECE_IDENTITY = 2
+BF_PIECE_ROWMAJOR = 4
+BF_ITEM_ROWMAJOR = 1 << 17
 
 
 def _view(ptr, count, dtype):
@@ -65,6 +67,21 @@ def run_plan(op, x, transpose=False):
                     acc += src[io:io + mr]
                     continue
                 d0 = int(pc["dataOff"])
+                rowmajor = bool(int(pc["flags"]) & BF_PIECE_ROWMAJOR)
+                if rowmajor:
+                    # few-row leaves of real operands: element (r, c) = arena[d0 + r * ld + c], rows padded to the lane granule
+                    ld = int(pc["ld"])
+                    assert info.dtype != 0 and ld % epl == 0 and d0 % epl == 0
+                    if transpose:       # n rows of the forward piece, mr of its columns starting at d0
+                        assert d0 + (n - 1) * ld + (mr + epl - 1) // epl * epl <= len(arena)
+                        idx = d0 + np.arange(n)[None, :] * ld + np.arange(mr)[:, None]
+                        acc += arena[idx] @ src[io:io + n]
+                    else:
+                        assert int(it["mrFlags"]) & BF_ITEM_ROWMAJOR and ld >= n and mr <= 2 * epl
+                        blk = arena[d0:d0 + mr * ld].reshape(mr, ld)
+                        assert not blk[:, n:].any(), "row padding must be zero"
+                        acc += blk[:, :n] @ src[io:io + n]
+                    continue
                 if transpose:
                     # lanes j < mr on the columns of a forward piece: element (step s, lane j) = arena[d0 + j*ld + s]
                     ld = int(pc["ld"])
