@@ -793,7 +793,7 @@ static int loadPlan(FILE *fp, BfhipOperator *op, BfPlan *pl, FileHeader const *f
   pl->numRows = ph.numRows; pl->numCols = ph.numCols; pl->numStages = ph.numStages; pl->tempElems = ph.tempElems;
   pl->arenaElems = pl->transposed ? 0 : fh->arenaElems;
   pl->leafElems = fh->leafElems; pl->numLeaves = fh->numLeaves;
-  if (pl->epl != 16 / pl->elemSize || pl->xcap != 256 || pl->maxItemRows > 64 * pl->epl || (pl->transposed && pl->maxItemRows > 64))
+  if (pl->epl != 16 / pl->elemSize || pl->xcap != 256 || pl->maxItemRows > 64 * pl->epl || (pl->transposed && pl->maxItemRows > 128))
     return bfhipFail(BFABI_ERROR_FILE_ERROR, "corrupt plan header (lane granule / piece width / item height)");
   pl->stages = calloc(ph.numStages ? ph.numStages : 1, sizeof(BfStage));
   if (!pl->stages) return bfhipFail(BFABI_ERROR_MEMORY_ERROR, "host OOM");

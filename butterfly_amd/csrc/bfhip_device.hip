@@ -384,6 +384,57 @@ __global__ __launch_bounds__(BF_WAVES_PER_WG * 64) void bfStageKernelReal(StageP
   uint32_t const nrhs = p.nrhs;
   S *out = (it.mrFlags & BF_ITEM_OUT_Y) ? (S *)p.y : (S *)p.temp;
 
+  if (it.mrFlags & BF_ITEM_ROWMAJOR) {
+    // Few-row wide leaves (mr <= 2 EPL rows, stored row-major, rows padded with zeros to the lane granule): a lane
+    // owns 16 bytes of consecutive columns, loads them from every row of the piece and multiplies with the matching
+    // 16 bytes of x (staged in LDS like below, so any nrhs stride works); rows are summed over the wave at the end
+    // by a fixed butterfly.  No row padding is read and every lane is busy whatever mr is.
+    constexpr int RMAX = 2 * EPL;
+    for (uint32_t q = 0; q < nrhs; ++q) {
+      S racc[RMAX];
+#pragma unroll
+      for (int r = 0; r < RMAX; ++r) racc[r] = 0;
+      S ident = 0;                                   // lane r < mr: identity contributions to row r
+      for (uint32_t pi = 0; pi < it.numPieces; ++pi) {
+        BfDevPiece const pc = p.pieces[it.pieceBegin + pi];
+        S const *xin = (pc.flags & BF_PIECE_IN_X) ? (S const *)p.x : (S const *)p.temp;
+        xin += (uint64_t)pc.inOff * nrhs + q;
+        if (pc.flags & BF_PIECE_IDENTITY) {
+          if ((uint32_t)lane < mr) ident += xin[(uint64_t)lane * nrhs];
+          continue;
+        }
+        uint32_t const n = pc.ncols, ldr = pc.ld;
+        waveSync();   // previous piece's reads are done before overwriting
+        for (uint32_t j = lane; j < ldr; j += 64) xs[j] = j < n ? xin[(uint64_t)j * nrhs] : (S)0;
+        waveSync();
+        V const *rowp = arena + pc.dataOff / EPL;
+        uint32_t const unitsPerRow = ldr / EPL;
+        for (uint32_t u = lane; u < unitsPerRow; u += 64) {
+          V const xv = *(V const *)(xs + (uint64_t)u * EPL);
+          V a[RMAX];
+#pragma unroll
+          for (int r = 0; r < RMAX; ++r) if ((uint32_t)r < mr) a[r] = bfLoadStreamV(rowp + (uint64_t)r * unitsPerRow + u);   // mr is wave-uniform
+#pragma unroll
+          for (int r = 0; r < RMAX; ++r)
+            if ((uint32_t)r < mr) {
+#pragma unroll
+              for (int e = 0; e < EPL; ++e) racc[r] = fma(a[r].v[e], xv.v[e], racc[r]);
+            }
+        }
+      }
+      S mine = ident;
+#pragma unroll
+      for (int r = 0; r < RMAX; ++r) {
+        S t = racc[r];
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) t += __shfl_xor(t, m, 64);      // fixed order: deterministic
+        if ((uint32_t)lane == (uint32_t)r) mine += t;
+      }
+      if ((uint32_t)lane < mr) out[((uint64_t)it.outOff + lane) * nrhs + q] = mine;
+    }
+    return;
+  }
+
   for (uint32_t q = 0; q < nrhs; ++q) {
     S acc[EPL];
 #pragma unroll
@@ -485,6 +536,12 @@ __global__ __launch_bounds__(BF_WAVES_PER_WG * 64) void bfStageKernelT(StagePara
   U const *arena = (U const *)p.arena;               // 16-byte units
   uint32_t const nrhs = p.nrhs;
   S *out = (it.mrFlags & BF_ITEM_OUT_Y) ? (S *)p.y : (S *)p.temp;
+  uint32_t const nq = (mr + C - 1) / C;              // load instructions that touch a column of this item
+
+  // lane mapping for row-major pieces: CG_RM groups of EPL columns across the item's width, RL_RM row lanes
+  constexpr int CG_RM = (NQ * C) / EPL > 64 ? 64 : (NQ * C) / EPL;
+  constexpr int RL_RM = 64 / CG_RM;
+  uint32_t const cgRm = lane % CG_RM, rlRm = lane / CG_RM;
 
   for (uint32_t q = 0; q < nrhs; ++q) {
     S acc[NQ][NC];
@@ -492,6 +549,10 @@ __global__ __launch_bounds__(BF_WAVES_PER_WG * 64) void bfStageKernelT(StagePara
     for (int cq = 0; cq < NQ; ++cq)
 #pragma unroll
       for (int k = 0; k < NC; ++k) acc[cq][k] = 0;
+    S racc[EPL];
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) racc[e] = 0;
+    bool anyRowMajor = false;
     for (uint32_t wbase = 0; wbase < it.numPieces; wbase += 64) {
       uint32_t const wn = it.numPieces - wbase < 64 ? it.numPieces - wbase : 64;
       BfPieceWin const win = bfPieceWinLoad(p.pieces + it.pieceBegin + wbase, wn, lane);
@@ -508,6 +569,34 @@ __global__ __launch_bounds__(BF_WAVES_PER_WG * 64) void bfStageKernelT(StagePara
           }
           continue;
         }
+        if constexpr (!Traits<DT>::CPLX) {
+          if (pc.flags & BF_PIECE_ROWMAJOR) {
+            // rows of a row-major forward piece (few-row leaves): element (row s, column j) = arena[dataOff + s * ld + j].
+            // Lane = (column group cg of EPL consecutive columns, row lane rl): one 16-byte load per row, no reduction
+            // inside the piece; the RL row lanes are combined once per item below.
+            anyRowMajor = true;
+            uint32_t const n = pc.ncols;                          // rows taken (<= 2 EPL)
+            uint32_t const cgc = cgRm < (mr + EPL - 1) / EPL ? cgRm : (mr - 1) / EPL;   // clamp into the item's columns
+            U const *src = arena + pc.dataOff / EPL + cgc;
+            uint32_t const rowUnits = pc.ld / EPL;
+            // every row this lane owns is requested before the first is used (rows past n: clamped address, x = 0)
+            constexpr int ITERS = (2 * EPL + RL_RM - 1) / RL_RM;
+            U a[ITERS];
+            S xv[ITERS];
+#pragma unroll
+            for (int i = 0; i < ITERS; ++i) {
+              uint32_t const srow = rlRm + (uint32_t)i * RL_RM, sc = srow < n ? srow : n - 1;
+              a[i] = bfLoadStreamV(src + (uint64_t)sc * rowUnits);
+              S const xr = xin[(uint64_t)sc * nrhs];
+              xv[i] = srow < n ? xr : (S)0;
+            }
+#pragma unroll
+            for (int i = 0; i < ITERS; ++i)
+#pragma unroll
+              for (int e = 0; e < EPL; ++e) racc[e] = fma(a[i].v[e], xv[i], racc[e]);
+            continue;
+          }
+        }
         uint32_t const stride = pc.ld / EPL;         // 16-byte units between columns (forward mrPad / EPL)
         uint32_t const n = pc.ncols;                 // rows of the forward piece taken (a piece may be entered part-way)
         uint32_t const units = (n + EPL - 1) / EPL;  // 16-byte units per column that hold them
@@ -518,7 +607,7 @@ __global__ __launch_bounds__(BF_WAVES_PER_WG * 64) void bfStageKernelT(StagePara
           uint32_t const ru = rb + r < units ? rb + r : units - 1;
           U a[NQ];
 #pragma unroll
-          for (int cq = 0; cq < NQ; ++cq) a[cq] = bfLoadStreamV(src + jcol[cq] * stride + ru);
+          for (int cq = 0; cq < NQ; ++cq) if ((uint32_t)cq < nq) a[cq] = bfLoadStreamV(src + jcol[cq] * stride + ru);   // nq: wave-uniform
           S xv[UNIT];
 #pragma unroll
           for (int e = 0; e < EPL; ++e) {
@@ -534,6 +623,7 @@ __global__ __launch_bounds__(BF_WAVES_PER_WG * 64) void bfStageKernelT(StagePara
           }
 #pragma unroll
           for (int cq = 0; cq < NQ; ++cq) {
+            if ((uint32_t)cq >= nq) continue;
             if (Traits<DT>::CPLX) {
               acc[cq][0] = fma(a[cq].v[0], xv[0], acc[cq][0]); acc[cq][0] = fma(-a[cq].v[1], xv[NC - 1], acc[cq][0]);
               acc[cq][NC - 1] = fma(a[cq].v[0], xv[NC - 1], acc[cq][NC - 1]); acc[cq][NC - 1] = fma(a[cq].v[1], xv[0], acc[cq][NC - 1]);
@@ -552,6 +642,24 @@ __global__ __launch_bounds__(BF_WAVES_PER_WG * 64) void bfStageKernelT(StagePara
       for (int cq = 0; cq < NQ; ++cq)
 #pragma unroll
         for (int k = 0; k < NC; ++k) acc[cq][k] += __shfl_xor(acc[cq][k], m, R);
+    if constexpr (!Traits<DT>::CPLX) {
+      if (anyRowMajor) {      // wave-uniform: same pieces for every lane
+#pragma unroll
+        for (int e = 0; e < EPL; ++e)
+#pragma unroll
+          for (int m = CG_RM; m < 64; m <<= 1) racc[e] += __shfl_xor(racc[e], m, 64);     // over the row lanes, fixed order
+        // column col's total sits in lane col / EPL, element col % EPL: hand it to the lane that stores col
+#pragma unroll
+        for (int cq = 0; cq < NQ; ++cq) {
+          uint32_t const col = c4 + C * cq < mr ? c4 + C * cq : 0;
+#pragma unroll
+          for (int e = 0; e < EPL; ++e) {
+            S const t = __shfl(racc[e], (int)(col / EPL), 64);
+            if ((int)(col % EPL) == e) acc[cq][0] += t;
+          }
+        }
+      }
+    }
     if (r == 0) {
 #pragma unroll
       for (int cq = 0; cq < NQ; ++cq)
@@ -617,13 +725,14 @@ __global__ __launch_bounds__(256) void bfSynthKernel(void *arenaV, BfSynthPiece 
   using S = typename Traits<DT>::S;
   constexpr bool CPLX = Traits<DT>::CPLX;
   BfSynthPiece const pc = pieces[blockIdx.x];
-  uint64_t total = (uint64_t)pc.mrPad * pc.ncols;
+  uint64_t total = pc.rowMajor ? (uint64_t)pc.mr * pc.ldr : (uint64_t)pc.mrPad * pc.ncols;
   S *dst = (S *)arenaV + pc.dataOff * (CPLX ? 2 : 1);
   for (uint64_t e = threadIdx.x; e < total; e += 256) {
-    uint32_t col = (uint32_t)(e / pc.mrPad);
-    uint32_t r = (uint32_t)(e - (uint64_t)col * pc.mrPad);
+    uint32_t col, r;
+    if (pc.rowMajor) { r = (uint32_t)(e / pc.ldr); col = (uint32_t)(e - (uint64_t)r * pc.ldr); }
+    else { col = (uint32_t)(e / pc.mrPad); r = (uint32_t)(e - (uint64_t)col * pc.mrPad); }
     S re = 0, im = 0;
-    if (r < pc.mr) {
+    if (r < pc.mr && col < pc.ncols) {
       uint64_t idx = pc.vbase + (uint64_t)(pc.row0 + r) * pc.leafCols + (pc.col0 + col);
       re = (S)(bfhip_synth_value(seed, idx, 0) * pc.scale);
       if (CPLX) im = (S)(bfhip_synth_value(seed, idx, 1) * pc.scale);

@@ -315,7 +315,7 @@ int bfPlanBuild(BfIr const *ir, BfPlanOptions const *po, BfPlan *plan) {
   if (T) {
     /* an item is 16 (or, for operands made of short leaves, 64) columns of A (one output each), whatever
      * the element size: the transposed kernel tiles a forward piece as 4 columns x 16 row units per load */
-    itemRows = po->tCols == 64 ? 64 : 16;
+    itemRows = po->tCols > 16 ? po->tCols : 16;
     plan->maxItemRows = itemRows;
     if (po->rowBlockEnd > 0) return bfhipFail(BFABI_ERROR_NOT_IMPLEMENTED, "transposed plan of a row-sharded operator");
   }

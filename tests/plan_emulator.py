@@ -85,7 +85,7 @@ def run_plan(op, x, transpose=False):
                 if transpose:
                     # lanes j < mr on the columns of a forward piece: element (step s, lane j) = arena[d0 + j*ld + s]
                     ld = int(pc["ld"])
-                    assert ld >= n and mr <= 64
+                    assert ld >= n and mr <= 128
                     # what bfStageKernelT may touch: columns j < mr, units clamped into the column
                     assert d0 + (mr - 1) * ld + (n + epl - 1) // epl * epl <= len(arena), "transposed piece reaches past the leaf arena"
                     idx = d0 + np.arange(mr)[:, None] * ld + np.arange(n)[None, :]

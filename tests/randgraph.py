@@ -115,3 +115,35 @@ def long_contraction_operand(rng, dtype):
             out[40021:] += vals[b].T @ v[p:p + d.rows[b]]; p += d.rows[b]
         return out
     return d, vals, apply_t, val
+
+
+def few_row_operand(rng):
+    """What a streamed butterfly ends in: row nodes of 1 - 8 rows whose leaves are hundreds to thousands of columns wide,
+    next to ordinary leaves in the same block column, with Identity terms on the few-row groups.  Real (f64) operand.
+    Returns (desc, vals, dense matrix)."""
+    from butterfly_amd import helm2_structure as hs
+    d = hs.Desc(dtype=1)
+    vals = {}
+    widths = [700, 130, 2900]                      # three block columns
+    co = np.concatenate([[0], np.cumsum(widths)])
+    heights = [5, 1, 8, 40, 3, 7, 64, 2, 6, 4]     # block rows: few-row ones (row-major) and ordinary ones
+    ro = np.concatenate([[0], np.cumsum(heights)])
+    m, n = int(ro[-1]), int(co[-1])
+    dense = np.zeros((m, n))
+    ch = []
+    for i, h in enumerate(heights):
+        for j, w in enumerate(widths):
+            if (i + j) % 4 == 3:
+                continue                            # a hole: BlockCoo-like sparsity
+            a = rng.standard_normal((h, w)) / np.sqrt(w)
+            leaf = d.add(hs.NODE_DENSE, h, w)
+            vals[leaf] = a
+            dense[ro[i]:ro[i + 1], co[j]:co[j] + w] += a
+            ch.append((leaf, int(ro[i]), int(co[j])))
+        if h <= 8:                                   # an Identity term on the same rows (pass-through of a previous level)
+            ident = d.add(hs.NODE_IDENTITY, h, h)
+            c0 = int(co[1]) + 3 * i
+            dense[ro[i]:ro[i + 1], c0:c0 + h] += np.eye(h)
+            ch.append((ident, int(ro[i]), c0))
+    d.root = d.add(hs.NODE_BLOCK, m, n, ch, hs.BF_TYPE_BLOCK_COO)
+    return d, vals, dense

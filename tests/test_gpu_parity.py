@@ -590,3 +590,25 @@ def test_long_contractions_on_gpu(dtype, demote):
     assert rel(op.apply_host(x), y_ref) <= tol
     assert rel(op.apply_transpose_host(v), apply_t(v)) <= tol
     op.close()
+
+
+@pytest.mark.parametrize("demote", [False, True])
+@pytest.mark.parametrize("nrhs", [1, 3])
+def test_few_row_leaves_on_gpu(demote, nrhs):
+    """Row-major few-row leaves (the pass-through W blocks of a streamed butterfly) through the real stage kernel and the
+    transposed kernel, mixed with column-major leaves and Identity terms in the same groups; f64 and f32, 1 and 3 RHS."""
+    import randgraph
+    from butterfly_amd import _capi
+    from butterfly_amd.operator import HipOperator
+    from oracle import bfref
+    rng = np.random.default_rng(41 + nrhs)
+    d, vals, dense = randgraph.few_row_operand(rng)        # (Identity terms off the block grid: the dense matrix is the answer)
+    m, n = dense.shape
+    op = HipOperator.from_desc(d, vals, flags=_capi.FLAG_ADJOINT, demote_to_f32=demote, max_rhs=nrhs)
+    tol = 3e-5 if demote else TOL
+    x = rng.standard_normal((n, nrhs)) if nrhs > 1 else rng.standard_normal(n)
+    v = rng.standard_normal((m, nrhs)) if nrhs > 1 else rng.standard_normal(m)
+    y = op.apply_host(x)
+    z = op.apply_transpose_host(v)
+    assert rel(y, dense @ x) <= tol and rel(z, dense.T @ v) <= tol
+    op.close()

@@ -136,6 +136,32 @@ def test_long_contractions_are_cut_into_several_groups(dtype):
     op.close()
 
 
+@pytest.mark.parametrize("demote", [False, True])
+def test_few_row_leaves_are_stored_row_major(demote):
+    """Row groups of <= 2 lane granules of rows and >= 128 columns (what a streamed butterfly's pass-through W blocks look
+    like: ~5 rows x thousands of columns) are packed row-major with zero-padded row ends; forward and transposed plans
+    read them as such, next to ordinary column-major leaves in the same block columns."""
+    rng = np.random.default_rng(31)
+    d, vals, dense = randgraph.few_row_operand(rng)
+    op = HipOperator.from_desc(d, vals, flags=_capi.FLAG_PLAN_ONLY | _capi.FLAG_ADJOINT, demote_to_f32=demote)
+    lib = _capi.load()
+    sv = _capi.BfhipStageView(); sv.structSize = C.sizeof(sv)
+    _capi.check(lib.bfhipPlanGetStage(op.handle, 0, C.byref(sv)))
+    items = np.frombuffer((C.c_char * (int(sv.numItems) * 16)).from_address(sv.items), dtype=_capi.ITEM_DTYPE)
+    rm = (items["mrFlags"] & plan_emulator.BF_ITEM_ROWMAJOR) != 0
+    rows = items["mrFlags"] & 0xFFFF
+    epl = 4 if demote else 2
+    assert rm.any() and (rows[rm] <= 2 * epl).all() and (rows[~rm & (items["numPieces"] > 0)] > 2 * epl).any()
+    x, v = rng.standard_normal(dense.shape[1]), rng.standard_normal(dense.shape[0])
+    tol = 2e-6 if demote else 1e-13
+    assert rel(plan_emulator.run_plan(op, x), dense @ x) < tol
+    assert rel(plan_emulator.run_plan(op, v, transpose=True), dense.T @ v) < tol
+    # no padded rows are stored for the few-row leaves: the arena holds (almost) exactly the leaf elements
+    st = op.stats()
+    assert st["arenaBytes"] <= 1.02 * st["leafBytes"]
+    op.close()
+
+
 def test_row_sharding_union_equals_full(helm2_cases):
     n, k = 2048, 128
     desc, tp, vals = helm2_cases(n, k)
