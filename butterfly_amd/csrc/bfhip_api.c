@@ -470,7 +470,7 @@ static int runPlan(BfhipOperator *op, BfPlan *plan, void const *dX, size_t nrhs,
   for (uint64_t s = 0; s < plan->numStages; ++s) {
     BfStage *st = &plan->stages[s];
     BfLaunchArgs a;
-    a.arena = op->dArena; a.items = st->dItems; a.pieces = st->dPieces; a.numItems = st->numItems;
+    a.arena = op->dArena; a.items = st->dItems; a.pieces = st->dPieces; a.numItems = st->numItems; a.firstSmall = st->firstSmall;
     a.x = dX; a.y = dY; a.temp = op->dTemp; a.zero = op->dZero; a.nrhs = (uint32_t)nrhs; a.dtype = plan->dtype; a.maxRows = st->maxRows;
     a.transposed = plan->transposed;
     if (prof && (rc = bfdevEventRecord(op->evStart[evBase + s], stream))) goto out;
@@ -733,11 +733,26 @@ static int validateStage(BfPlan const *pl, uint64_t arenaElems, BfStage const *s
     BfDevItem const *it = &items[i];
     uint32_t const mr = it->mrFlags & 0xffffu;
     uint64_t const outLen = (it->mrFlags & BF_ITEM_OUT_Y) ? outY : temp;
-    if (!mr || mr > pl->maxItemRows || mr > st->maxRows || (it->mrFlags & ~(0xffffu | BF_ITEM_OUT_Y | BF_ITEM_ROWMAJOR)) ||
+    if (!mr || mr > pl->maxItemRows || mr > st->maxRows || (it->mrFlags & ~(0xffffu | BF_ITEM_OUT_Y | BF_ITEM_ROWMAJOR | BF_ITEM_MERGED | BF_ITEM_SMALL)) ||
+        ((it->mrFlags & BF_ITEM_SMALL) != 0) != (i >= st->firstSmall) ||
         ((it->mrFlags & BF_ITEM_ROWMAJOR) && (pl->transposed || pl->dtype == BFHIP_C128 || mr > 2 * pl->epl)) ||
         (uint64_t)it->outOff + mr > outLen || (uint64_t)it->pieceBegin + it->numPieces > st->numPieces)
       return bfhipFail(BFABI_ERROR_FILE_ERROR, "corrupt operator file: item %llu out of bounds", (unsigned long long)i);
     uint32_t const mrPad = (mr + pl->epl - 1) / pl->epl * pl->epl;
+    if (it->mrFlags & (BF_ITEM_MERGED | BF_ITEM_SMALL)) {     /* the kernel reads the dense pieces as one block from the first one's offset */
+      int const sm = (it->mrFlags & BF_ITEM_SMALL) != 0;
+      uint64_t next = 0, dense = 0;
+      int badm = pl->transposed || pl->dtype == BFHIP_C128 || (it->mrFlags & BF_ITEM_ROWMAJOR) || it->numPieces > (sm ? BF_SMALL_PIECES : 64u) ||
+                 (sm && mr > 2 * pl->epl);
+      for (uint32_t k = 0; k < it->numPieces && !badm; ++k) {
+        BfDevPiece const *pc = &pieces[it->pieceBegin + k];
+        if (pc->flags & BF_PIECE_IDENTITY) continue;
+        if (dense && pc->dataOff != next) badm = 1;
+        next = pc->dataOff + (uint64_t)mrPad * pc->ncols; dense += pc->ncols;
+      }
+      if (badm || (!dense && !sm) || dense > (sm ? BF_SMALL_COLS : BF_MERGE_COLS))
+        return bfhipFail(BFABI_ERROR_FILE_ERROR, "corrupt operator file: merged item %llu is not one block", (unsigned long long)i);
+    }
     for (uint32_t k = 0; k < it->numPieces; ++k) {
       BfDevPiece const *pc = &pieces[it->pieceBegin + k];
       uint64_t const inLen = (pc->flags & BF_PIECE_IN_X) ? inX : temp;
@@ -750,7 +765,7 @@ static int validateStage(BfPlan const *pl, uint64_t arenaElems, BfStage const *s
                pc->dataOff + (uint64_t)(pc->ncols - 1) * pc->ld + (mr + pl->epl - 1) / pl->epl * pl->epl > arenaElems ||
                (uint64_t)pc->inOff + pc->ncols > inLen;
       else if (rm)
-        bad |= !pc->ncols || pc->ncols > pl->xcap || pc->ld % pl->epl || pc->ld < pc->ncols || pc->dataOff % pl->epl ||
+        bad |= !pc->ncols || pc->ld % pl->epl || pc->ld < pc->ncols || pc->dataOff % pl->epl ||   /* x is read from global memory: no xcap */
                pc->dataOff + (uint64_t)mr * pc->ld > arenaElems || (uint64_t)pc->inOff + pc->ncols > inLen;
       else if (pl->transposed)
         bad |= !pc->ld || pc->ld % pl->epl || pc->ncols > pc->ld || pc->dataOff % pl->epl ||
@@ -807,7 +822,11 @@ static int loadPlan(FILE *fp, BfhipOperator *op, BfPlan *pl, FileHeader const *f
     void *hItems = NULL, *hPieces = NULL;
     rc = readMetaArray(fp, &st->dItems, &hItems, st->numItems * sizeof(BfDevItem), &op->metaBytes);
     if (!rc) rc = readMetaArray(fp, &st->dPieces, &hPieces, st->numPieces * sizeof(BfDevPiece), &op->metaBytes);
-    if (!rc) rc = validateStage(pl, fh->arenaElems, st, hItems, hPieces);
+    if (!rc) {       /* small items are the tail of the list (validateStage checks that they are nowhere else) */
+      st->firstSmall = st->numItems;
+      while (st->firstSmall && (((BfDevItem const *)hItems)[st->firstSmall - 1].mrFlags & BF_ITEM_SMALL)) --st->firstSmall;
+      rc = validateStage(pl, fh->arenaElems, st, hItems, hPieces);
+    }
     free(hItems); free(hPieces);
     if (!rc && sh.numReduce) {
       st->reduce = calloc(sh.numReduce, sizeof(BfReduce));

@@ -356,6 +356,210 @@ __global__ __launch_bounds__(BF_WAVES_PER_WG * 64, BF_MFMA_WAVES_PER_SIMD) void 
   }
 }
 
+// One row-major piece of MR rows (see the row-major branch of bfStageKernelReal): lane owns 16-byte units u = lane,
+// lane + 64, ... of every row; UNR units are in flight at once, so (MR + 1) * UNR independent loads per lane.  All
+// addresses are a wave-uniform base plus a 32-bit lane offset (a piece is < 64 KiB per row set).
+template <int DT, int MR>
+__device__ __forceinline__ void bfRowMajorPiece(void const *rowpV, uint32_t upr, typename Traits<DT>::S const *xin, uint32_t n,
+                                                uint32_t nrhs, int lane, typename Traits<DT>::S *racc) {
+  using S = typename Traits<DT>::S;
+  constexpr int EPL = Traits<DT>::EPL;
+  struct __attribute__((aligned(16))) V { S v[EPL]; };
+  struct __attribute__((packed, aligned(sizeof(S)))) VU { S v[EPL]; };     // x: element-aligned 16 bytes
+  char const *rowp = (char const *)rowpV;
+  constexpr int UNR = MR <= 2 ? 4 : MR <= 4 ? 2 : 1;
+  uint32_t const rowBytes = upr * 16u;
+  uint32_t const full = nrhs == 1 ? n / EPL : 0;        // units whose x is one contiguous in-range 16-byte load
+  uint32_t u = (uint32_t)lane;
+  if (UNR > 1) {
+#pragma unroll 1
+    for (; u + 64u * (UNR - 1) < full; u += 64u * UNR) {
+      V a[UNR][MR];
+      VU xv[UNR];
+#pragma unroll
+      for (int k = 0; k < UNR; ++k) {
+#pragma unroll
+        for (int r = 0; r < MR; ++r) a[k][r] = bfLoadStreamV((V const *)(rowp + ((uint32_t)r * rowBytes + (u + 64u * k) * 16u)));
+      }
+#pragma unroll
+      for (int k = 0; k < UNR; ++k) xv[k] = *(VU const *)((char const *)xin + (u + 64u * k) * 16u);
+#pragma unroll
+      for (int k = 0; k < UNR; ++k) {
+#pragma unroll
+        for (int r = 0; r < MR; ++r) {
+#pragma unroll
+          for (int e = 0; e < EPL; ++e) racc[r] = fma(a[k][r].v[e], xv[k].v[e], racc[r]);
+        }
+      }
+    }
+  }
+#pragma unroll 1
+  for (; u < full; u += 64u) {
+    V a[MR];
+#pragma unroll
+    for (int r = 0; r < MR; ++r) a[r] = bfLoadStreamV((V const *)(rowp + ((uint32_t)r * rowBytes + u * 16u)));
+    VU const xv = *(VU const *)((char const *)xin + u * 16u);
+#pragma unroll
+    for (int r = 0; r < MR; ++r) {
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) racc[r] = fma(a[r].v[e], xv.v[e], racc[r]);
+    }
+  }
+  // what is left: the ragged last unit (nrhs == 1), or everything with strided x (nrhs > 1); x past column n is
+  // taken as zero so that the zero row padding never meets a NaN
+#pragma unroll 1
+  for (; u < upr; u += 64u) {
+    V a[MR];
+#pragma unroll
+    for (int r = 0; r < MR; ++r) a[r] = bfLoadStreamV((V const *)(rowp + ((uint32_t)r * rowBytes + u * 16u)));
+    S xv[EPL];
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) xv[e] = u * EPL + e < n ? xin[(uint64_t)(u * EPL + e) * nrhs] : (S)0;
+#pragma unroll
+    for (int r = 0; r < MR; ++r) {
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) racc[r] = fma(a[r].v[e], xv[e], racc[r]);
+    }
+  }
+}
+
+// Four small items per wavefront, one per group of 16 lanes (BF_ITEM_SMALL: at most 2 lane granules of rows, at most
+// BF_SMALL_PIECES pieces, dense parts one contiguous mrPad x n block with n <= BF_SMALL_COLS).  A streamed butterfly's
+// inner factors are hundreds of thousands of such items (row nodes of ~5 rows: an identity term plus a leaf of ~50
+// columns); one per wavefront they cost a launch slot and four dependent memory round trips each for ~1 KB of data.
+// Group lane gl = (column c = gl / ms, row slot rs = gl % ms) exactly like the full-width kernel with 16 lanes.
+template <int DT>
+__global__ __launch_bounds__(BF_WAVES_PER_WG * 64) __attribute__((amdgpu_waves_per_eu(4, 8))) void bfStageKernelSmall(StageParams p) {
+  using S = typename Traits<DT>::S;
+  constexpr int EPL = Traits<DT>::EPL;
+  struct __attribute__((aligned(16))) V { S v[EPL]; };
+  __shared__ __attribute__((aligned(16))) unsigned char ldsRaw[BF_WAVES_PER_WG][4 * BF_SMALL_COLS * sizeof(S)];
+  int const wave = threadIdx.x >> 6;
+  int const lane = threadIdx.x & 63;
+  uint32_t const item0 = __builtin_amdgcn_readfirstlane((blockIdx.x * BF_WAVES_PER_WG + wave) * 4u);
+  if (item0 >= p.numItems) return;
+  S *xs = (S *)ldsRaw[wave];
+  constexpr int XT = BF_SMALL_COLS / 16;           // x columns a lane gathers
+  constexpr int AS = 8;                            // A loads in flight per lane and batch
+  uint32_t const gid = (uint32_t)lane >> 4, gl = (uint32_t)lane & 15u;
+  uint32_t const idx = item0 + gid;
+  bool const valid = idx < p.numItems;
+  BfDevItem it = p.items[valid ? idx : p.numItems - 1];
+  uint32_t const mr = valid ? (it.mrFlags & 0xffffu) : 0u;
+  uint32_t const np = valid ? it.numPieces : 0u;
+  uint32_t const ms = mr > (uint32_t)EPL ? 2u : 1u;
+  uint32_t const c = ms == 2 ? gl >> 1 : gl, rs = ms == 2 ? gl & 1u : 0u, g16 = 16u / ms;
+  // piece descriptors: group lane k holds piece k
+  BfDevPiece my;
+  my.dataOff = 0; my.inOff = 0; my.ncols = 0; my.flags = 0; my.ld = 0;
+  if (gl < np) my = p.pieces[it.pieceBegin + gl];
+  uint32_t npMax = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    uint32_t const v = (uint32_t)__builtin_amdgcn_readlane((int)np, 16 * k);
+    npMax = v > npMax ? v : npMax;
+  }
+  V const *arena = (V const *)p.arena;
+  uint32_t const nrhs = p.nrhs;
+  S *out = (it.mrFlags & BF_ITEM_OUT_Y) ? (S *)p.y : (S *)p.temp;
+  S *xg = xs + gid * BF_SMALL_COLS;                // the group's x block in LDS
+  for (uint32_t q = 0; q < nrhs; ++q) {
+    S acc[EPL];
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) acc[e] = 0;
+    uint32_t src[XT];
+    uint32_t srcX = 0;
+#pragma unroll
+    for (int t = 0; t < XT; ++t) src[t] = ~0u;
+    uint32_t base = 0, dataLo = 0, dataHi = 0;
+    for (uint32_t k = 0; k < npMax; ++k) {
+      int const from = (int)(gid * 16u + k);
+      uint32_t const flags = (uint32_t)__shfl((int)my.flags, from, 64);
+      uint32_t const inOff = (uint32_t)__shfl((int)my.inOff, from, 64);
+      uint32_t const ncols = (uint32_t)__shfl((int)my.ncols, from, 64);
+      uint32_t const dLo = (uint32_t)__shfl((int)(uint32_t)my.dataOff, from, 64);
+      uint32_t const dHi = (uint32_t)__shfl((int)(uint32_t)(my.dataOff >> 32), from, 64);
+      if (k >= np) continue;
+      if (flags & BF_PIECE_IDENTITY) {
+        if (c == 0) {
+          S const *xin = ((flags & BF_PIECE_IN_X) ? (S const *)p.x : (S const *)p.temp) + (uint64_t)inOff * nrhs + q;
+#pragma unroll
+          for (int e = 0; e < EPL; ++e) {
+            uint32_t const row = rs * EPL + e;
+            if (row < mr) acc[e] += xin[(uint64_t)row * nrhs];
+          }
+        }
+        continue;
+      }
+      if (base == 0) { dataLo = dLo; dataHi = dHi; }
+#pragma unroll
+      for (int t = 0; t < XT; ++t) {
+        uint32_t const J = gl + 16u * t - base;          // wraps below base
+        if (J < ncols) { src[t] = inOff + J; srcX = (flags & BF_PIECE_IN_X) ? srcX | (1u << t) : srcX & ~(1u << t); }
+      }
+      base += ncols;
+    }
+    uint32_t const n = base;                             // per group
+    uint32_t const steps = (n + g16 - 1) / g16;          // <= 16 (ms == 2) or 8
+    V const *ap = arena + (((uint64_t)dataHi << 32) | dataLo) / EPL + gl;     // unit (column c + s g16, slot rs) = gl + 16 s
+    V a[AS];
+#pragma unroll
+    for (int k = 0; k < AS; ++k) {
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) a[k].v[e] = 0;
+      if ((uint32_t)k < steps && c + k * g16 < n) a[k] = bfLoadStreamV(ap + 16 * k);
+    }
+    S xr[XT];
+#pragma unroll
+    for (int t = 0; t < XT; ++t)
+      xr[t] = src[t] != ~0u ? (((srcX >> t) & 1u) ? (S const *)p.x : (S const *)p.temp)[(uint64_t)src[t] * nrhs + q] : (S)0;
+    waveSync();
+#pragma unroll
+    for (int t = 0; t < XT; ++t) xg[gl + 16 * t] = xr[t];          // columns >= n hold zero
+    waveSync();
+#pragma unroll
+    for (int k = 0; k < AS; ++k) {
+      uint32_t const col = c + k * g16;
+      S const xv = col < BF_SMALL_COLS ? xg[col] : (S)0;
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) acc[e] = fma(a[k].v[e], xv, acc[e]);
+    }
+    if (__builtin_amdgcn_ballot_w64(steps > (uint32_t)AS)) {        // only ms == 2 blocks wider than 64 columns
+#pragma unroll
+      for (int k = 0; k < AS; ++k) {
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) a[k].v[e] = 0;
+        if ((uint32_t)(k + AS) < steps && c + (k + AS) * g16 < n) a[k] = bfLoadStreamV(ap + 16 * (k + AS));
+      }
+#pragma unroll
+      for (int k = 0; k < AS; ++k) {
+        uint32_t const col = c + (k + AS) * g16;
+        S const xv = col < BF_SMALL_COLS ? xg[col] : (S)0;
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) acc[e] = fma(a[k].v[e], xv, acc[e]);
+      }
+    }
+    // sum over the group's columns: fixed butterfly inside the 16 lanes (deterministic)
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) {
+      S t = acc[e];
+      t += __shfl_xor(t, 8, 64);
+      t += __shfl_xor(t, 4, 64);
+      t += __shfl_xor(t, 2, 64);
+      S const u = __shfl_xor(t, 1, 64);
+      if (ms == 1) t += u;
+      acc[e] = t;
+    }
+    if (c == 0) {
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) {
+        uint32_t const row = rs * EPL + e;
+        if (row < mr) out[((uint64_t)it.outOff + row) * nrhs + q] = acc[e];
+      }
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------
 // real stage kernel (f64: 2 rows per lane, f32: 4 rows per lane)
 // ---------------------------------------------------------------------------
@@ -369,6 +573,9 @@ __global__ __launch_bounds__(BF_WAVES_PER_WG * 64) void bfStageKernelReal(StageP
   int const lane = threadIdx.x & 63;
   uint32_t item = __builtin_amdgcn_readfirstlane(blockIdx.x * BF_WAVES_PER_WG + wave);
   if (item >= p.numItems) return;
+  S *xs = (S *)ldsRaw[wave];
+  V const *arena = (V const *)p.arena;
+  uint32_t const nrhs = p.nrhs;
   BfDevItem const it = p.items[item];
   uint32_t const mr = it.mrFlags & 0xffffu;
   uint32_t const ms = (mr + EPL - 1) / EPL;        // row slots
@@ -379,47 +586,43 @@ __global__ __launch_bounds__(BF_WAVES_PER_WG * 64) void bfStageKernelReal(StageP
   uint32_t const lc = active ? (uint32_t)lane : G - 1;
   uint32_t const c = lc / ms;
   uint32_t const rs = lc - c * ms;
-  S *xs = (S *)ldsRaw[wave];
-  V const *arena = (V const *)p.arena;
-  uint32_t const nrhs = p.nrhs;
   S *out = (it.mrFlags & BF_ITEM_OUT_Y) ? (S *)p.y : (S *)p.temp;
 
   if (it.mrFlags & BF_ITEM_ROWMAJOR) {
     // Few-row wide leaves (mr <= 2 EPL rows, stored row-major, rows padded with zeros to the lane granule): a lane
     // owns 16 bytes of consecutive columns, loads them from every row of the piece and multiplies with the matching
-    // 16 bytes of x (staged in LDS like below, so any nrhs stride works); rows are summed over the wave at the end
-    // by a fixed butterfly.  No row padding is read and every lane is busy whatever mr is.
+    // 16 bytes of x, read straight from global memory (no LDS, no hand-off between lanes, so a piece may be as wide
+    // as a task); rows are summed over the wave at the end by a fixed butterfly.  No row padding is read and every
+    // lane is busy whatever mr is.  Piece descriptors come 64 at a time, one per lane.
     constexpr int RMAX = 2 * EPL;
     for (uint32_t q = 0; q < nrhs; ++q) {
       S racc[RMAX];
 #pragma unroll
       for (int r = 0; r < RMAX; ++r) racc[r] = 0;
       S ident = 0;                                   // lane r < mr: identity contributions to row r
-      for (uint32_t pi = 0; pi < it.numPieces; ++pi) {
-        BfDevPiece const pc = p.pieces[it.pieceBegin + pi];
-        S const *xin = (pc.flags & BF_PIECE_IN_X) ? (S const *)p.x : (S const *)p.temp;
-        xin += (uint64_t)pc.inOff * nrhs + q;
-        if (pc.flags & BF_PIECE_IDENTITY) {
-          if ((uint32_t)lane < mr) ident += xin[(uint64_t)lane * nrhs];
-          continue;
-        }
-        uint32_t const n = pc.ncols, ldr = pc.ld;
-        waveSync();   // previous piece's reads are done before overwriting
-        for (uint32_t j = lane; j < ldr; j += 64) xs[j] = j < n ? xin[(uint64_t)j * nrhs] : (S)0;
-        waveSync();
-        V const *rowp = arena + pc.dataOff / EPL;
-        uint32_t const unitsPerRow = ldr / EPL;
-        for (uint32_t u = lane; u < unitsPerRow; u += 64) {
-          V const xv = *(V const *)(xs + (uint64_t)u * EPL);
-          V a[RMAX];
-#pragma unroll
-          for (int r = 0; r < RMAX; ++r) if ((uint32_t)r < mr) a[r] = bfLoadStreamV(rowp + (uint64_t)r * unitsPerRow + u);   // mr is wave-uniform
-#pragma unroll
-          for (int r = 0; r < RMAX; ++r)
-            if ((uint32_t)r < mr) {
-#pragma unroll
-              for (int e = 0; e < EPL; ++e) racc[r] = fma(a[r].v[e], xv.v[e], racc[r]);
-            }
+      for (uint32_t p0 = 0; p0 < it.numPieces; p0 += 64) {
+        uint32_t const np = it.numPieces - p0 < 64u ? it.numPieces - p0 : 64u;
+        BfPieceWin const win = bfPieceWinLoad(p.pieces + it.pieceBegin + p0, np, lane);
+        for (uint32_t pi = 0; pi < np; ++pi) {
+          BfDevPiece const pc = bfPieceWinGet(win, pi);
+          S const *xin = (pc.flags & BF_PIECE_IN_X) ? (S const *)p.x : (S const *)p.temp;
+          xin += (uint64_t)pc.inOff * nrhs + q;
+          if (pc.flags & BF_PIECE_IDENTITY) {
+            if ((uint32_t)lane < mr) ident += xin[(uint64_t)lane * nrhs];
+            continue;
+          }
+          V const *rowp = arena + pc.dataOff / EPL;
+          uint32_t const upr = pc.ld / EPL;
+          switch (mr) {                                // wave-uniform
+            case 1: bfRowMajorPiece<DT, 1>(rowp, upr, xin, pc.ncols, nrhs, lane, racc); break;
+            case 2: bfRowMajorPiece<DT, 2>(rowp, upr, xin, pc.ncols, nrhs, lane, racc); break;
+            case 3: bfRowMajorPiece<DT, 3>(rowp, upr, xin, pc.ncols, nrhs, lane, racc); break;
+            case 4: bfRowMajorPiece<DT, 4>(rowp, upr, xin, pc.ncols, nrhs, lane, racc); break;
+            case 5: bfRowMajorPiece<DT, (RMAX > 4 ? 5 : 4)>(rowp, upr, xin, pc.ncols, nrhs, lane, racc); break;
+            case 6: bfRowMajorPiece<DT, (RMAX > 4 ? 6 : 4)>(rowp, upr, xin, pc.ncols, nrhs, lane, racc); break;
+            case 7: bfRowMajorPiece<DT, (RMAX > 4 ? 7 : 4)>(rowp, upr, xin, pc.ncols, nrhs, lane, racc); break;
+            default: bfRowMajorPiece<DT, RMAX>(rowp, upr, xin, pc.ncols, nrhs, lane, racc); break;
+          }
         }
       }
       S mine = ident;
@@ -435,30 +638,102 @@ __global__ __launch_bounds__(BF_WAVES_PER_WG * 64) void bfStageKernelReal(StageP
     return;
   }
 
+  bool const merged = (it.mrFlags & BF_ITEM_MERGED) != 0;
   for (uint32_t q = 0; q < nrhs; ++q) {
     S acc[EPL];
 #pragma unroll
     for (int e = 0; e < EPL; ++e) acc[e] = 0;
-    for (uint32_t pi = 0; pi < it.numPieces; ++pi) {
-      BfDevPiece const pc = p.pieces[it.pieceBegin + pi];
-      S const *xin = (pc.flags & BF_PIECE_IN_X) ? (S const *)p.x : (S const *)p.temp;
-      xin += (uint64_t)pc.inOff * nrhs + q;
-      uint32_t const n = pc.ncols;
-      if (pc.flags & BF_PIECE_IDENTITY) {
-        if (c == 0 && active) {
+    uint32_t const npass = merged ? 1u : it.numPieces;
+    for (uint32_t pi = 0; pi < npass; ++pi) {
+      uint32_t n;
+      V const *ap;
+      if (merged) {
+        // <= 64 pieces whose dense parts are one contiguous mrPad x n block, n <= BF_MERGE_COLS (the planner packs an
+        // item's pieces back to back): lane l gathers x for columns l, l + 64, ... of the block from whichever piece
+        // holds them -- all pieces' loads in flight together -- and the block is contracted in one go.  A narrow
+        // item (what a streamed butterfly's inner factors are made of) costs three dependent memory round trips
+        // instead of three per piece.
+        constexpr int XS = BF_MERGE_COLS / 64;
+        uint32_t src[XS];                 // input element index of the lane's column t, ~0 = none
+        uint32_t srcX = 0;                // bit t: that index is into x (else the vector arena)
 #pragma unroll
-          for (int e = 0; e < EPL; ++e) {
-            uint32_t row = rs * EPL + e;
-            if (row < mr) acc[e] += xin[(uint64_t)row * nrhs];
+        for (int t = 0; t < XS; ++t) src[t] = ~0u;
+        uint32_t base = 0;
+        uint64_t data0 = 0;
+        BfPieceWin const win = bfPieceWinLoad(p.pieces + it.pieceBegin, it.numPieces, lane);
+        for (uint32_t k = 0; k < it.numPieces; ++k) {
+          BfDevPiece const pc = bfPieceWinGet(win, k);
+          if (pc.flags & BF_PIECE_IDENTITY) {
+            S const *xin = (pc.flags & BF_PIECE_IN_X) ? (S const *)p.x : (S const *)p.temp;
+            xin += (uint64_t)pc.inOff * nrhs + q;
+            if (c == 0 && active) {
+#pragma unroll
+              for (int e = 0; e < EPL; ++e) {
+                uint32_t row = rs * EPL + e;
+                if (row < mr) acc[e] += xin[(uint64_t)row * nrhs];
+              }
+            }
+            continue;
+          }
+          if (base == 0) data0 = pc.dataOff;
+#pragma unroll
+          for (int t = 0; t < XS; ++t) {
+            uint32_t const J = (uint32_t)lane + 64u * t - base;        // wraps below base
+            if (J < pc.ncols) { src[t] = pc.inOff + J; srcX = (pc.flags & BF_PIECE_IN_X) ? srcX | (1u << t) : srcX & ~(1u << t); }
+          }
+          base += pc.ncols;
+        }
+        n = base;
+        ap = arena + data0 / EPL + lc;
+        // a block of at most 2 wave loads is fetched before x is handed over, so both trips overlap
+        bool const tiny = n <= 2 * g;
+        V a2[2];
+        if (tiny) {
+#pragma unroll
+          for (int k = 0; k < 2; ++k) {
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) a2[k].v[e] = 0;
+            if (active && c + k * g < n) a2[k] = bfLoadStreamV(ap + (uint64_t)k * G);
           }
         }
-        continue;
+        S xg[XS];
+#pragma unroll
+        for (int t = 0; t < XS; ++t)
+          xg[t] = src[t] != ~0u ? (((srcX >> t) & 1u) ? (S const *)p.x : (S const *)p.temp)[(uint64_t)src[t] * nrhs + q] : (S)0;
+        waveSync();
+#pragma unroll
+        for (int t = 0; t < XS; ++t) if ((uint32_t)lane + 64u * t < n) xs[lane + 64 * t] = xg[t];
+        waveSync();
+        if (tiny) {
+#pragma unroll
+          for (int k = 0; k < 2; ++k) {
+            S xv = (active && c + k * g < n) ? xs[c + k * g] : (S)0;
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) acc[e] = fma(a2[k].v[e], xv, acc[e]);
+          }
+          continue;
+        }
+      } else {
+        BfDevPiece const pc = p.pieces[it.pieceBegin + pi];
+        S const *xin = (pc.flags & BF_PIECE_IN_X) ? (S const *)p.x : (S const *)p.temp;
+        xin += (uint64_t)pc.inOff * nrhs + q;
+        n = pc.ncols;
+        if (pc.flags & BF_PIECE_IDENTITY) {
+          if (c == 0 && active) {
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) {
+              uint32_t row = rs * EPL + e;
+              if (row < mr) acc[e] += xin[(uint64_t)row * nrhs];
+            }
+          }
+          continue;
+        }
+        waveSync();
+        for (uint32_t j = lane; j < n; j += 64) xs[j] = xin[(uint64_t)j * nrhs];
+        waveSync();
+        // dataOff is in elements; a lane load is EPL elements
+        ap = arena + pc.dataOff / EPL + lc;
       }
-      waveSync();
-      for (uint32_t j = lane; j < n; j += 64) xs[j] = xin[(uint64_t)j * nrhs];
-      waveSync();
-      // dataOff is in elements; a lane load is EPL elements
-      V const *ap = arena + pc.dataOff / EPL + lc;
       uint32_t const nfull = n / g;
       uint32_t j = c;
       uint32_t s = 0;
@@ -1029,8 +1304,25 @@ int bfdevLaunchStage(BfLaunchArgs const *a, void *stream) {
   }
   if (a->dtype == BFHIP_C128 && a->nrhs >= BF_MFMA_MIN_RHS) hipLaunchKernelGGL(bfStageKernelC128Mfma, dim3(grid), dim3(BF_WAVES_PER_WG * 64), 0, s, p);
   else if (a->dtype == BFHIP_C128) hipLaunchKernelGGL(bfStageKernelC128, dim3(grid), dim3(BF_WAVES_PER_WG * 64), 0, s, p);
-  else if (a->dtype == BFHIP_F64) hipLaunchKernelGGL(bfStageKernelReal<BFHIP_F64>, dim3(grid), dim3(BF_WAVES_PER_WG * 64), 0, s, p);
-  else if (a->dtype == BFHIP_F32) hipLaunchKernelGGL(bfStageKernelReal<BFHIP_F32>, dim3(grid), dim3(BF_WAVES_PER_WG * 64), 0, s, p);
+  else if (a->dtype == BFHIP_F64 || a->dtype == BFHIP_F32) {
+    // items [firstSmall, numItems) are small (BF_ITEM_SMALL): their own launch, four to a wavefront; the two launches
+    // write disjoint rows
+    uint64_t const firstSmall = a->firstSmall < a->numItems ? a->firstSmall : a->numItems;
+    uint64_t const numSmall = a->numItems - firstSmall;
+    p.numItems = (uint32_t)firstSmall;
+    grid = (uint32_t)((firstSmall + BF_WAVES_PER_WG - 1) / BF_WAVES_PER_WG);
+    if (grid) {
+      if (a->dtype == BFHIP_F64) hipLaunchKernelGGL(bfStageKernelReal<BFHIP_F64>, dim3(grid), dim3(BF_WAVES_PER_WG * 64), 0, s, p);
+      else hipLaunchKernelGGL(bfStageKernelReal<BFHIP_F32>, dim3(grid), dim3(BF_WAVES_PER_WG * 64), 0, s, p);
+    }
+    if (numSmall) {
+      p.items = (BfDevItem const *)a->items + firstSmall;
+      p.numItems = (uint32_t)numSmall;
+      grid = (uint32_t)((numSmall + 4 * BF_WAVES_PER_WG - 1) / (4 * BF_WAVES_PER_WG));
+      if (a->dtype == BFHIP_F64) hipLaunchKernelGGL(bfStageKernelSmall<BFHIP_F64>, dim3(grid), dim3(BF_WAVES_PER_WG * 64), 0, s, p);
+      else hipLaunchKernelGGL(bfStageKernelSmall<BFHIP_F32>, dim3(grid), dim3(BF_WAVES_PER_WG * 64), 0, s, p);
+    }
+  }
   else return bfhipFail(BFABI_ERROR_TYPE_ERROR, "unknown dtype %u", a->dtype);
   return hipFail(hipGetLastError(), "stage launch");
 }

@@ -75,6 +75,12 @@ typedef struct BfDevPiece {
 } BfDevPiece;
 
 #define BF_ITEM_OUT_Y (1u << 16)
+#define BF_ITEM_SMALL (1u << 19)      /* real, forward: <= 2 lane granules of rows, <= 16 pieces, <= BF_SMALL_COLS dense columns (one block);
+                                        * small items are the END of a stage's item list and run four to a wavefront */
+#define BF_SMALL_COLS 128u
+#define BF_SMALL_PIECES 16u
+#define BF_ITEM_MERGED (1u << 18)     /* real, column-major: <= 64 pieces whose dense parts are ONE contiguous mrPad x n block, n <= BF_MERGE_COLS */
+#define BF_MERGE_COLS 256u
 #define BF_ITEM_ROWMAJOR (1u << 17)   /* all dense pieces of the item are stored row-major (few-row leaves of real operands) */
 #define BF_PIECE_IN_X 1u
 #define BF_PIECE_IDENTITY 2u
@@ -107,6 +113,7 @@ typedef struct BfStage {
   BfDevPiece *pieces;
   BfPieceSrc *pieceSrc;
   uint32_t maxRows;          /* largest item row count */
+  uint64_t firstSmall;       /* items [firstSmall, numItems) carry BF_ITEM_SMALL */
   uint64_t leafElems;        /* algorithmic: sum m*n over this stage's leaves */
   uint64_t vecIn, vecOut;    /* algorithmic vector elements read / written */
   uint64_t numReduce;
@@ -199,6 +206,7 @@ typedef struct BfLaunchArgs {
   void const *items;
   void const *pieces;
   uint64_t numItems;
+  uint64_t firstSmall;   /* == numItems when the stage has no small items */
   void const *x;
   void *y;
   void *temp;

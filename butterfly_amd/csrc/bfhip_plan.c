@@ -256,10 +256,12 @@ typedef struct ItemTmp {
   uint64_t cost;
   uint64_t group;
   uint32_t rowBegin, rows;       /* chunk inside the group */
+  uint32_t small, pad;           /* runs four to a wavefront: sorted behind everything else */
 } ItemTmp;
 
 static int cmpItemCost(void const *pa, void const *pb) {
   ItemTmp const *a = pa, *b = pb;
+  if (a->small != b->small) return a->small < b->small ? -1 : 1;
   if (a->cost != b->cost) return a->cost > b->cost ? -1 : 1;      /* big first */
   if (a->group != b->group) return a->group < b->group ? -1 : 1;
   return a->rowBegin < b->rowBegin ? -1 : (a->rowBegin > b->rowBegin);
@@ -581,6 +583,9 @@ int bfPlanBuild(BfIr const *ir, BfPlanOptions const *po, BfPlan *plan) {
         uint64_t rows = m - r0 < chunk ? m - r0 : chunk;
         tmp[ni].group = g; tmp[ni].rowBegin = (uint32_t)r0; tmp[ni].rows = (uint32_t)rows;
         tmp[ni].cost = rows * colsSum;
+        /* colsSum < 128 also means "not row-major" */
+        tmp[ni].small = !T && plan->dtype != BFHIP_C128 && rows <= 2 * plan->epl && colsSum < BF_SMALL_COLS && piecesPerChunk <= BF_SMALL_PIECES;
+        tmp[ni].pad = 0;
         ++ni;
         numPieces += piecesPerChunk;
       }
@@ -594,9 +599,12 @@ int bfPlanBuild(BfIr const *ir, BfPlanOptions const *po, BfPlan *plan) {
     st->pieceSrc = malloc((numPieces ? numPieces : 1) * sizeof(BfPieceSrc));
     if (!st->items || !st->pieces || !st->pieceSrc) { free(tmp); rc = bfhipFail(BFABI_ERROR_MEMORY_ERROR, "host OOM"); goto stage_fail; }
     uint64_t np = 0;
+    uint64_t numBig = 0;
+    while (numBig < numItems && !tmp[numBig].small) ++numBig;
+    st->firstSmall = numBig + numZeroItems;        /* order: ordinary items (big first), zero fills, small items */
     for (uint64_t i = 0; i < numItems; ++i) {
       Group const *g = &groups[tmp[i].group];
-      BfDevItem *it = &st->items[i];
+      BfDevItem *it = &st->items[i < numBig ? i : i + numZeroItems];
       uint32_t mr = tmp[i].rows, r0 = tmp[i].rowBegin;
       uint32_t mrPad = (uint32_t)roundUp(mr, plan->epl);
       it->pieceBegin = (uint32_t)np;
@@ -613,6 +621,7 @@ int bfPlanBuild(BfIr const *ir, BfPlanOptions const *po, BfPlan *plan) {
       else outOff = b.bufs[g->outBuf].arenaOff + g->outOff + r0;
       if (outOff >= 0xffffffffu) { free(tmp); rc = bfhipFail(BFABI_ERROR_RUNTIME_ERROR, "vector arena exceeds 32-bit offsets"); goto stage_fail; }
       it->outOff = (uint32_t)outOff;
+      if (tmp[i].small) flags |= BF_ITEM_SMALL;
       it->mrFlags = mr | flags;
       if (mr > st->maxRows) st->maxRows = mr;
       for (uint64_t t = g->taskBegin; t < g->taskEnd; ++t) {
@@ -629,13 +638,17 @@ int bfPlanBuild(BfIr const *ir, BfPlanOptions const *po, BfPlan *plan) {
         }
         if (T) {
           /* every forward piece of this leaf whose column range holds this chunk of A's columns */
-          uint32_t colPiece0 = r0 / plan->xcap * plan->xcap;
-          uint64_t k = findFwd(po->fwdPieces, po->numFwdPieces, tk->leaf, colPiece0);
           uint64_t found = 0;
           /* this task contracts rows [sub0, sub0 + cols) of A; inBase already points at row sub0 of the input */
           uint64_t const ta = tk->sub0, tb = tk->sub0 + tk->cols;
+          /* column-major forward pieces start at multiples of xcap, row-major ones at multiples of BF_TASK_SPAN
+           * (row chunks of one leaf may be of either kind): look both up */
+          for (int pass = 0; pass < 2; ++pass) {
+          uint32_t const colPiece0 = pass ? r0 / BF_TASK_SPAN * BF_TASK_SPAN : r0 / plan->xcap * plan->xcap;
+          uint64_t k = findFwd(po->fwdPieces, po->numFwdPieces, tk->leaf, colPiece0);
           for (; k < po->numFwdPieces && po->fwdPieces[k].node == tk->leaf && po->fwdPieces[k].col0 == colPiece0; ++k) {
             BfFwdPiece const *fp = &po->fwdPieces[k];
+            if ((int)fp->rowMajor != pass || r0 + mr > fp->col0 + fp->ncols) continue;
             uint64_t const lo = fp->row0 > ta ? fp->row0 : ta, hi = (uint64_t)fp->row0 + fp->mr < tb ? (uint64_t)fp->row0 + fp->mr : tb;
             if (lo >= hi) continue;                          /* forward piece outside this task's rows */
             if (np >= numPieces) { free(tmp); rc = bfhipFail(BFABI_ERROR_RUNTIME_ERROR, "internal: transposed piece count"); goto stage_fail; }
@@ -658,11 +671,15 @@ int bfPlanBuild(BfIr const *ir, BfPlanOptions const *po, BfPlan *plan) {
             st->pieceSrc[np].node = tk->leaf; st->pieceSrc[np].row0 = (uint32_t)lo; st->pieceSrc[np].col0 = r0;
             ++np; ++found;
           }
+          }
           if (!found) { free(tmp); rc = bfhipFail(BFABI_ERROR_RUNTIME_ERROR, "internal: leaf missing from the forward plan"); goto stage_fail; }
           continue;
         }
-        for (uint64_t c0 = 0; c0 < tk->cols; c0 += plan->xcap) {
-          uint64_t nc = tk->cols - c0 < plan->xcap ? tk->cols - c0 : plan->xcap;
+        /* a column-major piece's x segment is staged in LDS (xcap columns); a row-major piece reads x from global
+         * memory and spans the whole task (<= BF_TASK_SPAN columns, starting at a multiple of it) */
+        uint64_t const pieceCols = rowMajor ? BF_TASK_SPAN : plan->xcap;
+        for (uint64_t c0 = 0; c0 < tk->cols; c0 += pieceCols) {
+          uint64_t nc = tk->cols - c0 < pieceCols ? tk->cols - c0 : pieceCols;
           BfDevPiece *pc = &st->pieces[np];
           if (inBase + c0 >= 0xffffffffu) { free(tmp); rc = bfhipFail(BFABI_ERROR_RUNTIME_ERROR, "vector arena exceeds 32-bit offsets"); goto stage_fail; }
           pc->dataOff = arenaTop; pc->inOff = (uint32_t)(inBase + c0); pc->ncols = (uint32_t)nc; pc->flags = inFlag; pc->ld = 0;
@@ -677,9 +694,17 @@ int bfPlanBuild(BfIr const *ir, BfPlanOptions const *po, BfPlan *plan) {
         }
       }
       it->numPieces = (uint32_t)(np - it->pieceBegin);
+      /* the pieces of an item are packed back to back: when they are few and narrow the kernel takes them as one
+       * block (one LDS hand-off and one dependent load chain per item instead of one per piece) */
+      if (!T && !rowMajor && plan->dtype != BFHIP_C128 && it->numPieces <= 64) {
+        uint64_t dense = 0;
+        for (uint32_t k = 0; k < it->numPieces; ++k)
+          if (!(st->pieces[it->pieceBegin + k].flags & BF_PIECE_IDENTITY)) dense += st->pieces[it->pieceBegin + k].ncols;
+        if (dense && dense <= BF_MERGE_COLS) it->mrFlags |= BF_ITEM_MERGED;
+      }
     }
     /* zero-fill items */
-    uint64_t ii = numItems;
+    uint64_t ii = numBig;
     for (uint64_t z = 0; z < numGaps; ++z) {
       for (uint64_t r0 = 0; r0 < gaps[z].len; r0 += plan->maxItemRows) {
         uint64_t rows = gaps[z].len - r0 < plan->maxItemRows ? gaps[z].len - r0 : plan->maxItemRows;

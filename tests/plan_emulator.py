@@ -19,6 +19,8 @@ BF_PIECE_IN_X = 1
 BF_PIECE_IDENTITY = 2
 BF_PIECE_ROWMAJOR = 4
 BF_ITEM_ROWMAJOR = 1 << 17
+BF_ITEM_MERGED = 1 << 18
+BF_ITEM_SMALL = 1 << 19
 
 
 def _view(ptr, count, dtype):
@@ -56,10 +58,25 @@ def run_plan(op, x, transpose=False):
         _capi.check(lib.bfhipPlanGetStage(op.handle, s, C.byref(sv)))
         items = _view(sv.items, int(sv.numItems), _capi.ITEM_DTYPE)
         pieces = _view(sv.pieces, int(sv.numPieces), _capi.PIECE_DTYPE)
+        small = (items["mrFlags"] & BF_ITEM_SMALL) != 0
+        if small.any():      # small items are the tail of the list (they get their own launch, four to a wavefront)
+            first = int(np.argmax(small))
+            assert small[first:].all() and not transpose and info.dtype != 0
+            assert ((items["mrFlags"][first:] & 0xFFFF) <= 2 * epl).all() and (items["numPieces"][first:] <= 16).all()
         for it in items:
             mr = int(it["mrFlags"]) & 0xFFFF
             mr_pad = mr if transpose else (mr + epl - 1) // epl * epl
             acc = np.zeros((mr, nrhs), dtype=dt)
+            if int(it["mrFlags"]) & (BF_ITEM_MERGED | BF_ITEM_SMALL) and (int(it["mrFlags"]) & BF_ITEM_MERGED or any(not int(pc["flags"]) & BF_PIECE_IDENTITY for pc in pieces[int(it["pieceBegin"]):int(it["pieceBegin"]) + int(it["numPieces"])])):
+                # the kernel reads the dense pieces as ONE mr_pad x n block starting at the first one's offset
+                mine = pieces[int(it["pieceBegin"]):int(it["pieceBegin"]) + int(it["numPieces"])]
+                dense = [pc for pc in mine if not int(pc["flags"]) & BF_PIECE_IDENTITY]
+                assert not transpose and info.dtype != 0 and len(mine) <= 64 and dense
+                assert sum(int(pc["ncols"]) for pc in dense) <= (128 if int(it["mrFlags"]) & BF_ITEM_SMALL else 256)
+                nxt = int(dense[0]["dataOff"])
+                for pc in dense:
+                    assert int(pc["dataOff"]) == nxt and not int(pc["flags"]) & BF_PIECE_ROWMAJOR
+                    nxt += mr_pad * int(pc["ncols"])
             for pc in pieces[int(it["pieceBegin"]):int(it["pieceBegin"]) + int(it["numPieces"])]:
                 src = x if (int(pc["flags"]) & BF_PIECE_IN_X) else temp
                 io, n = int(pc["inOff"]), int(pc["ncols"])
