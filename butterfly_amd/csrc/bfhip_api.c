@@ -336,17 +336,7 @@ int bfhipCompileIrFill(BfIr *ir, BfhipOptions const *opts, BfFillFn fill, void *
     BfPlanOptions pt = po;
     pt.fwdPieces = fwd;
     pt.numFwdPieces = nf;
-    /* The transposed kernel tiles a piece as (R row lanes x 64 / R columns) per load: R = 16 (16-column items) is
-     * exact for pieces whose height is a multiple of 16 lane units (fac_helm2: 16 - 64 rows of complex128); pieces
-     * of 5 - 15 units (fac_streamer: 20 - 60 rows of fp32 / fp64) leave a third of 16 row lanes idle, and R = 4
-     * (64-column items) wastes only the last 4-unit step.  Pick by the lane slots each tiling would spend. */
-    uint64_t slots16 = 0, slots4 = 0;
-    for (uint64_t k = 0; k < nf; ++k) {
-      uint64_t const u = (fwd[k].mr + op->plan.epl - 1) / op->plan.epl, w = fwd[k].ncols;
-      slots16 += (u + 15) / 16 * 16 * w;
-      slots4 += (u + 3) / 4 * 4 * w;
-    }
-    pt.tCols = (10 * slots4 < 8 * slots16) ? 64 : 16;
+    pt.tCols = 0;      /* item width (16 or 64 columns of A) chosen stage by stage */
     rc = bfPlanBuild(ir, &pt, &op->tplan);
     free(fwd);
     if (rc) goto done;
@@ -470,7 +460,7 @@ static int runPlan(BfhipOperator *op, BfPlan *plan, void const *dX, size_t nrhs,
   for (uint64_t s = 0; s < plan->numStages; ++s) {
     BfStage *st = &plan->stages[s];
     BfLaunchArgs a;
-    a.arena = op->dArena; a.items = st->dItems; a.pieces = st->dPieces; a.numItems = st->numItems; a.firstSmall = st->firstSmall;
+    a.arena = op->dArena; a.items = st->dItems; a.pieces = st->dPieces; a.numItems = st->numItems; a.firstSmall = st->firstSmall; a.numCoop = st->numCoop;
     a.x = dX; a.y = dY; a.temp = op->dTemp; a.zero = op->dZero; a.nrhs = (uint32_t)nrhs; a.dtype = plan->dtype; a.maxRows = st->maxRows;
     a.transposed = plan->transposed;
     if (prof && (rc = bfdevEventRecord(op->evStart[evBase + s], stream))) goto out;
@@ -826,6 +816,7 @@ static int loadPlan(FILE *fp, BfhipOperator *op, BfPlan *pl, FileHeader const *f
       st->firstSmall = st->numItems;
       while (st->firstSmall && (((BfDevItem const *)hItems)[st->firstSmall - 1].mrFlags & BF_ITEM_SMALL)) --st->firstSmall;
       rc = validateStage(pl, fh->arenaElems, st, hItems, hPieces);
+      if (!rc && pl->transposed) st->numCoop = bfPlanCountCoop(hItems, hPieces, st->numItems, pl->elemSize);
     }
     free(hItems); free(hPieces);
     if (!rc && sh.numReduce) {

@@ -60,6 +60,8 @@ struct StageParams {
   BfDevPiece const *pieces;
   uint32_t numItems;
   uint32_t nrhs;
+  uint32_t coopItems;    // transposed: items [0, coopItems) get a workgroup each, its 4 wavefronts share the pieces
+  uint32_t pad;
   void const *x;
   void *y;
   void *temp;
@@ -782,6 +784,12 @@ __global__ __launch_bounds__(BF_WAVES_PER_WG * 64) void bfStageKernelReal(StageP
 // with a fixed xor-butterfly inside the 16-lane row (deterministic).
 // ---------------------------------------------------------------------------
 #define BF_T_COLS 16
+// With 4 row lanes a load instruction takes 64 bytes of each column, half a 128-byte line; the other half is asked
+// for by the next block step.  Streamed (non-temporal) lines are not kept for it, so the wide kernel loads with the
+// default policy (measured on the streamed operand: every transposed stage 10 - 35 % shorter).
+#ifndef BF_T_WIDE_NT
+#define BF_T_WIDE_NT 0
+#endif
 
 // R = row lanes per column, C = 64 / R columns per load instruction, NQ loads in flight per block: an
 // item is up to NQ * C columns of A.
@@ -790,7 +798,7 @@ __global__ __launch_bounds__(BF_WAVES_PER_WG * 64) void bfStageKernelReal(StageP
 //     16-byte units): with 16 row lanes a 10-unit piece keeps 10 of 16 row lanes busy and a 36-column
 //     remainder 9 of 16 quads; with 4 row lanes a block covers 4 units x 16 columns, the row waste drops
 //     to the last 4-unit step and items are 4x larger.
-template <int DT, int R, int NQ>
+template <int DT, int R, int NQ, bool COOP>
 __global__ __launch_bounds__(BF_WAVES_PER_WG * 64) void bfStageKernelT(StageParams p) {
   constexpr int C = 64 / R;                          // columns per load instruction
   using S = typename Traits<DT>::S;
@@ -800,8 +808,14 @@ __global__ __launch_bounds__(BF_WAVES_PER_WG * 64) void bfStageKernelT(StagePara
   struct __attribute__((aligned(16))) U { S v[UNIT]; };
   int const wave = threadIdx.x >> 6;
   int const lane = threadIdx.x & 63;
-  uint32_t item = __builtin_amdgcn_readfirstlane(blockIdx.x * BF_WAVES_PER_WG + wave);
+  // the first coopItems items (the big ones: the list is sorted) get a workgroup each: wavefront w takes pieces
+  // w, w + 4, ... and the four partial results are added in LDS in a fixed order; the rest run one per wavefront
+  // (COOP = false: the stage has no such items and the kernel is the plain one-item-per-wavefront one)
+  __shared__ S coopBuf[COOP ? BF_WAVES_PER_WG : 1][COOP ? NQ * C : 1][NC];
+  bool const coop = COOP && blockIdx.x < p.coopItems;
+  uint32_t item = __builtin_amdgcn_readfirstlane(coop ? blockIdx.x : p.coopItems + (blockIdx.x - p.coopItems) * BF_WAVES_PER_WG + wave);
   if (item >= p.numItems) return;
+  uint32_t const wsel = coop ? (uint32_t)wave : 0u, wmask = coop ? BF_WAVES_PER_WG - 1u : 0u;
   BfDevItem const it = p.items[item];
   uint32_t const mr = it.mrFlags & 0xffffu;          // columns of A in this item (<= NQ * C)
   uint32_t const c4 = lane / R, r = lane % R;
@@ -832,6 +846,7 @@ __global__ __launch_bounds__(BF_WAVES_PER_WG * 64) void bfStageKernelT(StagePara
       uint32_t const wn = it.numPieces - wbase < 64 ? it.numPieces - wbase : 64;
       BfPieceWin const win = bfPieceWinLoad(p.pieces + it.pieceBegin + wbase, wn, lane);
       for (uint32_t pi = 0; pi < wn; ++pi) {
+        if (COOP && ((wbase + pi) & wmask) != wsel) continue;
         BfDevPiece const pc = bfPieceWinGet(win, pi);
         S const *xin = (pc.flags & BF_PIECE_IN_X) ? (S const *)p.x : (S const *)p.temp;
         xin += ((uint64_t)pc.inOff * nrhs + q) * NC;
@@ -861,7 +876,7 @@ __global__ __launch_bounds__(BF_WAVES_PER_WG * 64) void bfStageKernelT(StagePara
 #pragma unroll
             for (int i = 0; i < ITERS; ++i) {
               uint32_t const srow = rlRm + (uint32_t)i * RL_RM, sc = srow < n ? srow : n - 1;
-              a[i] = bfLoadStreamV(src + (uint64_t)sc * rowUnits);
+              a[i] = BF_T_WIDE_NT ? bfLoadStreamV(src + (uint64_t)sc * rowUnits) : src[(uint64_t)sc * rowUnits];
               S const xr = xin[(uint64_t)sc * nrhs];
               xv[i] = srow < n ? xr : (S)0;
             }
@@ -882,7 +897,7 @@ __global__ __launch_bounds__(BF_WAVES_PER_WG * 64) void bfStageKernelT(StagePara
           uint32_t const ru = rb + r < units ? rb + r : units - 1;
           U a[NQ];
 #pragma unroll
-          for (int cq = 0; cq < NQ; ++cq) if ((uint32_t)cq < nq) a[cq] = bfLoadStreamV(src + jcol[cq] * stride + ru);   // nq: wave-uniform
+          for (int cq = 0; cq < NQ; ++cq) if ((uint32_t)cq < nq) a[cq] = (R >= 8 || BF_T_WIDE_NT) ? bfLoadStreamV(src + jcol[cq] * stride + ru) : src[jcol[cq] * stride + ru];   // nq: wave-uniform
           S xv[UNIT];
 #pragma unroll
           for (int e = 0; e < EPL; ++e) {
@@ -934,6 +949,28 @@ __global__ __launch_bounds__(BF_WAVES_PER_WG * 64) void bfStageKernelT(StagePara
           }
         }
       }
+    }
+    if (COOP && coop) {
+      if (r == 0) {
+#pragma unroll
+        for (int cq = 0; cq < NQ; ++cq)
+#pragma unroll
+          for (int k = 0; k < NC; ++k) coopBuf[wave][c4 + C * cq][k] = acc[cq][k];
+      }
+      __syncthreads();
+      if (wave == 0 && r == 0) {
+#pragma unroll
+        for (int cq = 0; cq < NQ; ++cq)
+#pragma unroll
+          for (int k = 0; k < NC; ++k) {
+            S t = coopBuf[0][c4 + C * cq][k];
+#pragma unroll
+            for (int w = 1; w < BF_WAVES_PER_WG; ++w) t += coopBuf[w][c4 + C * cq][k];
+            acc[cq][k] = t;
+          }
+      }
+      __syncthreads();
+      if (wave != 0) continue;
     }
     if (r == 0) {
 #pragma unroll
@@ -1285,6 +1322,8 @@ int bfdevLaunchStage(BfLaunchArgs const *a, void *stream) {
   p.pieces = (BfDevPiece const *)a->pieces;
   p.numItems = (uint32_t)a->numItems;
   p.nrhs = a->nrhs;
+  p.coopItems = 0;
+  p.pad = 0;
   p.x = a->x;
   p.y = a->y;
   p.temp = a->temp;
@@ -1293,8 +1332,15 @@ int bfdevLaunchStage(BfLaunchArgs const *a, void *stream) {
   hipStream_t s = (hipStream_t)stream;
   if (a->transposed) {
     bool const wide = a->maxRows > 16;          // items of up to 64 columns of A (plans of short-leaf operands)
-#define BF_LAUNCH_T(DT) do { if (wide) hipLaunchKernelGGL((bfStageKernelT<DT, 4, 4>), dim3(grid), dim3(BF_WAVES_PER_WG * 64), 0, s, p); \
-                             else hipLaunchKernelGGL((bfStageKernelT<DT, 16, 4>), dim3(grid), dim3(BF_WAVES_PER_WG * 64), 0, s, p); } while (0)
+    // big items of many pieces: a workgroup each -- except the complex 16-column kernel, which needs 98 VGPRs with the
+    // shared-item code (4 wavefronts per SIMD instead of 5) and loses 5 % on fac_helm2's adjoint
+    uint64_t const nc = (a->dtype == BFHIP_C128 && !wide) ? 0 : a->numCoop < a->numItems ? a->numCoop : a->numItems;
+    p.coopItems = (uint32_t)nc;
+    grid = (uint32_t)(nc + (a->numItems - nc + BF_WAVES_PER_WG - 1) / BF_WAVES_PER_WG);
+#define BF_LAUNCH_T(DT) do { if (wide && nc) hipLaunchKernelGGL((bfStageKernelT<DT, 4, 4, true>), dim3(grid), dim3(BF_WAVES_PER_WG * 64), 0, s, p); \
+                             else if (wide) hipLaunchKernelGGL((bfStageKernelT<DT, 4, 4, false>), dim3(grid), dim3(BF_WAVES_PER_WG * 64), 0, s, p); \
+                             else if (nc) hipLaunchKernelGGL((bfStageKernelT<DT, 16, 4, true>), dim3(grid), dim3(BF_WAVES_PER_WG * 64), 0, s, p); \
+                             else hipLaunchKernelGGL((bfStageKernelT<DT, 16, 4, false>), dim3(grid), dim3(BF_WAVES_PER_WG * 64), 0, s, p); } while (0)
     if (a->dtype == BFHIP_C128) BF_LAUNCH_T(BFHIP_C128);
     else if (a->dtype == BFHIP_F64) BF_LAUNCH_T(BFHIP_F64);
     else if (a->dtype == BFHIP_F32) BF_LAUNCH_T(BFHIP_F32);

@@ -222,6 +222,21 @@ int bfPlanFwdPieces(BfPlan const *plan, BfFwdPiece **out, uint64_t *count) {
   return 0;
 }
 
+/* Transposed items are sorted big first; the leading ones that stream at least BF_COOP_BYTES get a workgroup each
+ * when they average at least BF_COOP_PIECES pieces: a block column of a streamed butterfly is hundreds of few-row pieces,
+ * one dependent load each.  Items of a few tall pieces (fac_helm2) are 3 - 6 % slower shared than alone. */
+uint64_t bfPlanCountCoop(BfDevItem const *items, BfDevPiece const *pieces, uint64_t numItems, uint32_t elemSize) {
+  uint64_t k = 0, np = 0;
+  for (; k < numItems; ++k) {
+    uint64_t cols = 0;
+    for (uint32_t i = 0; i < items[k].numPieces; ++i)
+      if (!(pieces[items[k].pieceBegin + i].flags & BF_PIECE_IDENTITY)) cols += pieces[items[k].pieceBegin + i].ncols;
+    if ((items[k].mrFlags & 0xffffu) * cols * elemSize < BF_COOP_BYTES) break;
+    np += items[k].numPieces;
+  }
+  return np >= BF_COOP_PIECES * k ? k : 0;
+}
+
 /* first table entry of (node, column piece containing col) */
 static uint64_t findFwd(BfFwdPiece const *t, uint64_t n, uint64_t node, uint32_t colPiece0) {
   uint64_t lo = 0, hi = n;
@@ -318,7 +333,7 @@ int bfPlanBuild(BfIr const *ir, BfPlanOptions const *po, BfPlan *plan) {
     /* an item is 16 (or, for operands made of short leaves, 64) columns of A (one output each), whatever
      * the element size: the transposed kernel tiles a forward piece as 4 columns x 16 row units per load */
     itemRows = po->tCols > 16 ? po->tCols : 16;
-    plan->maxItemRows = itemRows;
+    plan->maxItemRows = po->tCols ? itemRows : 64;      /* tCols == 0: chosen stage by stage below */
     if (po->rowBlockEnd > 0) return bfhipFail(BFABI_ERROR_NOT_IMPLEMENTED, "transposed plan of a row-sharded operator");
   }
 
@@ -411,6 +426,24 @@ int bfPlanBuild(BfIr const *ir, BfPlanOptions const *po, BfPlan *plan) {
      * output rows; the planner's overlap machinery below then gives each a private slot and one
      * deterministic reduce.  The cap is 1 MiB per item, less when the stage is too small to fill the GPU
      * otherwise (>= ~4096 items wanted), never below the regular item size. */
+    /* The transposed kernel tiles a piece as (R row lanes x 64 / R columns) per load: R = 16 (16-column items) is
+     * exact for pieces whose height is a multiple of 16 lane units (fac_helm2: 16 - 64 rows of complex128; the tall
+     * leaves of a streamed butterfly's first factors) and reads whole 256-byte runs; pieces of 1 - 15 units (the
+     * streamer's later factors) leave most of 16 row lanes idle, and R = 4 (64-column items) wastes only the last
+     * 4-unit step.  Each stage picks by the lane slots either tiling would spend on its leaves. */
+    if (T && !po->tCols) {
+      uint64_t slots16 = 0, slots4 = 0;
+      for (uint64_t t = tBegin; t < tEnd; ++t) {
+        Task const *tk = &b.tasks[t];
+        if (ir->kind[tk->leaf] != BFHIP_NODE_DENSE || tk->sub0) continue;
+        for (uint64_t k = findFwd(po->fwdPieces, po->numFwdPieces, tk->leaf, 0); k < po->numFwdPieces && po->fwdPieces[k].node == tk->leaf; ++k) {
+          uint64_t const u = (po->fwdPieces[k].mr + plan->epl - 1) / plan->epl, w = po->fwdPieces[k].ncols;
+          slots16 += (u + 15) / 16 * 16 * w;
+          slots4 += (u + 3) / 4 * 4 * w;
+        }
+      }
+      itemRows = (10 * slots4 < 8 * slots16) ? 64 : 16;
+    }
     uint64_t stageElems = 0;
     for (uint64_t t = tBegin; t < tEnd; ++t) stageElems += b.tasks[t].rows * b.tasks[t].cols;
     uint64_t capBytes = 1u << 20;
@@ -719,6 +752,7 @@ int bfPlanBuild(BfIr const *ir, BfPlanOptions const *po, BfPlan *plan) {
     }
     st->numItems = totalItems;
     st->numPieces = np;
+    st->numCoop = T ? bfPlanCountCoop(st->items, st->pieces, numItems, plan->elemSize) : 0;
     /* algorithmic counts */
     for (uint64_t t = tBegin; t < tEnd; ++t)
       if (ir->kind[b.tasks[t].leaf] == BFHIP_NODE_DENSE) { st->leafElems += b.tasks[t].rows * b.tasks[t].cols; plan->numLeaves += b.tasks[t].sub0 == 0; }
