@@ -388,6 +388,9 @@ def main():
         y_full = step(x)
     torch.cuda.synchronize()
     op.stage_profile(reset=True)
+    # an event pair per launch costs ~4 us of stream time: bracket one apply in four of the timed region
+    ev_every = 4 if args.steps >= 8 else 1
+    op.set_profile_sampling(ev_every)
     if use_pg:
         dist.barrier()
     torch.cuda.synchronize()
@@ -404,6 +407,7 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     ms, launches, sbytes = op.stage_profile()
+    op.set_profile_sampling(1)
 
     # multi-GPU: per-rank leaf bytes, the slowest rank's local stages, and the collective, separately
     # (a few extra steps outside the timed region: reading the events synchronizes the host)
@@ -443,13 +447,15 @@ def main():
                         "frac": tf / FP64_MFMA_PEAK_TFLOPS, "traffic": None, "kernel": "bfStageKernelC128Mfma",
                         "launches_per_apply": len(ms), "avg_launch_ms": avg_launch_ms,
                         "algorithmic_flops_per_apply": flops_per_apply, "hbm_gbs_algorithmic": achieved,
-                        "kernel_ms_per_apply": kern_ms / max(launches.max(), 1)}
+                        "kernel_ms_per_apply": kern_ms / max(launches.max(), 1),
+                        "event_sampling": f"HIP events around every launch of 1 apply in {ev_every} of the timed region"}
         else:
             roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                         "kernel": "bfStageKernelC128" if not real else f"bfStageKernelReal<{dtype}>", "launches_per_apply": len(ms),
                         "avg_launch_ms": avg_launch_ms, "algorithmic_bytes_per_launch": bytes_per_apply / len(ms),
-                        "algorithmic_bytes_per_apply": bytes_per_apply, "kernel_ms_per_apply": kern_ms / max(launches.max(), 1)}
+                        "algorithmic_bytes_per_apply": bytes_per_apply, "kernel_ms_per_apply": kern_ms / max(launches.max(), 1),
+                        "event_sampling": f"HIP events around every launch of 1 apply in {ev_every} of the timed region"}
         # `traffic` = HBM bytes PER LAUNCH (like `achieved`), from the COMMITTED rocprofv3 --pmc profile of this
         # very command (FETCH_SIZE / WRITE_SIZE in separate passes, gfx950 x2 FETCH correction): counters cannot
         # be read from inside the process, so it is not measured in this run and other configurations report null.

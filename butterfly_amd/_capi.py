@@ -306,6 +306,8 @@ def load():
     lib.bfhipNumBytes.restype = C.c_size_t
     lib.bfhipGetStageProfile.argtypes = [vp, vp, vp, vp, C.c_int]
     lib.bfhipGetStageProfile.restype = C.c_int
+    lib.bfhipSetProfileSampling.argtypes = [vp, C.c_uint32]
+    lib.bfhipSetProfileSampling.restype = C.c_int
     lib.bfhipPlanGetInfo.argtypes = [vp, C.POINTER(BfhipPlanInfo)]
     lib.bfhipPlanGetInfo.restype = C.c_int
     lib.bfhipPlanGetStage.argtypes = [vp, C.c_uint64, C.POINTER(BfhipStageView)]

@@ -69,6 +69,8 @@ struct BfhipOperator {
   uint64_t *stageLaunches;
   uint32_t lastNrhs;
   uint64_t evIssued, evHarvested;   /* applies whose events were recorded / read back */
+  uint64_t applyCount;              /* forward applies so far */
+  uint32_t profEvery;               /* events around one apply in profEvery (0, 1: every apply) */
   /* BFHIP_FLAG_PLAN_ONLY: the IR is kept (borrowed leaf pointers!) for bfhipPlanPackArena */
   BfIr *ir;
   uint64_t seed;
@@ -439,6 +441,14 @@ int bfhipGetStageProfile(BfhipOperator *op, double *ms, uint64_t *launches, uint
   return 0;
 }
 
+int bfhipSetProfileSampling(BfhipOperator *op, uint32_t every) {
+  if (!op) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "NULL operator");
+  if (!(op->flags & BFHIP_FLAG_PROFILE)) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "operator was not compiled with BFHIP_FLAG_PROFILE");
+  op->profEvery = every;
+  op->applyCount = 0;
+  return 0;
+}
+
 /* ---- apply ------------------------------------------------------------------ */
 static int runPlan(BfhipOperator *op, BfPlan *plan, void const *dX, size_t nrhs, void *dY, void *stream) {
   if (!op || !dX || !dY) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "NULL argument");
@@ -453,7 +463,8 @@ static int runPlan(BfhipOperator *op, BfPlan *plan, void const *dX, size_t nrhs,
     if ((rc = bfdevSync(stream))) goto out;
     if ((rc = ensureTemp(op, (uint32_t)nrhs))) goto out;
   }
-  int const prof = (op->flags & BFHIP_FLAG_PROFILE) != 0 && plan == &op->plan;
+  int const prof = (op->flags & BFHIP_FLAG_PROFILE) != 0 && plan == &op->plan && (op->profEvery <= 1 || op->applyCount % op->profEvery == 0);
+  if (plan == &op->plan) ++op->applyCount;
   /* timing never makes an apply wait for the previous one: only when all BF_EV_POOL event sets are in flight is the oldest read back */
   if (prof && op->evIssued - op->evHarvested >= BF_EV_POOL && (rc = harvestEvents(op, op->evIssued - BF_EV_POOL + 1))) goto out;
   uint64_t const evBase = prof ? (op->evIssued % BF_EV_POOL) * plan->numStages : 0;

@@ -261,6 +261,10 @@ class HipOperator:
                                              1 if reset else 0))
         return ms, launches, nbytes
 
+    def set_profile_sampling(self, every):
+        """Bracket one apply in `every` with events (bfhipSetProfileSampling)."""
+        check(self._lib.bfhipSetProfileSampling(self._h, int(every)))
+
     # ---- reference-vtable shim ---------------------------------------------
     def as_bfmat(self, owns=False):
         """A BfMat* whose Mul / MulVec / RmulVec run on the device (bfhipMatNew).  With
