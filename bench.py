@@ -388,8 +388,9 @@ def main():
         y_full = step(x)
     torch.cuda.synchronize()
     op.stage_profile(reset=True)
-    # an event pair per launch costs ~4 us of stream time: bracket one apply in four of the timed region
-    ev_every = 4 if args.steps >= 8 else 1
+    # an event pair between two launches costs ~10 us of stream time (kernels without one in between start back to
+    # back): bracket four applies of the timed region, the others run as a caller's would
+    ev_every = max(4, args.steps // 4) if args.steps >= 8 else 1
     op.set_profile_sampling(ev_every)
     if use_pg:
         dist.barrier()

@@ -241,7 +241,16 @@ int bfhipSetProfileSampling(BfhipOperator *op, uint32_t every);
  * layouts: BfDevItem = {u32 pieceBegin, numPieces, outOff, mrFlags},
  * BfDevPiece = {u64 dataOff; u32 inOff, ncols, flags, ld}; in the transposed
  * plan a piece is a forward piece read with lanes on its columns: element
- * (step s, lane j) = arena[dataOff + j*ld + s], ncols = number of steps. */
+ * (step s, lane j) = arena[dataOff + j*ld + s], ncols = number of steps.
+ * mrFlags = rows | flags: 1<<16 the item writes y (else the vector arena);
+ * 1<<17 ROWMAJOR (real operands, <= 2 lane granules of rows: the item's dense
+ * pieces are stored row by row, element (r, c) = arena[dataOff + r*ld + c],
+ * rows zero-padded to the granule, one piece per <= 1024-column task);
+ * 1<<18 MERGED (column-major dense pieces are one contiguous block of <= 256
+ * columns, contracted in one go); 1<<19 SMALL (<= 2 granules of rows, <= 16
+ * pieces, < 128 columns: such items are the END of a stage's list and run
+ * four to a wavefront in their own launch).  Piece flags: 1 reads x (else the
+ * vector arena), 2 identity (no data: adds the input rows), 4 row-major. */
 typedef struct BfhipPlanInfo {
   uint32_t structSize, dtype, elemSize, epl, xcap, reserved;
   uint64_t numRows, numCols, numStages, arenaElems, tempElems;

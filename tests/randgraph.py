@@ -147,3 +147,27 @@ def few_row_operand(rng):
             ch.append((ident, int(ro[i]), c0))
     d.root = d.add(hs.NODE_BLOCK, m, n, ch, hs.BF_TYPE_BLOCK_COO)
     return d, vals, dense
+
+
+def narrow_items_operand(rng):
+    """The inner factors of a streamed butterfly in one BlockCoo: 40 block rows, most of 1 - 8 rows (two leaves of a few
+    dozen columns plus an Identity term), every fifth of 20 - 90 rows, and 11 rows nobody writes.  Real (f64) operand.
+    Returns (desc, vals, dense matrix)."""
+    from butterfly_amd import helm2_structure as hs
+    d = hs.Desc(dtype=1)
+    vals, ch, r0 = {}, [], 0
+    blocks = []
+    for i in range(40):
+        h = int(rng.integers(1, 9)) if i % 5 else int(rng.integers(20, 90))
+        if i == 17:
+            r0 += 11; blocks.append(np.zeros((11, 300)))     # rows nobody writes: a zero-fill item
+        row = np.zeros((h, 300))
+        for c0, w in ((3 * i, int(rng.integers(4, 50))), (150 + i, int(rng.integers(4, 60)))):
+            a = rng.standard_normal((h, w)); leaf = d.add(hs.NODE_DENSE, h, w); vals[leaf] = a
+            ch.append((leaf, r0, c0)); row[:, c0:c0 + w] += a
+        if h <= 8:
+            ident = d.add(hs.NODE_IDENTITY, h, h); ch.append((ident, r0, 280)); row[:, 280:280 + h] += np.eye(h)
+        blocks.append(row); r0 += h
+    dense = np.vstack(blocks)
+    d.root = d.add(hs.NODE_BLOCK, dense.shape[0], 300, ch, hs.BF_TYPE_BLOCK_COO)
+    return d, vals, dense

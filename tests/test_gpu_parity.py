@@ -603,6 +603,15 @@ def test_few_row_leaves_on_gpu(demote, nrhs):
     from oracle import bfref
     rng = np.random.default_rng(41 + nrhs)
     d, vals, dense = randgraph.few_row_operand(rng)        # (Identity terms off the block grid: the dense matrix is the answer)
+    _check_against_dense(d, vals, dense, rng, demote, nrhs)
+    # merged narrow items, small items four to a wavefront (their own launch), a zero fill between them
+    d, vals, dense = randgraph.narrow_items_operand(rng)
+    _check_against_dense(d, vals, dense, rng, demote, nrhs)
+
+
+def _check_against_dense(d, vals, dense, rng, demote, nrhs):
+    from butterfly_amd import _capi
+    from butterfly_amd.operator import HipOperator
     m, n = dense.shape
     op = HipOperator.from_desc(d, vals, flags=_capi.FLAG_ADJOINT, demote_to_f32=demote, max_rhs=nrhs)
     tol = 3e-5 if demote else TOL

@@ -162,6 +162,34 @@ def test_few_row_leaves_are_stored_row_major(demote):
     op.close()
 
 
+@pytest.mark.parametrize("demote", [False, True])
+def test_narrow_items_are_merged_and_small_ones_close_the_list(demote):
+    """What the inner factors of a streamed butterfly are made of: row nodes of 1 - 8 rows whose terms are an Identity
+    and a leaf of a few dozen columns, next to ordinary leaves.  Items whose dense pieces span <= 256 columns are flagged
+    MERGED (one contiguous block), those of <= 2 lane granules of rows and < 128 columns SMALL -- and the small ones are
+    the END of the stage's item list, behind the zero fills (they get their own launch, four to a wavefront)."""
+    rng = np.random.default_rng(5)
+    d, vals, dense = randgraph.narrow_items_operand(rng)
+    op = HipOperator.from_desc(d, vals, flags=_capi.FLAG_PLAN_ONLY | _capi.FLAG_ADJOINT, demote_to_f32=demote)
+    lib = _capi.load()
+    sv = _capi.BfhipStageView(); sv.structSize = C.sizeof(sv)
+    _capi.check(lib.bfhipPlanGetStage(op.handle, 0, C.byref(sv)))
+    items = np.frombuffer((C.c_char * (int(sv.numItems) * 16)).from_address(sv.items), dtype=_capi.ITEM_DTYPE)
+    small = (items["mrFlags"] & plan_emulator.BF_ITEM_SMALL) != 0
+    merged = (items["mrFlags"] & plan_emulator.BF_ITEM_MERGED) != 0
+    epl = 4 if demote else 2
+    first = int(np.argmax(small))
+    assert small.sum() >= 10 and small[first:].all() and not small[:first].any()
+    assert ((items["mrFlags"][small] & 0xFFFF) <= 2 * epl).all()
+    assert merged[~small & (items["numPieces"] > 0)].all()          # every ordinary item here is < 256 columns wide
+    assert (items["numPieces"][:first] == 0).any()                  # the zero fill sits before the small items
+    x, v = rng.standard_normal(300), rng.standard_normal(dense.shape[0])
+    tol = 2e-6 if demote else 1e-13
+    assert rel(plan_emulator.run_plan(op, x), dense @ x) < tol
+    assert rel(plan_emulator.run_plan(op, v, transpose=True), dense.T @ v) < tol
+    op.close()
+
+
 def test_row_sharding_union_equals_full(helm2_cases):
     n, k = 2048, 128
     desc, tp, vals = helm2_cases(n, k)
