@@ -392,6 +392,8 @@ def main():
     # back): bracket four applies of the timed region, the others run as a caller's would
     ev_every = max(4, args.steps // 4) if args.steps >= 8 else 1
     op.set_profile_sampling(ev_every)
+    if sharded is not None:
+        sharded.set_timing(False)          # the local / collective split is measured after the timed region
     if use_pg:
         dist.barrier()
     torch.cuda.synchronize()
@@ -414,6 +416,7 @@ def main():
     # (a few extra steps outside the timed region: reading the events synchronizes the host)
     multi = None
     if sharded is not None:
+        sharded.set_timing(True)
         loc, coll = [], []
         for _ in range(5):
             step(x)

@@ -340,6 +340,8 @@ def load():
     lib.bfhipShardedApplyDevice.restype = C.c_int
     lib.bfhipShardedLastTimes.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     lib.bfhipShardedLastTimes.restype = C.c_int
+    lib.bfhipShardedSetTiming.argtypes = [vp, C.c_int]
+    lib.bfhipShardedSetTiming.restype = C.c_int
     lib.bfhipShardedFree.argtypes = [C.POINTER(vp)]
     lib.bfhipShardedFree.restype = None
     lib.bfhipErrorString.argtypes = [C.c_int]

@@ -90,6 +90,7 @@ struct BfhipSharded {
   Seg *hSegs;
   hipEvent_t e0, e1, e2;
   int timed;
+  int timing;       // record the three events (default on)
 };
 
 extern "C" {
@@ -198,6 +199,7 @@ int bfhipShardedCreate(BfhipOperator *op, BfhipComm *comm, BfhipShardSpec const 
     }
     free(rowsOf);
   }
+  s->timing = 1;
   if (!rc) rc = hipFailS(hipEventCreate(&s->e0), "hipEventCreate");
   if (!rc) rc = hipFailS(hipEventCreate(&s->e1), "hipEventCreate");
   if (!rc) rc = hipFailS(hipEventCreate(&s->e2), "hipEventCreate");
@@ -217,17 +219,17 @@ int bfhipShardedApplyDevice(BfhipSharded *s, void const *dX, size_t nrhs, void *
   if (rc) return rc;
   ncclDataType_t const dt = s->dtype == BFHIP_F32 ? ncclFloat32 : ncclFloat64;
   size_t const scalarsPerElem = s->dtype == BFHIP_C128 ? 2 : 1;
-  (void)hipEventRecord(s->e0, stream);
+  if (s->timing) (void)hipEventRecord(s->e0, stream);
   if (s->mode == BFHIP_SHARD_BLOCKS) {
     rc = bfhipApplyDevice(s->op, dX, nrhs, dY, stream);
-    (void)hipEventRecord(s->e1, stream);
+    if (s->timing) (void)hipEventRecord(s->e1, stream);
     // partial results add up; disjoint supports make the sum exact in any order
     if (!rc) rc = ncclFail(g.AllReduce(dY, dY, (size_t)s->numRowsGlobal * nrhs * scalarsPerElem, dt, ncclSum, s->comm->comm, stream), "ncclAllReduce");
   } else {
     size_t const rowBytes = nrhs * s->elemSize;
     char *slot = (char *)s->dGather + (size_t)s->comm->rank * s->maxRows * rowBytes;
     rc = bfhipApplyDevice(s->op, dX, nrhs, slot, stream);
-    (void)hipEventRecord(s->e1, stream);
+    if (s->timing) (void)hipEventRecord(s->e1, stream);
     if (!rc) rc = ncclFail(g.AllGather(slot, s->dGather, (size_t)s->maxRows * nrhs * scalarsPerElem, dt, s->comm->comm, stream), "ncclAllGather");
     if (!rc && s->numSegs) {
       // unit = the largest power of two <= 16 bytes dividing a row; buffers are 16-byte aligned
@@ -244,14 +246,14 @@ int bfhipShardedApplyDevice(BfhipSharded *s, void const *dX, size_t nrhs, void *
       }
     }
   }
-  (void)hipEventRecord(s->e2, stream);
-  s->timed = !rc;
+  if (s->timing) (void)hipEventRecord(s->e2, stream);
+  s->timed = !rc && s->timing;
   if (prev >= 0 && prev != s->comm->device) (void)hipSetDevice(prev);
   return rc;
 }
 
 int bfhipShardedLastTimes(BfhipSharded *s, double *localMs, double *collectiveMs) {
-  if (!s || !s->timed) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "no sharded apply has run yet");
+  if (!s || !s->timed) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "the last sharded apply was not timed (none ran, it failed, or bfhipShardedSetTiming(0))");
   int rc = hipFailS(hipEventSynchronize(s->e2), "hipEventSynchronize");
   float a = 0, b = 0;
   if (!rc) rc = hipFailS(hipEventElapsedTime(&a, s->e0, s->e1), "hipEventElapsedTime");
@@ -259,6 +261,13 @@ int bfhipShardedLastTimes(BfhipSharded *s, double *localMs, double *collectiveMs
   if (localMs) *localMs = a;
   if (collectiveMs) *collectiveMs = b;
   return rc;
+}
+
+int bfhipShardedSetTiming(BfhipSharded *s, int enabled) {
+  if (!s) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "NULL argument");
+  s->timing = enabled != 0;
+  if (!s->timing) s->timed = 0;
+  return 0;
 }
 
 }  // extern "C"

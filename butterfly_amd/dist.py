@@ -203,6 +203,11 @@ class RcclShardedApply:
                                                       C.c_void_p(s.cuda_stream)))
         return self._y
 
+    def set_timing(self, enabled):
+        """Record (or not) the three events behind last_times(); they cost ~17 us of stream time per step."""
+        from . import _capi
+        _capi.check(self._lib.bfhipShardedSetTiming(self._sh, 1 if enabled else 0))
+
     def last_times(self):
         """(local stage ms, collective ms) of the most recent step, from hipEvents on its stream."""
         import ctypes as C

@@ -207,6 +207,9 @@ int bfhipShardedCreate(BfhipOperator *op, BfhipComm *comm, const BfhipShardSpec 
 int bfhipShardedApplyDevice(BfhipSharded *sh, const void *dX, size_t nrhs, void *dY, void *stream);
 /* hipEvent times of the most recent apply: stage kernels, and collective (+ reordering).  Synchronizes. */
 int bfhipShardedLastTimes(BfhipSharded *sh, double *localMs, double *collectiveMs);
+/* The three events behind bfhipShardedLastTimes cost ~17 us of stream time per apply (they are what keeps the stage
+ * kernels, the collective and the next apply apart): on by default, turn them off for production loops. */
+int bfhipShardedSetTiming(BfhipSharded *sh, int enabled);
 void bfhipShardedFree(BfhipSharded **sh);     /* neither the operator nor the communicator is released */
 
 /* Left-preconditioned form: the reference's M argument (src/linalg.c:47-49,90-97,131,159).  `solveM` is a device
