@@ -369,7 +369,7 @@ __device__ __forceinline__ void bfRowMajorPiece(void const *rowpV, uint32_t upr,
   struct __attribute__((aligned(16))) V { S v[EPL]; };
   struct __attribute__((packed, aligned(sizeof(S)))) VU { S v[EPL]; };     // x: element-aligned 16 bytes
   char const *rowp = (char const *)rowpV;
-  constexpr int UNR = MR <= 2 ? 4 : MR <= 4 ? 2 : 1;
+  constexpr int UNR = MR <= 2 ? 4 : 2;
   uint32_t const rowBytes = upr * 16u;
   uint32_t const full = nrhs == 1 ? n / EPL : 0;        // units whose x is one contiguous in-range 16-byte load
   uint32_t u = (uint32_t)lane;
