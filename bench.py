@@ -538,6 +538,29 @@ def main():
             lhs = torch.sum(yx.to(torch.complex128 if not real else torch.float64) * xt.to(torch.complex128 if not real else torch.float64))
             rhs = torch.sum(x.to(lhs.dtype) * yt.to(lhs.dtype))
             out["adjoint"]["transpose_identity_rel"] = float(abs(lhs - rhs) / max(abs(lhs), 1e-300))
+            if streamer and args.nrhs == 1:
+                # the path's caller: cov_matvec of examples/covariance/lbo_cov.c:48-60 as one device call
+                # (permute, A^T, GammaLam twice, A, permute), with a random diagonal and row permutation
+                gam = torch.rand(ncols, dtype=tdtype, device=dev) + 0.5
+                perm = torch.randperm(n, device=dev)
+                rev = torch.empty_like(perm); rev[perm] = torch.arange(n, device=dev)
+                for _ in range(2):
+                    zc = op.cov_matvec_device(gam, perm, rev, xt)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(args.steps):
+                    zc = op.cov_matvec_device(gam, perm, rev, xt)
+                torch.cuda.synchronize()
+                cov_ms = (time.perf_counter() - t1) / args.steps * 1e3
+                # check against the two applies done separately
+                t_ = torch.empty_like(xt); t_[rev] = xt
+                u_ = op.apply_transpose_device(t_).clone() * gam * gam
+                z_ = op.apply_device(u_)
+                zr = torch.empty_like(z_); zr[perm] = z_
+                out["cov_matvec"] = {"ms_per_product": cov_ms, "products_per_s": 1e3 / cov_ms,
+                                     "hbm_gbs": 2 * st["leafBytes"] / 1e9 / (cov_ms / 1e3),
+                                     "rel_vs_separate_applies": float(torch.linalg.norm(zc - zr) / torch.linalg.norm(zr)),
+                                     "note": "bfhipCovMatvecDevice: z = P A diag(g)^2 A^T P' v, everything resident"}
         if args.pcie:
             out["pcie_inclusive"] = {"ms_per_apply": pcie_ms, "matvec_per_s": args.nrhs / (pcie_ms / 1e3),
                                      "note": "bfhipApply: pack into pinned staging + H2D x + apply + D2H y + unpack"}

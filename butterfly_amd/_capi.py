@@ -306,6 +306,10 @@ def load():
     lib.bfhipNumBytes.restype = C.c_size_t
     lib.bfhipGetStageProfile.argtypes = [vp, vp, vp, vp, C.c_int]
     lib.bfhipGetStageProfile.restype = C.c_int
+    lib.bfhipCovSampleDevice.argtypes = [vp, vp, vp, vp, vp, vp]
+    lib.bfhipCovSampleDevice.restype = C.c_int
+    lib.bfhipCovMatvecDevice.argtypes = [vp, vp, vp, vp, vp, vp, vp]
+    lib.bfhipCovMatvecDevice.restype = C.c_int
     lib.bfhipSetProfileSampling.argtypes = [vp, C.c_uint32]
     lib.bfhipSetProfileSampling.restype = C.c_int
     lib.bfhipPlanGetInfo.argtypes = [vp, C.POINTER(BfhipPlanInfo)]

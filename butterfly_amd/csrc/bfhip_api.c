@@ -70,6 +70,7 @@ struct BfhipOperator {
   uint32_t lastNrhs;
   uint64_t evIssued, evHarvested;   /* applies whose events were recorded / read back */
   uint64_t applyCount;              /* forward applies so far */
+  void *dCov;                       /* scratch of the covariance products (2 vectors of the longer side) */
   uint32_t profEvery;               /* events around one apply in profEvery (0, 1: every apply) */
   /* BFHIP_FLAG_PLAN_ONLY: the IR is kept (borrowed leaf pointers!) for bfhipPlanPackArena */
   BfIr *ir;
@@ -110,6 +111,7 @@ void bfhipFree(BfhipOperator **pop) {
   bfdevFree(op->dTemp);
   bfdevFree(op->dZero);
   bfdevFree(op->dX);
+  bfdevFree(op->dCov);
   bfdevFree(op->dY);
   bfdevHostFreePinned(op->hX);
   bfdevHostFreePinned(op->hY);
@@ -505,6 +507,57 @@ int bfhipApplyTransposeDevice(BfhipOperator *op, void const *dX, size_t nrhs, vo
   if (!op) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "NULL operator");
   if (!op->hasTplan) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "operator was not compiled with BFHIP_FLAG_ADJOINT");
   return runPlan(op, &op->tplan, dX, nrhs, dY, stream);
+}
+
+/* ---- covariance products (the caller of the real path) ------------------------ */
+static int covScratch(BfhipOperator *op) {
+  if (op->dCov) return 0;
+  /* two vectors of the longer side: [permuted input | A^T result] resp. [scaled input | A result] */
+  uint64_t const big = op->plan.numRows > op->plan.numCols ? op->plan.numRows : op->plan.numCols;
+  return bfdevMalloc(&op->dCov, 2 * big * op->plan.elemSize + 32);
+}
+
+int bfhipCovSampleDevice(BfhipOperator *op, void const *dGammaLam, uint64_t const *dRowPerm, void const *dW, void *dZ, void *stream) {
+  if (!op || !dW || !dZ) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "NULL argument");
+  if (op->plan.dtype == BFHIP_C128) return bfhipFail(BFABI_ERROR_TYPE_ERROR, "covariance products are defined for real operators");
+  if (op->flags & BFHIP_FLAG_PLAN_ONLY) return bfhipFail(BFABI_ERROR_RUNTIME_ERROR, "operator was compiled with BFHIP_FLAG_PLAN_ONLY: no device operator exists");
+  int rc, prev = -1;
+  bfdevGetDevice(&prev);
+  if (prev != op->device && (rc = bfdevSetDevice(op->device))) return rc;
+  uint64_t const m = op->plan.numRows, n = op->plan.numCols, big = m > n ? m : n;
+  size_t const es = op->plan.elemSize;
+  if ((rc = covScratch(op))) goto out;
+  char *t0 = op->dCov, *t1 = (char *)op->dCov + big * es;
+  void const *xin = dW;
+  if (dGammaLam) { if ((rc = bfdevScalePermute(t0, dW, dGammaLam, 1, NULL, n, op->plan.dtype, stream))) goto out; xin = t0; }
+  if ((rc = runPlan(op, &op->plan, xin, 1, dRowPerm ? (void *)t1 : dZ, stream))) goto out;
+  if (dRowPerm) rc = bfdevScalePermute(dZ, t1, NULL, 0, dRowPerm, m, op->plan.dtype, stream);
+out:
+  if (prev >= 0 && prev != op->device) bfdevSetDevice(prev);
+  return rc;
+}
+
+int bfhipCovMatvecDevice(BfhipOperator *op, void const *dGammaLam, uint64_t const *dRowPerm, uint64_t const *dRevRowPerm, void const *dV, void *dZ, void *stream) {
+  if (!op || !dV || !dZ) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "NULL argument");
+  if (op->plan.dtype == BFHIP_C128) return bfhipFail(BFABI_ERROR_TYPE_ERROR, "covariance products are defined for real operators");
+  if (!op->hasTplan) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "operator was not compiled with BFHIP_FLAG_ADJOINT");
+  if (op->flags & BFHIP_FLAG_PLAN_ONLY) return bfhipFail(BFABI_ERROR_RUNTIME_ERROR, "operator was compiled with BFHIP_FLAG_PLAN_ONLY: no device operator exists");
+  int rc, prev = -1;
+  bfdevGetDevice(&prev);
+  if (prev != op->device && (rc = bfdevSetDevice(op->device))) return rc;
+  uint64_t const m = op->plan.numRows, n = op->plan.numCols, big = m > n ? m : n;
+  size_t const es = op->plan.elemSize;
+  if ((rc = covScratch(op))) goto out;
+  char *t0 = op->dCov, *t1 = (char *)op->dCov + big * es;
+  void const *vin = dV;
+  if (dRevRowPerm) { if ((rc = bfdevScalePermute(t0, dV, NULL, 0, dRevRowPerm, m, op->plan.dtype, stream))) goto out; vin = t0; }
+  if ((rc = runPlan(op, &op->tplan, vin, 1, t1, stream))) goto out;                 /* tmp2 = Phi^T v */
+  if (dGammaLam && (rc = bfdevScalePermute(t1, t1, dGammaLam, 2, NULL, n, op->plan.dtype, stream))) goto out;   /* GammaLam twice */
+  if ((rc = runPlan(op, &op->plan, t1, 1, dRowPerm ? (void *)t0 : dZ, stream))) goto out;
+  if (dRowPerm) rc = bfdevScalePermute(dZ, t0, NULL, 0, dRowPerm, m, op->plan.dtype, stream);
+out:
+  if (prev >= 0 && prev != op->device) bfdevSetDevice(prev);
+  return rc;
 }
 
 static int applyHost(BfhipOperator *op, int transpose, void const *X, size_t ldx, size_t nrhs, void *Y, size_t ldy) {

@@ -1029,6 +1029,18 @@ __global__ __launch_bounds__(256) void bfReduceKernel(ReduceBatch const B) {
   for (int c = 0; c < NC; ++c) dest[idx * NC + c] = acc[c];
 }
 
+// dst[perm ? perm[i] : i] = src[i] * (scale ? scale[i]^power : 1): the vector plumbing around the two applies of a
+// covariance product (bfVecRealPermute scatters: out[perm[i]] = in[i], src/vec_real.c:312-329; a BfMatDiagReal applied
+// once or twice, examples/covariance/lbo_cov.c:36-60)
+template <typename S>
+__global__ __launch_bounds__(256) void bfScalePermuteKernel(S *dst, S const *src, S const *scale, int power, uint64_t const *perm, uint64_t n) {
+  uint64_t const i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  S v = src[i];
+  if (scale) { S const g = scale[i]; v *= power == 2 ? g * g : g; }
+  dst[perm ? perm[i] : i] = v;
+}
+
 // ---------------------------------------------------------------------------
 // synthetic operand fill: one workgroup per piece
 // ---------------------------------------------------------------------------
@@ -1371,6 +1383,15 @@ int bfdevLaunchStage(BfLaunchArgs const *a, void *stream) {
   }
   else return bfhipFail(BFABI_ERROR_TYPE_ERROR, "unknown dtype %u", a->dtype);
   return hipFail(hipGetLastError(), "stage launch");
+}
+
+int bfdevScalePermute(void *dst, void const *src, void const *scale, int power, uint64_t const *perm, uint64_t n, uint32_t dtype, void *stream) {
+  if (!n) return 0;
+  uint32_t const grid = (uint32_t)((n + 255) / 256);
+  if (dtype == BFHIP_F64) hipLaunchKernelGGL(bfScalePermuteKernel<double>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (double *)dst, (double const *)src, (double const *)scale, power, perm, n);
+  else if (dtype == BFHIP_F32) hipLaunchKernelGGL(bfScalePermuteKernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (float *)dst, (float const *)src, (float const *)scale, power, perm, n);
+  else return bfhipFail(BFABI_ERROR_TYPE_ERROR, "scale/permute: real element types only");
+  return hipFail(hipGetLastError(), "scale/permute launch");
 }
 
 int bfdevLaunchReduce(BfReduceArgs const *a, uint32_t count, void *stream) {

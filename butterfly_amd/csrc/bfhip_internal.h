@@ -233,6 +233,7 @@ typedef struct BfReduceArgs {
 } BfReduceArgs;
 /* all `count` reduces (one stage; same temp / nrhs / dtype) in as few launches as possible */
 int bfdevLaunchReduce(BfReduceArgs const *a, uint32_t count, void *stream);
+int bfdevScalePermute(void *dst, void const *src, void const *scale, int power, uint64_t const *perm, uint64_t n, uint32_t dtype, void *stream);
 
 /* device-resident GMRES building blocks (complex128; bfhip_gmres.c drives them).
  * Vectors are n x nrhs row-major; reductions are per RHS column, two-stage and

@@ -261,6 +261,28 @@ class HipOperator:
                                              1 if reset else 0))
         return ms, launches, nbytes
 
+    def cov_sample_device(self, gamma_lam, row_perm, w):
+        """z = P A diag(gamma_lam) w on the device (sample_z of examples/covariance/lbo_cov.c:36-45); torch tensors on
+        this operator's device, gamma_lam / row_perm (int64, scatter order) may be None."""
+        import torch
+        z = torch.empty(self.stats()["numRows"], dtype=w.dtype, device=w.device)
+        s = torch.cuda.current_stream(w.device)
+        check(self._lib.bfhipCovSampleDevice(self._h, C.c_void_p(gamma_lam.data_ptr()) if gamma_lam is not None else None,
+                                             C.c_void_p(row_perm.data_ptr()) if row_perm is not None else None,
+                                             C.c_void_p(w.data_ptr()), C.c_void_p(z.data_ptr()), C.c_void_p(s.cuda_stream)))
+        return z
+
+    def cov_matvec_device(self, gamma_lam, row_perm, rev_row_perm, v):
+        """z = P A diag(gamma_lam)^2 A^T P' v on the device (cov_matvec of examples/covariance/lbo_cov.c:48-60)."""
+        import torch
+        z = torch.empty_like(v)
+        s = torch.cuda.current_stream(v.device)
+        check(self._lib.bfhipCovMatvecDevice(self._h, C.c_void_p(gamma_lam.data_ptr()) if gamma_lam is not None else None,
+                                             C.c_void_p(row_perm.data_ptr()) if row_perm is not None else None,
+                                             C.c_void_p(rev_row_perm.data_ptr()) if rev_row_perm is not None else None,
+                                             C.c_void_p(v.data_ptr()), C.c_void_p(z.data_ptr()), C.c_void_p(s.cuda_stream)))
+        return z
+
     def set_profile_sampling(self, every):
         """Bracket one apply in `every` with events (bfhipSetProfileSampling)."""
         check(self._lib.bfhipSetProfileSampling(self._h, int(every)))

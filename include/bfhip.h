@@ -237,6 +237,20 @@ int bfhipGetStageProfile(BfhipOperator *op, double *ms, uint64_t *launches, uint
  * an N = 65536 apply, 0.3 % of the headline one.  The sampled launches are timed exactly as before. */
 int bfhipSetProfileSampling(BfhipOperator *op, uint32_t every);
 
+/* ---- covariance products: the caller of the real path ------------------------ */
+/* examples/covariance/lbo_cov.c:36-60 wraps the streamed butterfly Phi (N x J) in two products, both called in loops:
+ *   sample_z:    z = P Phi GammaLam w                         (MulVec, MulVec, bfVecPermute)
+ *   cov_matvec:  z = P Phi GammaLam GammaLam Phi^T P' v       (bfVecPermute, RmulVec, MulVec x3, bfVecPermute)
+ * with GammaLam a BfMatDiagReal (its J diagonal entries are passed here) and P, P' = bfVecRealPermute with rowPerm /
+ * revRowPerm, which SCATTERS: out[perm[i]] = in[i] (src/vec_real.c:312-329).  Through the vtable shim every step is a
+ * host vector (two PCIe round trips per product); these entries keep everything on the device, on `stream`:
+ * permute, A^T, scale, A, permute.  dGammaLam [numCols] in the operator's element type (NULL: identity), perms
+ * uint64 [numRows] (= BfPerm.index; NULL: identity), dW [numCols], dV and dZ [numRows].  Real operators only
+ * (TYPE_ERROR otherwise); bfhipCovMatvecDevice needs BFHIP_FLAG_ADJOINT. */
+int bfhipCovSampleDevice(BfhipOperator *op, const void *dGammaLam, const uint64_t *dRowPerm, const void *dW, void *dZ, void *stream);
+int bfhipCovMatvecDevice(BfhipOperator *op, const void *dGammaLam, const uint64_t *dRowPerm, const uint64_t *dRevRowPerm,
+                         const void *dV, void *dZ, void *stream);
+
 /* ---- plan inspection (no device needed) ---------------------------------- */
 /* The flattened per-stage layout, as the kernels see it.  Valid only for an
  * operator compiled with BFHIP_FLAG_PLAN_ONLY (the host mirrors are dropped

@@ -185,6 +185,7 @@ STUB(bfdevEventCreate)
 STUB(bfdevEventElapsed)
 STUB(bfdevEventRecord)
 STUB(bfdevEventSync)
+STUB(bfdevScalePermute)
 STUB(bfdevGetDevice)
 STUB(bfdevHostAllocPinned)
 void bfdevHostFreePinned(void *p) { if (p) { fprintf(stderr, "device layer reached: bfdevHostFreePinned(non-NULL)\n"); abort(); } }

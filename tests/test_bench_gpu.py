@@ -71,6 +71,8 @@ def test_streamer_workload_contract():
     assert d["config"]["num_cols"] == 32 * 32 and d["config"]["graph"]["identity"] > 0
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["value"] > 0
     assert d["adjoint"]["transpose_identity_rel"] < 1e-4
+    # the path's caller (cov_matvec of lbo_cov.c:48-60) as one device call, checked against the two applies
+    assert d["cov_matvec"]["rel_vs_separate_applies"] < 1e-5 and d["cov_matvec"]["ms_per_product"] > 0
 
 
 def run_streamer():

@@ -470,6 +470,54 @@ def test_rectangular_cov_matvec_through_the_shim(m, n):
     op.close()
 
 
+@pytest.mark.parametrize("demote", [False, True])
+def test_fused_covariance_products_match_the_oracle_sequence(demote):
+    """sample_z and cov_matvec of examples/covariance/lbo_cov.c:36-60 as ONE device call each
+    (bfhipCovSampleDevice / bfhipCovMatvecDevice) against the same sequence run step by step through the oracle's
+    dispatch: bfVecRealPermute scatters (out[perm[i]] = in[i], src/vec_real.c:312-329), GammaLam is a diagonal applied
+    once (sample) or twice (matvec)."""
+    import torch
+    import randgraph
+    from butterfly_amd import _capi
+    from butterfly_amd.operator import HipOperator
+    from oracle import bfref
+    rng = np.random.default_rng(77)
+    m, n = 211, 93
+    desc, vals = randgraph.random_operand(rng, depth=4, size_hint=120, cplx=False, m=m, n=n)
+    A = bfref.from_desc(desc, vals)
+    gam = rng.random(n) + 0.1
+    row_perm = rng.permutation(m)
+    rev = np.empty(m, dtype=np.int64); rev[row_perm] = np.arange(m)      # bfPermGetReversePerm: the inverse permutation
+
+    def permute(x, perm):                 # bfVecRealPermute
+        out = np.empty_like(x); out[perm] = x
+        return out
+    w, v = rng.standard_normal(n), rng.standard_normal(m)
+    z_sample = permute(bfref.mat_mul_vec(A, gam * w), row_perm)
+    t = bfref.mat_rmul_vec(A, permute(v, rev))
+    z_cov = permute(bfref.mat_mul_vec(A, gam * (gam * t)), row_perm)
+    op = HipOperator.from_bfmat(A.ptr.value, flags=_capi.FLAG_ADJOINT, demote_to_f32=demote)
+    dt = torch.float32 if demote else torch.float64
+    dev = torch.device("cuda", 0)
+    tg = torch.from_numpy(gam).to(dev).to(dt)
+    tp = torch.from_numpy(row_perm.astype(np.int64)).to(dev)
+    tr = torch.from_numpy(rev).to(dev)
+    tol = 3e-5 if demote else TOL
+    got = op.cov_sample_device(tg, tp, torch.from_numpy(w).to(dev).to(dt)).cpu().numpy()
+    assert rel(got, z_sample) <= tol
+    got = op.cov_matvec_device(tg, tp, tr, torch.from_numpy(v).to(dev).to(dt)).cpu().numpy()
+    assert rel(got, z_cov) <= tol
+    # identity diagonal and permutations: plain A A^T v
+    got = op.cov_matvec_device(None, None, None, torch.from_numpy(v).to(dev).to(dt)).cpu().numpy()
+    assert rel(got, bfref.mat_mul_vec(A, bfref.mat_rmul_vec(A, v))) <= tol
+    op.close()
+    # complex operators and operators without the transposed plan are refused, not crashed
+    op2 = HipOperator.from_bfmat(A.ptr.value)
+    with pytest.raises(_capi.BfhipError):
+        op2.cov_matvec_device(None, None, None, torch.from_numpy(v).to(dev))
+    op2.close()
+
+
 def test_shim_nested_inside_an_oracle_block_dense(helm2_cases):
     """The device operator as ONE block of a reference container: bfMatBlockDenseMul takes every
     block through bfMatGet(block, BF_POLICY_VIEW) = the block's GetView slot, multiplies, and
