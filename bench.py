@@ -21,6 +21,10 @@ over xGMI, issued by libbfhip.so on the apply stream.
 Prints ONE JSON line on rank 0 (contract in the round prompt): metric, value, roofline{...} for the stage
 kernel from hipEvents inside the library, and cpu_baseline{...} = the CPU oracle (oracle/bfref.c, a port of
 the reference's bfMatMul / bfMatMulVec) timed on a bounded sample of the same operand on this box.
+The default line (N = 262144, one GPU) also carries two extra keys measured after the headline loop, so that the
+driver's own run times them: `nrhs64` (BASELINE configs[2], FP64-MFMA kernel) and `configs4_streamer` (the
+--workload streamer measurement at N = 1M, in a child process: ~2.3 minutes, most of it laying out the operand on
+the host); --no-extra / --no-streamer skip them.
 """
 from __future__ import annotations
 
@@ -58,7 +62,8 @@ def parse_args(argv):
     ap.add_argument("--seed", type=int, default=1234)
     ap.add_argument("--cpu-budget-gb", type=float, default=4.0, help="leaf bytes of the cpu_baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extra", action="store_true", help="skip the 64-RHS measurement appended to the default line")
+    ap.add_argument("--no-extra", action="store_true", help="skip the 64-RHS and configs[4] measurements appended to the default line")
+    ap.add_argument("--no-streamer", action="store_true", help="skip only the configs[4] (streamed butterfly) measurement appended to the default line")
     ap.add_argument("--dtype", choices=["c128", "f64", "f32"], default=None,
                     help="helm2: c128 (headline); f64 / f32 = the same block layout with real values (a kernel proxy).  "
                          "streamer: f32 (default; the build's extension, configs[4]) or f64 (the reference's type)")
@@ -628,6 +633,28 @@ def main():
             o64.close()
         except Exception as e:
             out["nrhs64"] = {"error": repr(e)}
+
+        # BASELINE configs[4] rides along too: the streamed real butterfly at N = 1M x 65536 columns, fp32, in a child
+        # process of its own (its operand is laid out by 2 - 3 minutes of host Python; bounded at 5 minutes)
+        if not args.no_streamer:
+            import subprocess
+            try:
+                torch.cuda.empty_cache()
+                cmd = [sys.executable, os.path.abspath(__file__), "--workload", "streamer", "--steps", "10", "--warmup", "2", "--adjoint",
+                       "--no-cpu-baseline", "--no-extra", "--seed", str(args.seed)]
+                env = dict(os.environ)
+                for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+                    env.pop(k, None)
+                pr = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env)
+                line = [ln for ln in pr.stdout.splitlines() if ln.startswith("{")]
+                if pr.returncode != 0 or not line:
+                    raise RuntimeError(f"child exit {pr.returncode}: {pr.stderr[-300:]}")
+                c = json.loads(line[-1])
+                out["configs4_streamer"] = {"config": c["config"]["workload"], "metric": c["metric"], "value": c["value"], "unit": c["unit"],
+                                            "dtype": c["dtype"], "steps": c["steps"], "ms_per_step": c["ms_per_step"], "roofline": c["roofline"],
+                                            "adjoint": c.get("adjoint"), "cov_matvec": c.get("cov_matvec")}
+            except Exception as e:
+                out["configs4_streamer"] = {"error": repr(e)[:400]}
 
     if rank == 0:
         real_stdout.write(json.dumps(out) + "\n")
