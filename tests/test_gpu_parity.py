@@ -403,6 +403,59 @@ def test_save_load_round_trip(tmp_path, helm2_cases):
         assert e.value.code == 6, what
 
 
+def test_item_class_flags_of_a_file_are_checked(tmp_path):
+    """Round 2's item classes are promises the kernels rely on (a MERGED / SMALL item's dense pieces are one contiguous
+    block of bounded width, SMALL items close the list, a ROWMAJOR item has at most two lane granules of rows): a file
+    that breaks one of them is a FILE_ERROR, a faithful one loads and applies bit-identically."""
+    import randgraph
+    from butterfly_amd import _capi
+    from butterfly_amd.operator import HipOperator
+    rng = np.random.default_rng(12)
+    d, vals, dense = randgraph.narrow_items_operand(rng)
+    op = HipOperator.from_desc(d, vals, flags=_capi.FLAG_ADJOINT)
+    x, v = rng.standard_normal(dense.shape[1]), rng.standard_normal(dense.shape[0])
+    y, z = op.apply_host(x), op.apply_transpose_host(v)
+    path = tmp_path / "narrow.bfhip"
+    op.save(path)
+    op.close()
+    op2 = HipOperator.load(path)
+    assert np.array_equal(op2.apply_host(x), y) and np.array_equal(op2.apply_transpose_host(v), z)
+    op2.close()
+    raw = bytearray(path.read_bytes())
+    # 88-byte file header, 40-byte plan header, 56-byte stage header {numItems, numPieces, ...}, then stage 0's items
+    num_items = int.from_bytes(raw[128:136], "little")
+    items = np.frombuffer(bytes(raw[184:184 + 16 * num_items]), dtype=_capi.ITEM_DTYPE)
+    small = np.nonzero(items["mrFlags"] & (1 << 19))[0]
+    merged = np.nonzero((items["mrFlags"] & (1 << 18)) != 0)[0]
+    assert len(small) >= 10 and len(merged) >= 1 and small[-1] == num_items - 1
+
+    def flip(index, xor=0, set_rows=None):
+        b = bytearray(raw)
+        off = 184 + 16 * int(index) + 12
+        f = int.from_bytes(b[off:off + 4], "little") ^ xor
+        if set_rows is not None:
+            f = (f & ~0xFFFF) | set_rows
+        b[off:off + 4] = f.to_bytes(4, "little")
+        bad = tmp_path / "flags.bfhip"
+        bad.write_bytes(bytes(b))
+        with pytest.raises(_capi.BfhipError) as e:
+            HipOperator.load(bad)
+        assert e.value.code == 6
+    flip(0, xor=1 << 19)                 # a SMALL item at the head of the list
+    flip(small[-1], set_rows=40)         # a small item taller than two lane granules
+    flip(merged[0], xor=1 << 17)         # MERGED and ROWMAJOR at once
+    flip(0, xor=1 << 21)                 # an unknown flag
+    # the class is a scheduling promise, not a layout: the first small item without its flag simply runs as an ordinary item
+    b = bytearray(raw)
+    off = 184 + 16 * int(small[0]) + 12
+    b[off:off + 4] = (int.from_bytes(b[off:off + 4], "little") ^ (1 << 19)).to_bytes(4, "little")
+    ok = tmp_path / "unflagged.bfhip"
+    ok.write_bytes(bytes(b))
+    op3 = HipOperator.load(ok)
+    assert rel(op3.apply_host(x), y) <= TOL
+    op3.close()
+
+
 @pytest.mark.parametrize("seed", range(3))
 def test_deeply_nested_real_graphs_forward_and_transposed(seed):
     """The survey's fac_streamer sample nests all three block types and Identity leaves up to 9 deep
