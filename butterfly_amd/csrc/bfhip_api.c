@@ -790,6 +790,7 @@ static int validateStage(BfPlan const *pl, uint64_t arenaElems, BfStage const *s
     if (!mr || mr > pl->maxItemRows || mr > st->maxRows || (it->mrFlags & ~(0xffffu | BF_ITEM_OUT_Y | BF_ITEM_ROWMAJOR | BF_ITEM_MERGED | BF_ITEM_SMALL)) ||
         ((it->mrFlags & BF_ITEM_SMALL) != 0) != (i >= st->firstSmall) ||
         ((it->mrFlags & BF_ITEM_ROWMAJOR) && (pl->transposed || pl->dtype == BFHIP_C128 || mr > 2 * pl->epl)) ||
+        (pl->transposed && mr > 64) ||       /* bfStageKernelT: at most 64 columns of A per item */
         (uint64_t)it->outOff + mr > outLen || (uint64_t)it->pieceBegin + it->numPieces > st->numPieces)
       return bfhipFail(BFABI_ERROR_FILE_ERROR, "corrupt operator file: item %llu out of bounds", (unsigned long long)i);
     uint32_t const mrPad = (mr + pl->epl - 1) / pl->epl * pl->epl;

@@ -603,7 +603,10 @@ int bfPlanBuild(BfIr const *ir, BfPlanOptions const *po, BfPlan *plan) {
       gr->chunkRows = (uint32_t)chunk;
       numItems += (gr->rows + chunk - 1) / chunk;
     }
-    for (uint64_t z = 0; z < numGaps; ++z) numZeroItems += (gaps[z].len + plan->maxItemRows - 1) / plan->maxItemRows;
+    /* zero fills run in the stage's kernel: forward 64 row slots, transposed this stage's 16 or 64 columns (a 64-row fill
+     * in a 16-column stage would push the whole stage onto the 64-column kernel) */
+    uint64_t const zeroChunk = T ? itemRows : plan->maxItemRows;
+    for (uint64_t z = 0; z < numGaps; ++z) numZeroItems += (gaps[z].len + zeroChunk - 1) / zeroChunk;
     ItemTmp *tmp = malloc((numItems + numZeroItems + 1) * sizeof(ItemTmp));
     if (!tmp) { rc = bfhipFail(BFABI_ERROR_MEMORY_ERROR, "host OOM"); goto stage_fail; }
     uint64_t ni = 0;
@@ -739,8 +742,8 @@ int bfPlanBuild(BfIr const *ir, BfPlanOptions const *po, BfPlan *plan) {
     /* zero-fill items */
     uint64_t ii = numBig;
     for (uint64_t z = 0; z < numGaps; ++z) {
-      for (uint64_t r0 = 0; r0 < gaps[z].len; r0 += plan->maxItemRows) {
-        uint64_t rows = gaps[z].len - r0 < plan->maxItemRows ? gaps[z].len - r0 : plan->maxItemRows;
+      for (uint64_t r0 = 0; r0 < gaps[z].len; r0 += zeroChunk) {
+        uint64_t rows = gaps[z].len - r0 < zeroChunk ? gaps[z].len - r0 : zeroChunk;
         BfDevItem *it = &st->items[ii++];
         it->pieceBegin = (uint32_t)np; it->numPieces = 0;
         uint64_t outOff = gaps[z].buf == by ? gaps[z].off + r0 : b.bufs[gaps[z].buf].arenaOff + gaps[z].off + r0;

@@ -58,6 +58,8 @@ def run_plan(op, x, transpose=False):
         _capi.check(lib.bfhipPlanGetStage(op.handle, s, C.byref(sv)))
         items = _view(sv.items, int(sv.numItems), _capi.ITEM_DTYPE)
         pieces = _view(sv.pieces, int(sv.numPieces), _capi.PIECE_DTYPE)
+        if transpose:        # bfStageKernelT: at most 64 columns of A per item
+            assert ((items["mrFlags"] & 0xFFFF) <= 64).all()
         small = (items["mrFlags"] & BF_ITEM_SMALL) != 0
         if small.any():      # small items are the tail of the list (they get their own launch, four to a wavefront)
             first = int(np.argmax(small))

@@ -171,3 +171,21 @@ def narrow_items_operand(rng):
     dense = np.vstack(blocks)
     d.root = d.add(hs.NODE_BLOCK, dense.shape[0], 300, ch, hs.BF_TYPE_BLOCK_COO)
     return d, vals, dense
+
+
+def few_row_column_operand(rng, leaves=70, width=900):
+    """A block column of a streamed butterfly's W factor: `leaves` few-row leaves (1 - 8 rows, `width` columns) stacked
+    on top of one another with two tall leaves among them -- in the transposed plan a chain of that many pieces per
+    item (the workgroup-shared path), row-major and column-major pieces over the same outputs.  Real (f64) operand.
+    Returns (desc, vals, dense matrix)."""
+    from butterfly_amd import helm2_structure as hs
+    d = hs.Desc(dtype=1)
+    vals, ch, r0 = {}, [], 0
+    blocks = []
+    for i in range(leaves):
+        h = 100 + i if i in (7, 41) else int(rng.integers(1, 9))
+        a = rng.standard_normal((h, width)) / np.sqrt(width)
+        leaf = d.add(hs.NODE_DENSE, h, width); vals[leaf] = a
+        ch.append((leaf, r0, 0)); blocks.append(a); r0 += h
+    d.root = d.add(hs.NODE_BLOCK, r0, width, ch, hs.BF_TYPE_BLOCK_DENSE)
+    return d, vals, np.vstack(blocks)

@@ -710,6 +710,20 @@ def test_few_row_leaves_on_gpu(demote, nrhs):
     _check_against_dense(d, vals, dense, rng, demote, nrhs)
 
 
+@pytest.mark.parametrize("demote", [False, True])
+def test_transposed_chain_of_few_row_pieces_on_gpu(demote):
+    """A block column of 70 - 300 few-row leaves: transposed items that are chains of hundreds of row-major and
+    column-major pieces (shared by a workgroup), windows of more than 64 piece descriptors, leaves whose last forward
+    task is too narrow for the row-major layout."""
+    import randgraph
+    rng = np.random.default_rng(99)
+    for leaves, width in ((70, 900), (300, 2100)):
+        d, vals, dense = randgraph.few_row_column_operand(rng, leaves, width)
+        _check_against_dense(d, vals, dense, rng, demote, 1)
+    d, vals, dense = randgraph.few_row_column_operand(rng, 90, 520)
+    _check_against_dense(d, vals, dense, rng, demote, 3)
+
+
 def _check_against_dense(d, vals, dense, rng, demote, nrhs):
     from butterfly_amd import _capi
     from butterfly_amd.operator import HipOperator

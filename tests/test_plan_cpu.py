@@ -190,6 +190,22 @@ def test_narrow_items_are_merged_and_small_ones_close_the_list(demote):
     op.close()
 
 
+@pytest.mark.parametrize("demote", [False, True])
+def test_transposed_plan_of_a_block_column_of_few_row_leaves(demote):
+    """A block column of a streamed butterfly's W factor under the transposed plan: chains of dozens of few-row pieces
+    per item (row-major and column-major ones over the same outputs), leaves of 2100 columns whose last forward task
+    (52 columns) is too narrow for the row-major layout."""
+    rng = np.random.default_rng(98)
+    for leaves, width in ((70, 900), (40, 2100)):
+        d, vals, dense = randgraph.few_row_column_operand(rng, leaves, width)
+        op = HipOperator.from_desc(d, vals, flags=_capi.FLAG_PLAN_ONLY | _capi.FLAG_ADJOINT, demote_to_f32=demote)
+        x, v = rng.standard_normal(dense.shape[1]), rng.standard_normal(dense.shape[0])
+        tol = 2e-6 if demote else 1e-13
+        assert rel(plan_emulator.run_plan(op, x), dense @ x) < tol
+        assert rel(plan_emulator.run_plan(op, v, transpose=True), dense.T @ v) < tol
+        op.close()
+
+
 def test_row_sharding_union_equals_full(helm2_cases):
     n, k = 2048, 128
     desc, tp, vals = helm2_cases(n, k)
