@@ -487,7 +487,7 @@ def main():
                 pass
         # context for `frac` (informational; `peak` stays the guide's figure): what a pure stream of
         # non-temporal reads / a bare loop of these MFMAs reaches on an MI355X of this pool
-        for key, fn, fld in (("measured_stream_read_gbs", "r1_hbm_peak.json", "read_nt_gbs"), ("measured_mfma_loop_tflops", "r1_mfma_peak.json", "fp64_mfma_16x16x4_tflops")):
+        for key, fn, fld in (("measured_stream_read_gbs", "r2_hbm_peak.json", "read_nt_gbs"), ("measured_mfma_loop_tflops", "r2_mfma_peak.json", "fp64_mfma_16x16x4_tflops")):
             if (roofline["bound"] == "hbm") == (fld == "read_nt_gbs"):
                 try:
                     roofline[key] = json.load(open(os.path.join(ROOT, "profiles", fn)))[fld]

@@ -24,15 +24,21 @@ __global__ __launch_bounds__(256) void readStream(u4 const *src, uint64_t unitsP
 }
 
 int main() {
-  uint64_t const bytes = 64ull << 30, waves = 256ull * 8 * 4 * 16;      // 128 KiB... chunks sized below
+  // 131072 wavefronts of 512 KiB each is the stage kernels' regime (items of ~100 KiB, all wave slots busy); fewer,
+  // longer streams (32768 x 2 MiB) read 2 % faster: both are reported, the larger one is the ceiling
+  uint64_t const bytes = 64ull << 30;
+  double best[2] = {0, 0};
+  double res[3] = {0, 0, 0};
+  for (uint64_t waves : {256ull * 8 * 4 * 16, 256ull * 8 * 4 * 4}) {
   uint64_t const unitsPerWave = bytes / 16 / waves / 512 * 512;
-  void *a, *b; unsigned *sink;
-  if (hipMalloc(&a, bytes) != hipSuccess || hipMalloc(&b, bytes) != hipSuccess) { printf("alloc failed\n"); return 1; }
-  hipMalloc((void **)&sink, 4);
-  hipMemset(a, 0, bytes); hipMemset(b, 0, bytes);
+  static void *a = nullptr, *b = nullptr; static unsigned *sink = nullptr;
+  if (!a) {
+    if (hipMalloc(&a, bytes) != hipSuccess || hipMalloc(&b, bytes) != hipSuccess) { printf("alloc failed\n"); return 1; }
+    hipMalloc((void **)&sink, 4);
+    hipMemset(a, 0, bytes); hipMemset(b, 0, bytes);
+  }
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   float ms;
-  double res[3];
   for (int mode = 0; mode < 3; ++mode) {
     for (int rep = 0; rep < 2; ++rep) {
       hipEventRecord(e0);
@@ -44,8 +50,11 @@ int main() {
     }
     double const moved = mode == 2 ? 2.0 * bytes : (double)unitsPerWave * 16 * waves;
     res[mode] = moved / ms / 1e6;
+    if (mode < 2 && res[mode] > best[mode]) best[mode] = res[mode];
   }
-  printf("{\"read_nt_gbs\": %.1f, \"read_plain_gbs\": %.1f, \"memcpy_d2d_read_plus_write_gbs\": %.1f, \"bytes\": %llu}\n", res[0], res[1], res[2],
+  if (waves == 256ull * 8 * 4 * 16) printf("{\"read_nt_gbs_131072_waves\": %.1f, \"read_plain_gbs_131072_waves\": %.1f, ", res[0], res[1]);
+  }
+  printf("\"read_nt_gbs\": %.1f, \"read_plain_gbs\": %.1f, \"memcpy_d2d_read_plus_write_gbs\": %.1f, \"bytes\": %llu}\n", best[0], best[1], res[2],
          (unsigned long long)bytes);
   return 0;
 }
