@@ -1038,7 +1038,8 @@ __global__ __launch_bounds__(256) void bfScalePermuteKernel(S *dst, S const *src
   if (i >= n) return;
   S v = src[i];
   if (scale) { S const g = scale[i]; v *= power == 2 ? g * g : g; }
-  dst[perm ? perm[i] : i] = v;
+  uint64_t const j = perm ? perm[i] : i;
+  if (j < n) dst[j] = v;          // an index outside the vector (not a permutation) is dropped, never written
 }
 
 // ---------------------------------------------------------------------------
