@@ -1020,7 +1020,8 @@ __global__ __launch_bounds__(256) void bfReduceKernel(ReduceBatch const B) {
   T acc[NC];
 #pragma unroll
   for (int c = 0; c < NC; ++c) acc[c] = 0;
-  for (uint32_t s = b; s < e; ++s) {
+#pragma unroll 8
+  for (uint32_t s = b; s < e; ++s) {          // same order as before; the unrolled loads are issued together
     T const *src = temp + ((uint64_t)(E.srcBias[s] + (int64_t)row) * nrhs + q) * NC;
 #pragma unroll
     for (int c = 0; c < NC; ++c) acc[c] += src[c];
