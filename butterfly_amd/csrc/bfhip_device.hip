@@ -845,8 +845,8 @@ __global__ __launch_bounds__(BF_WAVES_PER_WG * 64) void bfStageKernelT(StagePara
     for (uint32_t wbase = 0; wbase < it.numPieces; wbase += 64) {
       uint32_t const wn = it.numPieces - wbase < 64 ? it.numPieces - wbase : 64;
       BfPieceWin const win = bfPieceWinLoad(p.pieces + it.pieceBegin + wbase, wn, lane);
-      for (uint32_t pi = 0; pi < wn; ++pi) {
-        if (COOP && ((wbase + pi) & wmask) != wsel) continue;
+      uint32_t const pstep = wmask + 1u;               // this wavefront's pieces: wsel, wsel + pstep, ... (wbase is a multiple of 64)
+      for (uint32_t pi = wsel; pi < wn; pi += pstep) {
         BfDevPiece const pc = bfPieceWinGet(win, pi);
         S const *xin = (pc.flags & BF_PIECE_IN_X) ? (S const *)p.x : (S const *)p.temp;
         xin += ((uint64_t)pc.inOff * nrhs + q) * NC;
@@ -869,10 +869,18 @@ __global__ __launch_bounds__(BF_WAVES_PER_WG * 64) void bfStageKernelT(StagePara
             uint32_t const cgc = cgRm < (mr + EPL - 1) / EPL ? cgRm : (mr - 1) / EPL;   // clamp into the item's columns
             U const *src = arena + pc.dataOff / EPL + cgc;
             uint32_t const rowUnits = pc.ld / EPL;
-            // every row this lane owns is requested before the first is used (rows past n: clamped address, x = 0)
+            // every row this lane owns is requested before the first is used (rows past n: clamped address, x = 0).
+            // A block column of a streamed butterfly is a chain of hundreds of such ~1 KB pieces: when the wavefront's
+            // next piece is row-major too, both are requested before either is used (two pieces in flight for 10 VGPRs)
             constexpr int ITERS = (2 * EPL + RL_RM - 1) / RL_RM;
-            U a[ITERS];
-            S xv[ITERS];
+            bool dual = pi + pstep < wn;
+            BfDevPiece pc2 = pc;
+            if (dual) {
+              pc2 = bfPieceWinGet(win, pi + pstep);
+              dual = (pc2.flags & (BF_PIECE_ROWMAJOR | BF_PIECE_IDENTITY)) == BF_PIECE_ROWMAJOR;
+            }
+            U a[ITERS], a2[ITERS];
+            S xv[ITERS], xv2[ITERS];
 #pragma unroll
             for (int i = 0; i < ITERS; ++i) {
               uint32_t const srow = rlRm + (uint32_t)i * RL_RM, sc = srow < n ? srow : n - 1;
@@ -880,10 +888,30 @@ __global__ __launch_bounds__(BF_WAVES_PER_WG * 64) void bfStageKernelT(StagePara
               S const xr = xin[(uint64_t)sc * nrhs];
               xv[i] = srow < n ? xr : (S)0;
             }
+            if (dual) {                                             // wave-uniform
+              S const *xin2 = ((pc2.flags & BF_PIECE_IN_X) ? (S const *)p.x : (S const *)p.temp) + ((uint64_t)pc2.inOff * nrhs + q);
+              uint32_t const n2 = pc2.ncols;
+              U const *src2 = arena + pc2.dataOff / EPL + cgc;
+              uint32_t const rowUnits2 = pc2.ld / EPL;
+#pragma unroll
+              for (int i = 0; i < ITERS; ++i) {
+                uint32_t const srow = rlRm + (uint32_t)i * RL_RM, sc = srow < n2 ? srow : n2 - 1;
+                a2[i] = BF_T_WIDE_NT ? bfLoadStreamV(src2 + (uint64_t)sc * rowUnits2) : src2[(uint64_t)sc * rowUnits2];
+                S const xr = xin2[(uint64_t)sc * nrhs];
+                xv2[i] = srow < n2 ? xr : (S)0;
+              }
+            }
 #pragma unroll
             for (int i = 0; i < ITERS; ++i)
 #pragma unroll
               for (int e = 0; e < EPL; ++e) racc[e] = fma(a[i].v[e], xv[i], racc[e]);
+            if (dual) {
+#pragma unroll
+              for (int i = 0; i < ITERS; ++i)
+#pragma unroll
+                for (int e = 0; e < EPL; ++e) racc[e] = fma(a2[i].v[e], xv2[i], racc[e]);
+              pi += pstep;                                          // the second piece is done
+            }
             continue;
           }
         }
