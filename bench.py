@@ -94,7 +94,9 @@ def launch_ranks(args, argv):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
            "--master-port", str(free_port()), os.path.abspath(__file__)] + argv
     log("bench.py: starting", args.gpus, "ranks:", " ".join(cmd))
-    p = subprocess.run(cmd, stdout=subprocess.PIPE, text=True)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL between processes needs it on this driver
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, text=True, env=env)
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
     if p.returncode != 0 or not lines:
         log(f"bench.py: rank processes failed (exit code {p.returncode}, {len(lines)} JSON line(s))")
@@ -238,6 +240,7 @@ def cpu_baseline_streamer(graph, seed, budget_bytes):
 def main():
     argv = sys.argv[1:]
     args = parse_args(argv)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # before HIP starts: dmabuf IPC for RCCL between rank processes
     # BENCH_FORCE_LAUNCH=1 (tests): go through the launcher path with a single rank as well
     if (args.gpus > 1 or os.environ.get("BENCH_FORCE_LAUNCH") == "1") and "WORLD_SIZE" not in os.environ:
         launch_ranks(args, argv)          # never returns
