@@ -442,7 +442,7 @@ __global__ __launch_bounds__(BF_WAVES_PER_WG * 64) __attribute__((amdgpu_waves_p
   if (item0 >= p.numItems) return;
   S *xs = (S *)ldsRaw[wave];
   constexpr int XT = BF_SMALL_COLS / 16;           // x columns a lane gathers
-  constexpr int AS = 8;                            // A loads in flight per lane and batch
+  constexpr int AS = 4;                            // A loads in flight per lane and batch (8: 122 VGPRs, 4 waves/SIMD; 4: 94, 5 waves)
   uint32_t const gid = (uint32_t)lane >> 4, gl = (uint32_t)lane & 15u;
   uint32_t const idx = item0 + gid;
   bool const valid = idx < p.numItems;
@@ -519,26 +519,21 @@ __global__ __launch_bounds__(BF_WAVES_PER_WG * 64) __attribute__((amdgpu_waves_p
 #pragma unroll
     for (int t = 0; t < XT; ++t) xg[gl + 16 * t] = xr[t];          // columns >= n hold zero
     waveSync();
+    for (uint32_t b0 = 0;;) {                            // batches of AS block steps; the first was requested before the hand-off
 #pragma unroll
-    for (int k = 0; k < AS; ++k) {
-      uint32_t const col = c + k * g16;
-      S const xv = col < BF_SMALL_COLS ? xg[col] : (S)0;
+      for (int k = 0; k < AS; ++k) {
+        uint32_t const col = c + (b0 + k) * g16;
+        S const xv = col < BF_SMALL_COLS ? xg[col] : (S)0;
 #pragma unroll
-      for (int e = 0; e < EPL; ++e) acc[e] = fma(a[k].v[e], xv, acc[e]);
-    }
-    if (__builtin_amdgcn_ballot_w64(steps > (uint32_t)AS)) {        // only ms == 2 blocks wider than 64 columns
+        for (int e = 0; e < EPL; ++e) acc[e] = fma(a[k].v[e], xv, acc[e]);
+      }
+      b0 += AS;
+      if (!__builtin_amdgcn_ballot_w64(b0 < steps)) break;         // wave-uniform: some group has more columns
 #pragma unroll
       for (int k = 0; k < AS; ++k) {
 #pragma unroll
         for (int e = 0; e < EPL; ++e) a[k].v[e] = 0;
-        if ((uint32_t)(k + AS) < steps && c + (k + AS) * g16 < n) a[k] = bfLoadStreamV(ap + 16 * (k + AS));
-      }
-#pragma unroll
-      for (int k = 0; k < AS; ++k) {
-        uint32_t const col = c + (k + AS) * g16;
-        S const xv = col < BF_SMALL_COLS ? xg[col] : (S)0;
-#pragma unroll
-        for (int e = 0; e < EPL; ++e) acc[e] = fma(a[k].v[e], xv, acc[e]);
+        if (b0 + k < steps && c + (b0 + k) * g16 < n) a[k] = bfLoadStreamV(ap + 16 * (b0 + k));
       }
     }
     // sum over the group's columns: fixed butterfly inside the 16 lanes (deterministic)
