@@ -330,6 +330,7 @@ int bfhipCompileIrFill(BfIr *ir, BfhipOptions const *opts, BfFillFn fill, void *
   }
   po.minChunkRows = o.maxRhs >= 3 ? 32 : 16;   /* operators compiled for RHS blocks run on the matrix-core kernel */
   po.rowBlockBegin = o.rowBlockBegin;
+  po.rowAlignBytes = (o.flags & BFHIP_FLAG_ADJOINT) ? 128 : 0;
   po.rowBlockEnd = o.rowBlockEnd;
   if ((rc = bfPlanBuild(ir, &po, &op->plan))) goto done;
   op->leafBytesAlgorithmic = op->plan.leafElems * op->plan.elemSize;
