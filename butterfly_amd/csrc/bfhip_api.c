@@ -798,12 +798,13 @@ static int validateStage(BfPlan const *pl, uint64_t arenaElems, BfStage const *s
     if (it->mrFlags & (BF_ITEM_MERGED | BF_ITEM_SMALL)) {     /* the kernel reads the dense pieces as one block from the first one's offset */
       int const sm = (it->mrFlags & BF_ITEM_SMALL) != 0;
       uint64_t next = 0, dense = 0;
-      int badm = pl->transposed || pl->dtype == BFHIP_C128 || (it->mrFlags & BF_ITEM_ROWMAJOR) || it->numPieces > (sm ? BF_SMALL_PIECES : 64u) ||
-                 (sm && mr > 2 * pl->epl);
+      int const smRm = sm && (it->mrFlags & BF_ITEM_ROWMAJOR);      /* small items: row-major pieces, no contiguity promise */
+      int badm = pl->transposed || pl->dtype == BFHIP_C128 || (!sm && (it->mrFlags & BF_ITEM_ROWMAJOR)) || it->numPieces > (sm ? BF_SMALL_PIECES : 64u) ||
+                 (sm && (mr > 2 * pl->epl || !(it->mrFlags & BF_ITEM_ROWMAJOR)));
       for (uint32_t k = 0; k < it->numPieces && !badm; ++k) {
         BfDevPiece const *pc = &pieces[it->pieceBegin + k];
         if (pc->flags & BF_PIECE_IDENTITY) continue;
-        if (dense && pc->dataOff != next) badm = 1;
+        if (!smRm && dense && pc->dataOff != next) badm = 1;
         next = pc->dataOff + (uint64_t)mrPad * pc->ncols; dense += pc->ncols;
       }
       if (badm || (!dense && !sm) || dense > (sm ? BF_SMALL_COLS : BF_MERGE_COLS))

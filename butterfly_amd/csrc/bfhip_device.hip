@@ -426,31 +426,28 @@ __device__ __forceinline__ void bfRowMajorPiece(void const *rowpV, uint32_t upr,
 }
 
 // Four small items per wavefront, one per group of 16 lanes (BF_ITEM_SMALL: at most 2 lane granules of rows, at most
-// BF_SMALL_PIECES pieces, dense parts one contiguous mrPad x n block with n <= BF_SMALL_COLS).  A streamed butterfly's
-// inner factors are hundreds of thousands of such items (row nodes of ~5 rows: an identity term plus a leaf of ~50
-// columns); one per wavefront they cost a launch slot and four dependent memory round trips each for ~1 KB of data.
-// Group lane gl = (column c = gl / ms, row slot rs = gl % ms) exactly like the full-width kernel with 16 lanes.
+// BF_SMALL_PIECES pieces, fewer than BF_SMALL_COLS dense columns in all).  A streamed butterfly's inner factors are
+// hundreds of thousands of such items (row nodes of ~5 rows: an identity term plus a leaf of ~50 columns); one per
+// wavefront they cost a launch slot and four dependent memory round trips each for ~1 KB of data.  Their dense pieces
+// are stored ROW-major like the wide few-row leaves (rows end on the lane granule, nothing else is padded: 5 rows take
+// 5/8 of what the column-major layout reads): group lane gl owns 16-byte column units gl and gl + 16 of every row, x
+// comes straight from global memory, the rows are summed inside the 16 lanes by a fixed butterfly.  No LDS.
 template <int DT>
 __global__ __launch_bounds__(BF_WAVES_PER_WG * 64) __attribute__((amdgpu_waves_per_eu(4, 8))) void bfStageKernelSmall(StageParams p) {
   using S = typename Traits<DT>::S;
   constexpr int EPL = Traits<DT>::EPL;
+  constexpr int RMAX = 2 * EPL;
   struct __attribute__((aligned(16))) V { S v[EPL]; };
-  __shared__ __attribute__((aligned(16))) unsigned char ldsRaw[BF_WAVES_PER_WG][4 * BF_SMALL_COLS * sizeof(S)];
   int const wave = threadIdx.x >> 6;
   int const lane = threadIdx.x & 63;
   uint32_t const item0 = __builtin_amdgcn_readfirstlane((blockIdx.x * BF_WAVES_PER_WG + wave) * 4u);
   if (item0 >= p.numItems) return;
-  S *xs = (S *)ldsRaw[wave];
-  constexpr int XT = BF_SMALL_COLS / 16;           // x columns a lane gathers
-  constexpr int AS = 4;                            // A loads in flight per lane and batch (8: 122 VGPRs, 4 waves/SIMD; 4: 94, 5 waves)
   uint32_t const gid = (uint32_t)lane >> 4, gl = (uint32_t)lane & 15u;
   uint32_t const idx = item0 + gid;
   bool const valid = idx < p.numItems;
   BfDevItem it = p.items[valid ? idx : p.numItems - 1];
   uint32_t const mr = valid ? (it.mrFlags & 0xffffu) : 0u;
   uint32_t const np = valid ? it.numPieces : 0u;
-  uint32_t const ms = mr > (uint32_t)EPL ? 2u : 1u;
-  uint32_t const c = ms == 2 ? gl >> 1 : gl, rs = ms == 2 ? gl & 1u : 0u, g16 = 16u / ms;
   // piece descriptors: group lane k holds piece k
   BfDevPiece my;
   my.dataOff = 0; my.inOff = 0; my.ncols = 0; my.flags = 0; my.ld = 0;
@@ -464,96 +461,55 @@ __global__ __launch_bounds__(BF_WAVES_PER_WG * 64) __attribute__((amdgpu_waves_p
   V const *arena = (V const *)p.arena;
   uint32_t const nrhs = p.nrhs;
   S *out = (it.mrFlags & BF_ITEM_OUT_Y) ? (S *)p.y : (S *)p.temp;
-  S *xg = xs + gid * BF_SMALL_COLS;                // the group's x block in LDS
   for (uint32_t q = 0; q < nrhs; ++q) {
-    S acc[EPL];
+    S racc[RMAX];
 #pragma unroll
-    for (int e = 0; e < EPL; ++e) acc[e] = 0;
-    uint32_t src[XT];
-    uint32_t srcX = 0;
-#pragma unroll
-    for (int t = 0; t < XT; ++t) src[t] = ~0u;
-    uint32_t base = 0, dataLo = 0, dataHi = 0;
+    for (int r = 0; r < RMAX; ++r) racc[r] = 0;
+    S ident = 0;                                       // group lane r: identity contributions to row r
     for (uint32_t k = 0; k < npMax; ++k) {
       int const from = (int)(gid * 16u + k);
       uint32_t const flags = (uint32_t)__shfl((int)my.flags, from, 64);
       uint32_t const inOff = (uint32_t)__shfl((int)my.inOff, from, 64);
       uint32_t const ncols = (uint32_t)__shfl((int)my.ncols, from, 64);
+      uint32_t const ld = (uint32_t)__shfl((int)my.ld, from, 64);
       uint32_t const dLo = (uint32_t)__shfl((int)(uint32_t)my.dataOff, from, 64);
       uint32_t const dHi = (uint32_t)__shfl((int)(uint32_t)(my.dataOff >> 32), from, 64);
       if (k >= np) continue;
+      S const *xin = ((flags & BF_PIECE_IN_X) ? (S const *)p.x : (S const *)p.temp) + ((uint64_t)inOff * nrhs + q);
       if (flags & BF_PIECE_IDENTITY) {
-        if (c == 0) {
-          S const *xin = ((flags & BF_PIECE_IN_X) ? (S const *)p.x : (S const *)p.temp) + (uint64_t)inOff * nrhs + q;
-#pragma unroll
-          for (int e = 0; e < EPL; ++e) {
-            uint32_t const row = rs * EPL + e;
-            if (row < mr) acc[e] += xin[(uint64_t)row * nrhs];
-          }
-        }
+        if (gl < mr) ident += xin[(uint64_t)gl * nrhs];
         continue;
       }
-      if (base == 0) { dataLo = dLo; dataHi = dHi; }
+      uint32_t const upr = ld / EPL;                   // 16-byte units per row: <= BF_SMALL_COLS / EPL
+      V const *base = arena + (((uint64_t)dHi << 32) | dLo) / EPL;
+#pragma unroll 1
+      for (uint32_t u = gl; u < upr; u += 16u) {
+        V a[RMAX];
 #pragma unroll
-      for (int t = 0; t < XT; ++t) {
-        uint32_t const J = gl + 16u * t - base;          // wraps below base
-        if (J < ncols) { src[t] = inOff + J; srcX = (flags & BF_PIECE_IN_X) ? srcX | (1u << t) : srcX & ~(1u << t); }
-      }
-      base += ncols;
-    }
-    uint32_t const n = base;                             // per group
-    uint32_t const steps = (n + g16 - 1) / g16;          // <= 16 (ms == 2) or 8
-    V const *ap = arena + (((uint64_t)dataHi << 32) | dataLo) / EPL + gl;     // unit (column c + s g16, slot rs) = gl + 16 s
-    V a[AS];
+        for (int r = 0; r < RMAX; ++r) if ((uint32_t)r < mr) a[r] = bfLoadStreamV(base + (uint64_t)r * upr + u);
+        S xv[EPL];
 #pragma unroll
-    for (int k = 0; k < AS; ++k) {
+        for (int e = 0; e < EPL; ++e) xv[e] = u * EPL + e < ncols ? xin[(uint64_t)(u * EPL + e) * nrhs] : (S)0;   // the zero row padding never meets a NaN
 #pragma unroll
-      for (int e = 0; e < EPL; ++e) a[k].v[e] = 0;
-      if ((uint32_t)k < steps && c + k * g16 < n) a[k] = bfLoadStreamV(ap + 16 * k);
-    }
-    S xr[XT];
+        for (int r = 0; r < RMAX; ++r)
+          if ((uint32_t)r < mr) {
 #pragma unroll
-    for (int t = 0; t < XT; ++t)
-      xr[t] = src[t] != ~0u ? (((srcX >> t) & 1u) ? (S const *)p.x : (S const *)p.temp)[(uint64_t)src[t] * nrhs + q] : (S)0;
-    waveSync();
-#pragma unroll
-    for (int t = 0; t < XT; ++t) xg[gl + 16 * t] = xr[t];          // columns >= n hold zero
-    waveSync();
-    for (uint32_t b0 = 0;;) {                            // batches of AS block steps; the first was requested before the hand-off
-#pragma unroll
-      for (int k = 0; k < AS; ++k) {
-        uint32_t const col = c + (b0 + k) * g16;
-        S const xv = col < BF_SMALL_COLS ? xg[col] : (S)0;
-#pragma unroll
-        for (int e = 0; e < EPL; ++e) acc[e] = fma(a[k].v[e], xv, acc[e]);
-      }
-      b0 += AS;
-      if (!__builtin_amdgcn_ballot_w64(b0 < steps)) break;         // wave-uniform: some group has more columns
-#pragma unroll
-      for (int k = 0; k < AS; ++k) {
-#pragma unroll
-        for (int e = 0; e < EPL; ++e) a[k].v[e] = 0;
-        if (b0 + k < steps && c + (b0 + k) * g16 < n) a[k] = bfLoadStreamV(ap + 16 * (b0 + k));
+            for (int e = 0; e < EPL; ++e) racc[r] = fma(a[r].v[e], xv[e], racc[r]);
+          }
       }
     }
-    // sum over the group's columns: fixed butterfly inside the 16 lanes (deterministic)
+    // sum over the group's 16 lanes: fixed butterfly (deterministic); group lane r keeps row r
+    S mine = ident;
 #pragma unroll
-    for (int e = 0; e < EPL; ++e) {
-      S t = acc[e];
+    for (int r = 0; r < RMAX; ++r) {
+      S t = racc[r];
       t += __shfl_xor(t, 8, 64);
       t += __shfl_xor(t, 4, 64);
       t += __shfl_xor(t, 2, 64);
-      S const u = __shfl_xor(t, 1, 64);
-      if (ms == 1) t += u;
-      acc[e] = t;
+      t += __shfl_xor(t, 1, 64);
+      if (gl == (uint32_t)r) mine += t;
     }
-    if (c == 0) {
-#pragma unroll
-      for (int e = 0; e < EPL; ++e) {
-        uint32_t const row = rs * EPL + e;
-        if (row < mr) out[((uint64_t)it.outOff + row) * nrhs + q] = acc[e];
-      }
-    }
+    if (gl < mr) out[((uint64_t)it.outOff + gl) * nrhs + q] = mine;
   }
 }
 

@@ -650,7 +650,8 @@ int bfPlanBuild(BfIr const *ir, BfPlanOptions const *po, BfPlan *plan) {
        * of columns wide) are stored ROW-major: column-major they pad 5 rows to the 4- (fp32) or 2-row (fp64) lane
        * granule (+60 % bytes) and give the transposed kernel 2 of its 16 row lanes; row-major every lane owns
        * 16 bytes of consecutive columns, forward and transposed, and nothing is padded but the row ends. */
-      int const rowMajor = !T && plan->dtype != BFHIP_C128 && mr <= 2 * plan->epl && g->colsSum >= 128;
+      /* (the small items of a stage are row-major too, whatever their width: their kernel reads nothing else) */
+      int const rowMajor = !T && plan->dtype != BFHIP_C128 && mr <= 2 * plan->epl && (g->colsSum >= 128 || tmp[i].small);
       if (rowMajor) flags |= BF_ITEM_ROWMAJOR;
       if (g->reduced) outOff = g->slotOff + r0;
       else if (g->outBuf == by) { outOff = g->outOff + r0; flags |= BF_ITEM_OUT_Y; }
@@ -725,7 +726,8 @@ int bfPlanBuild(BfIr const *ir, BfPlanOptions const *po, BfPlan *plan) {
              * 64-column chunk of a row, what a transposed item reads, is then whole lines -- at 16-byte alignment it
              * touches three lines for two and the transposed stage fetches 1.4x its bytes (PMC) --
              * and the forward kernel's 1 KiB row loads are whole lines too (6.35 -> 6.57 TB/s on the W0 stage) */
-            uint64_t const al = po->rowAlignBytes > 16 ? po->rowAlignBytes / plan->elemSize : plan->epl;
+            /* (not the narrow pieces of small items: a 47-column row is 188 bytes) */
+            uint64_t const al = po->rowAlignBytes > 16 && nc >= 128 ? po->rowAlignBytes / plan->elemSize : plan->epl;
             arenaTop = roundUp(arenaTop, al);
             pc->dataOff = arenaTop;
             pc->flags |= BF_PIECE_ROWMAJOR;

@@ -69,7 +69,9 @@ def run_plan(op, x, transpose=False):
             mr = int(it["mrFlags"]) & 0xFFFF
             mr_pad = mr if transpose else (mr + epl - 1) // epl * epl
             acc = np.zeros((mr, nrhs), dtype=dt)
-            if int(it["mrFlags"]) & (BF_ITEM_MERGED | BF_ITEM_SMALL) and (int(it["mrFlags"]) & BF_ITEM_MERGED or any(not int(pc["flags"]) & BF_PIECE_IDENTITY for pc in pieces[int(it["pieceBegin"]):int(it["pieceBegin"]) + int(it["numPieces"])])):
+            if int(it["mrFlags"]) & BF_ITEM_SMALL:
+                assert int(it["mrFlags"]) & BF_ITEM_ROWMAJOR and not int(it["mrFlags"]) & BF_ITEM_MERGED      # small items: row-major pieces
+            if int(it["mrFlags"]) & BF_ITEM_MERGED and (int(it["mrFlags"]) & BF_ITEM_MERGED or any(not int(pc["flags"]) & BF_PIECE_IDENTITY for pc in pieces[int(it["pieceBegin"]):int(it["pieceBegin"]) + int(it["numPieces"])])):
                 # the kernel reads the dense pieces as ONE mr_pad x n block starting at the first one's offset
                 mine = pieces[int(it["pieceBegin"]):int(it["pieceBegin"]) + int(it["numPieces"])]
                 dense = [pc for pc in mine if not int(pc["flags"]) & BF_PIECE_IDENTITY]
