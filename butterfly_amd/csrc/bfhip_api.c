@@ -474,7 +474,7 @@ static int runPlan(BfhipOperator *op, BfPlan *plan, void const *dX, size_t nrhs,
   for (uint64_t s = 0; s < plan->numStages; ++s) {
     BfStage *st = &plan->stages[s];
     BfLaunchArgs a;
-    a.arena = op->dArena; a.items = st->dItems; a.pieces = st->dPieces; a.numItems = st->numItems; a.firstSmall = st->firstSmall; a.numCoop = st->numCoop;
+    a.arena = op->dArena; a.items = st->dItems; a.pieces = st->dPieces; a.numItems = st->numItems; a.firstSmall = st->firstSmall; a.numCoop = st->numCoop; a.numNarrow = st->numNarrow; a.numCoopNarrow = st->numCoopNarrow; a.maxRowsRest = st->maxRowsRest;
     a.x = dX; a.y = dY; a.temp = op->dTemp; a.zero = op->dZero; a.nrhs = (uint32_t)nrhs; a.dtype = plan->dtype; a.maxRows = st->maxRows;
     a.transposed = plan->transposed;
     if (prof && (rc = bfdevEventRecord(op->evStart[evBase + s], stream))) goto out;
@@ -788,7 +788,8 @@ static int validateStage(BfPlan const *pl, uint64_t arenaElems, BfStage const *s
     BfDevItem const *it = &items[i];
     uint32_t const mr = it->mrFlags & 0xffffu;
     uint64_t const outLen = (it->mrFlags & BF_ITEM_OUT_Y) ? outY : temp;
-    if (!mr || mr > pl->maxItemRows || mr > st->maxRows || (it->mrFlags & ~(0xffffu | BF_ITEM_OUT_Y | BF_ITEM_ROWMAJOR | BF_ITEM_MERGED | BF_ITEM_SMALL)) ||
+    if (!mr || mr > pl->maxItemRows || mr > st->maxRows || (it->mrFlags & ~(0xffffu | BF_ITEM_OUT_Y | BF_ITEM_ROWMAJOR | BF_ITEM_MERGED | BF_ITEM_SMALL | BF_ITEM_TNARROW)) ||
+        ((it->mrFlags & BF_ITEM_TNARROW) != 0) != (i < st->numNarrow) || ((it->mrFlags & BF_ITEM_TNARROW) && (!pl->transposed || mr > 16)) ||
         ((it->mrFlags & BF_ITEM_SMALL) != 0) != (i >= st->firstSmall) ||
         ((it->mrFlags & BF_ITEM_ROWMAJOR) && (pl->transposed || pl->dtype == BFHIP_C128 || mr > 2 * pl->epl)) ||
         (pl->transposed && mr > 64) ||       /* bfStageKernelT: at most 64 columns of A per item */
@@ -882,8 +883,18 @@ static int loadPlan(FILE *fp, BfhipOperator *op, BfPlan *pl, FileHeader const *f
     if (!rc) {       /* small items are the tail of the list (validateStage checks that they are nowhere else) */
       st->firstSmall = st->numItems;
       while (st->firstSmall && (((BfDevItem const *)hItems)[st->firstSmall - 1].mrFlags & BF_ITEM_SMALL)) --st->firstSmall;
+      st->numNarrow = 0;
+      while (st->numNarrow < st->numItems && (((BfDevItem const *)hItems)[st->numNarrow].mrFlags & BF_ITEM_TNARROW)) ++st->numNarrow;
       rc = validateStage(pl, fh->arenaElems, st, hItems, hPieces);
-      if (!rc && pl->transposed) st->numCoop = bfPlanCountCoop(hItems, hPieces, st->numItems, pl->elemSize);
+      if (!rc && pl->transposed) {
+        st->maxRowsRest = 0;
+        for (uint64_t i = st->numNarrow; i < st->numItems; ++i) {
+          uint32_t const mr = ((BfDevItem const *)hItems)[i].mrFlags & 0xffffu;
+          if (mr > st->maxRowsRest) st->maxRowsRest = mr;
+        }
+        st->numCoopNarrow = bfPlanCountCoop(hItems, hPieces, st->numNarrow, pl->elemSize);
+        st->numCoop = bfPlanCountCoop((BfDevItem const *)hItems + st->numNarrow, hPieces, st->numItems - st->numNarrow, pl->elemSize);
+      }
     }
     free(hItems); free(hPieces);
     if (!rc && sh.numReduce) {

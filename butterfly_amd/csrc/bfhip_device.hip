@@ -1324,21 +1324,33 @@ int bfdevLaunchStage(BfLaunchArgs const *a, void *stream) {
   uint32_t grid = (uint32_t)((a->numItems + BF_WAVES_PER_WG - 1) / BF_WAVES_PER_WG);
   hipStream_t s = (hipStream_t)stream;
   if (a->transposed) {
-    bool const wide = a->maxRows > 16;          // items of up to 64 columns of A (plans of short-leaf operands)
-    // big items of many pieces: a workgroup each -- except the complex 16-column kernel, which needs 98 VGPRs with the
-    // shared-item code (4 wavefronts per SIMD instead of 5) and loses 5 % on fac_helm2's adjoint
-    uint64_t const nc = (a->dtype == BFHIP_C128 && !wide) ? 0 : a->numCoop < a->numItems ? a->numCoop : a->numItems;
-    p.coopItems = (uint32_t)nc;
-    grid = (uint32_t)(nc + (a->numItems - nc + BF_WAVES_PER_WG - 1) / BF_WAVES_PER_WG);
+    // two ranges of items, two launches: [0, numNarrow) are <= 16 columns of tall leaves (16 row lanes, whole 256-byte
+    // runs, streamed loads), the rest up to 64 columns of short pieces (4 row lanes) unless the stage has none wider
+    // than 16.  In either range the leading big items of many pieces get a workgroup each -- except on the complex
+    // 16-column kernel, which needs 98 VGPRs with the shared-item code (4 wavefronts per SIMD instead of 5) and loses
+    // 5 % on fac_helm2's adjoint.
+    uint64_t const numNarrow = a->numNarrow < a->numItems ? a->numNarrow : a->numItems;
+    for (int range = 0; range < 2; ++range) {
+      uint64_t const first = range ? numNarrow : 0, count = range ? a->numItems - numNarrow : numNarrow;
+      if (!count) continue;
+      bool const wide = range == 1 && a->maxRowsRest > 16;
+      uint64_t nc = range ? a->numCoop : a->numCoopNarrow;
+      if (nc > count) nc = count;
+      if (a->dtype == BFHIP_C128 && !wide) nc = 0;
+      p.items = (BfDevItem const *)a->items + first;
+      p.numItems = (uint32_t)count;
+      p.coopItems = (uint32_t)nc;
+      grid = (uint32_t)(nc + (count - nc + BF_WAVES_PER_WG - 1) / BF_WAVES_PER_WG);
 #define BF_LAUNCH_T(DT) do { if (wide && nc) hipLaunchKernelGGL((bfStageKernelT<DT, 4, 4, true>), dim3(grid), dim3(BF_WAVES_PER_WG * 64), 0, s, p); \
                              else if (wide) hipLaunchKernelGGL((bfStageKernelT<DT, 4, 4, false>), dim3(grid), dim3(BF_WAVES_PER_WG * 64), 0, s, p); \
                              else if (nc) hipLaunchKernelGGL((bfStageKernelT<DT, 16, 4, true>), dim3(grid), dim3(BF_WAVES_PER_WG * 64), 0, s, p); \
                              else hipLaunchKernelGGL((bfStageKernelT<DT, 16, 4, false>), dim3(grid), dim3(BF_WAVES_PER_WG * 64), 0, s, p); } while (0)
-    if (a->dtype == BFHIP_C128) BF_LAUNCH_T(BFHIP_C128);
-    else if (a->dtype == BFHIP_F64) BF_LAUNCH_T(BFHIP_F64);
-    else if (a->dtype == BFHIP_F32) BF_LAUNCH_T(BFHIP_F32);
-    else return bfhipFail(BFABI_ERROR_TYPE_ERROR, "unknown dtype %u", a->dtype);
+      if (a->dtype == BFHIP_C128) BF_LAUNCH_T(BFHIP_C128);
+      else if (a->dtype == BFHIP_F64) BF_LAUNCH_T(BFHIP_F64);
+      else if (a->dtype == BFHIP_F32) BF_LAUNCH_T(BFHIP_F32);
+      else return bfhipFail(BFABI_ERROR_TYPE_ERROR, "unknown dtype %u", a->dtype);
 #undef BF_LAUNCH_T
+    }
     return hipFail(hipGetLastError(), "transposed stage launch");
   }
   if (a->dtype == BFHIP_C128 && a->nrhs >= BF_MFMA_MIN_RHS) hipLaunchKernelGGL(bfStageKernelC128Mfma, dim3(grid), dim3(BF_WAVES_PER_WG * 64), 0, s, p);

@@ -78,6 +78,7 @@ typedef struct BfDevPiece {
 #define BF_COOP_BYTES (32u << 10)     /* transposed items at least this large are shared by the 4 wavefronts of a workgroup if they average BF_COOP_PIECES pieces */
 #define BF_COOP_PIECES 8u
 uint64_t bfPlanCountCoop(BfDevItem const *items, BfDevPiece const *pieces, uint64_t numItems, uint32_t elemSize);
+#define BF_ITEM_TNARROW (1u << 20)    /* transposed plans: an item of <= 16 columns of a tall leaf (16-row-lane kernel); such items are the START of the list */
 #define BF_ITEM_SMALL (1u << 19)      /* real, forward: <= 2 lane granules of rows, <= 16 pieces, <= BF_SMALL_COLS dense columns (one block);
                                         * small items are the END of a stage's item list and run four to a wavefront */
 #define BF_SMALL_COLS 128u
@@ -117,7 +118,9 @@ typedef struct BfStage {
   BfPieceSrc *pieceSrc;
   uint32_t maxRows;          /* largest item row count */
   uint64_t firstSmall;       /* items [firstSmall, numItems) carry BF_ITEM_SMALL */
-  uint64_t numCoop;          /* transposed plans: the first numCoop items get a whole workgroup each (a scheduling hint) */
+  uint64_t numNarrow;        /* transposed plans: items [0, numNarrow) carry BF_ITEM_TNARROW (<= 16 columns of A: their own launch) */
+  uint32_t maxRowsRest, padRest;   /* largest item of the rest */
+  uint64_t numCoopNarrow, numCoop;   /* the first items of either range that get a whole workgroup each (a scheduling hint) */
   uint64_t leafElems;        /* algorithmic: sum m*n over this stage's leaves */
   uint64_t vecIn, vecOut;    /* algorithmic vector elements read / written */
   uint64_t numReduce;
@@ -212,7 +215,8 @@ typedef struct BfLaunchArgs {
   void const *pieces;
   uint64_t numItems;
   uint64_t firstSmall;   /* == numItems when the stage has no small items */
-  uint64_t numCoop;      /* transposed: leading items that get a workgroup each */
+  uint64_t numNarrow, numCoopNarrow, numCoop;      /* transposed: see BfStage */
+  uint32_t maxRowsRest;
   void const *x;
   void *y;
   void *temp;

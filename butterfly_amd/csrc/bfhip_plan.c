@@ -47,6 +47,7 @@ typedef struct Task {
   uint64_t rows, cols;
   uint64_t sub0;       /* offset of this task inside its leaf along the contracted dimension (long leaves are cut) */
   uint64_t seq;        /* emission order: fixes the summation order */
+  uint32_t cls, pad;   /* transposed plans: 1 = rows of a tall leaf (>= 16 lane units: the 16-column kernel reads whole 256-byte runs) */
 } Task;
 
 /* A leaf is contracted in sub-tasks of at most this many columns (forward) / rows (transposed):
@@ -247,13 +248,14 @@ static uint64_t findFwd(BfFwdPiece const *t, uint64_t n, uint64_t node, uint32_t
   return lo;
 }
 
-/* sort tasks by (stage, outBuf, outOff, rows, seq) */
+/* sort tasks by (stage, outBuf, outOff, rows, class, seq) */
 static int cmpTask(void const *pa, void const *pb) {
   Task const *a = pa, *b = pb;
   if (a->stage != b->stage) return a->stage < b->stage ? -1 : 1;
   if (a->outBuf != b->outBuf) return a->outBuf < b->outBuf ? -1 : 1;
   if (a->outOff != b->outOff) return a->outOff < b->outOff ? -1 : 1;
   if (a->rows != b->rows) return a->rows < b->rows ? -1 : 1;
+  if (a->cls != b->cls) return a->cls < b->cls ? -1 : 1;
   return a->seq < b->seq ? -1 : (a->seq > b->seq);
 }
 
@@ -264,6 +266,7 @@ typedef struct Group {
   uint64_t slotOff;              /* vector-arena offset of its private slot, if reduced */
   int reduced;
   uint64_t colsSum, piecesPerChunk;
+  uint32_t cls;                  /* transposed: 1 = 16-column items (tall leaves) */
   uint32_t chunkRows;            /* rows per item of this group */
 } Group;
 
@@ -271,12 +274,13 @@ typedef struct ItemTmp {
   uint64_t cost;
   uint64_t group;
   uint32_t rowBegin, rows;       /* chunk inside the group */
-  uint32_t small, pad;           /* runs four to a wavefront: sorted behind everything else */
+  uint32_t small, narrow;        /* small: runs four to a wavefront, sorted behind everything else; narrow: 16-column transposed item, sorted first */
 } ItemTmp;
 
 static int cmpItemCost(void const *pa, void const *pb) {
   ItemTmp const *a = pa, *b = pb;
   if (a->small != b->small) return a->small < b->small ? -1 : 1;
+  if (a->narrow != b->narrow) return a->narrow > b->narrow ? -1 : 1;
   if (a->cost != b->cost) return a->cost > b->cost ? -1 : 1;      /* big first */
   if (a->group != b->group) return a->group < b->group ? -1 : 1;
   return a->rowBegin < b->rowBegin ? -1 : (a->rowBegin > b->rowBegin);
@@ -404,6 +408,9 @@ int bfPlanBuild(BfIr const *ir, BfPlanOptions const *po, BfPlan *plan) {
   uint64_t top = 0;
   for (uint64_t i = 2; i < b.numBufs; ++i) b.bufs[i].arenaOff = arenaAlloc(&top, b.bufs[i].len);
 
+  if (T && !po->tCols)     /* tall leaves get 16-column items of their own (below) */
+    for (uint64_t t = 0; t < b.numTasks; ++t)
+      b.tasks[t].cls = ir->kind[b.tasks[t].leaf] == BFHIP_NODE_DENSE && ir->rows[b.tasks[t].leaf] >= 16u * plan->epl;
   qsort(b.tasks, b.numTasks, sizeof(Task), cmpTask);
 
   /* ---- 2..4 per stage --------------------------------------------------- */
@@ -430,12 +437,14 @@ int bfPlanBuild(BfIr const *ir, BfPlanOptions const *po, BfPlan *plan) {
      * exact for pieces whose height is a multiple of 16 lane units (fac_helm2: 16 - 64 rows of complex128; the tall
      * leaves of a streamed butterfly's first factors) and reads whole 256-byte runs; pieces of 1 - 15 units (the
      * streamer's later factors) leave most of 16 row lanes idle, and R = 4 (64-column items) wastes only the last
-     * 4-unit step.  Each stage picks by the lane slots either tiling would spend on its leaves. */
+     * 4-unit step.  Tall leaves (>= 16 units) always get 16-column items; for the others each stage picks by the lane
+     * slots either tiling would spend on them.  A block column that holds both kinds becomes two groups over the same
+     * outputs (slots + reduce, like any overlap) and the stage two launches (BfStage.numNarrow). */
     if (T && !po->tCols) {
       uint64_t slots16 = 0, slots4 = 0;
       for (uint64_t t = tBegin; t < tEnd; ++t) {
         Task const *tk = &b.tasks[t];
-        if (ir->kind[tk->leaf] != BFHIP_NODE_DENSE || tk->sub0) continue;
+        if (ir->kind[tk->leaf] != BFHIP_NODE_DENSE || tk->sub0 || tk->cls) continue;
         for (uint64_t k = findFwd(po->fwdPieces, po->numFwdPieces, tk->leaf, 0); k < po->numFwdPieces && po->fwdPieces[k].node == tk->leaf; ++k) {
           uint64_t const u = (po->fwdPieces[k].mr + plan->epl - 1) / plan->epl, w = po->fwdPieces[k].ncols;
           slots16 += (u + 15) / 16 * 16 * w;
@@ -450,13 +459,16 @@ int bfPlanBuild(BfIr const *ir, BfPlanOptions const *po, BfPlan *plan) {
     if (stageElems * plan->elemSize / 4096 < capBytes) capBytes = stageElems * plan->elemSize / 4096;
     if (capBytes < BF_ITEM_BYTES) capBytes = BF_ITEM_BYTES;
     uint64_t const floorRowsCap = T ? itemRows : (uint64_t)(po->minChunkRows ? po->minChunkRows : 16) * plan->epl;
-    uint64_t capCols = capBytes / (floorRowsCap * plan->elemSize);
-    if (capCols < BF_TASK_SPAN) capCols = BF_TASK_SPAN;
+    uint64_t capColsCls[2];
+    capColsCls[0] = capBytes / (floorRowsCap * plan->elemSize);
+    capColsCls[1] = capBytes / (16u * plan->elemSize);
+    for (int c = 0; c < 2; ++c) if (capColsCls[c] < BF_TASK_SPAN) capColsCls[c] = BF_TASK_SPAN;
     for (uint64_t t = tBegin; t < tEnd;) {
       uint64_t u = t + 1;
       uint64_t span = b.tasks[t].cols;
+      uint64_t const capCols = capColsCls[b.tasks[t].cls];
       while (u < tEnd && b.tasks[u].outBuf == b.tasks[t].outBuf && b.tasks[u].outOff == b.tasks[t].outOff && b.tasks[u].rows == b.tasks[t].rows &&
-             span + b.tasks[u].cols <= capCols) { span += b.tasks[u].cols; ++u; }
+             b.tasks[u].cls == b.tasks[t].cls && span + b.tasks[u].cols <= capCols) { span += b.tasks[u].cols; ++u; }
       if (numGroups == capGroups) {
         capGroups *= 2;
         Group *p = realloc(groups, capGroups * sizeof(Group));
@@ -465,7 +477,7 @@ int bfPlanBuild(BfIr const *ir, BfPlanOptions const *po, BfPlan *plan) {
       }
       Group *g = &groups[numGroups++];
       g->taskBegin = t; g->taskEnd = u; g->outBuf = b.tasks[t].outBuf; g->outOff = b.tasks[t].outOff; g->rows = b.tasks[t].rows;
-      g->slotOff = 0; g->reduced = 0;
+      g->slotOff = 0; g->reduced = 0; g->cls = b.tasks[t].cls;
       t = u;
     }
 
@@ -592,7 +604,7 @@ int bfPlanBuild(BfIr const *ir, BfPlanOptions const *po, BfPlan *plan) {
         else if (T) { gr->piecesPerChunk += (tk->cols + 15) / 16 + 2; gr->colsSum += tk->cols; }   /* upper bound: forward row chunks have >= 16 rows, one may straddle each end */
         else { gr->piecesPerChunk += (tk->cols + plan->xcap - 1) / plan->xcap; gr->colsSum += tk->cols; }
       }
-      uint64_t chunk = itemRows;
+      uint64_t chunk = gr->cls ? 16 : itemRows;
       if (!T && gr->colsSum) {
         uint64_t const gran = 16 * plan->epl;
         uint64_t const floorRows = (po->minChunkRows ? po->minChunkRows : 16) * plan->epl;
@@ -621,7 +633,7 @@ int bfPlanBuild(BfIr const *ir, BfPlanOptions const *po, BfPlan *plan) {
         tmp[ni].cost = rows * colsSum;
         /* colsSum < 128 also means "not row-major" */
         tmp[ni].small = !T && plan->dtype != BFHIP_C128 && rows <= 2 * plan->epl && colsSum < BF_SMALL_COLS && piecesPerChunk <= BF_SMALL_PIECES;
-        tmp[ni].pad = 0;
+        tmp[ni].narrow = groups[g].cls;
         ++ni;
         numPieces += piecesPerChunk;
       }
@@ -637,7 +649,10 @@ int bfPlanBuild(BfIr const *ir, BfPlanOptions const *po, BfPlan *plan) {
     uint64_t np = 0;
     uint64_t numBig = 0;
     while (numBig < numItems && !tmp[numBig].small) ++numBig;
-    st->firstSmall = numBig + numZeroItems;        /* order: ordinary items (big first), zero fills, small items */
+    st->firstSmall = numBig + numZeroItems;        /* order: ordinary items (transposed: 16-column ones first; big first), zero fills, small items */
+    st->numNarrow = 0;
+    while (st->numNarrow < numItems && tmp[st->numNarrow].narrow) ++st->numNarrow;
+    st->maxRowsRest = 0;
     for (uint64_t i = 0; i < numItems; ++i) {
       Group const *g = &groups[tmp[i].group];
       BfDevItem *it = &st->items[i < numBig ? i : i + numZeroItems];
@@ -659,6 +674,8 @@ int bfPlanBuild(BfIr const *ir, BfPlanOptions const *po, BfPlan *plan) {
       if (outOff >= 0xffffffffu) { free(tmp); rc = bfhipFail(BFABI_ERROR_RUNTIME_ERROR, "vector arena exceeds 32-bit offsets"); goto stage_fail; }
       it->outOff = (uint32_t)outOff;
       if (tmp[i].small) flags |= BF_ITEM_SMALL;
+      if (tmp[i].narrow) flags |= BF_ITEM_TNARROW;
+      else if (mr > st->maxRowsRest) st->maxRowsRest = mr;
       it->mrFlags = mr | flags;
       if (mr > st->maxRows) st->maxRows = mr;
       for (uint64_t t = g->taskBegin; t < g->taskEnd; ++t) {
@@ -760,11 +777,13 @@ int bfPlanBuild(BfIr const *ir, BfPlanOptions const *po, BfPlan *plan) {
         it->outOff = (uint32_t)outOff;
         it->mrFlags = (uint32_t)rows | (gaps[z].buf == by ? BF_ITEM_OUT_Y : 0);
         if (rows > st->maxRows) st->maxRows = (uint32_t)rows;
+        if (rows > st->maxRowsRest) st->maxRowsRest = (uint32_t)rows;
       }
     }
     st->numItems = totalItems;
     st->numPieces = np;
-    st->numCoop = T ? bfPlanCountCoop(st->items, st->pieces, numItems, plan->elemSize) : 0;
+    st->numCoopNarrow = T ? bfPlanCountCoop(st->items, st->pieces, st->numNarrow, plan->elemSize) : 0;
+    st->numCoop = T ? bfPlanCountCoop(st->items + st->numNarrow, st->pieces, numItems - st->numNarrow, plan->elemSize) : 0;
     /* algorithmic counts */
     for (uint64_t t = tBegin; t < tEnd; ++t)
       if (ir->kind[b.tasks[t].leaf] == BFHIP_NODE_DENSE) { st->leafElems += b.tasks[t].rows * b.tasks[t].cols; plan->numLeaves += b.tasks[t].sub0 == 0; }

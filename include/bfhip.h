@@ -266,7 +266,9 @@ int bfhipCovMatvecDevice(BfhipOperator *op, const void *dGammaLam, const uint64_
  * 1<<18 MERGED (column-major dense pieces are one contiguous block of <= 256
  * columns, contracted in one go); 1<<19 SMALL (<= 2 granules of rows, <= 16
  * pieces, < 128 columns: such items are the END of a stage's list and run
- * four to a wavefront in their own launch).  Piece flags: 1 reads x (else the
+ * four to a wavefront in their own launch; their pieces are row-major too);
+ * 1<<20 TNARROW (transposed plans: <= 16 columns of a tall leaf; such items
+ * are the START of a stage's list and run on the 16-row-lane kernel).  Piece flags: 1 reads x (else the
  * vector arena), 2 identity (no data: adds the input rows), 4 row-major. */
 typedef struct BfhipPlanInfo {
   uint32_t structSize, dtype, elemSize, epl, xcap, reserved;

@@ -21,6 +21,7 @@ BF_PIECE_ROWMAJOR = 4
 BF_ITEM_ROWMAJOR = 1 << 17
 BF_ITEM_MERGED = 1 << 18
 BF_ITEM_SMALL = 1 << 19
+BF_ITEM_TNARROW = 1 << 20
 
 
 def _view(ptr, count, dtype):
@@ -60,6 +61,10 @@ def run_plan(op, x, transpose=False):
         pieces = _view(sv.pieces, int(sv.numPieces), _capi.PIECE_DTYPE)
         if transpose:        # bfStageKernelT: at most 64 columns of A per item
             assert ((items["mrFlags"] & 0xFFFF) <= 64).all()
+        narrow = (items["mrFlags"] & BF_ITEM_TNARROW) != 0
+        if narrow.any():     # 16-column items of tall leaves open a transposed stage's list (their own launch)
+            k = int(narrow.sum())
+            assert transpose and narrow[:k].all() and ((items["mrFlags"][:k] & 0xFFFF) <= 16).all()
         small = (items["mrFlags"] & BF_ITEM_SMALL) != 0
         if small.any():      # small items are the tail of the list (they get their own launch, four to a wavefront)
             first = int(np.argmax(small))
