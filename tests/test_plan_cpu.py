@@ -203,6 +203,17 @@ def test_transposed_plan_of_a_block_column_of_few_row_leaves(demote):
         tol = 2e-6 if demote else 1e-13
         assert rel(plan_emulator.run_plan(op, x), dense @ x) < tol
         assert rel(plan_emulator.run_plan(op, v, transpose=True), dense.T @ v) < tol
+        # the two tall leaves of the column get 16-column items of their own, at the head of the transposed stage's list
+        lib = _capi.load()
+        info = _capi.BfhipPlanInfo(); info.structSize = C.sizeof(info)
+        _capi.check(lib.bfhipPlanGetInfo(op.handle, C.byref(info)))
+        sv = _capi.BfhipStageView(); sv.structSize = C.sizeof(sv)
+        _capi.check(lib.bfhipPlanGetStage(op.handle, int(info.numStages), C.byref(sv)))
+        items = np.frombuffer((C.c_char * (int(sv.numItems) * 16)).from_address(sv.items), dtype=_capi.ITEM_DTYPE)
+        narrow = (items["mrFlags"] & plan_emulator.BF_ITEM_TNARROW) != 0
+        k = int(narrow.sum())
+        assert 0 < k < len(items) and narrow[:k].all() and ((items["mrFlags"][:k] & 0xFFFF) <= 16).all()
+        assert ((items["mrFlags"][k:] & 0xFFFF) > 16).any() and int(sv.numReduce) >= 1
         op.close()
 
 
