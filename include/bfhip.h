@@ -262,7 +262,9 @@ int bfhipCovMatvecDevice(BfhipOperator *op, const void *dGammaLam, const uint64_
  * mrFlags = rows | flags: 1<<16 the item writes y (else the vector arena);
  * 1<<17 ROWMAJOR (real operands, <= 2 lane granules of rows: the item's dense
  * pieces are stored row by row, element (r, c) = arena[dataOff + r*ld + c],
- * rows zero-padded to the granule, one piece per <= 1024-column task);
+ * row ends zero-padded: ld is a multiple of the granule, and of 128 bytes for
+ * pieces of >= 128 columns, whose rows start on 128-byte lines; one piece per
+ * <= 1024-column task);
  * 1<<18 MERGED (column-major dense pieces are one contiguous block of <= 256
  * columns, contracted in one go); 1<<19 SMALL (<= 2 granules of rows, <= 16
  * pieces, < 128 columns: such items are the END of a stage's list and run
