@@ -262,14 +262,8 @@ class Desc:
         begin = np.zeros(n + 1, dtype=np.uint64)
         np.cumsum(counts, out=begin[1:])
         tot = int(begin[-1])
-        cn = np.empty(tot, dtype=np.uint64)
-        r0 = np.empty(tot, dtype=np.uint64)
-        c0 = np.empty(tot, dtype=np.uint64)
-        p = 0
-        for ch in self.children:
-            for (c, a, b) in ch:
-                cn[p], r0[p], c0[p] = c, a, b
-                p += 1
+        flat = np.fromiter((v for ch in self.children for t in ch for v in t), dtype=np.uint64, count=3 * tot).reshape(tot, 3)
+        cn, r0, c0 = (np.ascontiguousarray(flat[:, k]) for k in range(3))
         return dict(kind=np.asarray(self.kind, dtype=np.uint8),
                     rows=np.asarray(self.rows, dtype=np.uint64),
                     cols=np.asarray(self.cols, dtype=np.uint64),

@@ -97,10 +97,12 @@ class BlockDiag:
     __slots__ = ("blocks", "ro", "co", "m", "n")
 
     def __init__(self, blocks):
-        self.blocks = list(blocks)
-        self.ro = _offsets(b.m for b in self.blocks)
-        self.co = _offsets(b.n for b in self.blocks)
-        self.m, self.n = self.ro[-1], self.co[-1]
+        self.blocks = blocks = list(blocks)
+        ro, co, r, c = [0], [0], 0, 0
+        for b in blocks:
+            r += b.m; c += b.n
+            ro.append(r); co.append(c)
+        self.ro, self.co, self.m, self.n = ro, co, r, c
 
     def num_bytes(self):
         return sum(b.num_bytes() for b in self.blocks)
@@ -699,27 +701,35 @@ def to_desc(root, with_values=True):
     children sit at their (row offset, column offset) exactly as bfhip_ir.c reads them from a BfMat."""
     d = Desc(dtype=1)
     vals = {}
+    # (Desc.add inlined: millions of nodes; sizes are Python ints already, child lists are fresh)
+    kinds, rows, cols, children, bkinds = d.kind, d.rows, d.cols, d.children, d.block_kind
+
+    def add(kind, m, n, ch=(), bk=0):
+        kinds.append(kind); rows.append(m); cols.append(n); children.append(ch); bkinds.append(bk)
+        return len(kinds) - 1
 
     def rec(mat):
-        if isinstance(mat, Dense):
-            node = d.add(NODE_DENSE, mat.m, mat.n)
+        t = type(mat)
+        if t is Dense:
+            node = add(NODE_DENSE, mat.m, mat.n)
             if with_values and mat.a is not None:
                 vals[node] = np.ascontiguousarray(mat.a, dtype=np.float64)
             return node
-        if isinstance(mat, Identity):
-            return d.add(NODE_IDENTITY, mat.m, mat.n)
-        if isinstance(mat, Product):
-            return d.add(NODE_PRODUCT, mat.m, mat.n, [(rec(f), 0, 0) for f in mat.factors])
-        if isinstance(mat, BlockDiag):
-            ch = [(rec(b), mat.ro[k], mat.co[k]) for k, b in enumerate(mat.blocks)]
-            return d.add(NODE_BLOCK, mat.m, mat.n, ch, BF_TYPE_BLOCK_DIAG)
-        if isinstance(mat, BlockDense):
+        if t is Identity:
+            return add(NODE_IDENTITY, mat.m, mat.n)
+        if t is Product:
+            return add(NODE_PRODUCT, mat.m, mat.n, [(rec(f), 0, 0) for f in mat.factors])
+        if t is BlockDiag:
+            ro, co = mat.ro, mat.co
+            ch = [(rec(b), ro[k], co[k]) for k, b in enumerate(mat.blocks)]
+            return add(NODE_BLOCK, mat.m, mat.n, ch, BF_TYPE_BLOCK_DIAG)
+        if t is BlockDense:
             ch = [(rec(mat.blocks[p * mat.nbc + q]), mat.ro[p], mat.co[q]) for p in range(mat.nbr) for q in range(mat.nbc)]
-            return d.add(NODE_BLOCK, mat.m, mat.n, ch, BF_TYPE_BLOCK_DENSE)
-        if isinstance(mat, BlockCoo):
+            return add(NODE_BLOCK, mat.m, mat.n, ch, BF_TYPE_BLOCK_DENSE)
+        if t is BlockCoo:
             ch = [(rec(b), i, j) for i, j, b in zip(mat.i0s, mat.j0s, mat.blocks)]
-            return d.add(NODE_BLOCK, mat.m, mat.n, ch, BF_TYPE_BLOCK_COO)
-        raise TypeError(type(mat))
+            return add(NODE_BLOCK, mat.m, mat.n, ch, BF_TYPE_BLOCK_COO)
+        raise TypeError(t)
     d.root = rec(root)
     return d, vals
 
