@@ -736,8 +736,8 @@ __global__ __launch_bounds__(BF_WAVES_PER_WG * 64) void bfStageKernelReal(StageP
 // ---------------------------------------------------------------------------
 #define BF_T_COLS 16
 // With 4 row lanes a load instruction takes 64 bytes of each column, half a 128-byte line; the other half is asked
-// for by the next block step.  Streamed (non-temporal) lines are not kept for it, so the wide kernel loads with the
-// default policy (measured on the streamed operand: every transposed stage 10 - 35 % shorter).
+// for by the next block step.  Streamed (non-temporal) lines are not kept for it, so the wide kernel loads its
+// column-major pieces with the default policy (row-major pieces are whole 128-byte lines read once: streamed) (measured on the streamed operand: every transposed stage 10 - 35 % shorter).
 #ifndef BF_T_WIDE_NT
 #define BF_T_WIDE_NT 0
 #endif
@@ -835,7 +835,7 @@ __global__ __launch_bounds__(BF_WAVES_PER_WG * 64) void bfStageKernelT(StagePara
 #pragma unroll
             for (int i = 0; i < ITERS; ++i) {
               uint32_t const srow = rlRm + (uint32_t)i * RL_RM, sc = srow < n ? srow : n - 1;
-              a[i] = BF_T_WIDE_NT ? bfLoadStreamV(src + (uint64_t)sc * rowUnits) : src[(uint64_t)sc * rowUnits];
+              a[i] = bfLoadStreamV(src + (uint64_t)sc * rowUnits);
               S const xr = xin[(uint64_t)sc * nrhs];
               xv[i] = srow < n ? xr : (S)0;
             }
@@ -847,7 +847,7 @@ __global__ __launch_bounds__(BF_WAVES_PER_WG * 64) void bfStageKernelT(StagePara
 #pragma unroll
               for (int i = 0; i < ITERS; ++i) {
                 uint32_t const srow = rlRm + (uint32_t)i * RL_RM, sc = srow < n2 ? srow : n2 - 1;
-                a2[i] = BF_T_WIDE_NT ? bfLoadStreamV(src2 + (uint64_t)sc * rowUnits2) : src2[(uint64_t)sc * rowUnits2];
+                a2[i] = bfLoadStreamV(src2 + (uint64_t)sc * rowUnits2);
                 S const xr = xin2[(uint64_t)sc * nrhs];
                 xv2[i] = srow < n2 ? xr : (S)0;
               }
