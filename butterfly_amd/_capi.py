@@ -45,6 +45,12 @@ class BfhipStats(C.Structure):
 
 
 SHARD_ROWS, SHARD_BLOCKS = 0, 1
+GMRES_ORTH_DEFAULT, GMRES_ORTH_CGS2, GMRES_ORTH_MGS = 0, 1, 2
+
+
+class BfhipGmresOptions(C.Structure):
+    _fields_ = [("structSize", C.c_uint32), ("orthogonalization", C.c_uint32), ("tol", C.c_double),
+                ("maxNumIter", C.c_size_t), ("solveM", C.c_void_p)]
 
 
 class BfhipShardSpec(C.Structure):
@@ -296,6 +302,9 @@ def load():
     lib.bfhipSolveGMRESPrecondDevice.argtypes = [vp, vp, vp, C.c_size_t, vp, C.c_double, C.c_size_t, C.POINTER(C.c_size_t),
                                                  C.POINTER(C.c_double), vp, vp]
     lib.bfhipSolveGMRESPrecondDevice.restype = C.c_int
+    lib.bfhipSolveGMRESOptsDevice.argtypes = [vp, C.POINTER(BfhipGmresOptions), vp, C.c_size_t, vp, C.POINTER(C.c_size_t),
+                                              C.POINTER(C.c_double), vp, vp]
+    lib.bfhipSolveGMRESOptsDevice.restype = C.c_int
     lib.bfhipGetStats.argtypes = [vp, C.POINTER(BfhipStats)]
     lib.bfhipGetStats.restype = C.c_int
     lib.bfhipGetNumRows.argtypes = [vp]

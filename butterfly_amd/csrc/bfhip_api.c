@@ -499,6 +499,21 @@ out:
   return rc;
 }
 
+/* grow the vector arena for `nrhs` right-hand sides now (not stream-ordered: synchronizes the device's default
+ * stream), so that later applies of up to that many cannot fail on an allocation */
+int bfhipOperatorReserveRhs(BfhipOperator *op, uint32_t nrhs) {
+  if (!op || !nrhs) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "NULL operator / zero nrhs");
+  if (op->flags & BFHIP_FLAG_PLAN_ONLY) return bfhipFail(BFABI_ERROR_RUNTIME_ERROR, "operator was compiled with BFHIP_FLAG_PLAN_ONLY: no device operator exists");
+  if (op->tempRhs >= nrhs) return 0;
+  int prev = -1, rc;
+  bfdevGetDevice(&prev);
+  if (prev != op->device && (rc = bfdevSetDevice(op->device))) return rc;
+  rc = bfdevSync(NULL);
+  if (!rc) rc = ensureTemp(op, nrhs);
+  if (prev >= 0 && prev != op->device) bfdevSetDevice(prev);
+  return rc;
+}
+
 int bfhipApplyDevice(BfhipOperator *op, void const *dX, size_t nrhs, void *dY, void *stream) {
   if (!op) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "NULL operator");
   return runPlan(op, &op->plan, dX, nrhs, dY, stream);
@@ -782,6 +797,16 @@ static int readMetaArray(FILE *fp, void **d, void **h, size_t bytes, uint64_t *m
 /* A file is untrusted input: every offset the kernels will dereference is checked against the
  * sizes in the header before the operator is accepted (a truncated or corrupt file must not turn
  * into device out-of-bounds accesses). */
+/* offset + extent <= len without wrapping: offsets and extents come straight from the file as 64-bit values,
+ * and `off + ext > len` accepts off = 2^64 - 16 (the sum wraps to a small value) */
+static int fitsIn(uint64_t off, uint64_t ext, uint64_t len) { return off <= len && ext <= len - off; }
+/* a * b + c, saturating at UINT64_MAX */
+static uint64_t mulAddSat(uint64_t a, uint64_t b, uint64_t c) {
+  uint64_t r;
+  if (__builtin_mul_overflow(a, b, &r) || __builtin_add_overflow(r, c, &r)) return UINT64_MAX;
+  return r;
+}
+
 static int validateStage(BfPlan const *pl, uint64_t arenaElems, BfStage const *st, BfDevItem const *items, BfDevPiece const *pieces) {
   uint64_t const inX = pl->numCols, outY = pl->numRows, temp = pl->tempElems;
   for (uint64_t i = 0; i < st->numItems; ++i) {
@@ -793,7 +818,7 @@ static int validateStage(BfPlan const *pl, uint64_t arenaElems, BfStage const *s
         ((it->mrFlags & BF_ITEM_SMALL) != 0) != (i >= st->firstSmall) ||
         ((it->mrFlags & BF_ITEM_ROWMAJOR) && (pl->transposed || pl->dtype == BFHIP_C128 || mr > 2 * pl->epl)) ||
         (pl->transposed && mr > 64) ||       /* bfStageKernelT: at most 64 columns of A per item */
-        (uint64_t)it->outOff + mr > outLen || (uint64_t)it->pieceBegin + it->numPieces > st->numPieces)
+        !fitsIn(it->outOff, mr, outLen) || !fitsIn(it->pieceBegin, it->numPieces, st->numPieces))
       return bfhipFail(BFABI_ERROR_FILE_ERROR, "corrupt operator file: item %llu out of bounds", (unsigned long long)i);
     uint32_t const mrPad = (mr + pl->epl - 1) / pl->epl * pl->epl;
     if (it->mrFlags & (BF_ITEM_MERGED | BF_ITEM_SMALL)) {     /* the kernel reads the dense pieces as one block from the first one's offset */
@@ -806,7 +831,7 @@ static int validateStage(BfPlan const *pl, uint64_t arenaElems, BfStage const *s
         BfDevPiece const *pc = &pieces[it->pieceBegin + k];
         if (pc->flags & BF_PIECE_IDENTITY) continue;
         if (!smRm && dense && pc->dataOff != next) badm = 1;
-        next = pc->dataOff + (uint64_t)mrPad * pc->ncols; dense += pc->ncols;
+        next = mulAddSat(mrPad, pc->ncols, pc->dataOff); dense += pc->ncols;
       }
       if (badm || (!dense && !sm) || dense > (sm ? BF_SMALL_COLS : BF_MERGE_COLS))
         return bfhipFail(BFABI_ERROR_FILE_ERROR, "corrupt operator file: merged item %llu is not one block", (unsigned long long)i);
@@ -817,21 +842,21 @@ static int validateStage(BfPlan const *pl, uint64_t arenaElems, BfStage const *s
       int bad = (pc->flags & ~(BF_PIECE_IN_X | BF_PIECE_IDENTITY | BF_PIECE_ROWMAJOR)) != 0;
       int const rm = (pc->flags & BF_PIECE_ROWMAJOR) != 0;
       if (!(pc->flags & BF_PIECE_IDENTITY) && !pl->transposed && rm != ((it->mrFlags & BF_ITEM_ROWMAJOR) != 0)) bad = 1;
-      if (pc->flags & BF_PIECE_IDENTITY) bad |= (uint64_t)pc->inOff + mr > inLen;
+      if (pc->flags & BF_PIECE_IDENTITY) bad |= !fitsIn(pc->inOff, mr, inLen);
       else if (pl->transposed && rm)      /* rows of a row-major forward piece: ncols rows, mr columns from dataOff */
         bad |= !pc->ld || pc->ld % pl->epl || pc->dataOff % pl->epl || pl->dtype == BFHIP_C128 || !pc->ncols ||
-               pc->dataOff + (uint64_t)(pc->ncols - 1) * pc->ld + (mr + pl->epl - 1) / pl->epl * pl->epl > arenaElems ||
-               (uint64_t)pc->inOff + pc->ncols > inLen;
+               !fitsIn(pc->dataOff, mulAddSat(pc->ncols - 1, pc->ld, (mr + pl->epl - 1) / pl->epl * pl->epl), arenaElems) ||
+               !fitsIn(pc->inOff, pc->ncols, inLen);
       else if (rm)
         bad |= !pc->ncols || pc->ld % pl->epl || pc->ld < pc->ncols || pc->dataOff % pl->epl ||   /* x is read from global memory: no xcap */
-               pc->dataOff + (uint64_t)mr * pc->ld > arenaElems || (uint64_t)pc->inOff + pc->ncols > inLen;
+               !fitsIn(pc->dataOff, mulAddSat(mr, pc->ld, 0), arenaElems) || !fitsIn(pc->inOff, pc->ncols, inLen);
       else if (pl->transposed)
         bad |= !pc->ld || pc->ld % pl->epl || pc->ncols > pc->ld || pc->dataOff % pl->epl ||
-               pc->dataOff + (uint64_t)(mr - 1) * pc->ld + (pc->ncols + pl->epl - 1) / pl->epl * pl->epl > arenaElems ||
-               (uint64_t)pc->inOff + pc->ncols > inLen;
+               !fitsIn(pc->dataOff, mulAddSat(mr - 1, pc->ld, (pc->ncols + pl->epl - 1) / pl->epl * pl->epl), arenaElems) ||
+               !fitsIn(pc->inOff, pc->ncols, inLen);
       else
         bad |= !pc->ncols || pc->ncols > pl->xcap || pc->dataOff % pl->epl ||
-               pc->dataOff + (uint64_t)mrPad * pc->ncols > arenaElems || (uint64_t)pc->inOff + pc->ncols > inLen;
+               !fitsIn(pc->dataOff, mulAddSat(mrPad, pc->ncols, 0), arenaElems) || !fitsIn(pc->inOff, pc->ncols, inLen);
       if (bad) return bfhipFail(BFABI_ERROR_FILE_ERROR, "corrupt operator file: piece %u of item %llu out of bounds", k, (unsigned long long)i);
     }
   }
@@ -840,7 +865,7 @@ static int validateStage(BfPlan const *pl, uint64_t arenaElems, BfStage const *s
 
 static int validateReduce(BfPlan const *pl, BfReduce const *rd, uint32_t const *rowInterval, uint32_t const *ivBegin, int64_t const *srcBias) {
   uint64_t const destLen = rd->destSpace == BF_SPACE_Y ? pl->numRows : pl->tempElems;
-  if ((rd->destSpace != BF_SPACE_Y && rd->destSpace != BF_SPACE_TEMP) || rd->destOff + rd->numRows > destLen || rd->numIntervals > rd->numRows + 1)
+  if ((rd->destSpace != BF_SPACE_Y && rd->destSpace != BF_SPACE_TEMP) || !fitsIn(rd->destOff, rd->numRows, destLen) || rd->numIntervals > rd->numRows + 1)
     return bfhipFail(BFABI_ERROR_FILE_ERROR, "corrupt operator file: reduce destination out of bounds");
   if (ivBegin[0] != 0 || ivBegin[rd->numIntervals] > rd->numSrc) return bfhipFail(BFABI_ERROR_FILE_ERROR, "corrupt operator file: reduce interval table");
   for (uint64_t i = 0; i < rd->numIntervals; ++i)
@@ -849,8 +874,8 @@ static int validateReduce(BfPlan const *pl, BfReduce const *rd, uint32_t const *
     uint32_t const iv = rowInterval[r];
     if (iv >= rd->numIntervals) return bfhipFail(BFABI_ERROR_FILE_ERROR, "corrupt operator file: reduce row %llu", (unsigned long long)r);
     for (uint32_t k = ivBegin[iv]; k < ivBegin[iv + 1]; ++k) {
-      int64_t const src = srcBias[k] + (int64_t)r;
-      if (src < 0 || (uint64_t)src >= pl->tempElems) return bfhipFail(BFABI_ERROR_FILE_ERROR, "corrupt operator file: reduce source out of bounds");
+      int64_t src;
+      if (__builtin_add_overflow(srcBias[k], (int64_t)r, &src) || src < 0 || (uint64_t)src >= pl->tempElems) return bfhipFail(BFABI_ERROR_FILE_ERROR, "corrupt operator file: reduce source out of bounds");
     }
   }
   return 0;

@@ -45,7 +45,7 @@ static void applyGivens(cplx *z0p, cplx *z1p, cplx c, cplx s) {
   *z1p = s * z0 + c * z1;
 }
 
-static int solveDevice(BfhipOperator *op, BfhipOperator *precond, void const *dB, size_t nrhs, void const *dX0, double tol,
+static int solveDevice(BfhipOperator *op, BfhipOperator *precond, int orth, void const *dB, size_t nrhs, void const *dX0, double tol,
                        size_t maxNumIter, size_t *numIter, double *residual, void *dX, void *stream);
 
 /* the Krylov basis and every staging buffer live on the OPERATOR's device, whatever device is
@@ -61,21 +61,49 @@ int bfhipSolveGMRESDevice(BfhipOperator *op, void const *dB, size_t nrhs, void c
  * the reference ("the residual will be determined from the preconditioned residual vectors", :41-43). */
 int bfhipSolveGMRESPrecondDevice(BfhipOperator *op, BfhipOperator *solveM, void const *dB, size_t nrhs, void const *dX0, double tol,
                                  size_t maxNumIter, size_t *numIter, double *residual, void *dX, void *stream) {
-  if (!op) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "NULL argument");
+  BfhipGmresOptions o;
+  memset(&o, 0, sizeof o);
+  o.structSize = sizeof o; o.orthogonalization = BFHIP_GMRES_ORTH_DEFAULT; o.tol = tol; o.maxNumIter = maxNumIter; o.solveM = solveM;
+  return bfhipSolveGMRESOptsDevice(op, &o, dB, nrhs, dX0, numIter, residual, dX, stream);
+}
+
+/* The solver with its choices spelled out per call (BfhipGmresOptions, include/bfhip.h): orthogonalisation order,
+ * tolerance, iteration cap, left preconditioner. */
+int bfhipSolveGMRESOptsDevice(BfhipOperator *op, BfhipGmresOptions const *opt, void const *dB, size_t nrhs, void const *dX0,
+                              size_t *numIter, double *residual, void *dX, void *stream) {
+  if (!op || !opt || opt->structSize < sizeof(BfhipGmresOptions)) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "NULL argument / BfhipGmresOptions.structSize too small");
+  BfhipOperator *solveM = opt->solveM;
+  double const tol = opt->tol;
+  size_t const maxNumIter = opt->maxNumIter;
+  if (opt->orthogonalization > BFHIP_GMRES_ORTH_MGS) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "unknown orthogonalization %u", opt->orthogonalization);
+  int orth = (int)opt->orthogonalization;
+  if (orth == BFHIP_GMRES_ORTH_DEFAULT) {       /* the environment decides only where the caller did not */
+    char const *mgsEnv = getenv("BFHIP_GMRES_MGS");
+    orth = mgsEnv && mgsEnv[0] == '1' ? BFHIP_GMRES_ORTH_MGS : BFHIP_GMRES_ORTH_CGS2;
+  }
   if (solveM && (bfhipOperatorDevice(solveM) != bfhipOperatorDevice(op) || bfhipGetNumRows(solveM) != bfhipGetNumRows(op) ||
                  bfhipGetNumCols(solveM) != bfhipGetNumRows(op)))
     return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "the preconditioner must be an n x n operator on the operator's device (linalg.c:92-97)");
+  if (solveM) {
+    /* the Krylov vectors are complex128: a real preconditioner would be applied to them as if they were real n-vectors */
+    BfhipStats ms;
+    memset(&ms, 0, sizeof ms);
+    ms.structSize = sizeof ms;
+    int rcs = bfhipGetStats(solveM, &ms);
+    if (rcs) return rcs;
+    if (ms.dtype != BFHIP_C128) return bfhipFail(BFABI_ERROR_TYPE_ERROR, "the preconditioner must be a complex128 operator like the system it preconditions");
+  }
   int prev = -1, dev = bfhipOperatorDevice(op);
   if (dev < 0) return bfhipFail(BFABI_ERROR_RUNTIME_ERROR, "operator has no device (compiled with BFHIP_FLAG_PLAN_ONLY)");
   bfdevGetDevice(&prev);
   int rc = prev != dev ? bfdevSetDevice(dev) : 0;
   if (rc) return rc;
-  rc = solveDevice(op, solveM, dB, nrhs, dX0, tol, maxNumIter, numIter, residual, dX, stream);
+  rc = solveDevice(op, solveM, orth, dB, nrhs, dX0, tol, maxNumIter, numIter, residual, dX, stream);
   if (prev >= 0 && prev != dev) bfdevSetDevice(prev);
   return rc;
 }
 
-static int solveDevice(BfhipOperator *op, BfhipOperator *precond, void const *dB, size_t nrhs, void const *dX0, double tol,
+static int solveDevice(BfhipOperator *op, BfhipOperator *precond, int orth, void const *dB, size_t nrhs, void const *dX0, double tol,
                        size_t maxNumIter, size_t *numIter, double *residual, void *dX, void *stream) {
   if (!op || !dB || !dX) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "NULL argument");
   if (maxNumIter == 0) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "maxNumIter must be positive (linalg.c:81-82)");
@@ -92,8 +120,7 @@ static int solveDevice(BfhipOperator *op, BfhipOperator *precond, void const *dB
   uint32_t nb = (uint32_t)((n + 255) / 256);          /* row blocks = partial sums per RHS and dot */
   if (nb > 1024) nb = 1024;
   if (nb == 0) nb = 1;
-  char const *mgsEnv = getenv("BFHIP_GMRES_MGS");
-  int const useMgs = mgsEnv && mgsEnv[0] == '1';
+  int const useMgs = orth == BFHIP_GMRES_ORTH_MGS;
 
   void *dV = NULL, *dW = NULL, *dPartA = NULL, *dPartB = NULL, *dH = NULL, *dY = NULL, *dAX0 = NULL;
   void *dPartAll = NULL, *dH1 = NULL, *dH2 = NULL;     /* CGS2: partials of all dots, coefficients of the two passes */

@@ -182,6 +182,8 @@ struct BfhipOperator;
 int bfhipCompileIrFill(BfIr *ir, struct BfhipOptions const *opts, BfFillFn fill, void *fillCtx, struct BfhipOperator **out);
 /* HIP ordinal the operator lives on; -1 for a plan-only operator */
 int bfhipOperatorDevice(struct BfhipOperator const *op);
+/* vector arena for `nrhs` right-hand sides allocated now, so that applies of up to that many cannot fail on it */
+int bfhipOperatorReserveRhs(struct BfhipOperator *op, uint32_t nrhs);
 
 /* ------------------------------------------------------------------------
  * Device layer (implemented in bfhip_device.hip)

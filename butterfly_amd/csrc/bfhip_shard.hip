@@ -31,6 +31,7 @@ struct Rccl {
   ncclResult_t (*GetUniqueId)(ncclUniqueId *);
   ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int);
   ncclResult_t (*CommDestroy)(ncclComm_t);
+  ncclResult_t (*CommAbort)(ncclComm_t);
   ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t);
   ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t);
   const char *(*GetErrorString)(ncclResult_t);
@@ -45,7 +46,7 @@ int loadRccl() {
     for (int i = 0; i < 2 && !lib; ++i) lib = dlopen(names[i], RTLD_NOW | RTLD_GLOBAL | (pass == 0 ? RTLD_NOLOAD : 0));
   if (!lib) return bfhipFail(BFABI_ERROR_RUNTIME_ERROR, "RCCL not found (librccl.so.1): %s", dlerror());
 #define SYM(field, name) do { *(void **)&g.field = dlsym(lib, name); if (!g.field) return bfhipFail(BFABI_ERROR_RUNTIME_ERROR, "RCCL lacks %s", name); } while (0)
-  SYM(GetUniqueId, "ncclGetUniqueId"); SYM(CommInitRank, "ncclCommInitRank"); SYM(CommDestroy, "ncclCommDestroy");
+  SYM(GetUniqueId, "ncclGetUniqueId"); SYM(CommInitRank, "ncclCommInitRank"); SYM(CommDestroy, "ncclCommDestroy"); SYM(CommAbort, "ncclCommAbort");
   SYM(AllGather, "ncclAllGather"); SYM(AllReduce, "ncclAllReduce"); SYM(GetErrorString, "ncclGetErrorString");
 #undef SYM
   g.lib = lib;
@@ -78,11 +79,12 @@ __global__ __launch_bounds__(256) void bfScatterSegmentsKernel(Seg const *segs, 
 
 }  // namespace
 
-struct BfhipComm { ncclComm_t comm; int nranks, rank, device; };
+struct BfhipComm { ncclComm_t comm; int nranks, rank, device; int aborted; };
 
 struct BfhipSharded {
   BfhipOperator *op;
   BfhipComm *comm;
+  int device;                    // copied at create time: freeing never dereferences the communicator
   uint32_t mode, dtype, elemSize, maxRhs, numSegs;
   uint64_t numRowsGlobal, myRows, maxRows;
   void *dGather;                 // rows mode: nranks * maxRows * maxRhs elements
@@ -126,7 +128,7 @@ int bfhipCommInitRank(void const *id128, int nranks, int rank, int device, Bfhip
 
 void bfhipCommDestroy(BfhipComm **pc) {
   if (!pc || !*pc) return;
-  if ((*pc)->comm && g.CommDestroy) (void)g.CommDestroy((*pc)->comm);
+  if ((*pc)->comm && !(*pc)->aborted && g.CommDestroy) (void)g.CommDestroy((*pc)->comm);      // an aborted communicator is already gone
   free(*pc);
   *pc = NULL;
 }
@@ -136,7 +138,7 @@ void bfhipShardedFree(BfhipSharded **ps) {
   BfhipSharded *s = *ps;
   int prev = -1;
   (void)hipGetDevice(&prev);
-  (void)hipSetDevice(s->comm->device);
+  (void)hipSetDevice(s->device);
   (void)hipFree(s->dGather); (void)hipFree(s->dSegs);
   if (s->e0) (void)hipEventDestroy(s->e0);
   if (s->e1) (void)hipEventDestroy(s->e1);
@@ -159,7 +161,7 @@ int bfhipShardedCreate(BfhipOperator *op, BfhipComm *comm, BfhipShardSpec const 
   if (bfhipOperatorDevice(op) != comm->device) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "operator lives on device %d, communicator on %d", bfhipOperatorDevice(op), comm->device);
   BfhipSharded *s = (BfhipSharded *)calloc(1, sizeof *s);
   if (!s) return bfhipFail(BFABI_ERROR_MEMORY_ERROR, "host OOM");
-  s->op = op; s->comm = comm; s->mode = spec->mode; s->dtype = st.dtype;
+  s->op = op; s->comm = comm; s->device = comm->device; s->mode = spec->mode; s->dtype = st.dtype;
   s->elemSize = st.dtype == BFHIP_C128 ? 16 : st.dtype == BFHIP_F64 ? 8 : 4;
   s->maxRhs = maxRhs ? maxRhs : 1;
   s->numRowsGlobal = spec->numRowsGlobal;
@@ -200,6 +202,9 @@ int bfhipShardedCreate(BfhipOperator *op, BfhipComm *comm, BfhipShardSpec const 
     free(rowsOf);
   }
   s->timing = 1;
+  // every allocation a step could need happens here: a step that fails on ONE rank after the others have enqueued
+  // their half of the collective would leave them waiting forever
+  if (!rc) rc = bfhipOperatorReserveRhs(op, s->maxRhs);
   if (!rc) rc = hipFailS(hipEventCreate(&s->e0), "hipEventCreate");
   if (!rc) rc = hipFailS(hipEventCreate(&s->e1), "hipEventCreate");
   if (!rc) rc = hipFailS(hipEventCreate(&s->e2), "hipEventCreate");
@@ -212,10 +217,11 @@ int bfhipShardedCreate(BfhipOperator *op, BfhipComm *comm, BfhipShardSpec const 
 int bfhipShardedApplyDevice(BfhipSharded *s, void const *dX, size_t nrhs, void *dY, void *streamV) {
   if (!s || !dX || !dY) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "NULL argument");
   if (!nrhs || nrhs > s->maxRhs) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "nrhs %zu exceeds the %u this sharded apply was created for", nrhs, s->maxRhs);
+  if (s->comm->aborted) return bfhipFail(BFABI_ERROR_RUNTIME_ERROR, "the communicator was aborted after a failed step on this rank");
   hipStream_t stream = (hipStream_t)streamV;
   int prev = -1;
   (void)hipGetDevice(&prev);
-  int rc = prev != s->comm->device ? hipFailS(hipSetDevice(s->comm->device), "hipSetDevice") : 0;
+  int rc = prev != s->device ? hipFailS(hipSetDevice(s->device), "hipSetDevice") : 0;
   if (rc) return rc;
   ncclDataType_t const dt = s->dtype == BFHIP_F32 ? ncclFloat32 : ncclFloat64;
   size_t const scalarsPerElem = s->dtype == BFHIP_C128 ? 2 : 1;
@@ -223,7 +229,9 @@ int bfhipShardedApplyDevice(BfhipSharded *s, void const *dX, size_t nrhs, void *
   if (s->mode == BFHIP_SHARD_BLOCKS) {
     rc = bfhipApplyDevice(s->op, dX, nrhs, dY, stream);
     if (s->timing) (void)hipEventRecord(s->e1, stream);
-    // partial results add up; disjoint supports make the sum exact in any order
+    // partial results add up: the (row, col) blocks of one block row sit on different ranks, so rows receive several
+    // non-zero partial sums and the order RCCL adds them in is its own -- equal to the one-GPU result to rounding
+    // (1e-14 relative), not bit for bit; "rows" mode is the bit-identical one
     if (!rc) rc = ncclFail(g.AllReduce(dY, dY, (size_t)s->numRowsGlobal * nrhs * scalarsPerElem, dt, ncclSum, s->comm->comm, stream), "ncclAllReduce");
   } else {
     size_t const rowBytes = nrhs * s->elemSize;
@@ -246,9 +254,17 @@ int bfhipShardedApplyDevice(BfhipSharded *s, void const *dX, size_t nrhs, void *
       }
     }
   }
+  if (rc && !s->comm->aborted && s->comm->nranks > 1) {
+    // the local stages or the collective failed to enqueue on THIS rank (arguments and allocations were settled
+    // at create time, so this is a launch / runtime failure): the other ranks may already be inside the collective.
+    // Abort the communicator -- their pending operation returns with an error instead of hanging -- and refuse
+    // further steps on it.
+    (void)g.CommAbort(s->comm->comm);
+    s->comm->aborted = 1;
+  }
   if (s->timing) (void)hipEventRecord(s->e2, stream);
   s->timed = !rc && s->timing;
-  if (prev >= 0 && prev != s->comm->device) (void)hipSetDevice(prev);
+  if (prev >= 0 && prev != s->device) (void)hipSetDevice(prev);
   return rc;
 }
 

@@ -237,18 +237,25 @@ class HipOperator:
                                         C.byref(it), C.byref(res), x.ctypes.data, nrhs))
         return (x[:, 0] if one_d else x), int(it.value), float(res.value)
 
-    def solve_gmres_device(self, b, x0=None, tol=1e-12, max_num_iter=100, precond=None):
+    def solve_gmres_device(self, b, x0=None, tol=1e-12, max_num_iter=100, precond=None, orth="default"):
         """Device-resident form on torch tensors; returns (x, num_iter, residual).  `precond`: a HipOperator
-        applying the action of M^{-1} (the reference's left preconditioner M through bfMatSolve)."""
+        applying the action of M^{-1} (the reference's left preconditioner M through bfMatSolve).  `orth`:
+        "cgs2" (batched, the default), "mgs" (the reference's order, src/linalg.c:174-184) or "default"
+        (cgs2 unless BFHIP_GMRES_MGS=1 is set)."""
         import torch
         nrhs = 1 if b.dim() == 1 else b.shape[1]
         x = torch.empty_like(b)
         it = C.c_size_t(0)
         res = C.c_double(0)
         s = torch.cuda.current_stream(b.device)
-        check(self._lib.bfhipSolveGMRESPrecondDevice(self._h, precond.handle if precond is not None else None, C.c_void_p(b.data_ptr()), nrhs,
-                                                     C.c_void_p(x0.data_ptr()) if x0 is not None else None, tol, max_num_iter,
-                                                     C.byref(it), C.byref(res), C.c_void_p(x.data_ptr()), C.c_void_p(s.cuda_stream)))
+        o = _capi.BfhipGmresOptions()
+        o.structSize = C.sizeof(o)
+        o.orthogonalization = {"default": _capi.GMRES_ORTH_DEFAULT, "cgs2": _capi.GMRES_ORTH_CGS2, "mgs": _capi.GMRES_ORTH_MGS}[orth]
+        o.tol, o.maxNumIter = tol, max_num_iter
+        o.solveM = precond.handle if precond is not None else None
+        check(self._lib.bfhipSolveGMRESOptsDevice(self._h, C.byref(o), C.c_void_p(b.data_ptr()), nrhs,
+                                                  C.c_void_p(x0.data_ptr()) if x0 is not None else None,
+                                                  C.byref(it), C.byref(res), C.c_void_p(x.data_ptr()), C.c_void_p(s.cuda_stream)))
         return x, int(it.value), float(res.value)
 
     def stage_profile(self, reset=False):

@@ -184,7 +184,8 @@ int bfhipSolveGMRESDevice(BfhipOperator *op, const void *dB, size_t nrhs, const 
  *                     compacted; the step ends with ONE in-place ncclAllGather (xGMI) and a small kernel
  *                     that puts the segments into global row order in dY.
  * BFHIP_SHARD_BLOCKS: this rank's operator yields a full-length partial y (its (row, col) blocks at
- *                     their original offsets, zeros elsewhere); the step ends with ONE ncclAllReduce.
+ *                     their original offsets, zeros elsewhere); the step ends with ONE ncclAllReduce.  The
+ *                     summation order is RCCL's: equal to one GPU to rounding, not bit for bit (ROWS is).
  * Everything is enqueued on `stream` behind the stage kernels; nothing synchronizes the host.  RCCL is
  * looked up at run time (the copy already in the process, else librccl.so.1); without it these entry
  * points return RUNTIME_ERROR and the rest of the library works. */
@@ -210,13 +211,35 @@ int bfhipShardedLastTimes(BfhipSharded *sh, double *localMs, double *collectiveM
 /* The three events behind bfhipShardedLastTimes cost ~17 us of stream time per apply (they are what keeps the stage
  * kernels, the collective and the next apply apart): on by default, turn them off for production loops. */
 int bfhipShardedSetTiming(BfhipSharded *sh, int enabled);
-void bfhipShardedFree(BfhipSharded **sh);     /* neither the operator nor the communicator is released */
+/* Neither the operator nor the communicator is released.  Order: free the sharded objects of a communicator before
+ * bfhipCommDestroy (a sharded object keeps a pointer to it for its steps; freeing itself does not touch it). */
+void bfhipShardedFree(BfhipSharded **sh);
+/* Failure semantics of a step: arguments are checked and every allocation is made in bfhipShardedCreate (the vector
+ * arena for maxRhs included), so a step cannot fail on one rank for a reason the others do not share.  If a launch
+ * still fails locally with more than one rank, the communicator is aborted (ncclCommAbort: the peers' collective
+ * returns an error instead of hanging), the step returns non-zero and later steps on that communicator are refused. */
 
 /* Left-preconditioned form: the reference's M argument (src/linalg.c:47-49,90-97,131,159).  `solveM` is a device
  * operator that applies what bfMatSolve(M, .) computes, i.e. the action of M^{-1} (n x n, same device and dtype
  * as `op`); NULL = no preconditioner.  As in the reference the residual is then the preconditioned one. */
 int bfhipSolveGMRESPrecondDevice(BfhipOperator *op, BfhipOperator *solveM, const void *dB, size_t nrhs, const void *dX0, double tol,
                                  size_t maxNumIter, size_t *numIter, double *residual, void *dX, void *stream);
+
+/* The same solver with its choices per call.  Orthogonalisation: the reference runs modified Gram-Schmidt one basis
+ * vector at a time (src/linalg.c:174-184); CGS2 (classical Gram-Schmidt, two batched passes: 7 launches per iteration
+ * whatever j is) is equally stable, 20 % faster on the device and may differ from the reference by one iteration;
+ * MGS reproduces the reference's H and iteration count.  DEFAULT = CGS2 unless the environment variable
+ * BFHIP_GMRES_MGS=1 asks for MGS (an override for hosts that cannot pass options; an explicit choice here wins). */
+enum { BFHIP_GMRES_ORTH_DEFAULT = 0, BFHIP_GMRES_ORTH_CGS2 = 1, BFHIP_GMRES_ORTH_MGS = 2 };
+typedef struct BfhipGmresOptions {
+  uint32_t structSize;          /* = sizeof(BfhipGmresOptions) */
+  uint32_t orthogonalization;   /* BFHIP_GMRES_ORTH_* */
+  double tol;
+  size_t maxNumIter;
+  BfhipOperator *solveM;        /* left preconditioner (action of M^{-1}; complex128, n x n, same device) or NULL */
+} BfhipGmresOptions;
+int bfhipSolveGMRESOptsDevice(BfhipOperator *op, const BfhipGmresOptions *opt, const void *dB, size_t nrhs, const void *dX0,
+                              size_t *numIter, double *residual, void *dX, void *stream);
 
 /* ---- introspection ------------------------------------------------------- */
 int bfhipGetStats(const BfhipOperator *op, BfhipStats *stats);

@@ -115,7 +115,7 @@ def test_left_preconditioned_gmres(system, monkeypatch):
     """bfSolveGMRES(A, B, X0, tol, maxNumIter, &numIter, M) with a left preconditioner (src/linalg.c:90-97,131,159):
     M^{-1} = block-Jacobi inverse of the dense system, applied as a device operator of its own."""
     import torch
-    from butterfly_amd import helm2_structure as hs
+    from butterfly_amd import _capi, helm2_structure as hs
     from butterfly_amd.operator import HipOperator
     desc, root, vals, dense, A, b = system
     n = dense.shape[0]
@@ -138,14 +138,32 @@ def test_left_preconditioned_gmres(system, monkeypatch):
     _, it_plain, _ = linalg_ref.solve_gmres(lambda v: bfref.mat_mul(A, v), bb, tol=1e-10, max_num_iter=80)
     assert it_ref <= it_plain
     bd = torch.from_numpy(np.ascontiguousarray(bb)).cuda()
-    monkeypatch.setenv("BFHIP_GMRES_MGS", "1")
-    x, it, res = op.solve_gmres_device(bd, tol=1e-10, max_num_iter=80, precond=pre)
+    # the reference's order as an explicit per-call option (no environment involved) ...
+    x, it, res = op.solve_gmres_device(bd, tol=1e-10, max_num_iter=80, precond=pre, orth="mgs")
     assert it == it_ref and abs(res - hist[-1]) <= 1e-6 * hist[-1] + 1e-16
     assert rel(x.cpu().numpy(), x_ref) < 1e-9
-    monkeypatch.delenv("BFHIP_GMRES_MGS")
-    x, it, res = op.solve_gmres_device(bd, tol=1e-10, max_num_iter=80, precond=pre)
+    # ... which wins over the environment override, both ways
+    monkeypatch.setenv("BFHIP_GMRES_MGS", "1")
+    x, it, res = op.solve_gmres_device(bd, tol=1e-10, max_num_iter=80, precond=pre, orth="cgs2")
     assert abs(it - it_ref) <= 1
     assert rel(x.cpu().numpy(), np.linalg.solve(dense, bb)) < 1e-8
+    xe, ite, _ = op.solve_gmres_device(bd, tol=1e-10, max_num_iter=80, precond=pre)          # default: the environment decides
+    assert ite == it_ref
+    monkeypatch.delenv("BFHIP_GMRES_MGS")
+    x2, it2, res = op.solve_gmres_device(bd, tol=1e-10, max_num_iter=80, precond=pre)
+    assert it2 == it and torch.equal(x2, x)
+    # a real preconditioner would be applied to the complex Krylov vectors as if they were real: TYPE_ERROR
+    dr = hs.Desc(dtype=1)
+    chr_ = []
+    for s_ in range(0, n, 64):
+        e_ = min(s_ + 64, n)
+        chr_.append((dr.add(hs.NODE_IDENTITY, e_ - s_, e_ - s_), s_, s_))
+    dr.root = dr.add(hs.NODE_BLOCK, n, n, chr_, hs.BF_TYPE_BLOCK_DIAG)
+    pre_real = HipOperator.from_desc(dr, None)
+    with pytest.raises(_capi.BfhipError) as e:
+        op.solve_gmres_device(bd, precond=pre_real)
+    assert e.value.code == 7
+    pre_real.close()
     # shape / device mismatches are refused like linalg.c:92-97
     small = HipOperator.from_desc(d, pv, root=ch[0][0])
     with pytest.raises(Exception):

@@ -401,6 +401,33 @@ def test_save_load_round_trip(tmp_path, helm2_cases):
         with pytest.raises(_capi.BfhipError) as e:
             HipOperator.load(corrupt)
         assert e.value.code == 6, what
+    # 64-bit offsets near 2^64: `dataOff + extent` / `destOff + numRows` wrap to a small value, so the
+    # bounds checks must be subtractions.  Walk the forward plan: per stage a 56-byte header {numItems, numPieces,
+    # leafElems, vecIn, vecOut, numReduce, ...}, items (16 B), pieces (24 B, dataOff first), then per reduce a 40-byte
+    # header {destOff, numRows, numIntervals, numSrc, destSpace} + rowInterval[numRows] + ivBegin[numIntervals + 1] + srcBias[numSrc]
+    u64 = lambda b, o: int.from_bytes(b[o:o + 8], "little")
+    num_stages, pos = u64(raw, 88), 128
+    piece0 = reduce0 = None
+    for _ in range(num_stages):
+        ni, npc, nred = u64(raw, pos), u64(raw, pos + 8), u64(raw, pos + 40)
+        pos += 56 + 16 * ni
+        if piece0 is None and npc:
+            piece0 = pos
+        pos += 24 * npc
+        for _ in range(nred):
+            if reduce0 is None:
+                reduce0 = pos
+            rows, niv, nsrc = u64(raw, pos + 8), u64(raw, pos + 16), u64(raw, pos + 24)
+            pos += 40 + 4 * rows + 4 * (niv + 1) + 8 * nsrc
+    assert piece0 is not None and reduce0 is not None
+    for off, what in ((piece0, "piece.dataOff"), (reduce0, "reduce.destOff")):
+        bad_bytes = bytearray(raw)
+        bad_bytes[off:off + 8] = (0xFFFFFFFFFFFFFFF0).to_bytes(8, "little")
+        corrupt = tmp_path / "corrupt64.bfhip"
+        corrupt.write_bytes(bytes(bad_bytes))
+        with pytest.raises(_capi.BfhipError) as e:
+            HipOperator.load(corrupt)
+        assert e.value.code == 6, what
 
 
 def test_item_class_flags_of_a_file_are_checked(tmp_path):

@@ -67,12 +67,22 @@ def test_golden_one_block():
     d2, root, perm, sn, tn = hs.single_product_structure(pts, float(ex["k"]), tuple(ex["src_path"]), tuple(ex["tgt_path"]))
     v2 = hb.leaf_values(d2, float(ex["k"]), pts[perm])
     assert d2.rows == desc.rows and d2.cols == desc.cols
-    # the factors come out of truncated least squares: entry by entry they move with the BLAS thread count (3e-4 on one
-    # factor under OPENBLAS_NUM_THREADS=2), the operator they make does not
     y2 = bfref.mat_mul(bfref.from_desc(d2, v2), ex["x"])
     assert rel(y2, ex["y_oracle"]) < 1e-12
-    close = [np.allclose(v2[node], vals[node], rtol=0, atol=1e-9 * np.abs(vals[node]).max()) for node in vals]
-    assert sum(close) >= len(close) - 1
+    # Factor by factor.  A KERNEL leaf is a table of Hankel values: entry-wise agreement.  A REEXP leaf is the truncated
+    # least-squares solution X of Z_equiv X = Z_orig (src/helm2.c:321-365, src/mat_dense_complex.c:1767-1849): its
+    # components along singular vectors with sigma ~ max(m, n) eps sigma_max are amplified rounding noise (they move with
+    # the BLAS thread count: 3e-4 entry-wise on one factor under OPENBLAS_NUM_THREADS=2), so X itself is only determined
+    # to eps * sigma_max / sigma_cut ~ 1 / max(m, n) -- but Z_equiv X, the field the equivalent sources radiate and the
+    # only thing the factorization uses, is backward stable: || Z_equiv (X2 - X1) || <= c eps || Z_orig ||.
+    tp = pts[perm]
+    for node, rc in d2.recipe.items():
+        if rc[0] == "kernel":
+            assert np.allclose(v2[node], vals[node], rtol=0, atol=1e-12 * np.abs(vals[node]).max()), node
+        else:
+            z_eq = hb.kernel_matrix(float(ex["k"]), hb.resolve_points(rc[2], tp), hb.resolve_points(rc[3], tp))
+            z_or = hb.kernel_matrix(float(ex["k"]), hb.resolve_points(rc[1], tp), hb.resolve_points(rc[3], tp))
+            assert np.linalg.norm(z_eq @ (v2[node] - vals[node])) <= 1e-10 * np.linalg.norm(z_or), node
 
 
 def test_golden_multilevel_vectors():
