@@ -75,8 +75,9 @@ def parse_args(argv):
     ap.add_argument("--emulate-rank", type=int, default=0)
     ap.add_argument("--python-layout", action="store_true", help="lay the operand out with butterfly_amd/helm2_structure.py instead of the C layout")
     ap.add_argument("--force-collective", action="store_true", help="rehearsal: run the sharded C-ABI path (RCCL communicator + collective) even with one rank")
-    ap.add_argument("--shard", choices=["auto", "rows", "blocks"], default="auto",
-                    help="multi-GPU: top-level block rows + all-gather, or (row, col) blocks + all-reduce")
+    ap.add_argument("--shard", choices=["auto", "rows", "rowblocks", "blocks"], default="auto",
+                    help="multi-GPU: rows = balanced contiguous row ranges (bfhipRowPartition) + ONE all-gather, bit-identical to one GPU (default); "
+                         "rowblocks = whole top-level block rows by LPT + all-gather; blocks = top-level (row, col) blocks by LPT + ONE all-reduce")
     return ap.parse_args(argv)
 
 
@@ -91,6 +92,9 @@ def free_port():
 def launch_ranks(args, argv):
     """--gpus N without a launcher: start N rank processes (torch.distributed.run on 127.0.0.1) BEFORE this
     process touches a GPU, relay rank 0's JSON line, and fail if any rank fails."""
+    # torch.distributed.run's own parser expands unambiguous prefixes even behind the script name: spell the aliases out
+    alias = {"--n": "--npoints", "--k": "--wavenumber"}
+    argv = [alias.get(a, a) for a in argv]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
            "--master-port", str(free_port()), os.path.abspath(__file__)] + argv
     log("bench.py: starting", args.gpus, "ranks:", " ".join(cmd))
@@ -257,29 +261,42 @@ def main():
     import torch.distributed as dist
     from butterfly_amd import _capi, helm2_structure as hs
     from butterfly_amd.dist import (RcclShardedApply, ShardLayout, assign_row_blocks, block_weights, choose_mode,
-                                    row_block_weights)
+                                    row_block_weights, row_partition)
     from butterfly_amd.operator import HipOperator
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # BENCH_DRY_RUN=1 (tests, CPU): everything a rank does before it selects its device -- arguments, rendezvous (gloo),
+    # the world-size check, the operand's layout and who owns what -- then one JSON line and out
+    dry = os.environ.get("BENCH_DRY_RUN") == "1"
+    dev = None
+    if not dry:
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
     use_pg = world > 1
     if use_pg:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", str(29500 + os.getpid() % 1000))
-        dist.init_process_group("nccl", device_id=dev)
+        if dry:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
         world = dist.get_world_size()
-    if world != args.gpus and rank == 0:
-        log(f"note: --gpus {args.gpus} but the launcher started {world} rank(s); reporting n_gpus = {world}")
+    if world != args.gpus:
+        # a line that says n_gpus = 8 must come from 8 ranks: refuse to measure anything else (no JSON, non-zero exit)
+        if rank == 0:
+            log(f"bench.py: --gpus {args.gpus} but the process group has {world} rank(s): refusing to run")
+        if use_pg:
+            dist.destroy_process_group()
+        sys.exit(2)
 
     streamer = args.workload == "streamer"
     dtype = args.dtype or ("f32" if streamer else "c128")
     if streamer and dtype == "c128":
         raise SystemExit("the streamed operand is real: --dtype f32 or f64")
-    if streamer and (world > 1 or args.emulate_world > 1):
-        raise SystemExit("configs[4] is a one-GPU workload: the streamed operand is one product, it has no top-level row blocks to deal out")
+    if streamer and (world > 1 or args.emulate_world > 1) and args.shard not in ("auto", "rows"):
+        raise SystemExit("the streamed operand is one product: it has no top-level blocks to deal out, only row ranges (--shard rows)")
     real = dtype != "c128"
     esz = {"c128": 16, "f64": 8, "f32": 4}[dtype]
     tdtype = {"c128": torch.complex128, "f64": torch.float64, "f32": torch.float32}[dtype]
@@ -310,7 +327,12 @@ def main():
         data = "synthetic (block structure laid out by the fac_streamer merge-and-split recursion under the fitted rank model; seeded values generated in HBM)"
         metric = "butterfly matvecs/sec (streamed real butterfly apply, examples/covariance)"
         top_rows, weights, row_offsets = [n], [total_leaf], np.array([0, n])
-        sworld, srank, mode, mine, owner, loads = 1, 0, "rows", [0], [0], [total_leaf]
+        sworld, srank = (args.emulate_world, max(args.emulate_rank, 0)) if args.emulate_world > 1 else (world, rank)
+        mode, cuts = "rows", [0, n]
+        owner, loads = [0], [total_leaf]
+        if sworld > 1:
+            cuts, loads = row_partition(desc, sworld)
+            top_rows, owner = [cuts[r + 1] - cuts[r] for r in range(sworld)], list(range(sworld))
     else:
         n = args.n or 262144
         ncols = n
@@ -328,7 +350,16 @@ def main():
         row_offsets = np.concatenate([[0], np.cumsum(top_rows)]).astype(np.int64)
         sworld, srank = (args.emulate_world, max(args.emulate_rank, 0)) if args.emulate_world > 1 else (world, rank)
         mode = choose_mode(desc, sworld, args.shard)
+        cuts = [0, n]
+        seg_rows = top_rows                     # the row segments of y the closing all-gather carries, in global order
         if mode == "rows":
+            # contiguous row ranges, cut one level or more below the top-level blocks: one segment per rank
+            if sworld > 1:
+                cuts, loads = row_partition(desc, sworld)
+            else:
+                loads = [total_leaf]
+            seg_rows, owner = [cuts[r + 1] - cuts[r] for r in range(sworld)], list(range(sworld))
+        elif mode == "rowblocks":
             owner, loads = assign_row_blocks(weights, sworld)
         else:
             bw = block_weights(desc)
@@ -342,20 +373,42 @@ def main():
     t_struct = time.time() - t0
     if rank == 0:
         log(f"structure: {workload}; nodes={desc.num_nodes} leafGB={total_leaf * esz / 1e9:.2f} [{t_struct:.1f}s]; "
-            f"shard mode={mode}; rank loads GB={[round(l * esz / 1e9, 2) for l in loads]}")
+            f"shard mode={mode}; rank loads GB={[round(l * esz / 1e9, 2) for l in loads]}; "
+            f"max/mean = {max(loads) / (sum(loads) / len(loads)):.3f}, replication = {sum(loads) / total_leaf:.3f}")
+
+    if dry:
+        # every rank laid the operand out and partitioned it on its own: they must agree before anything is compiled
+        mine_sig = [float(c) for c in cuts] + [float(v) for v in loads]
+        same = True
+        if use_pg:
+            sigs = [None] * world
+            dist.all_gather_object(sigs, mine_sig)
+            same = all(sg == sigs[0] for sg in sigs)
+        if rank == 0:
+            real_stdout.write(json.dumps({"dry_run": True, "n_gpus": world, "mode": mode, "cuts": [int(c) for c in cuts],
+                                          "rank_leaf_gb": [l * esz / 1e9 for l in loads], "imbalance": max(loads) / (sum(loads) / len(loads)),
+                                          "replication": sum(loads) / total_leaf, "ranks_agree": same, "workload": workload}) + "\n")
+            real_stdout.flush()
+        if use_pg:
+            dist.barrier()
+            dist.destroy_process_group()
+        sys.exit(0 if same else 3)
 
     def compile_shard(r, max_rhs):
         """The operator rank r of an `sworld`-rank job holds."""
+        rr = None
         if sworld == 1:
             root, rows = desc.root, n
         elif mode == "rows":
+            root, rows, rr = desc.root, cuts[r + 1] - cuts[r], (cuts[r], cuts[r + 1])
+        elif mode == "rowblocks":
             mine_r = [rb for rb in range(len(weights)) if owner[rb] == r]
             root, rows = hs.shard_desc(desc, mine_r)
         else:
             mine_r = [i for i in range(len(bowner)) if bowner[i] == r]
             root, rows = hs.shard_desc_blocks(desc, mine_r), n
         o = HipOperator.from_desc(desc, None, root=root, device=local_rank, flags=flags, seed=args.seed, max_rhs=max_rhs,
-                                  demote_to_f32=(dtype == "f32"))
+                                  demote_to_f32=(dtype == "f32"), row_range=rr)
         return o, rows
 
     t0 = time.time()
@@ -378,7 +431,7 @@ def main():
 
     sharded = None
     if (world > 1 or args.force_collective) and args.emulate_world <= 1:
-        layout = ShardLayout(top_rows, owner, world)
+        layout = ShardLayout(seg_rows if not streamer else top_rows, owner, world)
 
         def bcast(payload):
             box = [payload]
@@ -423,6 +476,7 @@ def main():
     # multi-GPU: per-rank leaf bytes, the slowest rank's local stages, and the collective, separately
     # (a few extra steps outside the timed region: reading the events synchronizes the host)
     multi = None
+    prof_rank = rank
     if sharded is not None:
         sharded.set_timing(True)
         loc, coll = [], []
@@ -430,17 +484,31 @@ def main():
             step(x)
             a, b = sharded.last_times()
             loc.append(a); coll.append(b)
-        v = torch.tensor([float(np.median(loc)), float(np.median(coll)), st["leafBytes"] / 1e9], dtype=torch.float64, device=dev)
+        # this rank's stage profile (kernel ms per apply, launches, algorithmic bytes per apply) travels too: the line's
+        # roofline is the SLOWEST rank's, the one that bounds the step
+        per_apply_ms = float(ms.sum()) / max(float(launches.max()), 1.0)
+        v = torch.tensor([float(np.median(loc)), float(np.median(coll)), st["leafBytes"] / 1e9, per_apply_ms], dtype=torch.float64, device=dev)
+        prof = torch.tensor(np.concatenate([ms, launches.astype(np.float64), sbytes.astype(np.float64)]), dtype=torch.float64, device=dev)
         if use_pg:
             allv = [torch.zeros_like(v) for _ in range(world)]
             dist.all_gather(allv, v)
+            allp = [torch.zeros_like(prof) for _ in range(world)]
+            dist.all_gather(allp, prof)
         else:
-            allv = [v]
+            allv, allp = [v], [prof]
         allv = torch.stack(allv).cpu().numpy()
-        multi = {"mode": mode, "collective": "ncclAllGather (in place) + segment reorder" if mode == "rows" else "ncclAllReduce (sum)",
-                 "rank_leaf_gb": [round(float(r[2]), 3) for r in allv], "rank_local_ms": [round(float(r[0]), 4) for r in allv],
+        allp = torch.stack(allp).cpu().numpy()
+        prof_rank = int(np.argmax(allv[:, 3]))
+        S_ = len(ms)
+        ms, launches, sbytes = allp[prof_rank, :S_], allp[prof_rank, S_:2 * S_].astype(np.uint64), allp[prof_rank, 2 * S_:].astype(np.uint64)
+        gb = allv[:, 2]
+        multi = {"mode": mode, "collective": "ncclAllReduce (sum)" if mode == "blocks" else "ncclAllGather (in place) + segment reorder",
+                 "rank_leaf_gb": [round(float(g), 3) for g in gb], "imbalance": float(gb.max() / gb.mean()),
+                 "replication": float(gb.sum() * 1e9 / (total_leaf * esz)),
+                 "rank_local_ms": [round(float(r[0]), 4) for r in allv], "rank_kernel_ms": [round(float(r[3]), 4) for r in allv],
                  "max_local_ms": float(allv[:, 0].max()), "collective_ms_per_rank": [round(float(r[1]), 4) for r in allv],
-                 "max_collective_ms": float(allv[:, 1].max()), "collective_bytes": int(n * args.nrhs * esz)}
+                 "max_collective_ms": float(allv[:, 1].max()), "collective_bytes": int(n * args.nrhs * esz),
+                 "roofline_rank": prof_rank, "bit_identical_to_one_gpu": mode != "blocks"}
 
     if rank == 0:
         kern_ms = float(ms.sum())
@@ -465,6 +533,7 @@ def main():
             roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                         "kernel": "bfStageKernelC128" if not real else f"bfStageKernelReal<{dtype}>", "launches_per_apply": len(ms),
+                        **({"rank": prof_rank, "note": "the slowest rank's stage kernels (it bounds the step); bytes = that rank's shard"} if multi else {}),
                         "avg_launch_ms": avg_launch_ms, "algorithmic_bytes_per_launch": bytes_per_apply / len(ms),
                         "algorithmic_bytes_per_apply": bytes_per_apply, "kernel_ms_per_apply": kern_ms / max(launches.max(), 1),
                         "event_sampling": f"HIP events around every launch of 1 apply in {ev_every} of the timed region"}
@@ -504,9 +573,10 @@ def main():
                 op.apply_host(x_host)
             pcie_ms = (time.perf_counter() - t1) / reps * 1e3
         config["stages"] = st["numStages"]
-        if not streamer:
-            config["sharding"] = ("none" if sworld == 1 else "top-level row blocks (LPT by leaf bytes) + one all-gather" if mode == "rows"
-                                  else "top-level (row, col) blocks (LPT by leaf bytes) + one all-reduce")
+        config["sharding"] = ("none" if sworld == 1 else
+                              "contiguous row ranges below the top-level blocks (bfhipRowPartition: balanced, source-side factors replicated) + one all-gather" if mode == "rows"
+                              else "top-level row blocks (LPT by leaf bytes) + one all-gather" if mode == "rowblocks"
+                              else "top-level (row, col) blocks (LPT by leaf bytes) + one all-reduce")
         out = {
             "metric": metric,
             "value": args.steps * args.nrhs / elapsed,
@@ -516,7 +586,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "strong" if not streamer else "weak",
+            "scaling": "strong",      # the operator is fixed: more GPUs share it
             "vs_baseline": None,
             "dtype": dtype,
             "data": data,
@@ -574,7 +644,8 @@ def main():
                                      "note": "bfhipApply: pack into pinned staging + H2D x + apply + D2H y + unpack"}
         if args.emulate_world > 1:
             out["emulated_shard"] = {"world": args.emulate_world, "rank": srank, "mode": mode, "shard_leaf_bytes": st["leafBytes"]}
-        if world == 1 and not args.no_cpu_baseline and args.emulate_world <= 1:
+        # rank 0 times the CPU baseline whatever the world size (the other ranks wait at the closing barrier)
+        if not args.no_cpu_baseline and args.emulate_world <= 1:
             try:
                 if streamer:
                     out["cpu_baseline"] = cpu_baseline_streamer(graph, args.seed, args.cpu_budget_gb * 1e9)
@@ -663,6 +734,8 @@ def main():
     if rank == 0:
         real_stdout.write(json.dumps(out) + "\n")
         real_stdout.flush()
+    if use_pg:
+        dist.barrier()            # ranks > 0 wait here while rank 0 times the CPU baseline
     if sharded is not None:
         sharded.close()
     if op is not None:

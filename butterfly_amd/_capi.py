@@ -23,7 +23,8 @@ ERROR_NAMES = {0: "BF_ERROR_NONE", 1: "BF_ERROR_INVALID_ARGUMENTS", 2: "BF_ERROR
 class BfhipOptions(C.Structure):
     _fields_ = [("structSize", C.c_uint32), ("device", C.c_int32), ("flags", C.c_uint32),
                 ("maxRhs", C.c_uint32), ("demoteToF32", C.c_uint32), ("reserved0", C.c_uint32),
-                ("seed", C.c_uint64), ("rowBlockBegin", C.c_uint64), ("rowBlockEnd", C.c_uint64)]
+                ("seed", C.c_uint64), ("rowBlockBegin", C.c_uint64), ("rowBlockEnd", C.c_uint64),
+                ("rowBegin", C.c_uint64), ("rowEnd", C.c_uint64)]
 
 
 class BfhipDesc(C.Structure):
@@ -285,6 +286,10 @@ def load():
     lib.bfhipCompile.restype = C.c_int
     lib.bfhipCompileDesc.argtypes = [C.POINTER(BfhipDesc), C.POINTER(BfhipOptions), C.POINTER(vp)]
     lib.bfhipCompileDesc.restype = C.c_int
+    lib.bfhipRowPartition.argtypes = [C.POINTER(BfhipDesc), C.c_uint32, vp, vp]
+    lib.bfhipRowPartition.restype = C.c_int
+    lib.bfhipRowPartitionMat.argtypes = [vp, C.c_uint32, vp, vp]
+    lib.bfhipRowPartitionMat.restype = C.c_int
     lib.bfhipApply.argtypes = [vp, vp, C.c_size_t, C.c_size_t, vp, C.c_size_t]
     lib.bfhipApply.restype = C.c_int
     lib.bfhipApplyDevice.argtypes = [vp, vp, C.c_size_t, vp, vp]

@@ -305,8 +305,8 @@ int bfhipCompileIrFill(BfIr *ir, BfhipOptions const *opts, BfFillFn fill, void *
   memset(&o, 0, sizeof o);
   o.device = -1;
   if (opts) {
-    if (opts->structSize < sizeof(BfhipOptions)) { bfIrFree(ir); return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "BfhipOptions.structSize too small"); }
-    o = *opts;
+    if (opts->structSize < BFHIP_OPTIONS_SIZE_V1) { bfIrFree(ir); return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "BfhipOptions.structSize too small"); }
+    memcpy(&o, opts, opts->structSize < sizeof o ? opts->structSize : sizeof o);      /* fields a shorter (older) struct lacks stay 0 */
   }
   BfhipOperator *op = calloc(1, sizeof *op);
   if (!op) { bfIrFree(ir); return bfhipFail(BFABI_ERROR_MEMORY_ERROR, "host OOM"); }
@@ -332,6 +332,8 @@ int bfhipCompileIrFill(BfIr *ir, BfhipOptions const *opts, BfFillFn fill, void *
   po.rowBlockBegin = o.rowBlockBegin;
   po.rowAlignBytes = 128;      /* rows of row-major pieces on 128-byte lines: the forward kernel gains 1 - 3 % on them, the transposed one 3 % */
   po.rowBlockEnd = o.rowBlockEnd;
+  po.rowBegin = o.rowBegin;
+  po.rowEnd = o.rowEnd;
   if ((rc = bfPlanBuild(ir, &po, &op->plan))) goto done;
   op->leafBytesAlgorithmic = op->plan.leafElems * op->plan.elemSize;
   if (o.flags & BFHIP_FLAG_ADJOINT) {
@@ -339,6 +341,7 @@ int bfhipCompileIrFill(BfIr *ir, BfhipOptions const *opts, BfFillFn fill, void *
     uint64_t nf = 0;
     if ((rc = bfPlanFwdPieces(&op->plan, &fwd, &nf))) goto done;
     BfPlanOptions pt = po;
+    if (po.rowEnd > 0 || po.rowBlockEnd > 0) { free(fwd); rc = bfhipFail(BFABI_ERROR_NOT_IMPLEMENTED, "BFHIP_FLAG_ADJOINT on a row-sharded operator"); goto done; }
     pt.fwdPieces = fwd;
     pt.numFwdPieces = nf;
     pt.tCols = 0;      /* item width (16 or 64 columns of A) chosen stage by stage */
@@ -406,6 +409,25 @@ int bfhipCompileDesc(BfhipDesc const *desc, BfhipOptions const *opts, BfhipOpera
   int rc = bfIrFromDesc(desc, &ir);
   if (rc) return rc;
   return bfhipCompileIrFill(&ir, opts, NULL, NULL, out);
+}
+
+int bfhipRowPartition(BfhipDesc const *desc, uint32_t world, uint64_t *cuts, uint64_t *leafElems) {
+  if (!desc || !cuts) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "NULL argument");
+  BfIr ir;
+  int rc = bfIrFromDesc(desc, &ir);
+  if (rc) return rc;
+  rc = bfPlanRowPartition(&ir, world, cuts, leafElems);
+  bfIrFree(&ir);
+  return rc;
+}
+int bfhipRowPartitionMat(void const *bfMat, uint32_t world, uint64_t *cuts, uint64_t *leafElems) {
+  if (!bfMat || !cuts) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "NULL argument");
+  BfIr ir;
+  int rc = bfIrFromBfMat(bfMat, &ir);
+  if (rc) return rc;
+  rc = bfPlanRowPartition(&ir, world, cuts, leafElems);
+  bfIrFree(&ir);
+  return rc;
 }
 
 /* ---- profiling helpers ------------------------------------------------------ */
@@ -977,8 +999,8 @@ int bfhipLoad(char const *path, BfhipOptions const *opts, BfhipOperator **out) {
   memset(&o, 0, sizeof o);
   o.device = -1;
   if (opts) {
-    if (opts->structSize < sizeof(BfhipOptions)) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "BfhipOptions.structSize too small");
-    o = *opts;
+    if (opts->structSize < BFHIP_OPTIONS_SIZE_V1) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "BfhipOptions.structSize too small");
+    memcpy(&o, opts, opts->structSize < sizeof o ? opts->structSize : sizeof o);
   }
   if (o.flags & BFHIP_FLAG_PLAN_ONLY) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "cannot load as plan-only");
   FILE *fp = fopen(path, "rb");

@@ -160,6 +160,7 @@ typedef struct BfPlanOptions {
   uint32_t xcap;
   uint32_t minChunkRows;     /* lower bound of the adaptive item height, in 16-byte row units (0 -> 16): 32 keeps the RHS-block kernel's two-slab passes full */
   uint64_t rowBlockBegin, rowBlockEnd;
+  uint64_t rowBegin, rowEnd;   /* row-range shard: keep what output rows [rowBegin, rowEnd) depend on; rowEnd == 0 -> all */
   /* transposed plan (A^T x): pieces are located in the forward plan's arena */
   BfFwdPiece const *fwdPieces;   /* sorted by (node, col0, row0); NULL -> forward plan */
   uint64_t numFwdPieces;
@@ -168,6 +169,8 @@ typedef struct BfPlanOptions {
 } BfPlanOptions;
 
 int bfPlanBuild(BfIr const *ir, BfPlanOptions const *po, BfPlan *plan);
+/* balanced contiguous row ranges for `world` ranks: cuts[world + 1], loads[world] (leaf elements each range keeps) or NULL */
+int bfPlanRowPartition(BfIr const *ir, uint32_t world, uint64_t *cuts, uint64_t *loads);
 /* table of the forward plan's pieces (needs its host mirrors); caller frees */
 int bfPlanFwdPieces(BfPlan const *plan, BfFwdPiece **out, uint64_t *count);
 void bfPlanFree(BfPlan *plan);

@@ -46,6 +46,7 @@ typedef struct Task {
   uint64_t outOff, inOff;
   uint64_t rows, cols;
   uint64_t sub0;       /* offset of this task inside its leaf along the contracted dimension (long leaves are cut) */
+  uint64_t rsub0;      /* first row of the leaf this task produces (row-range shards may trim a leaf that straddles a cut) */
   uint64_t seq;        /* emission order: fixes the summation order */
   uint32_t cls, pad;   /* transposed plans: 1 = rows of a tall leaf (>= 16 lane units: the 16-column kernel reads whole 256-byte runs) */
 } Task;
@@ -185,6 +186,222 @@ static int emitT(Builder *b, uint64_t node, uint32_t inBuf, uint64_t inOff, uint
   }
   }
   return bfhipFail(BFABI_ERROR_TYPE_ERROR, "unknown node kind");
+}
+
+
+/* ---- row-range shards: backward liveness over the task list --------------------------------------
+ * A rank of a multi-GPU job owns the output rows [rowBegin, rowEnd).  Every top-level block row of the
+ * reference is computed independently from the full x (bfMatBlockDenseMul, src/mat_block_dense.c:534-566), a
+ * nested BlockDense row block likewise (src/fac_helm2.c:814-858), and inside a product the evaluation factor is
+ * block diagonal over target nodes (src/fac_helm2.c:403-509) fed by radix-4 BlockCoo stages (:277-318): which
+ * leaves a set of output rows needs follows from the task list alone.  Walk the stages backwards: a task is live
+ * if any row it writes is live; a live task makes the input elements it reads live.  Dead tasks are dropped
+ * before grouping, so a shard holds exactly the leaves its rows depend on (the factors near the source end of a
+ * butterfly are needed by every target row and are replicated), and every surviving row group is the one the
+ * whole operator would have: the rows a rank produces are bit for bit those of the one-GPU plan. */
+static int cmpTask(void const *pa, void const *pb);
+
+typedef struct LiveMap {
+  uint64_t *bits;
+  uint64_t *base;        /* per buffer: first bit */
+  uint64_t numBits;
+} LiveMap;
+
+static void liveFree(LiveMap *lm) { free(lm->bits); free(lm->base); memset(lm, 0, sizeof *lm); }
+
+static int liveInit(LiveMap *lm, Buf const *bufs, uint64_t numBufs) {
+  memset(lm, 0, sizeof *lm);
+  lm->base = malloc((numBufs + 1) * 8);
+  if (!lm->base) return bfhipFail(BFABI_ERROR_MEMORY_ERROR, "host OOM (liveness)");
+  uint64_t acc = 0;
+  for (uint64_t i = 0; i < numBufs; ++i) { lm->base[i] = acc; acc += (bufs[i].len + 63) / 64 * 64; }
+  lm->base[numBufs] = acc;
+  lm->numBits = acc;
+  lm->bits = calloc(acc / 64 + 1, 8);
+  if (!lm->bits) { liveFree(lm); return bfhipFail(BFABI_ERROR_MEMORY_ERROR, "host OOM (liveness)"); }
+  return 0;
+}
+static void liveMark(LiveMap *lm, uint32_t buf, uint64_t off, uint64_t len) {
+  if (!len) return;
+  uint64_t a = lm->base[buf] + off, b = a + len;       /* [a, b) */
+  uint64_t wa = a / 64, wb = (b - 1) / 64;
+  uint64_t const ma = ~0ull << (a % 64), mb = ~0ull >> (63 - (b - 1) % 64);
+  if (wa == wb) { lm->bits[wa] |= ma & mb; return; }
+  lm->bits[wa] |= ma;
+  for (uint64_t w = wa + 1; w < wb; ++w) lm->bits[w] = ~0ull;
+  lm->bits[wb] |= mb;
+}
+static int liveAny(LiveMap const *lm, uint32_t buf, uint64_t off, uint64_t len) {
+  if (!len) return 0;
+  uint64_t a = lm->base[buf] + off, b = a + len;
+  uint64_t wa = a / 64, wb = (b - 1) / 64;
+  uint64_t const ma = ~0ull << (a % 64), mb = ~0ull >> (63 - (b - 1) % 64);
+  if (wa == wb) return (lm->bits[wa] & ma & mb) != 0;
+  if (lm->bits[wa] & ma) return 1;
+  for (uint64_t w = wa + 1; w < wb; ++w) if (lm->bits[w]) return 1;
+  return (lm->bits[wb] & mb) != 0;
+}
+static int liveBit(LiveMap const *lm, uint32_t buf, uint64_t off) {
+  uint64_t a = lm->base[buf] + off;
+  return (int)((lm->bits[a / 64] >> (a % 64)) & 1u);
+}
+
+/* Tasks sorted by stage (ascending).  Marks liveness from rows [rowBegin, rowEnd) of buffer `by`, trims the tasks
+ * that write y to that range, drops dead tasks (the array is compacted in place, order kept) and shifts y to start at
+ * rowBegin.  Buffers nothing live writes get length 0. */
+static int pruneToRowRange(Builder *b, uint32_t bx, uint32_t by, int32_t S, uint64_t rowBegin, uint64_t rowEnd, LiveMap *lm) {
+  int rc = liveInit(lm, b->bufs, b->numBufs);
+  if (rc) return rc;
+  liveMark(lm, by, rowBegin, rowEnd - rowBegin);
+  uint8_t *keep = calloc(b->numTasks ? b->numTasks : 1, 1);
+  uint8_t *written = calloc(b->numBufs, 1);
+  if (!keep || !written) { free(keep); free(written); return bfhipFail(BFABI_ERROR_MEMORY_ERROR, "host OOM (liveness)"); }
+  for (uint64_t t = b->numTasks; t-- > 0;) {        /* stages descending: every reader of a buffer comes before its writers */
+    Task *tk = &b->tasks[t];
+    if (!liveAny(lm, tk->outBuf, tk->outOff, tk->rows)) continue;
+    keep[t] = 1;
+    written[tk->outBuf] = 1;
+    if (tk->outBuf == by) {
+      /* trim to the range: the leaf's rows [rsub0, rsub0 + rows) */
+      uint64_t lo = tk->outOff > rowBegin ? tk->outOff : rowBegin;
+      uint64_t hi = tk->outOff + tk->rows < rowEnd ? tk->outOff + tk->rows : rowEnd;
+      tk->rsub0 += lo - tk->outOff;
+      if (b->ir->kind[tk->leaf] == BFHIP_NODE_IDENTITY) { tk->inOff += lo - tk->outOff; tk->cols = hi - lo; }   /* an identity copies row i to row i */
+      tk->outOff = lo - rowBegin;
+      tk->rows = hi - lo;
+    }
+    if (tk->inBuf != bx) liveMark(lm, tk->inBuf, tk->inOff, tk->cols);
+  }
+  (void)S;
+  uint64_t w = 0;
+  for (uint64_t t = 0; t < b->numTasks; ++t) if (keep[t]) b->tasks[w++] = b->tasks[t];
+  b->numTasks = w;
+  for (uint64_t i = 2; i < b->numBufs; ++i) if (!written[i]) b->bufs[i].len = 0;
+  /* y now holds the range only: shift its liveness bits to the front (gap fill below asks for them) */
+  for (uint64_t r = 0; r < rowEnd - rowBegin; ++r) {
+    uint64_t const a = lm->base[by] + r;
+    lm->bits[a / 64] |= 1ull << (a % 64);
+  }
+  b->bufs[by].len = rowEnd - rowBegin;
+  free(keep); free(written);
+  return 0;
+}
+
+
+/* ---- balanced row ranges for W ranks ---------------------------------------------------------------
+ * cuts[0] = 0 < cuts[1] < ... < cuts[W] = rows: rank r owns rows [cuts[r], cuts[r + 1]).  A cut is only placed where
+ * no leaf that writes y straddles it (a "clean" position: quadtree node boundaries in a fac_helm2 operand), so no leaf
+ * is trimmed and every rank's rows are bit for bit the one-GPU result.  The load of a range is what pruneToRowRange
+ * would keep for it: every task carries the hull [lo, hi) of the y rows that depend on it (propagated backwards through
+ * the intermediates: min / max per element), and load(a, b) = sum of leaf elements of the tasks whose hull meets
+ * [a, b) -- replication of the source-side factors included.  The largest load is minimised by bisection over a greedy
+ * sweep (a contiguous partition). */
+typedef struct PartTask { uint32_t lo, hi; uint64_t w; } PartTask;
+static int cmpPartTask(void const *pa, void const *pb) {
+  PartTask const *a = pa, *b = pb;
+  if (a->lo != b->lo) return a->lo < b->lo ? -1 : 1;
+  return a->hi < b->hi ? -1 : (a->hi > b->hi);
+}
+
+/* largest clean cut index j > i0 (at most jMax) with load(cut[i0], cut[j]) <= L; 0 if even i0 + 1 exceeds L */
+static uint64_t partAdvance(PartTask const *pt, uint64_t npt, uint64_t const *cut, uint64_t i0, uint64_t jMax, uint64_t L, uint64_t *loadOut) {
+  uint64_t const a = cut[i0];
+  uint64_t acc = 0, k = 0, best = 0, bestLoad = 0;
+  for (uint64_t j = i0 + 1; j <= jMax; ++j) {
+    uint64_t const bnd = cut[j];
+    while (k < npt && pt[k].lo < bnd) { if (pt[k].hi > a) acc += pt[k].w; ++k; }
+    if (acc > L) break;
+    best = j; bestLoad = acc;
+  }
+  if (loadOut) *loadOut = bestLoad;
+  return best;
+}
+
+int bfPlanRowPartition(BfIr const *ir, uint32_t world, uint64_t *cuts, uint64_t *loads) {
+  if (!world) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "zero ranks");
+  Builder b;
+  memset(&b, 0, sizeof b);
+  b.ir = ir;
+  int rc = 0;
+  uint32_t bx, by;
+  uint64_t const root = ir->root, N = ir->rows[root];
+  int32_t const S = (int32_t)ir->depth[root];
+  uint32_t *lo = NULL, *hi = NULL;
+  uint64_t *base = NULL, *cut = NULL;
+  int32_t *interior = NULL;
+  PartTask *pt = NULL;
+  if (N >= 0xffffffffu) return bfhipFail(BFABI_ERROR_RUNTIME_ERROR, "operator too tall for 32-bit row indices");
+  if ((rc = newBuf(&b, ir->cols[root], -1, &bx))) goto done;
+  if ((rc = newBuf(&b, N, S - 1, &by))) goto done;
+  if ((rc = emit(&b, root, bx, 0, by, 0, S - 1))) goto done;
+  qsort(b.tasks, b.numTasks, sizeof(Task), cmpTask);
+  base = malloc((b.numBufs + 1) * 8);
+  if (!base) { rc = bfhipFail(BFABI_ERROR_MEMORY_ERROR, "host OOM"); goto done; }
+  uint64_t tot = 0;
+  for (uint64_t i = 0; i < b.numBufs; ++i) { base[i] = tot; if (i != bx) tot += b.bufs[i].len; }
+  lo = malloc((tot + 1) * 4); hi = malloc((tot + 1) * 4);
+  pt = malloc((b.numTasks + 1) * sizeof *pt);
+  interior = calloc(N + 2, sizeof *interior);
+  if (!lo || !hi || !pt || !interior) { rc = bfhipFail(BFABI_ERROR_MEMORY_ERROR, "host OOM (row partition)"); goto done; }
+  for (uint64_t e = 0; e < tot; ++e) { lo[e] = 0xffffffffu; hi[e] = 0; }
+  for (uint64_t r = 0; r < N; ++r) { lo[base[by] + r] = (uint32_t)r; hi[base[by] + r] = (uint32_t)r + 1; }
+  uint64_t npt = 0, total = 0;
+  for (uint64_t t = b.numTasks; t-- > 0;) {
+    Task const *tk = &b.tasks[t];
+    uint32_t L = 0xffffffffu, H = 0;
+    uint64_t const o = base[tk->outBuf] + tk->outOff;
+    for (uint64_t r = 0; r < tk->rows; ++r) { if (lo[o + r] < L) L = lo[o + r]; if (hi[o + r] > H) H = hi[o + r]; }
+    if (L == 0xffffffffu) continue;                      /* nothing reads what it writes */
+    if (tk->inBuf != bx) {
+      uint64_t const i0 = base[tk->inBuf] + tk->inOff;
+      for (uint64_t c = 0; c < tk->cols; ++c) { if (L < lo[i0 + c]) lo[i0 + c] = L; if (H > hi[i0 + c]) hi[i0 + c] = H; }
+    }
+    if (tk->outBuf == by && tk->rows > 1) { interior[tk->outOff + 1] += 1; interior[tk->outOff + tk->rows] -= 1; }
+    if (ir->kind[tk->leaf] != BFHIP_NODE_DENSE) continue;
+    pt[npt].lo = L; pt[npt].hi = H; pt[npt].w = tk->rows * tk->cols;
+    total += pt[npt].w;
+    ++npt;
+  }
+  qsort(pt, npt, sizeof *pt, cmpPartTask);
+  /* clean cut positions, 0 and N included */
+  uint64_t ncut = 0;
+  cut = malloc((N + 2) * 8);
+  if (!cut) { rc = bfhipFail(BFABI_ERROR_MEMORY_ERROR, "host OOM"); goto done; }
+  int32_t depthIn = 0;
+  for (uint64_t p = 0; p <= N; ++p) { depthIn += interior[p]; if (p == 0 || p == N || depthIn == 0) cut[ncut++] = p; }
+  if (ncut - 1 < world) { rc = bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "the operator's %llu rows can be cut at %llu places only: not enough for %u ranks", (unsigned long long)N, (unsigned long long)(ncut - 2), world); goto done; }
+  /* smallest L for which the greedy sweep covers all rows with `world` non-empty ranges */
+  uint64_t Llo = total / world, Lhi = 0;
+  for (uint64_t k = 0; k < npt; ++k) Lhi += pt[k].w;           /* = total: one rank holding everything */
+  for (int iter = 0; iter < 48 && Lhi - Llo > total / 100000 + 1; ++iter) {
+    uint64_t const L = Llo + (Lhi - Llo) / 2;
+    uint64_t i = 0;
+    int ok = 1;
+    for (uint32_t r = 0; r < world && ok; ++r) {
+      uint64_t const jMax = (ncut - 1) - (world - 1 - r);     /* leave a clean interval for every later rank */
+      uint64_t const j = partAdvance(pt, npt, cut, i, jMax, L, NULL);
+      if (!j) ok = 0; else i = j;
+    }
+    if (ok && i == ncut - 1) Lhi = L; else Llo = L + 1;
+  }
+  {
+    uint64_t i = 0;
+    cuts[0] = 0;
+    for (uint32_t r = 0; r < world; ++r) {
+      uint64_t const jMax = (ncut - 1) - (world - 1 - r);
+      uint64_t ld = 0;
+      uint64_t j = r + 1 == world ? ncut - 1 : partAdvance(pt, npt, cut, i, jMax, Lhi, NULL);
+      if (!j) j = i + 1;                                         /* a single leaf heavier than the target: it still goes somewhere */
+      (void)partAdvance(pt, npt, cut, i, j, UINT64_MAX, &ld);    /* the load of [cut[i], cut[j]) */
+      cuts[r + 1] = cut[j];
+      if (loads) loads[r] = ld;
+      i = j;
+    }
+  }
+done:
+  free(lo); free(hi); free(base); free(cut); free(interior); free(pt);
+  free(b.tasks); free(b.bufs);
+  return rc;
 }
 
 static int cmpFwdPiece(void const *pa, void const *pb) {
@@ -338,8 +555,12 @@ int bfPlanBuild(BfIr const *ir, BfPlanOptions const *po, BfPlan *plan) {
      * the element size: the transposed kernel tiles a forward piece as 4 columns x 16 row units per load */
     itemRows = po->tCols > 16 ? po->tCols : 16;
     plan->maxItemRows = po->tCols ? itemRows : 64;      /* tCols == 0: chosen stage by stage below */
-    if (po->rowBlockEnd > 0) return bfhipFail(BFABI_ERROR_NOT_IMPLEMENTED, "transposed plan of a row-sharded operator");
+    if (po->rowBlockEnd > 0 || po->rowEnd > 0) return bfhipFail(BFABI_ERROR_NOT_IMPLEMENTED, "transposed plan of a row-sharded operator");
   }
+  if (po->rowEnd > 0 && po->rowBlockEnd > 0) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "row range and row-block range are exclusive");
+  LiveMap lm;
+  memset(&lm, 0, sizeof lm);
+  uint64_t *fullStageElems = NULL;
 
   uint32_t bx, by;
   uint64_t root = ir->root;
@@ -404,14 +625,29 @@ int bfPlanBuild(BfIr const *ir, BfPlanOptions const *po, BfPlan *plan) {
     }
   }
 
-  /* vector arena: intermediates first */
-  uint64_t top = 0;
-  for (uint64_t i = 2; i < b.numBufs; ++i) b.bufs[i].arenaOff = arenaAlloc(&top, b.bufs[i].len);
-
   if (T && !po->tCols)     /* tall leaves get 16-column items of their own (below) */
     for (uint64_t t = 0; t < b.numTasks; ++t)
       b.tasks[t].cls = ir->kind[b.tasks[t].leaf] == BFHIP_NODE_DENSE && ir->rows[b.tasks[t].leaf] >= 16u * plan->epl;
   qsort(b.tasks, b.numTasks, sizeof(Task), cmpTask);
+
+  /* how long contractions are cut (below) depends on the size of the stage: a shard cuts like the whole operator,
+   * so that its rows are bit for bit the whole operator's */
+  fullStageElems = calloc((size_t)S + 1, 8);
+  if (!fullStageElems) { rc = bfhipFail(BFABI_ERROR_MEMORY_ERROR, "host OOM"); goto fail; }
+  for (uint64_t t = 0; t < b.numTasks; ++t) fullStageElems[b.tasks[t].stage] += b.tasks[t].rows * b.tasks[t].cols;
+
+  if (po->rowEnd > 0) {
+    /* row-range shard: keep what rows [rowBegin, rowEnd) of y depend on (see pruneToRowRange) */
+    if (po->rowBegin >= po->rowEnd || po->rowEnd > numRows) { rc = bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "row range [%llu, %llu) outside the operator's %llu rows", (unsigned long long)po->rowBegin, (unsigned long long)po->rowEnd, (unsigned long long)numRows); goto fail; }
+    if ((rc = pruneToRowRange(&b, bx, by, S, po->rowBegin, po->rowEnd, &lm))) goto fail;
+    qsort(b.tasks, b.numTasks, sizeof(Task), cmpTask);      /* trimmed tasks may have moved */
+    numRows = po->rowEnd - po->rowBegin;
+    plan->numRows = numRows;
+  }
+
+  /* vector arena: intermediates first */
+  uint64_t top = 0;
+  for (uint64_t i = 2; i < b.numBufs; ++i) b.bufs[i].arenaOff = arenaAlloc(&top, b.bufs[i].len);
 
   /* ---- 2..4 per stage --------------------------------------------------- */
   uint64_t arenaTop = 0;       /* leaf arena, elements */
@@ -453,8 +689,7 @@ int bfPlanBuild(BfIr const *ir, BfPlanOptions const *po, BfPlan *plan) {
       }
       itemRows = (10 * slots4 < 8 * slots16) ? 64 : 16;
     }
-    uint64_t stageElems = 0;
-    for (uint64_t t = tBegin; t < tEnd; ++t) stageElems += b.tasks[t].rows * b.tasks[t].cols;
+    uint64_t const stageElems = fullStageElems[s];
     uint64_t capBytes = 1u << 20;
     if (stageElems * plan->elemSize / 4096 < capBytes) capBytes = stageElems * plan->elemSize / 4096;
     if (capBytes < BF_ITEM_BYTES) capBytes = BF_ITEM_BYTES;
@@ -491,7 +726,10 @@ int bfPlanBuild(BfIr const *ir, BfPlanOptions const *po, BfPlan *plan) {
     uint64_t numGaps = 0, capGaps = 16;
     Gap *gaps = malloc(capGaps * sizeof(Gap));
     if (!st->reduce || !gaps) { free(groups); free(gaps); free(bufRead); rc = bfhipFail(BFABI_ERROR_MEMORY_ERROR, "host OOM"); goto fail; }
-#define PUSH_GAP(B, O, L) do { if ((L) > 0) { if (numGaps == capGaps) { capGaps *= 2; Gap *p_ = realloc(gaps, capGaps * sizeof(Gap)); if (!p_) { rc = bfhipFail(BFABI_ERROR_MEMORY_ERROR, "host OOM"); goto stage_fail; } gaps = p_; } gaps[numGaps].buf = (B); gaps[numGaps].off = (O); gaps[numGaps].len = (L); ++numGaps; } } while (0)
+#define PUSH_GAP1(B, O, L) do { if ((L) > 0) { if (numGaps == capGaps) { capGaps *= 2; Gap *p_ = realloc(gaps, capGaps * sizeof(Gap)); if (!p_) { rc = bfhipFail(BFABI_ERROR_MEMORY_ERROR, "host OOM"); goto stage_fail; } gaps = p_; } gaps[numGaps].buf = (B); gaps[numGaps].off = (O); gaps[numGaps].len = (L); ++numGaps; } } while (0)
+    /* a row-range shard zero-fills only what something reads (the live runs of the gap) */
+#define PUSH_GAP(B, O, L) do { if (!lm.bits) PUSH_GAP1(B, O, L); else { uint64_t const o_ = (O), e_ = o_ + (L); uint64_t r_ = o_; \
+      while (r_ < e_) { while (r_ < e_ && !liveBit(&lm, (B), r_)) ++r_; uint64_t const s_ = r_; while (r_ < e_ && liveBit(&lm, (B), r_)) ++r_; PUSH_GAP1(B, s_, r_ - s_); } } } while (0)
 
     {
       /* walk groups buffer by buffer */
@@ -686,7 +924,7 @@ int bfPlanBuild(BfIr const *ir, BfPlanOptions const *po, BfPlan *plan) {
         if (ir->kind[tk->leaf] == BFHIP_NODE_IDENTITY) {
           BfDevPiece *pc = &st->pieces[np];
           pc->dataOff = 0; pc->inOff = (uint32_t)(inBase + r0); pc->ncols = mr; pc->flags = inFlag | BF_PIECE_IDENTITY; pc->ld = 0;
-          st->pieceSrc[np].node = tk->leaf; st->pieceSrc[np].row0 = r0; st->pieceSrc[np].col0 = 0;
+          st->pieceSrc[np].node = tk->leaf; st->pieceSrc[np].row0 = (uint32_t)tk->rsub0 + r0; st->pieceSrc[np].col0 = 0;
           ++np;
           continue;
         }
@@ -737,7 +975,7 @@ int bfPlanBuild(BfIr const *ir, BfPlanOptions const *po, BfPlan *plan) {
           BfDevPiece *pc = &st->pieces[np];
           if (inBase + c0 >= 0xffffffffu) { free(tmp); rc = bfhipFail(BFABI_ERROR_RUNTIME_ERROR, "vector arena exceeds 32-bit offsets"); goto stage_fail; }
           pc->dataOff = arenaTop; pc->inOff = (uint32_t)(inBase + c0); pc->ncols = (uint32_t)nc; pc->flags = inFlag; pc->ld = 0;
-          st->pieceSrc[np].node = tk->leaf; st->pieceSrc[np].row0 = r0; st->pieceSrc[np].col0 = (uint32_t)(tk->sub0 + c0);
+          st->pieceSrc[np].node = tk->leaf; st->pieceSrc[np].row0 = (uint32_t)tk->rsub0 + r0; st->pieceSrc[np].col0 = (uint32_t)(tk->sub0 + c0);
           if (rowMajor) {
             /* every row starts on a 128-byte line (rowAlignBytes; +0.3 % arena on the streamed benchmark operand): a
              * 64-column chunk of a row, what a transposed item reads, is then whole lines -- at 16-byte alignment it
@@ -801,17 +1039,22 @@ int bfPlanBuild(BfIr const *ir, BfPlanOptions const *po, BfPlan *plan) {
     free(bufRead);
     goto fail;
 #undef PUSH_GAP
+#undef PUSH_GAP1
   }
   free(bufRead);
   plan->arenaElems = arenaTop;
   plan->tempElems = roundUp(top, 4);
   free(b.tasks);
   free(b.bufs);
+  free(fullStageElems);
+  liveFree(&lm);
   return 0;
 
 fail:
   free(b.tasks);
   free(b.bufs);
+  free(fullStageElems);
+  liveFree(&lm);
   bfPlanFree(plan);
   return rc ? rc : BFABI_ERROR_RUNTIME_ERROR;
 }

@@ -78,15 +78,31 @@ def block_weights(desc):
     return w
 
 
+def row_partition(desc, world, root=None):
+    """bfhipRowPartition: balanced contiguous row ranges (cuts[world + 1], leaf elements kept per rank).  Cuts fall on
+    clean positions only (no leaf writing y straddles one), one level or more below the top-level row blocks: the
+    level-3+ rows inside each level-2 BlockDense (reference src/fac_helm2.c:814-858) and the target-node boundaries of
+    the evaluation factors, with the source-side factors a range needs replicated."""
+    import ctypes as C
+
+    from . import _capi
+    lib = _capi.load()
+    da = _capi.DescArrays(desc, root=root)
+    cuts = np.zeros(world + 1, dtype=np.uint64)
+    loads = np.zeros(world, dtype=np.uint64)
+    _capi.check(lib.bfhipRowPartition(da.byref(), world, cuts.ctypes.data, loads.ctypes.data))
+    return [int(c) for c in cuts], [int(v) for v in loads]
+
+
 def choose_mode(desc, world, requested="auto"):
-    """'rows' (all-gather) or 'blocks' (all-reduce) for this operand and world size."""
-    if requested in ("rows", "blocks"):
+    """How the operator is dealt to `world` ranks:
+    'rows'      contiguous row RANGES from row_partition (balanced to a few % at any world size; ONE all-gather;
+                bit-identical to one GPU) -- the default;
+    'rowblocks' whole top-level block rows by LPT (round 2's "rows": 12 blocks on a circle bound 8 ranks at 6.2x);
+    'blocks'    top-level (row, col) blocks by LPT + ONE all-reduce (equal to one GPU to rounding only)."""
+    if requested in ("rows", "rowblocks", "blocks"):
         return requested
-    if world == 1:
-        return "rows"
-    _, lr = assign_row_blocks(row_block_weights(desc), world)
-    _, lb = assign_row_blocks(block_weights(desc), world)
-    return "rows" if max(lr) <= 1.02 * max(lb) else "blocks"
+    return "rows"
 
 
 class ShardLayout:
@@ -177,11 +193,11 @@ class RcclShardedApply:
         _capi.check(lib.bfhipCommInitRank(ident, layout.world, rank, device_index, C.byref(self._comm)))
         spec = _capi.BfhipShardSpec()
         spec.structSize = C.sizeof(spec)
-        spec.mode = _capi.SHARD_ROWS if mode == "rows" else _capi.SHARD_BLOCKS
+        spec.mode = _capi.SHARD_BLOCKS if mode == "blocks" else _capi.SHARD_ROWS      # "rows" and "rowblocks": all-gather of row segments
         spec.numRowsGlobal = layout.n
         self._seg_rows = np.ascontiguousarray(layout.top_rows, dtype=np.uint64)
         self._seg_owner = np.ascontiguousarray(layout.owner, dtype=np.uint32)
-        if mode == "rows":
+        if mode != "blocks":
             spec.numSegments = len(self._seg_rows)
             spec.segRows, spec.segOwner = self._seg_rows.ctypes.data, self._seg_owner.ctypes.data
         self._sh = C.c_void_p()

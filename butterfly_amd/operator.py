@@ -18,7 +18,7 @@ from . import _capi
 from ._capi import BFHIP_C128, BFHIP_F32, BFHIP_F64, BfhipOptions, BfhipStats, DescArrays, check
 
 
-def _options(device=-1, flags=0, max_rhs=1, demote_to_f32=False, seed=0, row_blocks=None):
+def _options(device=-1, flags=0, max_rhs=1, demote_to_f32=False, seed=0, row_blocks=None, row_range=None):
     o = BfhipOptions()
     o.structSize = C.sizeof(BfhipOptions)
     o.device = device
@@ -28,6 +28,8 @@ def _options(device=-1, flags=0, max_rhs=1, demote_to_f32=False, seed=0, row_blo
     o.seed = seed
     if row_blocks is not None:
         o.rowBlockBegin, o.rowBlockEnd = row_blocks
+    if row_range is not None:
+        o.rowBegin, o.rowEnd = row_range
     return o
 
 

@@ -73,7 +73,15 @@ typedef struct BfhipOptions {
    * The operator then maps the full x to the concatenation of those rows. */
   uint64_t rowBlockBegin;
   uint64_t rowBlockEnd;
+  /* row-range sharding: keep exactly what output rows [rowBegin, rowEnd) depend on (any operand, not only a BLOCK
+   * root): leaves no kept row needs are dropped, source-side factors several ranges need are replicated, and the
+   * rows produced are bit for bit those of the whole operator when no leaf straddles the range ends (the cuts
+   * bfhipRowPartition returns).  rowEnd == 0 -> all rows.  Exclusive with rowBlockBegin/End.  (Fields added in
+   * round 3: a caller passing the shorter round-2 struct through structSize gets "all rows".) */
+  uint64_t rowBegin;
+  uint64_t rowEnd;
 } BfhipOptions;
+#define BFHIP_OPTIONS_SIZE_V1 48u   /* sizeof(BfhipOptions) before rowBegin / rowEnd */
 
 /* Flat description of an operand: the same expression tree as a BfMat graph,
  * as arrays.  Used (a) internally by bfhipCompile after walking a BfMat graph
@@ -129,6 +137,15 @@ int bfhipCompile(const void *bfMat, const BfhipOptions *opts, BfhipOperator **ou
 
 /* Same, from a flat descriptor. */
 int bfhipCompileDesc(const BfhipDesc *desc, const BfhipOptions *opts, BfhipOperator **out);
+
+/* Balanced contiguous row ranges for `world` ranks: cuts[0] = 0 < ... < cuts[world] = rows, rank r owning rows
+ * [cuts[r], cuts[r + 1]) (BfhipOptions.rowBegin/rowEnd).  Cuts fall only where no leaf that writes y straddles them
+ * (quadtree node boundaries of a fac_helm2 operand: the level-3 and deeper row blocks inside each level-2 BlockDense,
+ * reference src/fac_helm2.c:814-858), and the largest per-rank load -- leaf elements kept, replicated source-side
+ * factors included -- is minimised.  `leafElems` [world] may be NULL.  INVALID_ARGUMENTS if the operand offers fewer
+ * than `world` ranges.  No device is touched. */
+int bfhipRowPartition(const BfhipDesc *desc, uint32_t world, uint64_t *cuts, uint64_t *leafElems);
+int bfhipRowPartitionMat(const void *bfMat, uint32_t world, uint64_t *cuts, uint64_t *leafElems);
 
 /* ---- apply --------------------------------------------------------------- */
 

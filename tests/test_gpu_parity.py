@@ -699,6 +699,53 @@ def test_rccl_sharded_apply_one_rank_matches_plain_apply(helm2_cases, mode):
     op.close()
 
 
+@pytest.mark.parametrize("nrhs", [1, 5])
+def test_row_range_shards_are_the_one_gpu_result_bit_for_bit(nrhs):
+    """BfhipOptions.rowBegin/rowEnd with the cuts of bfhipRowPartition (one level or more below the top-level row blocks,
+    reference src/fac_helm2.c:814-858): every one of 8 ranks' operators, run on this GPU one after another, produces exactly
+    its rows of the unsharded apply -- same row groups, same items, same order of additions -- and together they hold
+    1.0x - 1.1x the operator's leaves (the first-applied factor of a split block row is replicated).  Also against the
+    oracle, and through the C-ABI's sharded step (1-rank communicator, the rank's segment gathered into place)."""
+    import torch
+    from butterfly_amd import helm2_structure as hs
+    from butterfly_amd.dist import RcclShardedApply, ShardLayout, row_partition
+    from butterfly_amd.operator import HipOperator
+    from oracle import bfref
+    n, k, world = 16384, 1024.0, 8
+    desc, perm = hs.native_multilevel_structure(hs.circle_points(n), k)
+    rng = np.random.default_rng(77)
+    shape = (n,) if nrhs == 1 else (n, nrhs)
+    x = (rng.standard_normal(shape) + 1j * rng.standard_normal(shape)) / np.sqrt(2)
+    xd = torch.from_numpy(x).cuda()
+    full = HipOperator.from_desc(desc, None, seed=5, max_rhs=nrhs)
+    y = full.apply_device(xd).clone()
+    total = full.stats()["leafElems"]
+    full.close()
+    y_ref = bfref.mat_mul(bfref.from_desc(desc, None, seed=5), x if nrhs > 1 else x[:, None]).reshape(shape)
+    assert rel(y.cpu().numpy(), y_ref) <= TOL
+    cuts, loads = row_partition(desc, world)
+    kept = 0
+    for r in range(world):
+        op = HipOperator.from_desc(desc, None, seed=5, max_rhs=nrhs, row_range=(cuts[r], cuts[r + 1]))
+        st = op.stats()
+        assert st["numRows"] == cuts[r + 1] - cuts[r] and st["leafElems"] == loads[r]
+        kept += st["leafElems"]
+        got = op.apply_device(xd)
+        torch.cuda.synchronize()
+        assert torch.equal(got, y[cuts[r]:cuts[r + 1]]), r
+        op.close()
+    assert total <= kept <= 1.12 * total
+    assert max(loads) <= 1.06 * (kept / world)
+    # the same operator behind the sharded step: a one-rank world owns everything, cut into 3 segments to be put in place
+    op = HipOperator.from_desc(desc, None, seed=5, max_rhs=nrhs)
+    step = RcclShardedApply(ShardLayout([cuts[2], cuts[5] - cuts[2], n - cuts[5]], [0, 0, 0], 1), 0, op, 0, nrhs=nrhs, mode="rows")
+    got = step(xd)
+    torch.cuda.synchronize()
+    assert torch.equal(got, y)
+    step.close()
+    op.close()
+
+
 @pytest.mark.parametrize("dtype,demote", [(0, False), (1, False), (1, True)])
 def test_long_contractions_on_gpu(dtype, demote):
     """Row groups cut into several groups (private slots + reduce) because their contraction is long: a

@@ -240,6 +240,73 @@ def test_row_sharding_union_equals_full(helm2_cases):
 
 
 # ---- error behaviour (mirrors the reference's BfError codes) ---------------
+@pytest.mark.parametrize("seed", range(8))
+def test_row_ranges_of_random_nested_graphs(seed):
+    """BfhipOptions.rowBegin/rowEnd on arbitrary graphs (products nested in all three block types, Identity leaves,
+    ragged sizes): the plan of rows [a, b) keeps what those rows depend on -- backward liveness over the task list --
+    and produces exactly rows [a, b) of the whole operator.  Arbitrary ends may trim a leaf (equal to rounding); the ends
+    bfhipRowPartition picks never do, and then the rows are the whole plan's bit for bit.  Real (f64, f32) and complex."""
+    rng = np.random.default_rng(4200 + seed)
+    cplx = seed % 2 == 1
+    desc, vals = randgraph.random_operand(rng, depth=int(rng.integers(2, 5)), size_hint=int(rng.integers(60, 220)), cplx=cplx)
+    m, n = desc.rows[desc.root], desc.cols[desc.root]
+    x = rng.standard_normal(n) + (1j * rng.standard_normal(n) if cplx else 0)
+    want = randgraph.densify(desc, vals, desc.root) @ x
+    for demote in ((False,) if cplx else (False, True)):
+        full = HipOperator.from_desc(desc, vals, demote_to_f32=demote, **PLAN)
+        y = plan_emulator.run_plan(full, x)
+        tol = 2e-5 if demote else 1e-12
+        assert rel(y + 1, want + 1) < tol
+        kept = 0
+        for _ in range(4):
+            a = int(rng.integers(0, m))
+            b = int(rng.integers(a + 1, m + 1))
+            op = HipOperator.from_desc(desc, vals, demote_to_f32=demote, row_range=(a, b), **PLAN)
+            st = op.stats()
+            assert st["numRows"] == b - a and st["leafElems"] <= full.stats()["leafElems"]
+            got = plan_emulator.run_plan(op, x)
+            assert not np.isnan(got).any()              # every row has an owner or a zero fill
+            assert rel(got + 1, y[a:b] + 1) < tol
+            kept += st["leafElems"]
+        # the cuts the library proposes: clean, covering, bit-identical
+        for world in (2, 3):
+            cuts = np.zeros(world + 1, dtype=np.uint64)
+            loads = np.zeros(world, dtype=np.uint64)
+            da = _capi.DescArrays(desc)
+            rc = _capi.load().bfhipRowPartition(da.byref(), world, cuts.ctypes.data, loads.ctypes.data)
+            if rc:                                      # an operand written by one tall leaf offers no place to cut
+                assert rc == 1
+                continue
+            assert cuts[0] == 0 and cuts[-1] == m and (np.diff(cuts.astype(np.int64)) > 0).all()
+            for r in range(world):
+                op = HipOperator.from_desc(desc, vals, demote_to_f32=demote, row_range=(int(cuts[r]), int(cuts[r + 1])), **PLAN)
+                assert op.stats()["leafElems"] == loads[r] or not cplx       # hulls are exact on these graphs unless a range skips a middle block
+                assert op.stats()["leafElems"] <= loads[r]
+                assert np.array_equal(plan_emulator.run_plan(op, x), y[int(cuts[r]):int(cuts[r + 1])])
+
+
+def test_row_range_arguments_are_checked(helm2_cases):
+    desc, tp, vals = helm2_cases(1024, 100)
+    for bad in ((5, 5), (9, 3), (0, 1025)):
+        with pytest.raises(_capi.BfhipError) as e:
+            HipOperator.from_desc(desc, vals, row_range=bad, **PLAN)
+        assert e.value.code == 1
+    with pytest.raises(_capi.BfhipError) as e:          # the transposed plan of a shard is not defined (its input would be the shard's rows)
+        HipOperator.from_desc(desc, vals, row_range=(0, 512), flags=_capi.FLAG_PLAN_ONLY | _capi.FLAG_ADJOINT)
+    assert e.value.code == 3
+    with pytest.raises(_capi.BfhipError) as e:
+        HipOperator.from_desc(desc, vals, row_range=(0, 512), row_blocks=(0, 1), **PLAN)
+    assert e.value.code == 1
+    # an options struct of the round-2 size (no rowBegin / rowEnd) still compiles: all rows
+    o = _capi.BfhipOptions()
+    o.structSize, o.device, o.flags, o.rowEnd = 48, -1, _capi.FLAG_PLAN_ONLY, 77
+    h = C.c_void_p()
+    da = _capi.DescArrays(desc, leaf_values=vals)
+    _capi.check(_capi.load().bfhipCompileDesc(da.byref(), C.byref(o), C.byref(h)))
+    assert _capi.load().bfhipGetNumRows(h) == 1024
+    _capi.load().bfhipFree(C.byref(h))
+
+
 def _compile_bfmat(ptr):
     lib = _capi.load()
     h = C.c_void_p()
