@@ -1,8 +1,9 @@
-"""BASELINE configs[3]: fac_helm2 N = 1 048 576, k = 65536 (919 GB of leaves), top-level blocks dealt to 8
-GPUs.  One GPU can hold any one rank's share (115 GB): this module compiles the HEAVIEST rank's shard of
-the 8-way split exactly as bench.py would on that rank, checks a top-level block of it against the oracle,
-ties the rest together with linearity / reproducibility, and drives the closing collective of the C-ABI
-(ncclAllReduce over the full-length partial y) with a 1-rank communicator."""
+"""BASELINE configs[3]: fac_helm2 N = 1 048 576, k = 65536 (919 GB of leaves), rows dealt to 8 GPUs with one
+RCCL all-gather.  One GPU can hold any one rank's share (~125 GB: 1/8 of the operator plus the replicated
+first-applied factors of the block row it shares): this module compiles the HEAVIEST rank's shard of the 8-way
+row partition exactly as bench.py would on that rank, checks a top-level block of it against the oracle, ties the
+rest together with linearity / reproducibility, and drives the closing collective of the C-ABI (in-place
+ncclAllGather + segment reorder) with a 1-rank communicator."""
 import numpy as np
 import pytest
 
@@ -21,22 +22,25 @@ def rel(a, b):
 def shard():
     import torch
     from butterfly_amd import helm2_structure as hs
-    from butterfly_amd.dist import assign_row_blocks, block_weights, choose_mode
+    from butterfly_amd.dist import block_weights, choose_mode, row_partition
     from butterfly_amd.operator import HipOperator
     if torch.cuda.get_device_properties(0).total_memory < 200e9:
         pytest.skip("needs the 288 GB of an MI355X")
     desc, _ = hs.native_multilevel_structure(hs.circle_points(N), N / 16.0)
-    assert choose_mode(desc, WORLD) == "blocks"            # 12 row blocks cannot balance 8 ranks; 144 blocks can
+    assert choose_mode(desc, WORLD) == "rows"
     bw = block_weights(desc)
-    owner, loads = assign_row_blocks(bw, WORLD)
-    assert max(loads) / (sum(loads) / WORLD) < 1.01        # LPT over 144 blocks: 8 x 115 GB
+    cuts, loads = row_partition(desc, WORLD)
+    # 12 top-level row blocks on 8 ranks: 4 block rows are split, their first-applied factors held twice
+    assert max(loads) / (sum(loads) / WORLD) < 1.04 and sum(loads) < 1.1 * sum(bw)
     heavy = int(np.argmax(loads))
-    mine = [i for i, o in enumerate(owner) if o == heavy]
-    root = hs.shard_desc_blocks(desc, mine)
-    op = HipOperator.from_desc(desc, None, root=root, device=0, seed=7)
+    a, b = cuts[heavy], cuts[heavy + 1]
+    op = HipOperator.from_desc(desc, None, device=0, seed=7, row_range=(a, b))
     st = op.stats()
-    assert st["leafBytes"] == loads[heavy] * 16 and st["leafBytes"] > 110e9
-    yield dict(desc=desc, op=op, mine=mine, bw=bw, rng=np.random.default_rng(5))
+    assert st["leafBytes"] == loads[heavy] * 16 and st["leafBytes"] > 110e9 and st["numRows"] == b - a
+    # the top-level blocks whose rows this rank holds completely
+    mine = [i for i, (node, r0, c0) in enumerate(desc.children[desc.root]) if a <= r0 and r0 + int(desc.rows[node]) <= b]
+    assert mine
+    yield dict(desc=desc, op=op, mine=mine, bw=bw, rng=np.random.default_rng(5), a=a, b=b, cuts=cuts)
     op.close()
 
 
@@ -45,19 +49,19 @@ def test_a_top_level_block_of_the_heaviest_shard_matches_the_oracle(shard):
     from butterfly_amd import helm2_structure as hs
     from oracle import bfref
     bfref.try_use_openblas()
-    desc, op, mine, bw, rng = shard["desc"], shard["op"], shard["mine"], shard["bw"], shard["rng"]
-    assert op.shape == (N, N)
-    i = min(mine, key=lambda j: bw[j])                     # the lightest block of this rank: ~1 GB, affordable for the oracle
+    desc, op, mine, bw, rng, a = shard["desc"], shard["op"], shard["mine"], shard["bw"], shard["rng"], shard["a"]
+    assert op.shape == (shard["b"] - a, N)
+    i = min(mine, key=lambda j: bw[j])                     # the lightest whole block of this rank: ~1 GB, affordable for the oracle
     node, r0, c0 = desc.children[desc.root][i]
     m, n = int(desc.rows[node]), int(desc.cols[node])
-    # no other block of this rank may share the column block AND the row block (then y[r0:r0+m] is A_rc x_c alone)
-    assert sum(1 for j in mine if desc.children[desc.root][j][1] == r0 and desc.children[desc.root][j][2] == c0) == 1
+    # no other block may share the column block AND the row block (then y[r0:r0+m] is A_rc x_c alone for x supported on c)
+    assert sum(1 for j in range(len(bw)) if desc.children[desc.root][j][1] == r0 and desc.children[desc.root][j][2] == c0) == 1
     x = np.zeros(N, dtype=complex)
     x[c0:c0 + n] = (rng.standard_normal(n) + 1j * rng.standard_normal(n)) / np.sqrt(2)
     y = op.apply_device(torch.from_numpy(x).cuda()).cpu().numpy()
     A = bfref.from_desc(desc, None, seed=7, root=hs.shard_desc_blocks(desc, [i]))
     want = bfref.mat_mul(A, x[:, None])[:, 0]
-    assert rel(y[r0:r0 + m], want[r0:r0 + m]) <= TOL, (i, m, n)
+    assert rel(y[r0 - a:r0 - a + m], want[r0:r0 + m]) <= TOL, (i, m, n)
 
 
 def test_linearity_and_reproducibility_of_the_shard(shard):
@@ -74,15 +78,16 @@ def test_linearity_and_reproducibility_of_the_shard(shard):
 
 
 def test_closing_collective_on_the_shard(shard):
-    """bfhipShardedApplyDevice in "blocks" mode on the 115 GB shard: local stages + ncclAllReduce of the
-    16 MB partial y on the apply stream (1-rank communicator: the sum of one term is the term)."""
+    """bfhipShardedApplyDevice in "rows" mode on the heaviest shard: local stages + the in-place ncclAllGather of this
+    rank's rows on the apply stream + the segment reorder (a 1-rank communicator whose world is this rank's row range,
+    cut into two segments so that the reorder kernel has something to put in place)."""
     import torch
     from butterfly_amd.dist import RcclShardedApply, ShardLayout
     desc, op, rng = shard["desc"], shard["op"], shard["rng"]
-    top_rows = desc.meta["top_rows"]
+    rows = shard["b"] - shard["a"]
     x = torch.from_numpy((rng.standard_normal(N) + 1j * rng.standard_normal(N)) / np.sqrt(2)).cuda()
     want = op.apply_device(x).clone()
-    step = RcclShardedApply(ShardLayout(top_rows, [0] * len(top_rows), 1), 0, op, 0, nrhs=1, mode="blocks")
+    step = RcclShardedApply(ShardLayout([rows // 3, rows - rows // 3], [0, 0], 1), 0, op, 0, nrhs=1, mode="rows")
     got = step(x)
     torch.cuda.synchronize()
     assert torch.equal(got, want)

@@ -1,0 +1,37 @@
+#!/bin/bash
+# One gpurun call = a list of bounded steps; a step that is killed at its limit ends the call (nothing further touches the GPU).
+#   gpurun --timeout 1200 -- 'bash tools/session.sh <tag> <step> [<step> ...]'     steps are functions below
+set -u
+TAG=$1; shift
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+O=$R/gpurun_out/$TAG
+mkdir -p $O
+cd $R
+step() { # name limit cmd...
+  local name=$1 lim=$2; shift 2
+  echo "== $name"
+  timeout -k 10 $lim "$@" > $O/$name.out 2> $O/$name.err
+  local rc=$?
+  echo "$name exit=$rc"
+  if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "step $name hit its limit: stopping"; tail -5 $O/$name.err; exit 1; fi
+}
+B="python bench.py"
+gputests()   { step pytest 900 python -m pytest tests -m gpu -x -q; tail -5 $O/pytest.out; }
+n65536()     { step bench_n65536 300 $B --npoints 65536 --steps 50 --warmup 5 --no-cpu-baseline --no-extra; grep "stage " $O/bench_n65536.err; cat $O/bench_n65536.out | cut -c1-400; }
+shards8()    { step shards8_rows 600 $B --emulate-world 8 --emulate-rank -1 --steps 20 --no-extra --no-cpu-baseline --shard rows;
+               step shards8_blocks 600 $B --emulate-world 8 --emulate-rank -1 --steps 20 --no-extra --no-cpu-baseline --shard blocks;
+               python - <<PY
+import json
+for m in ("rows", "blocks"):
+    try:
+        d = json.load(open("$O/shards8_%s.out" % m)); e = d["emulated_shard"]
+        print(m, "slowest", round(e["slowest_ms"], 4), [(round(t["leaf_gb"], 2), round(t["ms_per_apply"], 4)) for t in e["all_ranks"]])
+    except Exception as ex:
+        print(m, "failed", ex)
+PY
+             }
+shard0()     { step shard0_rows 300 $B --emulate-world 8 --emulate-rank 3 --steps 50 --no-extra --no-cpu-baseline --shard rows; grep "stage " $O/shard0_rows.err; }
+lanes()      { step lanes_n65536 300 python tools/exp_lanes.py --n 65536 --lanes 2 3 4; cat $O/lanes_n65536.out;
+               step lanes_shard8 400 python tools/exp_lanes.py --n 262144 --world 8 --lanes 2 3; cat $O/lanes_shard8.out; }
+headline()   { step bench_default 900 $B --steps 20 --warmup 5 "$@"; cat $O/bench_default.out | cut -c1-1500; grep "stage " $O/bench_default.err; }
+for s in "$@"; do $s; done
