@@ -513,28 +513,33 @@ def main():
     if rank == 0:
         kern_ms = float(ms.sum())
         n_launch = int(launches.sum())
+        applies = int(launches.max()) if len(launches) else 0          # sampled applies (every stage that launches does so once per apply)
+        per_apply = int((launches > 0).sum())                           # launches per apply: 1 when the plan runs as one dependency-driven launch
         bytes_per_apply = int(sbytes.sum())
         avg_launch_ms = kern_ms / max(n_launch, 1)
-        achieved = (bytes_per_apply * (n_launch / len(ms))) / 1e9 / (kern_ms / 1e3) if kern_ms > 0 else 0.0
+        achieved = bytes_per_apply * applies / 1e9 / (kern_ms / 1e3) if kern_ms > 0 else 0.0
+        one_launch = (not real) and args.nrhs <= 2 and op is not None and op.flow_status()[0]
         for s in range(len(ms)):
-            log(f"  stage {s}: {ms[s] / max(launches[s], 1):8.3f} ms/launch  {sbytes[s] / 1e9:8.3f} GB  "
-                f"{(sbytes[s] / 1e9) / (ms[s] / max(launches[s], 1) / 1e3) if ms[s] > 0 else 0:8.1f} GB/s")
+            if launches[s]:
+                log(f"  stage {s}: {ms[s] / max(launches[s], 1):8.3f} ms/launch  {sbytes[s] / 1e9:8.3f} GB  "
+                    f"{(sbytes[s] / 1e9) / (ms[s] / max(launches[s], 1) / 1e3) if ms[s] > 0 else 0:8.1f} GB/s" + ("   [all stages: one launch]" if one_launch else ""))
         if args.nrhs >= 3 and not real:
             # block of right-hand sides: 8*nrhs flops per leaf element (32 flop/B at nrhs=64) -> FP64-MFMA bound
             flops_per_apply = 8.0 * args.nrhs * st["leafElems"]
-            tf = flops_per_apply * (n_launch / len(ms)) / 1e12 / (kern_ms / 1e3) if kern_ms > 0 else 0.0
+            tf = flops_per_apply * applies / 1e12 / (kern_ms / 1e3) if kern_ms > 0 else 0.0
             roofline = {"bound": "mfma", "achieved": tf, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                         "frac": tf / FP64_MFMA_PEAK_TFLOPS, "traffic": None, "kernel": "bfStageKernelC128Mfma",
-                        "launches_per_apply": len(ms), "avg_launch_ms": avg_launch_ms,
+                        "launches_per_apply": per_apply, "avg_launch_ms": avg_launch_ms,
                         "algorithmic_flops_per_apply": flops_per_apply, "hbm_gbs_algorithmic": achieved,
                         "kernel_ms_per_apply": kern_ms / max(launches.max(), 1),
                         "event_sampling": f"HIP events around every launch of 1 apply in {ev_every} of the timed region"}
         else:
             roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                        "kernel": "bfStageKernelC128" if not real else f"bfStageKernelReal<{dtype}>", "launches_per_apply": len(ms),
+                        "kernel": ("bfFlowKernelC128" if one_launch else "bfStageKernelC128") if not real else f"bfStageKernelReal<{dtype}>",
+                        "launches_per_apply": per_apply,
                         **({"rank": prof_rank, "note": "the slowest rank's stage kernels (it bounds the step); bytes = that rank's shard"} if multi else {}),
-                        "avg_launch_ms": avg_launch_ms, "algorithmic_bytes_per_launch": bytes_per_apply / len(ms),
+                        "avg_launch_ms": avg_launch_ms, "algorithmic_bytes_per_launch": bytes_per_apply / max(per_apply, 1),
                         "algorithmic_bytes_per_apply": bytes_per_apply, "kernel_ms_per_apply": kern_ms / max(launches.max(), 1),
                         "event_sampling": f"HIP events around every launch of 1 apply in {ev_every} of the timed region"}
         # `traffic` = HBM bytes PER LAUNCH (like `achieved`), from the COMMITTED rocprofv3 --pmc profile of this
@@ -551,7 +556,7 @@ def main():
                        "bfStageKernelC128_per_launch" if args.nrhs == 1 else "bfStageKernelC128Mfma_per_launch")
                 pm = json.load(open(prof))[key]
                 roofline["traffic"] = pm["hbm_bytes"]
-                roofline["traffic_per_apply"] = pm["hbm_bytes"] * len(ms)
+                roofline["traffic_per_apply"] = pm["hbm_bytes"] * pm.get("launches_per_apply", len(ms))
                 roofline["traffic_source"] = (f"profiles/{rnd}_pmc_summary.json [{key}]: from the committed profile of this command "
                                               "(rocprofv3 --pmc, separate passes), NOT measured in this run; per launch, as `achieved`")
                 break

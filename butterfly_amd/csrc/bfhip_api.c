@@ -75,6 +75,12 @@ struct BfhipOperator {
   /* BFHIP_FLAG_PLAN_ONLY: the IR is kept (borrowed leaf pointers!) for bfhipPlanPackArena */
   BfIr *ir;
   uint64_t seed;
+  /* dependency-driven launch of the forward plan (complex128, nrhs <= 2): flat copies of the index tables */
+  int flow;
+  void *dFlowItems, *dFlowPieces, *dFlowItemOut, *dFlowWriters, *dFlowCounters;
+  uint32_t flowNumItems, flowGrid, flowEpoch, flowQueueBase, flowMaxWriters;
+  uint64_t flowNumBufs;
+  uint8_t evFlow[64];               /* per event set: that apply ran as ONE launch (its time is recorded under stage 0) */
 };
 
 #define BF_ARENA_SLACK 256u
@@ -110,6 +116,7 @@ void bfhipFree(BfhipOperator **pop) {
   bfdevFree(op->dArena);
   bfdevFree(op->dTemp);
   bfdevFree(op->dZero);
+  bfdevFree(op->dFlowItems); bfdevFree(op->dFlowPieces); bfdevFree(op->dFlowItemOut); bfdevFree(op->dFlowWriters); bfdevFree(op->dFlowCounters);
   bfdevFree(op->dX);
   bfdevFree(op->dCov);
   bfdevFree(op->dY);
@@ -280,12 +287,67 @@ static void dropPlanMirrors(BfPlan *plan) {
     free(st->pieceSrc); st->pieceSrc = NULL;
     free(st->pieces); st->pieces = NULL;
     free(st->items); st->items = NULL;
+    free(st->pieceBuf); st->pieceBuf = NULL;
+    free(st->itemBuf); st->itemBuf = NULL;
     for (uint64_t r = 0; r < st->numReduce; ++r) {
       free(st->reduce[r].rowInterval); st->reduce[r].rowInterval = NULL;
       free(st->reduce[r].ivBegin); st->reduce[r].ivBegin = NULL;
       free(st->reduce[r].srcBias); st->reduce[r].srcBias = NULL;
     }
   }
+}
+
+
+/* Flat index tables for the dependency-driven launch (bfFlowKernelC128): all stages' items in stage order with global
+ * piece indices, pieces carrying the id of the vector they read, per item the vector it writes, per vector its number
+ * of writers, and the counters.  Needs the host mirrors of the plan. */
+static int buildFlow(BfhipOperator *op) {
+  BfPlan const *pl = &op->plan;
+  uint64_t ni = 0, np = 0;
+  for (uint64_t s = 0; s < pl->numStages; ++s) { ni += pl->stages[s].numItems; np += pl->stages[s].numPieces; }
+  if (!ni || ni >= 0x7fffffffu || np >= 0xffffffffu) return 0;       /* nothing to run / too large for 32-bit tickets: staged launches */
+  BfDevItem *items = malloc(ni * sizeof *items);
+  BfDevPiece *pieces = malloc((np ? np : 1) * sizeof *pieces);
+  uint32_t *itemOut = malloc(ni * 4);
+  int rc = 0;
+  if (!items || !pieces || !itemOut) { rc = bfhipFail(BFABI_ERROR_MEMORY_ERROR, "host OOM (flow tables)"); goto done; }
+  uint64_t i0 = 0, p0 = 0;
+  for (uint64_t s = 0; s < pl->numStages; ++s) {
+    BfStage const *st = &pl->stages[s];
+    for (uint64_t i = 0; i < st->numItems; ++i) {
+      items[i0 + i] = st->items[i];
+      items[i0 + i].pieceBegin = (uint32_t)(p0 + st->items[i].pieceBegin);
+      itemOut[i0 + i] = st->itemBuf[i];
+    }
+    for (uint64_t k = 0; k < st->numPieces; ++k) {
+      pieces[p0 + k] = st->pieces[k];
+      pieces[p0 + k].ld = st->pieceBuf[k];          /* column-major complex pieces do not use `ld` */
+    }
+    i0 += st->numItems; p0 += st->numPieces;
+  }
+  uint32_t maxW = 1;
+  for (uint64_t b = 0; b < pl->numBufs; ++b) if (pl->bufWriters[b] > maxW) maxW = pl->bufWriters[b];
+  uint64_t const nb = pl->numBufs < 2 ? 2 : pl->numBufs;
+  if ((rc = uploadArray(&op->dFlowItems, items, ni * sizeof *items, &op->metaBytes))) goto done;
+  if ((rc = uploadArray(&op->dFlowPieces, pieces, (np ? np : 1) * sizeof *pieces, &op->metaBytes))) goto done;
+  if ((rc = uploadArray(&op->dFlowItemOut, itemOut, ni * 4, &op->metaBytes))) goto done;
+  {
+    uint32_t *w = calloc(nb, 4);
+    if (!w) { rc = bfhipFail(BFABI_ERROR_MEMORY_ERROR, "host OOM (flow tables)"); goto done; }
+    memcpy(w, pl->bufWriters, pl->numBufs * 4);
+    rc = uploadArray(&op->dFlowWriters, w, nb * 4, &op->metaBytes);
+    free(w);
+    if (rc) goto done;
+  }
+  if ((rc = bfdevMalloc(&op->dFlowCounters, nb * 4))) goto done;
+  if ((rc = bfdevMemset(op->dFlowCounters, 0, nb * 4))) goto done;
+  if ((rc = bfdevFlowGrid(ni, &op->flowGrid))) goto done;
+  op->flowNumItems = (uint32_t)ni; op->flowNumBufs = nb; op->flowMaxWriters = maxW;
+  op->flowEpoch = 0; op->flowQueueBase = 0;
+  op->flow = 1;
+done:
+  free(items); free(pieces); free(itemOut);
+  return rc;
 }
 
 static int ensureTemp(BfhipOperator *op, uint32_t nrhs) {
@@ -367,6 +429,10 @@ int bfhipCompileIrFill(BfIr *ir, BfhipOptions const *opts, BfFillFn fill, void *
   if (op->hasTplan && (rc = uploadPlanMeta(op, &op->tplan))) goto done;
   /* leaf values: computed on the device by the caller's builder, or packed / synthesized from the IR */
   if ((rc = fill ? fill(&op->plan, ir, op->dArena, fillCtx) : packLeaves(op, ir, o.seed, NULL))) goto done;
+  {
+    char const *noFlow = getenv("BFHIP_NO_FLOW");       /* A/B switch; BFHIP_FLAG_NO_FLOW is the per-operator one */
+    if (op->plan.dtype == BFHIP_C128 && op->plan.flowOk && !(o.flags & BFHIP_FLAG_NO_FLOW) && !(noFlow && noFlow[0] == '1') && (rc = buildFlow(op))) goto done;
+  }
   /* host mirrors of the bulky per-piece arrays are no longer needed */
   dropPlanMirrors(&op->plan);
   dropPlanMirrors(&op->tplan);
@@ -436,7 +502,7 @@ static int harvestEvents(BfhipOperator *op, uint64_t upTo) {
   uint64_t const S = op->plan.numStages;
   for (; op->evHarvested < upTo; ++op->evHarvested) {
     uint64_t const slot = op->evHarvested % BF_EV_POOL;
-    for (uint64_t s = 0; s < S; ++s) {
+    for (uint64_t s = 0; s < (op->evFlow[slot] ? 1 : S); ++s) {
       float ms = 0;
       int rc = bfdevEventElapsed(op->evStart[slot * S + s], op->evStop[slot * S + s], &ms);
       if (rc) return rc;
@@ -457,10 +523,13 @@ int bfhipGetStageProfile(BfhipOperator *op, double *ms, uint64_t *launches, uint
   if (!(op->flags & BFHIP_FLAG_PROFILE)) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "operator was not compiled with BFHIP_FLAG_PROFILE");
   int rc = harvestEvents(op, op->evIssued);
   if (rc) return rc;
+  uint32_t const nr = op->lastNrhs ? op->lastNrhs : 1;
+  int const oneLaunch = op->flow && nr <= 2;        /* the whole apply is one launch: its time and bytes are reported under stage 0 */
   for (uint64_t s = 0; s < op->plan.numStages; ++s) {
     if (ms) ms[s] = op->stageMs[s];
     if (launches) launches[s] = op->stageLaunches[s];
-    if (bytes) bytes[s] = stageBytes(op, s, op->lastNrhs ? op->lastNrhs : 1);
+    if (bytes) bytes[s] = oneLaunch ? 0 : stageBytes(op, s, nr);
+    if (bytes && oneLaunch) bytes[0] += stageBytes(op, s, nr);
     if (reset) { op->stageMs[s] = 0; op->stageLaunches[s] = 0; }
   }
   return 0;
@@ -493,6 +562,39 @@ static int runPlan(BfhipOperator *op, BfPlan *plan, void const *dX, size_t nrhs,
   /* timing never makes an apply wait for the previous one: only when all BF_EV_POOL event sets are in flight is the oldest read back */
   if (prof && op->evIssued - op->evHarvested >= BF_EV_POOL && (rc = harvestEvents(op, op->evIssued - BF_EV_POOL + 1))) goto out;
   uint64_t const evBase = prof ? (op->evIssued % BF_EV_POOL) * plan->numStages : 0;
+  if (prof) op->evFlow[op->evIssued % BF_EV_POOL] = 0;
+  if (op->flow && plan == &op->plan && nrhs <= 2) {
+    /* the whole plan as ONE dependency-driven launch (bfFlowKernelC128), then the reduce passes into y */
+    uint32_t const perApply = op->flowNumItems + op->flowGrid * 4u;      /* tickets an apply consumes: every wavefront draws one past the end */
+    if (op->flowEpoch >= 0x7fffffffu / op->flowMaxWriters - 1 || op->flowQueueBase >= 0xffffffffu - 2u * perApply) {
+      if ((rc = bfdevMemsetAsync(op->dFlowCounters, 0, op->flowNumBufs * 4, stream))) goto out;      /* long before 32 bits wrap */
+      op->flowEpoch = 0; op->flowQueueBase = 0;
+    }
+    BfFlowArgs fa;
+    fa.arena = op->dArena; fa.items = op->dFlowItems; fa.pieces = op->dFlowPieces; fa.itemOut = op->dFlowItemOut; fa.writers = op->dFlowWriters;
+    fa.counters = op->dFlowCounters; fa.numItems = op->flowNumItems; fa.nrhs = (uint32_t)nrhs; fa.epoch = ++op->flowEpoch;
+    fa.queueBase = op->flowQueueBase; fa.gridWorkgroups = op->flowGrid; fa.x = dX; fa.y = dY; fa.temp = op->dTemp;
+    op->flowQueueBase += perApply;
+    if (prof) { op->evFlow[op->evIssued % BF_EV_POOL] = 1; if ((rc = bfdevEventRecord(op->evStart[evBase], stream))) goto out; }
+    if ((rc = bfdevLaunchFlow(&fa, stream))) goto out;
+    if (prof && (rc = bfdevEventRecord(op->evStop[evBase], stream))) goto out;
+    for (uint64_t s = 0; s < plan->numStages; ++s) {
+      BfStage *st = &plan->stages[s];
+      for (uint64_t r0 = 0; r0 < st->numReduce; r0 += 16) {
+        BfReduceArgs ra[16];
+        uint32_t const cnt = (uint32_t)(st->numReduce - r0 < 16 ? st->numReduce - r0 : 16);
+        for (uint32_t r = 0; r < cnt; ++r) {
+          BfReduce *rd = &st->reduce[r0 + r];
+          ra[r].rowInterval = rd->dRowInterval; ra[r].ivBegin = rd->dIvBegin; ra[r].srcBias = rd->dSrcBias;
+          ra[r].numRows = rd->numRows; ra[r].temp = op->dTemp; ra[r].nrhs = (uint32_t)nrhs; ra[r].dtype = plan->dtype;
+          ra[r].dest = dY;          /* flowOk: every reduce sums into y */
+        }
+        if ((rc = bfdevLaunchReduce(ra, cnt, stream))) goto out;
+      }
+    }
+    if (prof) { ++op->evIssued; op->lastNrhs = (uint32_t)nrhs; }
+    goto out;
+  }
   for (uint64_t s = 0; s < plan->numStages; ++s) {
     BfStage *st = &plan->stages[s];
     BfLaunchArgs a;
@@ -534,6 +636,28 @@ int bfhipOperatorReserveRhs(BfhipOperator *op, uint32_t nrhs) {
   if (!rc) rc = ensureTemp(op, nrhs);
   if (prev >= 0 && prev != op->device) bfdevSetDevice(prev);
   return rc;
+}
+
+/* Is the forward plan applied as ONE dependency-driven launch (1 - 2 right-hand sides), and has any of its waits ever
+ * given up?  (They cannot, by construction; the flag exists so that a broken invariant shows up as an error instead
+ * of a hung GPU.)  Synchronizes the device's default stream when the flag is read. */
+int bfhipFlowStatus(BfhipOperator *op, uint32_t *enabled, uint32_t *waitGaveUp) {
+  if (!op) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "NULL operator");
+  if (enabled) *enabled = (uint32_t)op->flow;
+  if (waitGaveUp) {
+    *waitGaveUp = 0;
+    if (op->flow) {
+      uint32_t two[2] = {0, 0};
+      int prev = -1, rc;
+      bfdevGetDevice(&prev);
+      if (prev != op->device && (rc = bfdevSetDevice(op->device))) return rc;
+      rc = bfdevMemcpyD2H(two, op->dFlowCounters, sizeof two);       /* [0] ticket queue, [1] error flag */
+      if (prev >= 0 && prev != op->device) bfdevSetDevice(prev);
+      if (rc) return rc;
+      *waitGaveUp = two[1];
+    }
+  }
+  return 0;
 }
 
 int bfhipApplyDevice(BfhipOperator *op, void const *dX, size_t nrhs, void *dY, void *stream) {

@@ -198,6 +198,143 @@ __global__ __launch_bounds__(BF_WAVES_PER_WG * 64) void bfStageKernelC128(StageP
   }
 }
 
+
+// ---------------------------------------------------------------------------
+// Dependency-driven launch of a whole complex128 plan ("flow"): ONE persistent
+// launch instead of one per stage.
+//
+// Stage launches synchronise far more than the butterfly needs: an item of stage
+// s + 1 reads the intermediate vectors of ITS product only (one per factor boundary,
+// src/mat_product.c:225-238), yet a kernel boundary makes it wait for every item of
+// stage s -- each launch pays its own ramp-up and its own tail (the last big items
+// run with the chip mostly empty).  At 10 GB per launch that is 2 %; at N = 65536 or
+// on a 1/8 shard the kernels are 0.13 - 0.5 ms and it is 10 %.
+//
+// Here the items of all stages form one list in stage order (big first inside a
+// stage); resident wavefronts take the next item from an atomic ticket.  Every
+// intermediate vector has a counter of the items that have written it: a piece that
+// reads vector b waits until counter[b] has reached the number of b's writers, an
+// item that has stored its rows releases them (agent-scope release: its stores reach
+// memory before the counter moves) and bumps the counter of the vector it wrote.
+// A ticket holder only ever waits for items with smaller tickets, which are held by
+// wavefronts already running and waiting, in turn, only for smaller ones: the item
+// with the smallest unfinished ticket never waits, so the list drains -- whatever
+// the order in which workgroups are dispatched.  Counters are not reset between
+// applies: apply number e waits for e * writers (the host resets them long before
+// 32 bits wrap).  The arithmetic of an item is that of bfStageKernelC128, operation
+// for operation: results are bit-identical to the staged launches.
+// ---------------------------------------------------------------------------
+struct FlowParams {
+  void const *arena;
+  BfDevItem const *items;        // all stages, pieceBegin global
+  BfDevPiece const *pieces;      // all stages; `ld` = id of the vector the piece reads (0: x)
+  uint32_t const *itemOut;       // per item: id of the intermediate it writes (0: y / a private slot: nobody waits)
+  uint32_t const *writers;       // per vector id: number of items that write it
+  uint32_t *counters;            // per vector id: items that have written it, summed over applies
+  uint32_t *queue;               // ticket counter (counters[-1] in memory)
+  uint32_t *error;               // set if a wait gave up (never, by construction)
+  uint32_t numItems, nrhs;
+  uint32_t epoch;                // 1-based apply number since the counters were last cleared
+  uint32_t queueBase;            // ticket value of item 0 in this apply
+  void const *x;
+  void *y;
+  void *temp;
+};
+
+#define BF_FLOW_SPIN_LIMIT (1u << 24)     // x ~0.3 us: seconds, then the wait gives up and raises `error` instead of hanging the GPU
+
+__device__ __forceinline__ void bfFlowWait(FlowParams const &p, uint32_t dep, int lane) {
+  uint32_t const want = p.writers[dep] * p.epoch;
+  if (lane == 0) {
+    uint32_t spins = 0;
+    while (__hip_atomic_load(p.counters + dep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+      __builtin_amdgcn_s_sleep(8);
+      if (++spins > BF_FLOW_SPIN_LIMIT) { __hip_atomic_store(p.error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+    }
+  }
+  // what the writers released is acquired by the whole wavefront (the other XCDs' L2s are not coherent with this one)
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+}
+
+__global__ __launch_bounds__(BF_WAVES_PER_WG * 64) void bfFlowKernelC128(FlowParams p) {
+  __shared__ __attribute__((aligned(16))) double2 lds[BF_WAVES_PER_WG][BF_XCAP];
+  int const wave = threadIdx.x >> 6;
+  int const lane = threadIdx.x & 63;
+  double2 *xs = lds[wave];
+  double2 const *arena = (double2 const *)p.arena;
+  uint32_t const nrhs = p.nrhs;
+  for (;;) {
+    uint32_t ticket = 0;
+    if (lane == 0) ticket = __hip_atomic_fetch_add(p.queue, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    uint32_t const item = (uint32_t)__builtin_amdgcn_readfirstlane((int)ticket) - p.queueBase;
+    if (item >= p.numItems) return;
+    BfDevItem const it = p.items[item];
+    uint32_t const mr = it.mrFlags & 0xffffu;
+    uint32_t const g = 64u / mr;
+    uint32_t const G = g * mr;
+    bool const active = (uint32_t)lane < G;
+    uint32_t const lc = active ? (uint32_t)lane : G - 1;
+    uint32_t const c = lc / mr;
+    uint32_t const r = lc - c * mr;
+    double2 *out = (it.mrFlags & BF_ITEM_OUT_Y) ? (double2 *)p.y : (double2 *)p.temp;
+    uint32_t ready = 0;          // the vector this wavefront last waited for (an item's pieces mostly read one)
+    for (uint32_t q = 0; q < nrhs; ++q) {
+      double accr = 0.0, acci = 0.0;
+      for (uint32_t pi = 0; pi < it.numPieces; ++pi) {
+        BfDevPiece const pc = p.pieces[it.pieceBegin + pi];
+        uint32_t const dep = (uint32_t)__builtin_amdgcn_readfirstlane((int)pc.ld);
+        if (dep && dep != ready) { bfFlowWait(p, dep, lane); ready = dep; }
+        double2 const *xin = (pc.flags & BF_PIECE_IN_X) ? (double2 const *)p.x : (double2 const *)p.temp;
+        xin += (uint64_t)pc.inOff * nrhs + q;
+        uint32_t const n = pc.ncols;
+        if (pc.flags & BF_PIECE_IDENTITY) {
+          if (c == 0 && active) {
+            double2 v = xin[(uint64_t)r * nrhs];
+            accr += v.x; acci += v.y;
+          }
+          continue;
+        }
+        waveSync();
+        for (uint32_t j = lane; j < n; j += 64) xs[j] = xin[(uint64_t)j * nrhs];
+        waveSync();
+        double2 const *ap = arena + pc.dataOff + lc;
+        uint32_t const nfull = n / g;
+        uint32_t j = c;
+        uint32_t s = 0;
+#pragma unroll 8
+        for (; s < nfull; ++s) {
+          double2 a = bfLoadStream(ap + (uint64_t)s * G);
+          double2 xv = xs[j];
+          accr = fma(a.x, xv.x, accr); accr = fma(-a.y, xv.y, accr);
+          acci = fma(a.x, xv.y, acci); acci = fma(a.y, xv.x, acci);
+          j += g;
+        }
+        uint32_t const rem = n - nfull * g;
+        if (active && c < rem) {
+          double2 a = bfLoadStream(ap + (uint64_t)nfull * G);
+          double2 xv = xs[j];
+          accr = fma(a.x, xv.x, accr); accr = fma(-a.y, xv.y, accr);
+          acci = fma(a.x, xv.y, acci); acci = fma(a.y, xv.x, acci);
+        }
+      }
+      waveSync();
+      xs[lane] = make_double2(accr, acci);
+      waveSync();
+      if ((uint32_t)lane < mr) {
+        double sr = 0.0, si = 0.0;
+        for (uint32_t cc = 0; cc < g; ++cc) { double2 v = xs[cc * mr + lane]; sr += v.x; si += v.y; }
+        out[((uint64_t)it.outOff + lane) * nrhs + q] = make_double2(sr, si);
+      }
+    }
+    uint32_t const od = p.itemOut[item];
+    if (od) {
+      // every lane's stores leave this XCD before the counter moves
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      if (lane == 0) __hip_atomic_fetch_add(p.counters + od, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------
 // complex128 stage kernel for blocks of right-hand sides (nrhs >= 3): the same
 // items and the same packed pieces, contracted on the FP64 matrix cores.
@@ -1377,6 +1514,39 @@ int bfdevLaunchStage(BfLaunchArgs const *a, void *stream) {
   else return bfhipFail(BFABI_ERROR_TYPE_ERROR, "unknown dtype %u", a->dtype);
   return hipFail(hipGetLastError(), "stage launch");
 }
+
+
+int bfdevLaunchFlow(BfFlowArgs const *a, void *stream) {
+  if (!a->numItems) return 0;
+  FlowParams p;
+  p.arena = a->arena;
+  p.items = (BfDevItem const *)a->items;
+  p.pieces = (BfDevPiece const *)a->pieces;
+  p.itemOut = (uint32_t const *)a->itemOut;
+  p.writers = (uint32_t const *)a->writers;
+  p.counters = (uint32_t *)a->counters;
+  p.queue = (uint32_t *)a->counters;            // slot 0: vector id 0 (x) has no counter of its own
+  p.error = (uint32_t *)a->counters + 1;        // slot 1: vector id 1 (y) neither
+  p.numItems = a->numItems; p.nrhs = a->nrhs; p.epoch = a->epoch; p.queueBase = a->queueBase;
+  p.x = a->x; p.y = a->y; p.temp = a->temp;
+  hipLaunchKernelGGL(bfFlowKernelC128, dim3(a->gridWorkgroups), dim3(BF_WAVES_PER_WG * 64), 0, (hipStream_t)stream, p);
+  return hipFail(hipGetLastError(), "flow launch");
+}
+
+// workgroups of the persistent launch: what the device holds at once (occupancy x CUs), never more than the items need
+int bfdevFlowGrid(uint64_t numItems, uint32_t *grid) {
+  int dev = 0, cus = 0, perCu = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, bfFlowKernelC128, BF_WAVES_PER_WG * 64, 0);
+  if (e != hipSuccess) return hipFail(e, "flow occupancy");
+  uint64_t g = (uint64_t)cus * (uint64_t)(perCu > 0 ? perCu : 1);
+  uint64_t const need = (numItems + BF_WAVES_PER_WG - 1) / BF_WAVES_PER_WG;
+  if (g > need) g = need;
+  *grid = (uint32_t)(g ? g : 1);
+  return 0;
+}
+int bfdevMemsetAsync(void *dst, int value, size_t bytes, void *stream) { return bytes ? hipFail(hipMemsetAsync(dst, value, bytes, (hipStream_t)stream), "hipMemsetAsync") : 0; }
 
 int bfdevScalePermute(void *dst, void const *src, void const *scale, int power, uint64_t const *perm, uint64_t n, uint32_t dtype, void *stream) {
   if (!n) return 0;

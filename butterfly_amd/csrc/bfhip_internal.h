@@ -125,6 +125,10 @@ typedef struct BfStage {
   uint64_t vecIn, vecOut;    /* algorithmic vector elements read / written */
   uint64_t numReduce;
   BfReduce *reduce;
+  /* dependency-driven launch (forward plans): which vector each piece reads / each item writes -- buffer ids of the
+   * planner: 0 = x (pieces) or "nothing a later item waits for" (items: y, private slots), >= 2 an intermediate */
+  uint32_t *pieceBuf;        /* [numPieces] */
+  uint32_t *itemBuf;         /* [numItems] */
   /* device copies */
   void *dItems, *dPieces;
 } BfStage;
@@ -142,6 +146,11 @@ typedef struct BfPlan {
   uint64_t tempElems;        /* vector arena elements per RHS */
   uint64_t numLeaves, leafElems;
   int transposed;            /* plan of A^T over the forward plan's arena */
+  /* dependency-driven launch: number of vectors (buffer ids < numBufs), how many items write each, and whether the plan
+   * qualifies (forward; every reduce pass sums into y, i.e. runs after all items) */
+  uint64_t numBufs;
+  uint32_t *bufWriters;      /* [numBufs] */
+  int flowOk;
 } BfPlan;
 
 /* where the forward plan put each (leaf, row chunk, column range): the
@@ -232,6 +241,19 @@ typedef struct BfLaunchArgs {
   int transposed;        /* pieces carry `ld`: lanes own columns of the forward pieces */
 } BfLaunchArgs;
 int bfdevLaunchStage(BfLaunchArgs const *a, void *stream);
+
+/* dependency-driven launch of a whole forward complex128 plan (bfFlowKernelC128): see bfhip_device.hip */
+typedef struct BfFlowArgs {
+  void const *arena;
+  void const *items, *pieces, *itemOut, *writers;   /* flat over all stages; pieces' `ld` holds the vector id they read */
+  void *counters;        /* uint32[numBufs]: [0] the ticket queue, [1] the error flag, [id >= 2] writes seen by vector id */
+  uint32_t numItems, nrhs, epoch, queueBase, gridWorkgroups;
+  void const *x;
+  void *y, *temp;
+} BfFlowArgs;
+int bfdevLaunchFlow(BfFlowArgs const *a, void *stream);
+int bfdevFlowGrid(uint64_t numItems, uint32_t *grid);
+int bfdevMemsetAsync(void *dst, int value, size_t bytes, void *stream);
 
 typedef struct BfReduceArgs {
   void const *rowInterval, *ivBegin, *srcBias;

@@ -512,13 +512,14 @@ void bfPlanFree(BfPlan *plan) {
   if (!plan) return;
   for (uint64_t s = 0; s < plan->numStages && plan->stages; ++s) {
     BfStage *st = &plan->stages[s];
-    free(st->items); free(st->pieces); free(st->pieceSrc);
+    free(st->items); free(st->pieces); free(st->pieceSrc); free(st->pieceBuf); free(st->itemBuf);
     for (uint64_t r = 0; r < st->numReduce; ++r) {
       free(st->reduce[r].rowInterval); free(st->reduce[r].ivBegin); free(st->reduce[r].srcBias);
     }
     free(st->reduce);
   }
   free(plan->stages);
+  free(plan->bufWriters);
   memset(plan, 0, sizeof *plan);
 }
 
@@ -614,6 +615,9 @@ int bfPlanBuild(BfIr const *ir, BfPlanOptions const *po, BfPlan *plan) {
   plan->numStages = (uint64_t)S;
   plan->stages = calloc((size_t)S, sizeof(BfStage));
   if (!plan->stages) { rc = bfhipFail(BFABI_ERROR_MEMORY_ERROR, "host OOM"); goto fail; }
+  plan->numBufs = b.numBufs;
+  plan->bufWriters = calloc(b.numBufs + 1, 4);
+  if (!plan->bufWriters) { rc = bfhipFail(BFABI_ERROR_MEMORY_ERROR, "host OOM"); goto fail; }
 
   /* invariant: every buffer is written in exactly one stage */
   for (uint64_t t = 0; t < b.numTasks; ++t) {
@@ -883,7 +887,9 @@ int bfPlanBuild(BfIr const *ir, BfPlanOptions const *po, BfPlan *plan) {
     st->items = malloc((totalItems ? totalItems : 1) * sizeof(BfDevItem));
     st->pieces = malloc((numPieces ? numPieces : 1) * sizeof(BfDevPiece));
     st->pieceSrc = malloc((numPieces ? numPieces : 1) * sizeof(BfPieceSrc));
-    if (!st->items || !st->pieces || !st->pieceSrc) { free(tmp); rc = bfhipFail(BFABI_ERROR_MEMORY_ERROR, "host OOM"); goto stage_fail; }
+    st->pieceBuf = calloc(numPieces ? numPieces : 1, 4);
+    st->itemBuf = calloc(totalItems ? totalItems : 1, 4);
+    if (!st->items || !st->pieces || !st->pieceSrc || !st->pieceBuf || !st->itemBuf) { free(tmp); rc = bfhipFail(BFABI_ERROR_MEMORY_ERROR, "host OOM"); goto stage_fail; }
     uint64_t np = 0;
     uint64_t numBig = 0;
     while (numBig < numItems && !tmp[numBig].small) ++numBig;
@@ -908,7 +914,7 @@ int bfPlanBuild(BfIr const *ir, BfPlanOptions const *po, BfPlan *plan) {
       if (rowMajor) flags |= BF_ITEM_ROWMAJOR;
       if (g->reduced) outOff = g->slotOff + r0;
       else if (g->outBuf == by) { outOff = g->outOff + r0; flags |= BF_ITEM_OUT_Y; }
-      else outOff = b.bufs[g->outBuf].arenaOff + g->outOff + r0;
+      else { outOff = b.bufs[g->outBuf].arenaOff + g->outOff + r0; st->itemBuf[i < numBig ? i : i + numZeroItems] = g->outBuf; ++plan->bufWriters[g->outBuf]; }
       if (outOff >= 0xffffffffu) { free(tmp); rc = bfhipFail(BFABI_ERROR_RUNTIME_ERROR, "vector arena exceeds 32-bit offsets"); goto stage_fail; }
       it->outOff = (uint32_t)outOff;
       if (tmp[i].small) flags |= BF_ITEM_SMALL;
@@ -925,6 +931,7 @@ int bfPlanBuild(BfIr const *ir, BfPlanOptions const *po, BfPlan *plan) {
           BfDevPiece *pc = &st->pieces[np];
           pc->dataOff = 0; pc->inOff = (uint32_t)(inBase + r0); pc->ncols = mr; pc->flags = inFlag | BF_PIECE_IDENTITY; pc->ld = 0;
           st->pieceSrc[np].node = tk->leaf; st->pieceSrc[np].row0 = (uint32_t)tk->rsub0 + r0; st->pieceSrc[np].col0 = 0;
+          st->pieceBuf[np] = tk->inBuf == bx ? 0 : tk->inBuf;
           ++np;
           continue;
         }
@@ -961,6 +968,7 @@ int bfPlanBuild(BfIr const *ir, BfPlanOptions const *po, BfPlan *plan) {
               pc->ld = fp->mrPad;
             }
             st->pieceSrc[np].node = tk->leaf; st->pieceSrc[np].row0 = (uint32_t)lo; st->pieceSrc[np].col0 = r0;
+            st->pieceBuf[np] = tk->inBuf == bx ? 0 : tk->inBuf;
             ++np; ++found;
           }
           }
@@ -976,6 +984,7 @@ int bfPlanBuild(BfIr const *ir, BfPlanOptions const *po, BfPlan *plan) {
           if (inBase + c0 >= 0xffffffffu) { free(tmp); rc = bfhipFail(BFABI_ERROR_RUNTIME_ERROR, "vector arena exceeds 32-bit offsets"); goto stage_fail; }
           pc->dataOff = arenaTop; pc->inOff = (uint32_t)(inBase + c0); pc->ncols = (uint32_t)nc; pc->flags = inFlag; pc->ld = 0;
           st->pieceSrc[np].node = tk->leaf; st->pieceSrc[np].row0 = (uint32_t)tk->rsub0 + r0; st->pieceSrc[np].col0 = (uint32_t)(tk->sub0 + c0);
+          st->pieceBuf[np] = tk->inBuf == bx ? 0 : tk->inBuf;
           if (rowMajor) {
             /* every row starts on a 128-byte line (rowAlignBytes; +0.3 % arena on the streamed benchmark operand): a
              * 64-column chunk of a row, what a transposed item reads, is then whole lines -- at 16-byte alignment it
@@ -1014,6 +1023,7 @@ int bfPlanBuild(BfIr const *ir, BfPlanOptions const *po, BfPlan *plan) {
         if (outOff >= 0xffffffffu) { free(tmp); rc = bfhipFail(BFABI_ERROR_RUNTIME_ERROR, "vector arena exceeds 32-bit offsets"); goto stage_fail; }
         it->outOff = (uint32_t)outOff;
         it->mrFlags = (uint32_t)rows | (gaps[z].buf == by ? BF_ITEM_OUT_Y : 0);
+        if (gaps[z].buf != by) { st->itemBuf[ii - 1] = gaps[z].buf; ++plan->bufWriters[gaps[z].buf]; }
         if (rows > st->maxRows) st->maxRows = (uint32_t)rows;
         if (rows > st->maxRowsRest) st->maxRowsRest = (uint32_t)rows;
       }
@@ -1042,6 +1052,10 @@ int bfPlanBuild(BfIr const *ir, BfPlanOptions const *po, BfPlan *plan) {
 #undef PUSH_GAP1
   }
   free(bufRead);
+  plan->flowOk = !T;
+  for (int32_t s = 0; s < S; ++s)
+    for (uint64_t r = 0; r < plan->stages[s].numReduce; ++r)
+      if (plan->stages[s].reduce[r].destSpace != BF_SPACE_Y) plan->flowOk = 0;      /* a reduce into an intermediate sits between two stages */
   plan->arenaElems = arenaTop;
   plan->tempElems = roundUp(top, 4);
   free(b.tasks);

@@ -149,6 +149,12 @@ class HipOperator:
         check(self._lib.bfhipGetStats(self._h, C.byref(st)))
         return st.as_dict()
 
+    def flow_status(self):
+        """(applies of 1 - 2 RHS run as one dependency-driven launch, one of its waits ever gave up) -- bfhipFlowStatus."""
+        en, bad = C.c_uint32(0), C.c_uint32(0)
+        check(self._lib.bfhipFlowStatus(self._h, C.byref(en), C.byref(bad)))
+        return bool(en.value), bool(bad.value)
+
     @property
     def dtype(self):
         return self.stats()["dtype"]

@@ -56,8 +56,11 @@ enum {
   BFHIP_FLAG_PROFILE = 1u << 0,  /* record hipEvents around every stage launch */
   BFHIP_FLAG_PLAN_ONLY = 1u << 1,/* build the host-side plan only: no device is touched, apply is refused;
                                     for inspecting the flattened layout (bfhipPlan* below) */
-  BFHIP_FLAG_ADJOINT = 1u << 2   /* also build the plan of A^T (bfhipApplyTranspose*, RmulVec of the shim):
+  BFHIP_FLAG_ADJOINT = 1u << 2,  /* also build the plan of A^T (bfhipApplyTranspose*, RmulVec of the shim):
                                     index metadata only, the packed leaf data is shared */
+  BFHIP_FLAG_NO_FLOW = 1u << 3   /* always one launch per stage.  Default for complex128 operators applied to 1 - 2 right-hand
+                                    sides: the whole plan as ONE dependency-driven launch (items wait for the intermediate
+                                    vectors they read, not for the previous stage; bit-identical results) */
 };
 
 typedef struct BfhipOptions {
@@ -266,11 +269,16 @@ size_t bfhipGetNumCols(const BfhipOperator *op);
  * (mat_block_coo.c:238-258, mat_dense_complex.c:452-455). */
 size_t bfhipNumBytes(const BfhipOperator *op);
 
+/* Whether applies of 1 - 2 right-hand sides run as one dependency-driven launch (see BFHIP_FLAG_NO_FLOW), and whether
+ * one of its waits ever gave up (0 by construction; checked by the test-suite after every flow test). */
+int bfhipFlowStatus(BfhipOperator *op, uint32_t *enabled, uint32_t *waitGaveUp);
+
 /* With BFHIP_FLAG_PROFILE: per-stage accumulated kernel time (ms) and launch
  * count since the last reset, measured with hipEvents on the apply stream.
  * `ms`/`launches`/`bytes` are [numStages] arrays (any may be NULL); `bytes`
  * receives the algorithmic bytes one launch of that stage moves for the nrhs
- * of the last apply.  Synchronizes the stream. */
+ * of the last apply.  Synchronizes the stream.  An operator whose applies run as ONE launch (bfhipFlowStatus)
+ * reports that launch under stage 0 -- time, launch count and the bytes of all stages -- and zeros elsewhere. */
 int bfhipGetStageProfile(BfhipOperator *op, double *ms, uint64_t *launches, uint64_t *bytes, int reset);
 /* Bracket only one apply in `every` with events (default 1: all of them).  An event pair per launch costs ~4 us of
  * stream time on this hardware (launch gaps of 10 us instead of 6, measured with rocprofv3 --kernel-trace): 2.5 % of
