@@ -301,7 +301,7 @@ static void dropPlanMirrors(BfPlan *plan) {
 /* Flat index tables for the dependency-driven launch (bfFlowKernelC128): all stages' items in stage order with global
  * piece indices, pieces carrying the id of the vector they read, per item the vector it writes, per vector its number
  * of writers, and the counters.  Needs the host mirrors of the plan. */
-static int buildFlow(BfhipOperator *op) {
+static int buildFlow(BfhipOperator *op, int hostOnly) {
   BfPlan const *pl = &op->plan;
   uint64_t ni = 0, np = 0;
   for (uint64_t s = 0; s < pl->numStages; ++s) { ni += pl->stages[s].numItems; np += pl->stages[s].numPieces; }
@@ -327,7 +327,28 @@ static int buildFlow(BfhipOperator *op) {
   }
   uint32_t maxW = 1;
   for (uint64_t b = 0; b < pl->numBufs; ++b) if (pl->bufWriters[b] > maxW) maxW = pl->bufWriters[b];
+  {
+    /* The launch drains iff the list, walked in ticket order by ONE worker, never waits: every vector a piece reads has
+     * been written completely by items earlier in the list.  Checked here, once, on the host. */
+    uint32_t *seen = calloc(pl->numBufs + 1, 4);
+    if (!seen) { rc = bfhipFail(BFABI_ERROR_MEMORY_ERROR, "host OOM (flow tables)"); goto done; }
+    for (uint64_t i = 0; i < ni && !rc; ++i) {
+      for (uint32_t k = 0; k < items[i].numPieces; ++k) {
+        uint32_t const dep = pieces[items[i].pieceBegin + k].ld;
+        if (dep >= pl->numBufs || (dep && (dep < 2 || !pl->bufWriters[dep] || seen[dep] != pl->bufWriters[dep]))) {
+          rc = bfhipFail(BFABI_ERROR_RUNTIME_ERROR, "internal: item %llu reads vector %u before it is complete (%u of %u writers)", (unsigned long long)i, dep,
+                         dep < pl->numBufs ? seen[dep] : 0, dep < pl->numBufs ? pl->bufWriters[dep] : 0);
+          break;
+        }
+      }
+      if (itemOut[i] >= pl->numBufs || itemOut[i] == 1) rc = bfhipFail(BFABI_ERROR_RUNTIME_ERROR, "internal: item %llu writes vector %u", (unsigned long long)i, itemOut[i]);
+      else if (itemOut[i]) ++seen[itemOut[i]];
+    }
+    free(seen);
+    if (rc) goto done;
+  }
   uint64_t const nb = pl->numBufs < 2 ? 2 : pl->numBufs;
+  if (hostOnly) { op->flow = 1; goto done; }        /* plan-only operators: the tables are built and checked, nothing is uploaded */
   if ((rc = uploadArray(&op->dFlowItems, items, ni * sizeof *items, &op->metaBytes))) goto done;
   if ((rc = uploadArray(&op->dFlowPieces, pieces, (np ? np : 1) * sizeof *pieces, &op->metaBytes))) goto done;
   if ((rc = uploadArray(&op->dFlowItemOut, itemOut, ni * 4, &op->metaBytes))) goto done;
@@ -413,6 +434,7 @@ int bfhipCompileIrFill(BfIr *ir, BfhipOptions const *opts, BfFillFn fill, void *
     op->hasTplan = 1;
   }
   if (planOnly) {
+    if (op->plan.dtype == BFHIP_C128 && op->plan.flowOk && !(o.flags & BFHIP_FLAG_NO_FLOW) && (rc = buildFlow(op, 1))) goto done;
     /* keep the IR (with its borrowed leaf pointers) for bfhipPlanPackArena */
     op->ir = malloc(sizeof *op->ir);
     if (!op->ir) { rc = bfhipFail(BFABI_ERROR_MEMORY_ERROR, "host OOM"); goto done; }
@@ -431,7 +453,7 @@ int bfhipCompileIrFill(BfIr *ir, BfhipOptions const *opts, BfFillFn fill, void *
   if ((rc = fill ? fill(&op->plan, ir, op->dArena, fillCtx) : packLeaves(op, ir, o.seed, NULL))) goto done;
   {
     char const *noFlow = getenv("BFHIP_NO_FLOW");       /* A/B switch; BFHIP_FLAG_NO_FLOW is the per-operator one */
-    if (op->plan.dtype == BFHIP_C128 && op->plan.flowOk && !(o.flags & BFHIP_FLAG_NO_FLOW) && !(noFlow && noFlow[0] == '1') && (rc = buildFlow(op))) goto done;
+    if (op->plan.dtype == BFHIP_C128 && op->plan.flowOk && !(o.flags & BFHIP_FLAG_NO_FLOW) && !(noFlow && noFlow[0] == '1') && (rc = buildFlow(op, 0))) goto done;
   }
   /* host mirrors of the bulky per-piece arrays are no longer needed */
   dropPlanMirrors(&op->plan);
@@ -578,6 +600,21 @@ static int runPlan(BfhipOperator *op, BfPlan *plan, void const *dX, size_t nrhs,
     if (prof) { op->evFlow[op->evIssued % BF_EV_POOL] = 1; if ((rc = bfdevEventRecord(op->evStart[evBase], stream))) goto out; }
     if ((rc = bfdevLaunchFlow(&fa, stream))) goto out;
     if (prof && (rc = bfdevEventRecord(op->evStop[evBase], stream))) goto out;
+    {
+      static int dbg = -1;
+      if (dbg < 0) { char const *e = getenv("BFHIP_FLOW_DEBUG"); dbg = e && e[0] == '1'; }
+      if (dbg) {      /* diagnostic: after the launch every vector's counter must stand at writers x epoch */
+        if ((rc = bfdevSync(stream))) goto out;
+        uint32_t *c = malloc(op->flowNumBufs * 4), *w = malloc(op->flowNumBufs * 4);
+        if (c && w && !bfdevMemcpyD2H(c, op->dFlowCounters, op->flowNumBufs * 4) && !bfdevMemcpyD2H(w, op->dFlowWriters, op->flowNumBufs * 4)) {
+          uint64_t bad = 0;
+          for (uint64_t b = 2; b < op->flowNumBufs; ++b) if (c[b] != w[b] * op->flowEpoch) { if (bad++ < 8) fprintf(stderr, "bfhip flow: vector %llu counter %u, expected %u x %u\n", (unsigned long long)b, c[b], w[b], op->flowEpoch); }
+          fprintf(stderr, "bfhip flow: epoch %u queue %u (base %u + %u items + %u waves) error %u, %llu of %llu counters off\n", op->flowEpoch, c[0], fa.queueBase, op->flowNumItems,
+                  op->flowGrid * 4u, c[1], (unsigned long long)bad, (unsigned long long)op->flowNumBufs);
+        }
+        free(c); free(w);
+      }
+    }
     for (uint64_t s = 0; s < plan->numStages; ++s) {
       BfStage *st = &plan->stages[s];
       for (uint64_t r0 = 0; r0 < st->numReduce; r0 += 16) {
@@ -646,7 +683,7 @@ int bfhipFlowStatus(BfhipOperator *op, uint32_t *enabled, uint32_t *waitGaveUp) 
   if (enabled) *enabled = (uint32_t)op->flow;
   if (waitGaveUp) {
     *waitGaveUp = 0;
-    if (op->flow) {
+    if (op->flow && !(op->flags & BFHIP_FLAG_PLAN_ONLY)) {
       uint32_t two[2] = {0, 0};
       int prev = -1, rc;
       bfdevGetDevice(&prev);

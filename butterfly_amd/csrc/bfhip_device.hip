@@ -31,6 +31,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 #include "bfhip_internal.h"
 #include "../../include/bfhip_abi.h"
@@ -236,21 +237,54 @@ struct FlowParams {
   uint32_t numItems, nrhs;
   uint32_t epoch;                // 1-based apply number since the counters were last cleared
   uint32_t queueBase;            // ticket value of item 0 in this apply
+  uint32_t spinLimit;            // a wait gives up after this many polls
   void const *x;
   void *y;
   void *temp;
 };
 
-#define BF_FLOW_SPIN_LIMIT (1u << 24)     // x ~0.3 us: seconds, then the wait gives up and raises `error` instead of hanging the GPU
+#define BF_FLOW_SPIN_LIMIT (1u << 21)     // x ~0.5 us: about a second (a legitimate wait is micro- to milliseconds), then the wait gives up and raises `error` instead of hanging the GPU
 
-__device__ __forceinline__ void bfFlowWait(FlowParams const &p, uint32_t dep, int lane) {
+// Nothing in the launch branches on "lane == 0": a lane-invariant condition inside the item loop invites the compiler to
+// give lane 0 and the other lanes loops of their own (the first version did exactly that: lanes 1..63 went round again
+// with ticket 0 while lane 0 drew the next one -- the wavefront never came back together and the launch never ended).
+// Tickets and counter updates are single-lane atomics issued with the exec mask narrowed inside one asm block; waits are
+// polled by all lanes at once (one request: same address) and decided on the broadcast value.
+__device__ __forceinline__ uint32_t bfFlowTicket(uint32_t *queue) {
+  uint32_t ret;
+  uint64_t saved;
+  asm volatile("s_mov_b64 %1, exec\n\t"
+               "s_mov_b64 exec, 1\n\t"
+               "global_atomic_add %0, %2, %3, %4 sc0\n\t"
+               "s_waitcnt vmcnt(0)\n\t"
+               "s_mov_b64 exec, %1"
+               : "=&v"(ret), "=&s"(saved)
+               : "v"(0u), "v"(1u), "s"(queue)
+               : "memory");
+  return (uint32_t)__builtin_amdgcn_readfirstlane((int)ret);      // lane 0 is active: the loop top is reached by whole wavefronts
+}
+__device__ __forceinline__ void bfFlowBump(uint32_t *counter) {
+  uint64_t saved;
+  // (the release fence before this call ends in buffer_wbl2; the writeback is complete when vmcnt drains -- the
+  // compiler cannot know that the asm below is the atomic the fence orders, so the wait is spelled out here)
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\t"
+               "s_mov_b64 %0, exec\n\t"
+               "s_mov_b64 exec, 1\n\t"
+               "global_atomic_add %1, %2, %3\n\t"
+               "s_mov_b64 exec, %0"
+               : "=&s"(saved)
+               : "v"(0u), "v"(1u), "s"(counter)
+               : "memory");
+}
+
+__device__ __forceinline__ void bfFlowWait(FlowParams const &p, uint32_t dep) {
   uint32_t const want = p.writers[dep] * p.epoch;
-  if (lane == 0) {
-    uint32_t spins = 0;
-    while (__hip_atomic_load(p.counters + dep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
-      __builtin_amdgcn_s_sleep(8);
-      if (++spins > BF_FLOW_SPIN_LIMIT) { __hip_atomic_store(p.error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
-    }
+  uint32_t spins = 0;
+  for (;;) {
+    uint32_t const seen = (uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(p.counters + dep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    if (seen >= want) break;
+    __builtin_amdgcn_s_sleep(8);
+    if (++spins > p.spinLimit) { __hip_atomic_store(p.error, dep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }      // every lane stores the same word
   }
   // what the writers released is acquired by the whole wavefront (the other XCDs' L2s are not coherent with this one)
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -264,9 +298,7 @@ __global__ __launch_bounds__(BF_WAVES_PER_WG * 64) void bfFlowKernelC128(FlowPar
   double2 const *arena = (double2 const *)p.arena;
   uint32_t const nrhs = p.nrhs;
   for (;;) {
-    uint32_t ticket = 0;
-    if (lane == 0) ticket = __hip_atomic_fetch_add(p.queue, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    uint32_t const item = (uint32_t)__builtin_amdgcn_readfirstlane((int)ticket) - p.queueBase;
+    uint32_t const item = bfFlowTicket(p.queue) - p.queueBase;
     if (item >= p.numItems) return;
     BfDevItem const it = p.items[item];
     uint32_t const mr = it.mrFlags & 0xffffu;
@@ -283,7 +315,7 @@ __global__ __launch_bounds__(BF_WAVES_PER_WG * 64) void bfFlowKernelC128(FlowPar
       for (uint32_t pi = 0; pi < it.numPieces; ++pi) {
         BfDevPiece const pc = p.pieces[it.pieceBegin + pi];
         uint32_t const dep = (uint32_t)__builtin_amdgcn_readfirstlane((int)pc.ld);
-        if (dep && dep != ready) { bfFlowWait(p, dep, lane); ready = dep; }
+        if (dep && dep != ready) { bfFlowWait(p, dep); ready = dep; }
         double2 const *xin = (pc.flags & BF_PIECE_IN_X) ? (double2 const *)p.x : (double2 const *)p.temp;
         xin += (uint64_t)pc.inOff * nrhs + q;
         uint32_t const n = pc.ncols;
@@ -326,11 +358,11 @@ __global__ __launch_bounds__(BF_WAVES_PER_WG * 64) void bfFlowKernelC128(FlowPar
         out[((uint64_t)it.outOff + lane) * nrhs + q] = make_double2(sr, si);
       }
     }
-    uint32_t const od = p.itemOut[item];
+    uint32_t const od = (uint32_t)__builtin_amdgcn_readfirstlane((int)p.itemOut[item]);
     if (od) {
       // every lane's stores leave this XCD before the counter moves
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      if (lane == 0) __hip_atomic_fetch_add(p.counters + od, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      bfFlowBump(p.counters + od);
     }
   }
 }
@@ -1528,6 +1560,9 @@ int bfdevLaunchFlow(BfFlowArgs const *a, void *stream) {
   p.queue = (uint32_t *)a->counters;            // slot 0: vector id 0 (x) has no counter of its own
   p.error = (uint32_t *)a->counters + 1;        // slot 1: vector id 1 (y) neither
   p.numItems = a->numItems; p.nrhs = a->nrhs; p.epoch = a->epoch; p.queueBase = a->queueBase;
+  static uint32_t spinLimit = 0;
+  if (!spinLimit) { char const *e = getenv("BFHIP_FLOW_SPIN"); spinLimit = e ? (uint32_t)strtoul(e, NULL, 10) : BF_FLOW_SPIN_LIMIT; if (!spinLimit) spinLimit = BF_FLOW_SPIN_LIMIT; }
+  p.spinLimit = spinLimit;
   p.x = a->x; p.y = a->y; p.temp = a->temp;
   hipLaunchKernelGGL(bfFlowKernelC128, dim3(a->gridWorkgroups), dim3(BF_WAVES_PER_WG * 64), 0, (hipStream_t)stream, p);
   return hipFail(hipGetLastError(), "flow launch");

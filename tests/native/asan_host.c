@@ -55,6 +55,21 @@ static int drive(double const *pts, uint64_t n, double const *tgt, uint64_t m, d
         o.rowBlockBegin = 1; o.rowBlockEnd = 3; o.flags = BFHIP_FLAG_PLAN_ONLY;
         CHECK(bfhipCompileDesc(d, &o, &op));
         bfhipFree(&op);
+        /* row ranges: the library's own cuts for 3 ranks, each compiled (liveness pruning), plus an unclean range */
+        uint64_t cuts[4], loads[3];
+        CHECK(bfhipRowPartition(d, 3, cuts, loads));
+        if (cuts[0] != 0 || cuts[3] != n || !loads[0]) return 4;
+        o.rowBlockBegin = o.rowBlockEnd = 0;
+        for (int r = 0; r < 3; ++r) {
+          o.rowBegin = cuts[r]; o.rowEnd = cuts[r + 1];
+          CHECK(bfhipCompileDesc(d, &o, &op));
+          if (bfhipGetNumRows(op) != cuts[r + 1] - cuts[r]) return 5;
+          bfhipFree(&op);
+        }
+        o.rowBegin = 3; o.rowEnd = n - 5;
+        CHECK(bfhipCompileDesc(d, &o, &op));
+        bfhipFree(&op);
+        o.rowBegin = o.rowEnd = 0;
       }
     }
   }
@@ -199,6 +214,9 @@ STUB(bfdevGmresResidual)
 STUB(bfdevGmresUpdate)
 STUB(bfdevHelm2Dense)
 STUB(bfdevLaunchReduce)
+STUB(bfdevLaunchFlow)
+STUB(bfdevFlowGrid)
+STUB(bfdevMemsetAsync)
 STUB(bfdevLaunchStage)
 STUB(bfdevMalloc)
 STUB(bfdevMemFree)
