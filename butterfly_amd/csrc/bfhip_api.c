@@ -322,6 +322,10 @@ static int buildFlow(BfhipOperator *op, int hostOnly) {
     for (uint64_t k = 0; k < st->numPieces; ++k) {
       pieces[p0 + k] = st->pieces[k];
       pieces[p0 + k].ld = st->pieceBuf[k];          /* column-major complex pieces do not use `ld` */
+      if (st->pieceBuf[k]) {                        /* the number of writers of that vector rides above the flag bits */
+        if (pl->bufWriters[st->pieceBuf[k]] >= (1u << 24)) { rc = 0; goto done; }      /* (never: a vector has one writer per <= 64 of its rows) -> staged launches */
+        pieces[p0 + k].flags |= pl->bufWriters[st->pieceBuf[k]] << 8;
+      }
     }
     i0 += st->numItems; p0 += st->numPieces;
   }

@@ -277,8 +277,26 @@ __device__ __forceinline__ void bfFlowBump(uint32_t *counter) {
                : "memory");
 }
 
-__device__ __forceinline__ void bfFlowWait(FlowParams const &p, uint32_t dep) {
-  uint32_t const want = p.writers[dep] * p.epoch;
+// Intermediate vectors are the only data that crosses between wavefronts inside the launch.  They are written with
+// agent-scope stores (sc1: written through this XCD's L2) and read with agent-scope loads (sc1: never served from a
+// stale line), so no cache-wide writeback / invalidate is needed around an item -- the first version fenced with
+// buffer_wbl2 / buffer_inv per item and per wait, and an operator whose last-stage items read a dozen vectors each ran
+// 2.6x slower than the staged launches.  Leaf data, x and the index tables are read-only: plain (streamed) loads.
+__device__ __forceinline__ double2 bfLoadCoherent(double2 const *p) {
+  unsigned long long const *q = (unsigned long long const *)p;
+  unsigned long long const a = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  unsigned long long const b = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return make_double2(__longlong_as_double((long long)a), __longlong_as_double((long long)b));
+}
+__device__ __forceinline__ void bfStoreCoherent(double2 *p, double2 v) {
+  unsigned long long *q = (unsigned long long *)p;
+  __hip_atomic_store(q, (unsigned long long)__double_as_longlong(v.x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(q + 1, (unsigned long long)__double_as_longlong(v.y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// poll until vector `dep` has all its writers (a legitimate wait is micro- to milliseconds; after spinLimit polls it
+// gives up and raises `error` instead of hanging the GPU)
+__device__ __forceinline__ void bfFlowWait(FlowParams const &p, uint32_t dep, uint32_t want) {
   uint32_t spins = 0;
   for (;;) {
     uint32_t const seen = (uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(p.counters + dep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
@@ -286,8 +304,6 @@ __device__ __forceinline__ void bfFlowWait(FlowParams const &p, uint32_t dep) {
     __builtin_amdgcn_s_sleep(8);
     if (++spins > p.spinLimit) { __hip_atomic_store(p.error, dep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }      // every lane stores the same word
   }
-  // what the writers released is acquired by the whole wavefront (the other XCDs' L2s are not coherent with this one)
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 }
 
 __global__ __launch_bounds__(BF_WAVES_PER_WG * 64) void bfFlowKernelC128(FlowParams p) {
@@ -301,6 +317,7 @@ __global__ __launch_bounds__(BF_WAVES_PER_WG * 64) void bfFlowKernelC128(FlowPar
     uint32_t const item = bfFlowTicket(p.queue) - p.queueBase;
     if (item >= p.numItems) return;
     BfDevItem const it = p.items[item];
+    uint32_t const od = (uint32_t)__builtin_amdgcn_readfirstlane((int)p.itemOut[item]);
     uint32_t const mr = it.mrFlags & 0xffffu;
     uint32_t const g = 64u / mr;
     uint32_t const G = g * mr;
@@ -309,25 +326,36 @@ __global__ __launch_bounds__(BF_WAVES_PER_WG * 64) void bfFlowKernelC128(FlowPar
     uint32_t const c = lc / mr;
     uint32_t const r = lc - c * mr;
     double2 *out = (it.mrFlags & BF_ITEM_OUT_Y) ? (double2 *)p.y : (double2 *)p.temp;
-    uint32_t ready = 0;          // the vector this wavefront last waited for (an item's pieces mostly read one)
     for (uint32_t q = 0; q < nrhs; ++q) {
       double accr = 0.0, acci = 0.0;
       for (uint32_t pi = 0; pi < it.numPieces; ++pi) {
         BfDevPiece const pc = p.pieces[it.pieceBegin + pi];
         uint32_t const dep = (uint32_t)__builtin_amdgcn_readfirstlane((int)pc.ld);
-        if (dep && dep != ready) { bfFlowWait(p, dep); ready = dep; }
+        uint32_t const want = (uint32_t)__builtin_amdgcn_readfirstlane((int)(pc.flags >> 8)) * p.epoch;      // writers of `dep` ride in the flag word
         double2 const *xin = (pc.flags & BF_PIECE_IN_X) ? (double2 const *)p.x : (double2 const *)p.temp;
         xin += (uint64_t)pc.inOff * nrhs + q;
         uint32_t const n = pc.ncols;
         if (pc.flags & BF_PIECE_IDENTITY) {
+          if (dep) bfFlowWait(p, dep, want);
           if (c == 0 && active) {
-            double2 v = xin[(uint64_t)r * nrhs];
+            double2 v = dep ? bfLoadCoherent(xin + (uint64_t)r * nrhs) : xin[(uint64_t)r * nrhs];
             accr += v.x; acci += v.y;
           }
           continue;
         }
-        waveSync();
-        for (uint32_t j = lane; j < n; j += 64) xs[j] = xin[(uint64_t)j * nrhs];
+        // the input sub-vector: requested together with the poll of its vector's counter -- the producers of all but the
+        // most recent vectors are long done, so the poll almost always confirms what was loaded and costs no round trip
+        waveSync();   // previous piece's reads are done before overwriting
+        if (dep) {
+          uint32_t const seen = __hip_atomic_load(p.counters + dep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          for (uint32_t j = lane; j < n; j += 64) xs[j] = bfLoadCoherent(xin + (uint64_t)j * nrhs);
+          if ((uint32_t)__builtin_amdgcn_readfirstlane((int)seen) < want) {       // not complete when asked: wait, then ask again
+            bfFlowWait(p, dep, want);
+            for (uint32_t j = lane; j < n; j += 64) xs[j] = bfLoadCoherent(xin + (uint64_t)j * nrhs);
+          }
+        } else {
+          for (uint32_t j = lane; j < n; j += 64) xs[j] = xin[(uint64_t)j * nrhs];
+        }
         waveSync();
         double2 const *ap = arena + pc.dataOff + lc;
         uint32_t const nfull = n / g;
@@ -355,15 +383,11 @@ __global__ __launch_bounds__(BF_WAVES_PER_WG * 64) void bfFlowKernelC128(FlowPar
       if ((uint32_t)lane < mr) {
         double sr = 0.0, si = 0.0;
         for (uint32_t cc = 0; cc < g; ++cc) { double2 v = xs[cc * mr + lane]; sr += v.x; si += v.y; }
-        out[((uint64_t)it.outOff + lane) * nrhs + q] = make_double2(sr, si);
+        double2 *dst = out + ((uint64_t)it.outOff + lane) * nrhs + q;
+        if (od) bfStoreCoherent(dst, make_double2(sr, si)); else *dst = make_double2(sr, si);      // later items read it / a later kernel does
       }
     }
-    uint32_t const od = (uint32_t)__builtin_amdgcn_readfirstlane((int)p.itemOut[item]);
-    if (od) {
-      // every lane's stores leave this XCD before the counter moves
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      bfFlowBump(p.counters + od);
-    }
+    if (od) bfFlowBump(p.counters + od);      // waits for this wavefront's stores (vmcnt) before the counter moves
   }
 }
 

@@ -264,15 +264,21 @@ def test_stage_profile_reports_every_stage(helm2_cases):
     from butterfly_amd import _capi
     from butterfly_amd.operator import HipOperator
     desc, tp, vals = helm2_cases(4096, 100)
-    op = HipOperator.from_desc(desc, vals, flags=_capi.FLAG_PROFILE)
     x = torch.randn(4096, dtype=torch.complex128, device="cuda")
-    for _ in range(3):
-        op.apply_device(x)
-    ms, launches, nbytes = op.stage_profile()
-    st = op.stats()
-    assert len(ms) == st["numStages"] and all(launches == 3) and all(ms > 0)
-    assert int(nbytes.sum()) == st["leafBytes"] + 16 * (st["vecElemsRead"] + st["vecElemsWritten"])
-    op.close()
+    for flags, one_launch in ((_capi.FLAG_PROFILE | _capi.FLAG_NO_FLOW, False), (_capi.FLAG_PROFILE, True)):
+        op = HipOperator.from_desc(desc, vals, flags=flags)
+        assert op.flow_status()[0] == one_launch
+        for _ in range(3):
+            op.apply_device(x)
+        ms, launches, nbytes = op.stage_profile()
+        st = op.stats()
+        assert len(ms) == st["numStages"]
+        if one_launch:      # the whole plan is one dependency-driven launch: reported under stage 0, with the bytes of all stages
+            assert launches[0] == 3 and ms[0] > 0 and not launches[1:].any() and not nbytes[1:].any()
+        else:
+            assert all(launches == 3) and all(ms > 0)
+        assert int(nbytes.sum()) == st["leafBytes"] + 16 * (st["vecElemsRead"] + st["vecElemsWritten"])
+        op.close()
 
 
 @pytest.mark.parametrize("nrhs", [3, 16, 20, 64, 70])
