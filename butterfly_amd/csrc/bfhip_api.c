@@ -438,7 +438,7 @@ int bfhipCompileIrFill(BfIr *ir, BfhipOptions const *opts, BfFillFn fill, void *
     op->hasTplan = 1;
   }
   if (planOnly) {
-    if (op->plan.dtype == BFHIP_C128 && op->plan.flowOk && !(o.flags & BFHIP_FLAG_NO_FLOW) && (rc = buildFlow(op, 1))) goto done;
+    if (op->plan.dtype == BFHIP_C128 && op->plan.flowOk && (o.flags & BFHIP_FLAG_FLOW) && (rc = buildFlow(op, 1))) goto done;
     /* keep the IR (with its borrowed leaf pointers) for bfhipPlanPackArena */
     op->ir = malloc(sizeof *op->ir);
     if (!op->ir) { rc = bfhipFail(BFABI_ERROR_MEMORY_ERROR, "host OOM"); goto done; }
@@ -456,8 +456,8 @@ int bfhipCompileIrFill(BfIr *ir, BfhipOptions const *opts, BfFillFn fill, void *
   /* leaf values: computed on the device by the caller's builder, or packed / synthesized from the IR */
   if ((rc = fill ? fill(&op->plan, ir, op->dArena, fillCtx) : packLeaves(op, ir, o.seed, NULL))) goto done;
   {
-    char const *noFlow = getenv("BFHIP_NO_FLOW");       /* A/B switch; BFHIP_FLAG_NO_FLOW is the per-operator one */
-    if (op->plan.dtype == BFHIP_C128 && op->plan.flowOk && !(o.flags & BFHIP_FLAG_NO_FLOW) && !(noFlow && noFlow[0] == '1') && (rc = buildFlow(op, 0))) goto done;
+    char const *envFlow = getenv("BFHIP_FLOW");         /* A/B switch for whole programs; BFHIP_FLAG_FLOW is the per-operator one */
+    if (op->plan.dtype == BFHIP_C128 && op->plan.flowOk && ((o.flags & BFHIP_FLAG_FLOW) || (envFlow && envFlow[0] == '1')) && (rc = buildFlow(op, 0))) goto done;
   }
   /* host mirrors of the bulky per-piece arrays are no longer needed */
   dropPlanMirrors(&op->plan);

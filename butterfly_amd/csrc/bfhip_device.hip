@@ -326,6 +326,7 @@ __global__ __launch_bounds__(BF_WAVES_PER_WG * 64) void bfFlowKernelC128(FlowPar
     uint32_t const c = lc / mr;
     uint32_t const r = lc - c * mr;
     double2 *out = (it.mrFlags & BF_ITEM_OUT_Y) ? (double2 *)p.y : (double2 *)p.temp;
+    uint32_t ready = 0;          // the vector this wavefront last saw complete (consecutive pieces often read the same one)
     for (uint32_t q = 0; q < nrhs; ++q) {
       double accr = 0.0, acci = 0.0;
       for (uint32_t pi = 0; pi < it.numPieces; ++pi) {
@@ -336,7 +337,7 @@ __global__ __launch_bounds__(BF_WAVES_PER_WG * 64) void bfFlowKernelC128(FlowPar
         xin += (uint64_t)pc.inOff * nrhs + q;
         uint32_t const n = pc.ncols;
         if (pc.flags & BF_PIECE_IDENTITY) {
-          if (dep) bfFlowWait(p, dep, want);
+          if (dep && dep != ready) { bfFlowWait(p, dep, want); ready = dep; }
           if (c == 0 && active) {
             double2 v = dep ? bfLoadCoherent(xin + (uint64_t)r * nrhs) : xin[(uint64_t)r * nrhs];
             accr += v.x; acci += v.y;
@@ -347,12 +348,11 @@ __global__ __launch_bounds__(BF_WAVES_PER_WG * 64) void bfFlowKernelC128(FlowPar
         // most recent vectors are long done, so the poll almost always confirms what was loaded and costs no round trip
         waveSync();   // previous piece's reads are done before overwriting
         if (dep) {
-          uint32_t const seen = __hip_atomic_load(p.counters + dep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          // the counter is seen complete BEFORE the vector is asked for: two loads of one wavefront to different
+          // addresses may sample memory in either order, so asking for both at once (tried: it hides the poll's round
+          // trip) can pair a complete counter with data from before the last writer -- GMRES stopped converging on it
+          if (dep != ready) { bfFlowWait(p, dep, want); ready = dep; }
           for (uint32_t j = lane; j < n; j += 64) xs[j] = bfLoadCoherent(xin + (uint64_t)j * nrhs);
-          if ((uint32_t)__builtin_amdgcn_readfirstlane((int)seen) < want) {       // not complete when asked: wait, then ask again
-            bfFlowWait(p, dep, want);
-            for (uint32_t j = lane; j < n; j += 64) xs[j] = bfLoadCoherent(xin + (uint64_t)j * nrhs);
-          }
         } else {
           for (uint32_t j = lane; j < n; j += 64) xs[j] = xin[(uint64_t)j * nrhs];
         }

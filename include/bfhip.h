@@ -58,9 +58,10 @@ enum {
                                     for inspecting the flattened layout (bfhipPlan* below) */
   BFHIP_FLAG_ADJOINT = 1u << 2,  /* also build the plan of A^T (bfhipApplyTranspose*, RmulVec of the shim):
                                     index metadata only, the packed leaf data is shared */
-  BFHIP_FLAG_NO_FLOW = 1u << 3   /* always one launch per stage.  Default for complex128 operators applied to 1 - 2 right-hand
-                                    sides: the whole plan as ONE dependency-driven launch (items wait for the intermediate
-                                    vectors they read, not for the previous stage; bit-identical results) */
+  BFHIP_FLAG_FLOW = 1u << 3      /* EXPERIMENTAL, complex128 operators applied to 1 - 2 right-hand sides: the whole plan as ONE
+                                    dependency-driven persistent launch (items wait for the intermediate vectors they read,
+                                    not for the previous stage; bit-identical results) instead of one launch per stage.
+                                    Measured slower than the staged launches on MI355X: off by default */
 };
 
 typedef struct BfhipOptions {
@@ -269,7 +270,7 @@ size_t bfhipGetNumCols(const BfhipOperator *op);
  * (mat_block_coo.c:238-258, mat_dense_complex.c:452-455). */
 size_t bfhipNumBytes(const BfhipOperator *op);
 
-/* Whether applies of 1 - 2 right-hand sides run as one dependency-driven launch (see BFHIP_FLAG_NO_FLOW), and whether
+/* Whether applies of 1 - 2 right-hand sides run as one dependency-driven launch (see BFHIP_FLAG_FLOW), and whether
  * one of its waits ever gave up (0 by construction; checked by the test-suite after every flow test). */
 int bfhipFlowStatus(BfhipOperator *op, uint32_t *enabled, uint32_t *waitGaveUp);
 

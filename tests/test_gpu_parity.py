@@ -265,7 +265,7 @@ def test_stage_profile_reports_every_stage(helm2_cases):
     from butterfly_amd.operator import HipOperator
     desc, tp, vals = helm2_cases(4096, 100)
     x = torch.randn(4096, dtype=torch.complex128, device="cuda")
-    for flags, one_launch in ((_capi.FLAG_PROFILE | _capi.FLAG_NO_FLOW, False), (_capi.FLAG_PROFILE, True)):
+    for flags, one_launch in ((_capi.FLAG_PROFILE, False), (_capi.FLAG_PROFILE | _capi.FLAG_FLOW, True)):
         op = HipOperator.from_desc(desc, vals, flags=flags)
         assert op.flow_status()[0] == one_launch
         for _ in range(3):
@@ -707,17 +707,17 @@ def test_rccl_sharded_apply_one_rank_matches_plain_apply(helm2_cases, mode):
 
 @pytest.mark.parametrize("n,k", [(4096, 100.0), (16384, 1024.0), (65536, 4096.0)])
 def test_one_dependency_driven_launch_equals_the_staged_launches(n, k):
-    """Default for complex128 operators at 1 - 2 right-hand sides: the whole plan as ONE persistent launch whose items
-    wait for the intermediate vectors they read (bfFlowKernelC128) instead of one launch per stage.  Same items, same
-    arithmetic: bit-identical to the staged launches (BFHIP_FLAG_NO_FLOW) and to itself over hundreds of applies (the
+    """BFHIP_FLAG_FLOW (experimental; complex128 operators at 1 - 2 right-hand sides): the whole plan as ONE persistent
+    launch whose items wait for the intermediate vectors they read (bfFlowKernelC128) instead of one launch per stage.
+    Same items, same arithmetic: bit-identical to the staged launches and to itself over hundreds of applies (the
     counters run on from apply to apply), equal to the oracle, and no wait ever gives up."""
     import torch
     from butterfly_amd import _capi, helm2_structure as hs
     from butterfly_amd.operator import HipOperator
     from oracle import bfref
     desc, perm = hs.native_multilevel_structure(hs.circle_points(n), k)
-    flow = HipOperator.from_desc(desc, None, seed=9, max_rhs=2, flags=_capi.FLAG_PROFILE)
-    staged = HipOperator.from_desc(desc, None, seed=9, max_rhs=2, flags=_capi.FLAG_NO_FLOW)
+    flow = HipOperator.from_desc(desc, None, seed=9, max_rhs=2, flags=_capi.FLAG_PROFILE | _capi.FLAG_FLOW)
+    staged = HipOperator.from_desc(desc, None, seed=9, max_rhs=2)
     assert flow.flow_status() == (True, False) and staged.flow_status() == (False, False)
     rng = np.random.default_rng(n)
     for nrhs in (1, 2):
@@ -735,6 +735,14 @@ def test_one_dependency_driven_launch_equals_the_staged_launches(n, k):
             flow.apply_device(x, y)
         torch.cuda.synchronize()
         assert torch.equal(y, want)
+        # a different x every apply: an intermediate left over from the apply before (a stale line, a read that overtook
+        # its poll) cannot hide behind equal inputs
+        ys, yf = torch.empty_like(got), torch.empty_like(got)
+        for i in range(40):
+            xi = torch.roll(x, i + 1, 0) * (1.0 + 0.125 * i)
+            staged.apply_device(xi, ys)
+            flow.apply_device(xi, yf)
+            assert torch.equal(yf, ys), i
     # three right-hand sides and more go to the matrix-core kernel, stage by stage, on the same operator
     x3 = torch.from_numpy((rng.standard_normal((n, 3)) + 1j * rng.standard_normal((n, 3))) / np.sqrt(2)).cuda()
     assert torch.equal(flow.apply_device(x3), staged.apply_device(x3))

@@ -16,14 +16,14 @@ from butterfly_amd.operator import HipOperator
 for n, k in ((2048, 128.0), (8192, 512.0)):
     desc, perm = hs.native_multilevel_structure(hs.circle_points(n), k)
     say("layout", n)
-    staged = HipOperator.from_desc(desc, None, seed=9, flags=_capi.FLAG_NO_FLOW)
+    staged = HipOperator.from_desc(desc, None, seed=9)
     say("staged compiled")
     rng = np.random.default_rng(0)
     x = torch.from_numpy(rng.standard_normal(n) + 1j * rng.standard_normal(n)).cuda()
     want = staged.apply_device(x)
     torch.cuda.synchronize()
     say("staged applied")
-    flow = HipOperator.from_desc(desc, None, seed=9)
+    flow = HipOperator.from_desc(desc, None, seed=9, flags=_capi.FLAG_FLOW)
     say("flow compiled", flow.flow_status())
     for rep in range(3):
         t0 = time.time()
