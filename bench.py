@@ -23,8 +23,8 @@ kernel from hipEvents inside the library, and cpu_baseline{...} = the CPU oracle
 the reference's bfMatMul / bfMatMulVec) timed on a bounded sample of the same operand on this box.
 The default line (N = 262144, one GPU) also carries two extra keys measured after the headline loop, so that the
 driver's own run times them: `nrhs64` (BASELINE configs[2], FP64-MFMA kernel) and `configs4_streamer` (the
---workload streamer measurement at N = 1M, in a child process: ~2.3 minutes, most of it laying out the operand on
-the host); --no-extra / --no-streamer skip them.
+--workload streamer measurement at N = 1M, in a child process: the operand is laid out in ~6 s by the C layout,
+compiled + synthesized in ~10 s, its CPU baseline sample takes ~20 s); --no-extra / --no-streamer skip them.
 """
 from __future__ import annotations
 
@@ -73,7 +73,7 @@ def parse_args(argv):
                     help="diagnostic: on ONE GPU, time the shard that rank --emulate-rank of an N-rank job would own (no collective); "
                          "--emulate-rank -1 times every rank's shard one after another")
     ap.add_argument("--emulate-rank", type=int, default=0)
-    ap.add_argument("--python-layout", action="store_true", help="lay the operand out with butterfly_amd/helm2_structure.py instead of the C layout")
+    ap.add_argument("--python-layout", action="store_true", help="lay the operand out with the Python restatements (helm2_structure.py / streamer_structure.py) instead of the C layouts")
     ap.add_argument("--force-collective", action="store_true", help="rehearsal: run the sharded C-ABI path (RCCL communicator + collective) even with one rank")
     ap.add_argument("--shard", choices=["auto", "rows", "rowblocks", "blocks"], default="auto",
                     help="multi-GPU: rows = balanced contiguous row ranges (bfhipRowPartition) + ONE all-gather, bit-identical to one GPU (default); "
@@ -195,34 +195,51 @@ def cpu_baseline_helm2(desc, seed, total_leaf_elems, weights, budget_bytes, nrhs
                 sample_seconds=best, parity_rel_l2=err)
 
 
-def cpu_baseline_streamer(graph, seed, budget_bytes):
+def cpu_baseline_streamer(desc, seed, budget_bytes):
     """Oracle bfMatMulVec on a bounded sample of the streamed operand: of every factor of the (first)
     product a prefix of its top-level blocks, `budget_bytes` of leaves in total, each timed as its own
-    sub-operator; extrapolated to the whole operand by leaf bytes (fp64, the reference's only type)."""
+    sub-operator; extrapolated to the whole operand by leaf bytes (fp64, the reference's only type).
+    `desc`: the operand's descriptor (root = the 1 x numFacs BlockDense row of products, src/fac_span.c:126-155)."""
     import numpy as np
-    from butterfly_amd import streamer_structure as ss
+    from butterfly_amd import helm2_structure as hs
     from oracle import bfref
     blas = _blas_one_thread()
-    prods = [b for b in graph.blocks if isinstance(b, ss.Product)] if isinstance(graph, ss.BlockDense) else [graph]
-    factors = [f for p in prods for f in p.factors]
-    total = sum(ss.graph_stats(f)["leafBytes"] for f in factors)
+    a = desc.arrays()
+    sub_elems = desc.subtree_leaf_elems()
+    kind, bkind = a["kind"], a["blockKind"]
+    top = [c for c, _, _ in desc.children[desc.root]] if kind[desc.root] == hs.NODE_BLOCK else [desc.root]
+    prods = [c for c in top if kind[c] == hs.NODE_PRODUCT] or top
+    factors = [f for p in prods for f, _, _ in desc.children[p]]
+    total = int(sum(int(sub_elems[f]) for f in factors)) * 8
     per = budget_bytes / max(len(factors), 1)
     rng = np.random.default_rng(seed)
     t_sum, b_sum, pieces = 0.0, 0, []
+    names = {hs.BF_TYPE_BLOCK_DIAG: "BlockDiag", hs.BF_TYPE_BLOCK_DENSE: "BlockDense", hs.BF_TYPE_BLOCK_COO: "BlockCoo"}
     for f in factors:
-        kids, acc = [], 0
-        for b in f.blocks:
-            kids.append(b)
-            acc += ss.graph_stats(b)["leafBytes"]
-            if acc >= per:
-                break
-        sub = ss.BlockDiag(kids) if isinstance(f, ss.BlockDiag) else ss.BlockDense.col(kids) if (isinstance(f, ss.BlockDense) and f.nbc == 1) else f
-        acc = ss.graph_stats(sub)["leafBytes"]
-        if acc == 0:
+        ch = desc.children[f] if kind[f] == hs.NODE_BLOCK else []
+        one_col = bool(ch) and all(c0 == 0 for _, _, c0 in ch) and bkind[f] == hs.BF_TYPE_BLOCK_DENSE
+        sub, taken = f, len(ch)
+        if ch and (bkind[f] == hs.BF_TYPE_BLOCK_DIAG or one_col):
+            # a prefix of a BlockDiag's blocks / of a one-column BlockDense's block rows is itself such a block matrix
+            kids, acc = [], 0
+            for c, r0, c0 in ch:
+                kids.append((c, r0, c0))
+                acc += int(sub_elems[c]) * 8
+                if acc >= per:
+                    break
+            taken = len(kids)
+            last = kids[-1]
+            m = last[1] + int(a["rows"][last[0]])
+            n = (last[2] + int(a["cols"][last[0]])) if bkind[f] == hs.BF_TYPE_BLOCK_DIAG else int(a["cols"][f])
+            sub = desc.add(hs.NODE_BLOCK, m, n, kids, int(bkind[f]))
+            a = desc.arrays()
+            acc_b = acc
+        else:
+            acc_b = int(sub_elems[f]) * 8
+        if acc_b == 0:
             continue
-        desc, _ = ss.to_desc(sub, with_values=False)
-        M = bfref.from_desc(desc, None, seed=seed)
-        x = rng.standard_normal(sub.n)
+        M = bfref.from_desc(desc, None, seed=seed, root=sub)
+        x = rng.standard_normal(int(a["cols"][sub]))
         best = None
         for _ in range(3):
             t0 = time.perf_counter()
@@ -230,8 +247,8 @@ def cpu_baseline_streamer(graph, seed, budget_bytes):
             dt = time.perf_counter() - t0
             best = dt if best is None else min(best, dt)
         t_sum += best
-        b_sum += acc
-        pieces.append(f"{type(f).__name__}[{len(kids)}/{len(f.blocks)}]")
+        b_sum += acc_b
+        pieces.append(f"{names.get(int(bkind[f]), 'leaf')}[{taken}/{len(ch)}]")
     frac = b_sum / total
     return dict(value=1.0 / (t_sum / frac), unit="matvec/s", cores=1, kind="port",
                 sample=(f"EXTRAPOLATED from a {frac * 100:.2f}% sample: a prefix of the top-level blocks of each of the {len(factors)} factors "
@@ -308,22 +325,34 @@ def main():
     if streamer:
         from butterfly_amd import streamer_structure as ss
         n = args.n or 1048576
-        tree = ss.Octree(ss.fibonacci_sphere(n), 1)
-        fd = args.freq_depth if args.freq_depth is not None else tree.max_depth - 3
+        pts3 = ss.fibonacci_sphere(n)
         wmax = float(np.sqrt(args.lmax * (args.lmax + 1.0)) * 1.0001)
-        counts, _ = ss.sphere_band_columns(wmax, fd)
-        st_run = ss.stream_structure(tree, wmax, fd, counts)
-        graph = st_run.get_mat()
-        gstats = ss.graph_stats(graph)
-        desc, _ = ss.to_desc(graph, with_values=False)
-        ncols = graph.n
+        if args.python_layout:
+            # the tested Python restatement of the recursion (minutes at N = 1M); the C layout below is held to it array for array
+            tree = ss.Octree(pts3, 1)
+            fd = args.freq_depth if args.freq_depth is not None else tree.max_depth - 3
+            counts, _ = ss.sphere_band_columns(wmax, fd)
+            st_run = ss.stream_structure(tree, wmax, fd, counts)
+            graph = st_run.get_mat()
+            gstats = ss.graph_stats(graph)
+            pdesc, _ = ss.to_desc(graph, with_values=False)
+            desc = hs.ArrayDesc(pdesc.arrays(), pdesc.root, 1, [], None, {})
+            desc.top_row_block = None
+            num_w = [len(f.W) for f in st_run.partial]
+        else:
+            fd = args.freq_depth if args.freq_depth is not None else ss.octree_depth(pts3) - 3      # lbo_cov.c:97-98
+            counts, _ = ss.sphere_band_columns(wmax, fd)
+            desc, _, gstats = ss.native_stream_structure(pts3, wmax, fd, counts)
+            num_w = [gstats["numW"]]
+        ncols = int(desc.cols[desc.root])
         total_leaf = gstats["leafBytes"] // 8
         workload = (f"fac_streamer butterfly of the N x J Laplace-Beltrami eigenvector matrix of a sphere (examples/covariance): N={n} octree rows, "
                     f"J={ncols} columns (lmax={args.lmax}), frequency tree depth {fd}, tol=1e-3 rank model, minNumRows=minNumCols=20, nrhs={args.nrhs}")
         config = {"workload": workload, "n": n, "num_cols": ncols, "lmax": args.lmax, "freq_depth": fd, "nrhs": args.nrhs,
-                  "leaf_bytes": total_leaf * esz, "num_w": [len(f.W) for f in st_run.partial],
+                  "leaf_bytes": total_leaf * esz, "num_w": num_w,
                   "graph": {k: gstats[k] for k in ("denseReal", "identity", "blockCoo", "blockDense", "blockDiag", "maxNest")},
-                  "dense_bytes": n * ncols * esz, "sharding": "none"}
+                  "dense_bytes": n * ncols * esz, "sharding": "none",
+                  "layout": "python restatement" if args.python_layout else "native (bfhipStreamerLayoutCreate)"}
         data = "synthetic (block structure laid out by the fac_streamer merge-and-split recursion under the fitted rank model; seeded values generated in HBM)"
         metric = "butterfly matvecs/sec (streamed real butterfly apply, examples/covariance)"
         top_rows, weights, row_offsets = [n], [total_leaf], np.array([0, n])
@@ -653,7 +682,7 @@ def main():
         if not args.no_cpu_baseline and args.emulate_world <= 1:
             try:
                 if streamer:
-                    out["cpu_baseline"] = cpu_baseline_streamer(graph, args.seed, args.cpu_budget_gb * 1e9)
+                    out["cpu_baseline"] = cpu_baseline_streamer(desc, args.seed, args.cpu_budget_gb * 1e9)
                 elif not real:
                     out["cpu_baseline"] = cpu_baseline_helm2(desc, args.seed, total_leaf, weights, args.cpu_budget_gb * 1e9, args.nrhs, x_host,
                                                              y_full.cpu().numpy(), row_offsets)
@@ -716,13 +745,13 @@ def main():
             out["nrhs64"] = {"error": repr(e)}
 
         # BASELINE configs[4] rides along too: the streamed real butterfly at N = 1M x 65536 columns, fp32, in a child
-        # process of its own (its operand is laid out by 2 - 3 minutes of host Python; bounded at 4.5 minutes, after which the key holds the error)
+        # process of its own (the C layout needs seconds; bounded at 4.5 minutes, after which the key holds the error)
         if not args.no_streamer:
             import subprocess
             try:
                 torch.cuda.empty_cache()
                 cmd = [sys.executable, os.path.abspath(__file__), "--workload", "streamer", "--steps", "10", "--warmup", "2", "--adjoint",
-                       "--no-cpu-baseline", "--no-extra", "--seed", str(args.seed)]
+                       "--no-extra", "--seed", str(args.seed), "--cpu-budget-gb", "2.0"]
                 env = dict(os.environ)
                 for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
                     env.pop(k, None)
@@ -733,7 +762,8 @@ def main():
                 c = json.loads(line[-1])
                 out["configs4_streamer"] = {"config": c["config"]["workload"], "metric": c["metric"], "value": c["value"], "unit": c["unit"],
                                             "dtype": c["dtype"], "steps": c["steps"], "ms_per_step": c["ms_per_step"], "roofline": c["roofline"],
-                                            "adjoint": c.get("adjoint"), "cov_matvec": c.get("cov_matvec")}
+                                            "adjoint": c.get("adjoint"), "cov_matvec": c.get("cov_matvec"), "cpu_baseline": c.get("cpu_baseline"),
+                                            "layout": c["config"].get("layout")}
             except Exception as e:
                 out["configs4_streamer"] = {"error": repr(e)[:400]}
 

@@ -232,6 +232,61 @@ class Helm2Layout:
         return self._arrays
 
 
+class BfhipStreamerSpec(C.Structure):
+    _fields_ = [("structSize", C.c_uint32), ("colDepth", C.c_uint32), ("wmax", C.c_double), ("bandColumns", C.c_void_p),
+                ("minNumRows", C.c_uint64), ("minNumCols", C.c_uint64), ("maxCols", C.c_uint64), ("alpha", C.c_double), ("delta", C.c_double)]
+
+
+class BfhipStreamerStats(C.Structure):
+    _fields_ = [("structSize", C.c_uint32), ("maxNest", C.c_uint32)] + [
+        (n, C.c_uint64) for n in ("numRows", "numCols", "numFacs", "numW", "rowNodes", "product", "blockCoo", "blockDense", "blockDiag",
+                                  "denseReal", "identity", "leafBytes", "svds", "merges", "feeds", "octreeDepth")]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_ if n != "structSize"}
+
+
+class StreamerLayout:
+    """bfhipStreamerLayoutCreate: the native (C) counterpart of streamer_structure.stream_structure + to_desc under the
+    rank model.  Exposes numpy copies of the descriptor arrays, the octree permutation and the graph statistics."""
+
+    def __init__(self, points, wmax, col_depth, band_columns, min_rows=20, min_cols=20, max_cols=None, alpha=1.75, delta=3.0):
+        lib = load()
+        pts = np.ascontiguousarray(points, dtype=np.float64)
+        assert pts.ndim == 2 and pts.shape[1] == 3
+        bands = np.ascontiguousarray(band_columns, dtype=np.uint64)
+        assert len(bands) == 1 << col_depth
+        spec = BfhipStreamerSpec()
+        spec.structSize = C.sizeof(spec)
+        spec.colDepth, spec.wmax, spec.bandColumns = int(col_depth), float(wmax), bands.ctypes.data
+        spec.minNumRows, spec.minNumCols, spec.maxCols = int(min_rows), int(min_cols), int(max_cols or 0)
+        spec.alpha, spec.delta = float(alpha), float(delta)
+        h = C.c_void_p()
+        check(lib.bfhipStreamerLayoutCreate(pts.ctypes.data, len(pts), C.byref(spec), C.byref(h)))
+        try:
+            d = lib.bfhipStreamerLayoutGetDesc(h).contents
+            n = int(d.numNodes)
+
+            def arr(ptr, count, dt):
+                return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), (count * np.dtype(dt).itemsize,)).view(dt).copy()
+            begin = arr(d.childBegin, n + 1, np.uint64)
+            nch = int(begin[-1])
+            self._arrays = dict(kind=arr(d.kind, n, np.uint8), rows=arr(d.rows, n, np.uint64), cols=arr(d.cols, n, np.uint64),
+                                childBegin=begin, childNode=arr(d.childNode, nch, np.uint64), childRow0=arr(d.childRow0, nch, np.uint64),
+                                childCol0=arr(d.childCol0, nch, np.uint64), blockKind=arr(d.blockKind, n, np.uint8))
+            self.dtype, self.root, self.num_nodes = int(d.dtype), int(d.root), n
+            self.perm = arr(lib.bfhipStreamerLayoutGetPerm(h), len(pts), np.uint64).astype(np.int64)
+            st = BfhipStreamerStats()
+            st.structSize = C.sizeof(st)
+            check(lib.bfhipStreamerLayoutGetStats(h, C.byref(st)))
+            self.stats = st.as_dict()
+        finally:
+            lib.bfhipStreamerLayoutFree(C.byref(h))
+
+    def arrays(self):
+        return self._arrays
+
+
 class DescArrays:
     """Keeps the numpy arrays behind a BfhipDesc alive."""
 
@@ -287,6 +342,8 @@ def load():
     lib.bfhipCompile.restype = C.c_int
     lib.bfhipCompileDesc.argtypes = [C.POINTER(BfhipDesc), C.POINTER(BfhipOptions), C.POINTER(vp)]
     lib.bfhipCompileDesc.restype = C.c_int
+    lib.bfhipDescSubtreeLeafElems.argtypes = [C.POINTER(BfhipDesc), vp]
+    lib.bfhipDescSubtreeLeafElems.restype = C.c_int
     lib.bfhipRowPartition.argtypes = [C.POINTER(BfhipDesc), C.c_uint32, vp, vp]
     lib.bfhipRowPartition.restype = C.c_int
     lib.bfhipRowPartitionMat.argtypes = [vp, C.c_uint32, vp, vp]
@@ -402,6 +459,18 @@ def load():
     lib.bfhipHelm2LayoutGetTreePoints.restype = vp
     lib.bfhipHelm2LayoutFree.argtypes = [C.POINTER(vp)]
     lib.bfhipHelm2LayoutFree.restype = None
+    lib.bfhipStreamerLayoutCreate.argtypes = [vp, C.c_uint64, C.POINTER(BfhipStreamerSpec), C.POINTER(vp)]
+    lib.bfhipStreamerLayoutCreate.restype = C.c_int
+    lib.bfhipStreamerLayoutGetDesc.argtypes = [vp]
+    lib.bfhipStreamerLayoutGetDesc.restype = C.POINTER(BfhipDesc)
+    lib.bfhipStreamerLayoutGetPerm.argtypes = [vp]
+    lib.bfhipStreamerLayoutGetPerm.restype = vp
+    lib.bfhipStreamerLayoutGetStats.argtypes = [vp, C.POINTER(BfhipStreamerStats)]
+    lib.bfhipStreamerLayoutGetStats.restype = C.c_int
+    lib.bfhipStreamerLayoutFree.argtypes = [C.POINTER(vp)]
+    lib.bfhipStreamerLayoutFree.restype = None
+    lib.bfhipStreamerOctreeDepth.argtypes = [vp, C.c_uint64, C.POINTER(C.c_uint32)]
+    lib.bfhipStreamerOctreeDepth.restype = C.c_int
     lib.bfhipFacHelm2MakeMultilevel.argtypes = [vp, vp, vp, C.c_uint64, C.POINTER(BfhipHelm2Problem), C.POINTER(BfhipOptions), C.POINTER(vp),
                                                 vp, C.POINTER(BfhipBuildStats)]
     lib.bfhipFacHelm2MakeMultilevel.restype = C.c_int

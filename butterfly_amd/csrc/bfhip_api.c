@@ -503,6 +503,47 @@ int bfhipCompileDesc(BfhipDesc const *desc, BfhipOptions const *opts, BfhipOpera
   return bfhipCompileIrFill(&ir, opts, NULL, NULL, out);
 }
 
+/* out[v] = leaf elements (sum of rows x cols over the dense leaves) under node v, for every node */
+int bfhipDescSubtreeLeafElems(BfhipDesc const *desc, uint64_t *out) {
+  if (!desc || !out || !desc->kind || !desc->rows || !desc->cols || !desc->childBegin) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "NULL argument");
+  uint64_t const n = desc->numNodes;
+  int ordered = 1;       /* children before parents (what the native layouts emit): one pass */
+  for (uint64_t v = 0; v < n && ordered; ++v)
+    for (uint64_t c = desc->childBegin[v]; c < desc->childBegin[v + 1]; ++c) if (desc->childNode[c] >= v) { ordered = 0; break; }
+  if (ordered) {
+    for (uint64_t v = 0; v < n; ++v) {
+      uint64_t t = desc->kind[v] == BFHIP_NODE_DENSE ? desc->rows[v] * desc->cols[v] : 0;
+      for (uint64_t c = desc->childBegin[v]; c < desc->childBegin[v + 1]; ++c) t += out[desc->childNode[c]];
+      out[v] = t;
+    }
+    return 0;
+  }
+  /* any order: memoised depth-first walk with an explicit stack (node, next child) */
+  uint8_t *done = calloc(n ? n : 1, 1);
+  uint64_t *stack = malloc((2 * n + 2) * 8);
+  if (!done || !stack) { free(done); free(stack); return bfhipFail(BFABI_ERROR_MEMORY_ERROR, "host OOM"); }
+  int rc = 0;
+  for (uint64_t r = 0; r < n && !rc; ++r) {
+    if (done[r]) continue;
+    uint64_t sp = 0;
+    stack[sp++] = r; stack[sp++] = desc->childBegin[r];
+    out[r] = desc->kind[r] == BFHIP_NODE_DENSE ? desc->rows[r] * desc->cols[r] : 0;
+    while (sp) {
+      uint64_t const v = stack[sp - 2], c = stack[sp - 1];
+      if (c == desc->childBegin[v + 1]) { done[v] = 1; sp -= 2; if (sp) out[stack[sp - 2]] += out[v]; continue; }
+      stack[sp - 1] = c + 1;
+      uint64_t const ch = desc->childNode[c];
+      if (ch >= n) { rc = bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "child index out of range"); break; }
+      if (done[ch]) { out[v] += out[ch]; continue; }
+      if (sp >= 2 * n) { rc = bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "descriptor is not a tree (cycle)"); break; }
+      out[ch] = desc->kind[ch] == BFHIP_NODE_DENSE ? desc->rows[ch] * desc->cols[ch] : 0;
+      stack[sp++] = ch; stack[sp++] = desc->childBegin[ch];
+    }
+  }
+  free(done); free(stack);
+  return rc;
+}
+
 int bfhipRowPartition(BfhipDesc const *desc, uint32_t world, uint64_t *cuts, uint64_t *leafElems) {
   if (!desc || !cuts) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "NULL argument");
   BfIr ir;

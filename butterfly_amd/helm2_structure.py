@@ -539,14 +539,12 @@ class ArrayDesc:
         return int((a["rows"].astype(np.int64) * a["cols"].astype(np.int64))[a["kind"] == NODE_DENSE].sum())
 
     def subtree_leaf_elems(self):
-        """Leaf elements under every node.  Children precede their parents in node order, so one
-        pass over the inner nodes in increasing id suffices."""
-        a = self._a
-        tot = (a["rows"].astype(np.int64) * a["cols"].astype(np.int64)) * (a["kind"] == NODE_DENSE)
-        begin, cn = a["childBegin"].astype(np.int64), a["childNode"].astype(np.int64)
-        for v in np.nonzero(begin[1:] > begin[:-1])[0]:
-            tot[v] += tot[cn[begin[v]:begin[v + 1]]].sum()
-        return tot
+        """Leaf elements under every node (bfhipDescSubtreeLeafElems)."""
+        from . import _capi
+        da = _capi.DescArrays(self)
+        out = np.zeros(self.num_nodes, dtype=np.uint64)
+        _capi.check(_capi.load().bfhipDescSubtreeLeafElems(da.byref(), out.ctypes.data))
+        return out.astype(np.int64)
 
 
 def native_multilevel_structure(points: np.ndarray, k: float, tgt_points: np.ndarray | None = None):

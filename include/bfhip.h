@@ -151,6 +151,10 @@ int bfhipCompileDesc(const BfhipDesc *desc, const BfhipOptions *opts, BfhipOpera
 int bfhipRowPartition(const BfhipDesc *desc, uint32_t world, uint64_t *cuts, uint64_t *leafElems);
 int bfhipRowPartitionMat(const void *bfMat, uint32_t world, uint64_t *cuts, uint64_t *leafElems);
 
+/* leafElems[v] = sum of rows x cols over the dense leaves under node v, for every node of the descriptor (what
+ * bfMatNumBytes / 16 resp. / 8 of that subtree's leaves is): balancing ranks, sampling sub-operators. */
+int bfhipDescSubtreeLeafElems(const BfhipDesc *desc, uint64_t *leafElems);
+
 /* ---- apply --------------------------------------------------------------- */
 
 /* Y[numRows x nrhs] = A * X[numCols x nrhs]; host buffers, row-major with

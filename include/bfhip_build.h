@@ -150,6 +150,43 @@ const uint64_t *bfhipHelm2LayoutGetPerm(const BfhipHelm2Layout *layout);        
 const double *bfhipHelm2LayoutGetTreePoints(const BfhipHelm2Layout *layout);    /* [2 * numPoints], tree order */
 void bfhipHelm2LayoutFree(BfhipHelm2Layout **layout);
 
+/* ---- layout of a streamed real butterfly (BASELINE configs[4]; host only) -------------------------------
+ * The block structure `bfFacSpanGetMat(bfFacStreamerGetFacSpan(fs))` hands to examples/covariance/lbo_cov.c:188-189
+ * -- a 1 x numFacs BlockDense row of products [Psi, W0, W1, ...] (src/fac_span.c:126-155, src/fac.c:53-75) -- laid out by
+ * the streamer's own recursion (octree rows with leaf size 1, complete binary frequency tree in post order,
+ * bfFacStreamerFeed, mergeAndSplit, epsilon-rank cut: see bfhip_streamer_layout.c) WITHOUT values: the truncated SVD of a
+ * block is answered by the rank model
+ *     rank(f, [w0, w1)) = (alpha sqrt(f) w1 + delta)^2 - max(alpha sqrt(f) w0 - delta, 0)^2,  f = rows / numPoints,
+ * clipped by the block and by the band's column count (the local Weyl count of a surface patch against a frequency band;
+ * butterfly_amd/streamer_structure.py: LboRankModel, fitted to SVD-driven structures).  This is how the benchmark operand
+ * of N = 1M rows x 65536 columns gets the shapes the reference would build; parity operands with real values come from
+ * the Python restatement + numpy SVDs (oracle/streamer_values.py), which this layout equals array for array under the
+ * same rank answers (tests/test_streamer_layout_cpu.py). */
+typedef struct BfhipStreamerSpec {
+  uint32_t structSize;          /* = sizeof(BfhipStreamerSpec) */
+  uint32_t colDepth;            /* depth of the frequency tree: 2^colDepth leaf bands over [0, wmax) */
+  double wmax;                  /* upper end of the frequency range */
+  const uint64_t *bandColumns;  /* [2^colDepth] columns fed per leaf band, left to right (0 allowed: still a feed) */
+  uint64_t minNumRows, minNumCols;   /* bfFacSpec.minNumRows / minNumCols (0 -> 20, lbo_cov.c:126-127) */
+  uint64_t maxCols;             /* stop feeding once this many columns are in (lbo_cov.c:139-143); 0 = all bands */
+  double alpha, delta;          /* rank model (0 -> 1.75, 3.0: the tol = 1e-3 fit) */
+} BfhipStreamerSpec;
+typedef struct BfhipStreamerStats {
+  uint32_t structSize, maxNest;
+  uint64_t numRows, numCols, numFacs, numW, rowNodes;      /* numW / rowNodes: of the last partial factorization */
+  uint64_t product, blockCoo, blockDense, blockDiag, denseReal, identity, leafBytes;   /* the graph, node by node (fp64 bytes) */
+  uint64_t svds, merges, feeds, octreeDepth;
+} BfhipStreamerStats;
+typedef struct BfhipStreamerLayout BfhipStreamerLayout;
+/* points: [3 * numPoints] in the caller's order; rows of the operand follow the octree (GetPerm: perm[t] = original index) */
+int bfhipStreamerLayoutCreate(const double *points, uint64_t numPoints, const BfhipStreamerSpec *spec, BfhipStreamerLayout **out);
+const BfhipDesc *bfhipStreamerLayoutGetDesc(const BfhipStreamerLayout *layout);      /* dtype BFHIP_F64, no leaf values */
+const uint64_t *bfhipStreamerLayoutGetPerm(const BfhipStreamerLayout *layout);
+int bfhipStreamerLayoutGetStats(const BfhipStreamerLayout *layout, BfhipStreamerStats *stats);
+void bfhipStreamerLayoutFree(BfhipStreamerLayout **layout);
+/* depth of the octree alone: lbo_cov.c:97-98 derives the frequency-tree depth from it (row-tree depth - 3) */
+int bfhipStreamerOctreeDepth(const double *points, uint64_t numPoints, uint32_t *depth);
+
 /* Points -> device operator in one call (layout + bfhipBuildHelm2): the device counterpart of
  * bfFacHelm2MakeMultilevel followed by the decorations of examples/simple/helm2_bie.c.  `points`,
  * `normals` (may be NULL for S), `colWeights` (may be NULL) are in the caller's ORIGINAL order;

@@ -77,6 +77,46 @@ static int drive(double const *pts, uint64_t n, double const *tgt, uint64_t m, d
   return 0;
 }
 
+/* the native layout of a streamed butterfly (rank model), compiled plan-only, forward and transposed */
+static int driveStreamerLayout(void) {
+  enum { N = 3000 };
+  double *pts = malloc(3 * N * sizeof *pts);
+  for (int i = 0; i < N; ++i) {           /* Fibonacci sphere */
+    double const x = 1 - 2.0 * (i + 0.5) / N, r = sqrt(1 - x * x), th = 3.141592653589793 * (sqrt(5.0) - 1) * i;
+    pts[3 * i] = x; pts[3 * i + 1] = r * cos(th); pts[3 * i + 2] = r * sin(th);
+  }
+  uint32_t depth = 0;
+  CHECK(bfhipStreamerOctreeDepth(pts, N, &depth));
+  uint64_t bands[8] = {30, 64, 90, 110, 12, 140, 160, 182};     /* (a band narrower than minNumCols takes the skinny path, src/fac.c:649-676) */
+  BfhipStreamerSpec spec;
+  memset(&spec, 0, sizeof spec);
+  spec.structSize = sizeof spec; spec.colDepth = 3; spec.wmax = 28.0; spec.bandColumns = bands;
+  for (uint64_t maxCols = 0; maxCols <= 300; maxCols += 300) {
+    spec.maxCols = maxCols;
+    BfhipStreamerLayout *lay = NULL;
+    CHECK(bfhipStreamerLayoutCreate(pts, N, &spec, &lay));
+    BfhipStreamerStats st;
+    memset(&st, 0, sizeof st);
+    st.structSize = sizeof st;
+    CHECK(bfhipStreamerLayoutGetStats(lay, &st));
+    if (st.numRows != N || !st.denseReal || !bfhipStreamerLayoutGetPerm(lay)) return 20;
+    BfhipOptions o;
+    memset(&o, 0, sizeof o);
+    o.structSize = sizeof o; o.device = -1; o.flags = BFHIP_FLAG_PLAN_ONLY | BFHIP_FLAG_ADJOINT; o.demoteToF32 = 1;
+    BfhipOperator *op = NULL;
+    CHECK(bfhipCompileDesc(bfhipStreamerLayoutGetDesc(lay), &o, &op));
+    if (bfhipGetNumRows(op) != N || bfhipGetNumCols(op) != st.numCols) return 21;
+    bfhipFree(&op);
+    uint64_t *sub = malloc(bfhipStreamerLayoutGetDesc(lay)->numNodes * 8);
+    CHECK(bfhipDescSubtreeLeafElems(bfhipStreamerLayoutGetDesc(lay), sub));
+    if (sub[bfhipStreamerLayoutGetDesc(lay)->root] * 8 != st.leafBytes) return 22;
+    free(sub);
+    bfhipStreamerLayoutFree(&lay);
+  }
+  free(pts);
+  return 0;
+}
+
 /* a small reference-style object graph with every node type the walker accepts */
 static double *randv(size_t count) {
   double *v = malloc(count * sizeof *v);
@@ -176,6 +216,7 @@ int main(void) {
   if (!rc) rc = drive(pts, n, tgt, m, 90.0);
   if (!rc) rc = drive(rnd, 3000, NULL, 0, 60.0);
   if (!rc) rc = driveGraph();
+  if (!rc) rc = driveStreamerLayout();
   if (!rc) rc = driveBadDescs();
   /* error paths */
   BfhipHelm2Layout *lay = NULL;

@@ -9,7 +9,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "butterfly_amd", "csrc")
-HOST = ["bfhip_ir.c", "bfhip_plan.c", "bfhip_api.c", "bfhip_gmres.c", "bfhip_build.c", "bfhip_layout.c"]
+HOST = ["bfhip_ir.c", "bfhip_plan.c", "bfhip_api.c", "bfhip_gmres.c", "bfhip_build.c", "bfhip_layout.c", "bfhip_streamer_layout.c"]
 
 
 def test_host_code_is_clean_under_sanitizers(tmp_path):
