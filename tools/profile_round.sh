@@ -1,7 +1,7 @@
 #!/bin/bash
 # Collects the rocprofv3 evidence committed under profiles/ (run on the GPU box via gpurun).
 #   usage: tools/profile_round.sh <round-tag> [helm2|streamer|all]      e.g. r2 helm2
-# (the streamed operand is laid out again in every pass, ~3 min each: run the two parts in separate gpurun calls)
+# (every pass lays its operand out and synthesizes it again: ~25 s for the headline operand, ~40 s for the streamed one)
 # Each PMC set is its own pass with --kernel-trace only (no --stats / sys-trace with --pmc).
 set -u
 TAG=${1:-r1}
@@ -27,11 +27,23 @@ run stats_r64  --kernel-trace --stats -- --nrhs 64 --steps 3 --warmup 1
 run mfma_r64   --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -- --nrhs 64 --steps 2 --warmup 1
 run fetch_r64  --kernel-trace --pmc FETCH_SIZE -- --nrhs 64 --steps 2 --warmup 1
 run write_r64  --kernel-trace --pmc WRITE_SIZE -- --nrhs 64 --steps 2 --warmup 1
+# BASELINE configs[1]: N = 65536, one right-hand side (short launches)
+run stats_n65536 --kernel-trace --stats -- --npoints 65536 --steps 20 --warmup 3
+run fetch_n65536 --kernel-trace --pmc FETCH_SIZE -- --npoints 65536 --steps 5 --warmup 1
+run write_n65536 --kernel-trace --pmc WRITE_SIZE -- --npoints 65536 --steps 5 --warmup 1
+# adjoint apply of the headline operand (bfStageKernelT)
+run stats_adj  --kernel-trace --stats -- --adjoint --steps 5 --warmup 1
+run fetch_adj  --kernel-trace --pmc FETCH_SIZE -- --adjoint --steps 3 --warmup 1
+run write_adj  --kernel-trace --pmc WRITE_SIZE -- --adjoint --steps 3 --warmup 1
 fi
 if [ "$PART" != "helm2" ]; then
-# BASELINE configs[4]: streamed real butterfly, N = 1M fp32 (bfStageKernelReal<f32>); each pass lays the operand out again (~3 min)
+# BASELINE configs[4]: streamed real butterfly, N = 1M fp32 (bfStageKernelReal<f32>)
 run stats_st   --kernel-trace --stats -- --workload streamer --steps 5 --warmup 1
 run fetch_st   --kernel-trace --pmc FETCH_SIZE -- --workload streamer --steps 2 --warmup 1
 run write_st   --kernel-trace --pmc WRITE_SIZE -- --workload streamer --steps 2 --warmup 1
+# its transposed apply (bfStageKernelT<f32>: 16- and 64-column kernels, shared items)
+run stats_stT  --kernel-trace --stats -- --workload streamer --adjoint --steps 5 --warmup 1
+run fetch_stT  --kernel-trace --pmc FETCH_SIZE -- --workload streamer --adjoint --steps 2 --warmup 1
+run write_stT  --kernel-trace --pmc WRITE_SIZE -- --workload streamer --adjoint --steps 2 --warmup 1
 fi
 ls $OUT

@@ -26,13 +26,41 @@ def counters(name):
 
 out = {"tag": tag, "note": "FETCH_SIZE/WRITE_SIZE in KiB; on gfx950 FETCH_SIZE counts half the bytes of a 16-B/lane streaming read "
        "(MI355X_MICROARCH.md, HBM): fetch bytes = FETCH_SIZE*1024*2; WRITE_SIZE exact.  SQ_* are summed over SEs/XCDs as rocprofv3 reports them."}
-for name in ("stats_r1", "stats_r64", "stats_st"):
+for name in ("stats_r1", "stats_r64", "stats_st", "stats_n65536", "stats_adj", "stats_stT"):
     for f in glob.glob(f"{src}/{name}/*/*_kernel_stats.csv"):
         shutil.copy(f, f"profiles/{tag}_{name}_kernel_stats.csv")
     if os.path.exists(f"{src}/{name}.json"):
         shutil.copy(f"{src}/{name}.json", f"profiles/{tag}_{name}_bench_under_rocprof.json")
-for name in ("fetch_r1", "write_r1", "lds_r1", "mfma_r64", "fetch_r64", "write_r64", "fetch_st", "write_st"):
+for name in ("fetch_r1", "write_r1", "lds_r1", "mfma_r64", "fetch_r64", "write_r64", "fetch_st", "write_st", "fetch_n65536", "write_n65536",
+             "fetch_adj", "write_adj", "fetch_stT", "write_stT"):
     out[name] = counters(name)
+
+
+def kernel_seconds(name, prefix):
+    """Sum of (end - start) over the dispatches of kernels whose name starts with `prefix`, from the kernel trace of pass `name`."""
+    tot, cnt = 0.0, 0
+    for f in glob.glob(f"{src}/{name}/*/*_kernel_trace.csv"):
+        for r in csv.DictReader(open(f)):
+            if r["Kernel_Name"].split("(")[0].startswith(prefix):
+                tot += (float(r["End_Timestamp"]) - float(r["Start_Timestamp"])) * 1e-9
+                cnt += 1
+    return tot, cnt
+
+
+def family_per_apply(fetch, write, prefix, applies_json):
+    """All kernels whose name starts with `prefix` (a transposed apply is several kernels per stage), per apply."""
+    try:
+        f = sum(v["FETCH_SIZE"]["sum"] for k, v in out[fetch].items() if k.startswith(prefix)) * 1024 * 2
+        w = sum(v["WRITE_SIZE"]["sum"] for k, v in out[write].items() if k.startswith(prefix)) * 1024
+        nf = sum(v["FETCH_SIZE"]["dispatches"] for k, v in out[fetch].items() if k.startswith(prefix))
+        b = json.load(open(f"{src}/{applies_json}.json"))
+        applies = b["steps"] + 2 + 1          # bench.py --adjoint: 2 warm-up applies + `steps` timed + 1 for the transpose identity
+        if not nf:
+            return None
+        return {"fetch_bytes_corrected": f / applies, "write_bytes": w / applies, "hbm_bytes": (f + w) / applies, "dispatches": nf, "applies": applies,
+                "algorithmic_bytes": b["config"]["leaf_bytes"], "ratio": (f + w) / applies / b["config"]["leaf_bytes"]}
+    except (KeyError, FileNotFoundError):
+        return None
 
 
 def per_launch(fetch, write, kern):
@@ -46,8 +74,12 @@ def per_launch(fetch, write, kern):
 
 out["bfStageKernelC128_per_launch"] = per_launch("fetch_r1", "write_r1", "bfStageKernelC128")
 out["bfStageKernelC128Mfma_per_launch"] = per_launch("fetch_r64", "write_r64", "bfStageKernelC128Mfma")
+out["bfStageKernelC128_n65536_per_launch"] = per_launch("fetch_n65536", "write_n65536", "bfStageKernelC128")
+out["bfStageKernelT_c128_adjoint_per_apply"] = family_per_apply("fetch_adj", "write_adj", "void bfStageKernelT", "fetch_adj")
+out["bfStageKernelT_f32_streamer_adjoint_per_apply"] = family_per_apply("fetch_stT", "write_stT", "void bfStageKernelT", "fetch_stT")
 out["bfStageKernelReal_f32_streamer_per_launch"] = next((v for v in (per_launch("fetch_st", "write_st", k) for k in list(out.get("fetch_st", {})) if "bfStageKernelReal" in k) if v), None)
-for nm, key in (("stats_r1", "bfStageKernelC128_per_launch"), ("stats_r64", "bfStageKernelC128Mfma_per_launch"), ("stats_st", "bfStageKernelReal_f32_streamer_per_launch")):
+for nm, key in (("stats_r1", "bfStageKernelC128_per_launch"), ("stats_r64", "bfStageKernelC128Mfma_per_launch"), ("stats_st", "bfStageKernelReal_f32_streamer_per_launch"),
+                ("stats_n65536", "bfStageKernelC128_n65536_per_launch")):
     p = f"{src}/{nm}.json"
     if os.path.exists(p) and out.get(key):
         b = json.load(open(p))
@@ -61,7 +93,13 @@ try:
     out["mfma_util_percent"] = {"formula": "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE(max over XCDs ~ sum/8) * 1024 SIMDs) * 100",
                                 "value": busy / (gui / 8 * 1024) * 100,
                                 "mfma_f64_ops_x512_flops": m["SQ_INSTS_VALU_MFMA_MOPS_F64"]["sum"] * 512}
+    # sustained core clock under the matrix-core kernel: cycles the GPU was active (per XCD) / the time its dispatches took
+    secs, cnt = kernel_seconds("mfma_r64", "bfStageKernelC128Mfma")
+    if secs > 0:
+        out["mfma_sustained_clock"] = {"formula": "GRBM_GUI_ACTIVE (sum over 8 XCDs / 8) / sum of the dispatches' durations (kernel trace of the same pass)",
+                                       "ghz": gui / 8 / secs * 1e-9, "dispatches": cnt, "seconds": secs, "peak_ghz": 2.4,
+                                       "mfma_busy_fraction": busy / (gui / 8 * 1024)}
 except KeyError:
     pass
 json.dump(out, open(f"profiles/{tag}_pmc_summary.json", "w"), indent=1)
-print(json.dumps({k: out[k] for k in out if k.endswith("per_launch") or k.startswith("mfma_util")}, indent=1))
+print(json.dumps({k: out[k] for k in out if k.endswith("per_launch") or k.endswith("per_apply") or k.startswith("mfma_")}, indent=1))
