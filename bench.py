@@ -75,9 +75,10 @@ def parse_args(argv):
     ap.add_argument("--emulate-rank", type=int, default=0)
     ap.add_argument("--python-layout", action="store_true", help="lay the operand out with the Python restatements (helm2_structure.py / streamer_structure.py) instead of the C layouts")
     ap.add_argument("--force-collective", action="store_true", help="rehearsal: run the sharded C-ABI path (RCCL communicator + collective) even with one rank")
-    ap.add_argument("--shard", choices=["auto", "rows", "rowblocks", "blocks"], default="auto",
+    ap.add_argument("--shard", choices=["auto", "rows", "rowblocks", "blocks", "rowsum"], default="auto",
                     help="multi-GPU: rows = balanced contiguous row ranges (bfhipRowPartition) + ONE all-gather, bit-identical to one GPU (default); "
-                         "rowblocks = whole top-level block rows by LPT + all-gather; blocks = top-level (row, col) blocks by LPT + ONE all-reduce")
+                         "rowblocks = whole top-level block rows by LPT + all-gather; blocks = top-level (row, col) blocks by LPT + ONE all-reduce; "
+                         "rowsum = whole block rows + column shares of the rest, ONE all-gather, shared rows' partials added in rank order (no replication)")
     return ap.parse_args(argv)
 
 
@@ -278,7 +279,7 @@ def main():
     import torch.distributed as dist
     from butterfly_amd import _capi, helm2_structure as hs
     from butterfly_amd.dist import (RcclShardedApply, ShardLayout, assign_row_blocks, block_weights, choose_mode,
-                                    row_block_weights, row_partition)
+                                    row_block_weights, row_partition, rowsum_partition)
     from butterfly_amd.operator import HipOperator
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -390,6 +391,9 @@ def main():
             seg_rows, owner = [cuts[r + 1] - cuts[r] for r in range(sworld)], list(range(sworld))
         elif mode == "rowblocks":
             owner, loads = assign_row_blocks(weights, sworld)
+        elif mode == "rowsum":
+            bowner, loads, rsegs = rowsum_partition(desc, sworld)
+            owner = [0] * len(weights)
         else:
             bw = block_weights(desc)
             bowner, loads = assign_row_blocks(bw, sworld)
@@ -433,6 +437,8 @@ def main():
         elif mode == "rowblocks":
             mine_r = [rb for rb in range(len(weights)) if owner[rb] == r]
             root, rows = hs.shard_desc(desc, mine_r)
+        elif mode == "rowsum":
+            root, _, rows = hs.shard_desc_children(desc, [i for i in range(len(bowner)) if bowner[i] == r])
         else:
             mine_r = [i for i in range(len(bowner)) if bowner[i] == r]
             root, rows = hs.shard_desc_blocks(desc, mine_r), n
@@ -460,7 +466,8 @@ def main():
 
     sharded = None
     if (world > 1 or args.force_collective) and args.emulate_world <= 1:
-        layout = ShardLayout(seg_rows if not streamer else top_rows, owner, world)
+        layout = (ShardLayout(top_rows, owner, world, segments=rsegs) if mode == "rowsum" else
+                  ShardLayout(seg_rows if not streamer else top_rows, owner, world))
 
         def bcast(payload):
             box = [payload]
@@ -537,7 +544,7 @@ def main():
                  "rank_local_ms": [round(float(r[0]), 4) for r in allv], "rank_kernel_ms": [round(float(r[3]), 4) for r in allv],
                  "max_local_ms": float(allv[:, 0].max()), "collective_ms_per_rank": [round(float(r[1]), 4) for r in allv],
                  "max_collective_ms": float(allv[:, 1].max()), "collective_bytes": int(n * args.nrhs * esz),
-                 "roofline_rank": prof_rank, "bit_identical_to_one_gpu": mode != "blocks"}
+                 "roofline_rank": prof_rank, "bit_identical_to_one_gpu": mode in ("rows", "rowblocks")}
 
     if rank == 0:
         kern_ms = float(ms.sum())
@@ -610,6 +617,7 @@ def main():
         config["sharding"] = ("none" if sworld == 1 else
                               "contiguous row ranges below the top-level blocks (bfhipRowPartition: balanced, source-side factors replicated) + one all-gather" if mode == "rows"
                               else "top-level row blocks (LPT by leaf bytes) + one all-gather" if mode == "rowblocks"
+                              else "whole top-level block rows + column shares of the rest (no replication) + one all-gather, shared rows' partials added in rank order" if mode == "rowsum"
                               else "top-level (row, col) blocks (LPT by leaf bytes) + one all-reduce")
         out = {
             "metric": metric,

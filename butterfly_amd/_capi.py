@@ -57,7 +57,8 @@ class BfhipGmresOptions(C.Structure):
 
 class BfhipShardSpec(C.Structure):
     _fields_ = [("structSize", C.c_uint32), ("mode", C.c_uint32), ("numRowsGlobal", C.c_uint64),
-                ("numSegments", C.c_uint32), ("reserved", C.c_uint32), ("segRows", C.c_void_p), ("segOwner", C.c_void_p)]
+                ("numSegments", C.c_uint32), ("reserved", C.c_uint32), ("segRows", C.c_void_p), ("segOwner", C.c_void_p),
+                ("segGlobalOff", C.c_void_p)]
 
 
 class BfhipPlanInfo(C.Structure):

@@ -64,6 +64,25 @@ int hipFailS(hipError_t e, char const *what) {
 
 struct Seg { uint64_t globalOff, srcOff, rows; };    // rows [globalOff, +rows) of y come from gather-buffer rows [srcOff, +rows)
 
+// Row ranges that several ranks contributed to (a block row shared by columns): y[row] = sum, in list order, of the
+// partials.  groups are sorted by globalOff and disjoint; group g's sources are srcOff[srcBegin[g] .. srcBegin[g + 1]).
+// One thread per scalar (double / float) of y; a range with one source is a plain copy.
+struct SumGroup { uint64_t globalOff, rows; uint32_t srcBegin, srcEnd; };
+template <typename T>
+__global__ __launch_bounds__(256) void bfSumSegmentsKernel(SumGroup const *groups, uint32_t numGroups, uint64_t const *srcOff, uint64_t numRows,
+                                                           T const *gathered, T *y, uint64_t scalarsPerRow) {
+  uint64_t const u = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (u >= numRows * scalarsPerRow) return;
+  uint64_t const row = u / scalarsPerRow, k = u - row * scalarsPerRow;
+  uint32_t lo = 0, hi = numGroups;
+  while (hi - lo > 1) { uint32_t mid = (lo + hi) / 2; if (groups[mid].globalOff <= row) lo = mid; else hi = mid; }
+  SumGroup const g = groups[lo];
+  uint64_t const r = row - g.globalOff;
+  T acc = gathered[(srcOff[g.srcBegin] + r) * scalarsPerRow + k];
+  for (uint32_t s = g.srcBegin + 1; s < g.srcEnd; ++s) acc += gathered[(srcOff[s] + r) * scalarsPerRow + k];      // fixed order
+  y[u] = acc;
+}
+
 // y[row][:] = gathered[srcOff(seg) + row - globalOff(seg)][:], one thread per unit of the row
 // (unit = 16 bytes when the row size allows, else 8 or 4); segments are sorted by globalOff
 template <typename U>
@@ -90,6 +109,9 @@ struct BfhipSharded {
   void *dGather;                 // rows mode: nranks * maxRows * maxRhs elements
   Seg *dSegs;
   Seg *hSegs;
+  SumGroup *dGroups;             // rows mode with shared ranges: the partials of a range are added after the gather
+  uint64_t *dSrcOff;
+  uint32_t numGroups;
   hipEvent_t e0, e1, e2;
   int timed;
   int timing;       // record the three events (default on)
@@ -139,7 +161,7 @@ void bfhipShardedFree(BfhipSharded **ps) {
   int prev = -1;
   (void)hipGetDevice(&prev);
   (void)hipSetDevice(s->device);
-  (void)hipFree(s->dGather); (void)hipFree(s->dSegs);
+  (void)hipFree(s->dGather); (void)hipFree(s->dSegs); (void)hipFree(s->dGroups); (void)hipFree(s->dSrcOff);
   if (s->e0) (void)hipEventDestroy(s->e0);
   if (s->e1) (void)hipEventDestroy(s->e1);
   if (s->e2) (void)hipEventDestroy(s->e2);
@@ -150,7 +172,8 @@ void bfhipShardedFree(BfhipSharded **ps) {
 }
 
 int bfhipShardedCreate(BfhipOperator *op, BfhipComm *comm, BfhipShardSpec const *spec, uint32_t maxRhs, BfhipSharded **out) {
-  if (!op || !comm || !spec || !out || spec->structSize < sizeof(BfhipShardSpec)) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "bad sharded-apply arguments");
+  if (!op || !comm || !spec || !out || spec->structSize < BFHIP_SHARDSPEC_SIZE_V1) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "bad sharded-apply arguments");
+  uint64_t const *segGlobalOff = spec->structSize >= sizeof(BfhipShardSpec) ? spec->segGlobalOff : NULL;
   *out = NULL;
   if (spec->mode != BFHIP_SHARD_ROWS && spec->mode != BFHIP_SHARD_BLOCKS) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "unknown shard mode");
   BfhipStats st;
@@ -180,7 +203,7 @@ int bfhipShardedCreate(BfhipOperator *op, BfhipComm *comm, BfhipShardSpec const 
       rowsOf[spec->segOwner[i]] += spec->segRows[i];
       pos += spec->segRows[i];
     }
-    if (!rc && pos != spec->numRowsGlobal) rc = bfhipFail(BFABI_ERROR_INCOMPATIBLE_SHAPES, "segments cover %llu rows, operator has %llu", (unsigned long long)pos, (unsigned long long)spec->numRowsGlobal);
+    if (!rc && !segGlobalOff && pos != spec->numRowsGlobal) rc = bfhipFail(BFABI_ERROR_INCOMPATIBLE_SHAPES, "segments cover %llu rows, operator has %llu", (unsigned long long)pos, (unsigned long long)spec->numRowsGlobal);
     if (!rc) {
       for (int r = 0; r < comm->nranks; ++r) if (rowsOf[r] > s->maxRows) s->maxRows = rowsOf[r];
       s->myRows = rowsOf[comm->rank];
@@ -191,10 +214,53 @@ int bfhipShardedCreate(BfhipOperator *op, BfhipComm *comm, BfhipShardSpec const 
       uint64_t g0 = 0;
       for (uint32_t i = 0; i < spec->numSegments; ++i) {
         uint32_t o = spec->segOwner[i];
-        s->hSegs[i].globalOff = g0; s->hSegs[i].srcOff = (uint64_t)o * s->maxRows + rowsOf[o]; s->hSegs[i].rows = spec->segRows[i];
+        s->hSegs[i].globalOff = segGlobalOff ? segGlobalOff[i] : g0; s->hSegs[i].srcOff = (uint64_t)o * s->maxRows + rowsOf[o]; s->hSegs[i].rows = spec->segRows[i];
         rowsOf[o] += spec->segRows[i]; g0 += spec->segRows[i];
       }
       s->numSegs = spec->numSegments;
+      if (segGlobalOff) {
+        // ranges in global order (stable: list order inside a range); identical ranges form one group, anything else
+        // that overlaps, or a row nobody computes, is refused
+        uint32_t const ns = spec->numSegments;
+        uint32_t *ord = (uint32_t *)malloc((ns ? ns : 1) * sizeof *ord);
+        SumGroup *hg = (SumGroup *)malloc((ns ? ns : 1) * sizeof *hg);
+        uint64_t *hsrc = (uint64_t *)malloc((ns ? ns : 1) * 8);
+        if (!ord || !hg || !hsrc) rc = bfhipFail(BFABI_ERROR_MEMORY_ERROR, "host OOM");
+        for (uint32_t i = 0; i < ns && !rc; ++i) ord[i] = i;
+        for (uint32_t i = 1; i < ns && !rc; ++i) {            // insertion sort by globalOff: segment lists are short (<= 16 ranges x ranks)
+          uint32_t v = ord[i], j = i;
+          while (j > 0 && s->hSegs[ord[j - 1]].globalOff > s->hSegs[v].globalOff) { ord[j] = ord[j - 1]; --j; }
+          ord[j] = v;
+        }
+        uint32_t ng = 0;
+        uint64_t covered = 0;
+        int shared = 0;
+        for (uint32_t i = 0; i < ns && !rc; ++i) {
+          Seg const *sg = &s->hSegs[ord[i]];
+          if (!sg->rows) continue;
+          if (ng && hg[ng - 1].globalOff == sg->globalOff && hg[ng - 1].rows == sg->rows) { hsrc[hg[ng - 1].srcEnd++] = sg->srcOff; shared = 1; continue; }
+          if (sg->globalOff != covered) { rc = bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "segment %u: ranges must tile the rows (identical ranges may repeat); row %llu", ord[i], (unsigned long long)covered); break; }
+          hg[ng].globalOff = sg->globalOff; hg[ng].rows = sg->rows;
+          hg[ng].srcBegin = ng ? hg[ng - 1].srcEnd : 0; hg[ng].srcEnd = hg[ng].srcBegin + 1;
+          hsrc[hg[ng].srcBegin] = sg->srcOff;
+          covered += sg->rows;
+          ++ng;
+        }
+        if (!rc && covered != spec->numRowsGlobal) rc = bfhipFail(BFABI_ERROR_INCOMPATIBLE_SHAPES, "segments cover %llu rows, operator has %llu", (unsigned long long)covered, (unsigned long long)spec->numRowsGlobal);
+        if (!rc && shared) {
+          s->numGroups = ng;
+          rc = hipFailS(hipMalloc((void **)&s->dGroups, ng * sizeof *hg), "hipMalloc(sum groups)");
+          if (!rc) rc = hipFailS(hipMalloc((void **)&s->dSrcOff, (size_t)ns * 8), "hipMalloc(sum sources)");
+          if (!rc) rc = hipFailS(hipMemcpy(s->dGroups, hg, ng * sizeof *hg, hipMemcpyHostToDevice), "hipMemcpy(sum groups)");
+          if (!rc) rc = hipFailS(hipMemcpy(s->dSrcOff, hsrc, (size_t)ns * 8, hipMemcpyHostToDevice), "hipMemcpy(sum sources)");
+        } else if (!rc) {
+          // every range has one owner after all: the plain reorder kernel needs the segments sorted by global row
+          Seg *sorted = (Seg *)malloc((ns ? ns : 1) * sizeof *sorted);
+          if (!sorted) rc = bfhipFail(BFABI_ERROR_MEMORY_ERROR, "host OOM");
+          else { for (uint32_t i = 0; i < ns; ++i) sorted[i] = s->hSegs[ord[i]]; memcpy(s->hSegs, sorted, ns * sizeof *sorted); free(sorted); }
+        }
+        free(ord); free(hg); free(hsrc);
+      }
       if (!rc) rc = hipFailS(hipMalloc(&s->dGather, (size_t)comm->nranks * s->maxRows * s->maxRhs * s->elemSize + 16), "hipMalloc(gather buffer)");
       if (!rc) rc = hipFailS(hipMalloc((void **)&s->dSegs, (s->numSegs ? s->numSegs : 1) * sizeof(Seg)), "hipMalloc(segments)");
       if (!rc) rc = hipFailS(hipMemcpy(s->dSegs, s->hSegs, s->numSegs * sizeof(Seg), hipMemcpyHostToDevice), "hipMemcpy(segments)");
@@ -239,7 +305,17 @@ int bfhipShardedApplyDevice(BfhipSharded *s, void const *dX, size_t nrhs, void *
     rc = bfhipApplyDevice(s->op, dX, nrhs, slot, stream);
     if (s->timing) (void)hipEventRecord(s->e1, stream);
     if (!rc) rc = ncclFail(g.AllGather(slot, s->dGather, (size_t)s->maxRows * nrhs * scalarsPerElem, dt, s->comm->comm, stream), "ncclAllGather");
-    if (!rc && s->numSegs) {
+    if (!rc && s->numGroups) {
+      // some ranges carry several ranks' partials: add them, in list order, into y
+      uint64_t const scalarsPerRow = nrhs * scalarsPerElem;
+      uint64_t const total = s->numRowsGlobal * scalarsPerRow;
+      uint32_t const grid = (uint32_t)((total + 255) / 256);
+      if (grid) {
+        if (s->dtype == BFHIP_F32) hipLaunchKernelGGL(bfSumSegmentsKernel<float>, dim3(grid), dim3(256), 0, stream, s->dGroups, s->numGroups, s->dSrcOff, s->numRowsGlobal, (float const *)s->dGather, (float *)dY, scalarsPerRow);
+        else hipLaunchKernelGGL(bfSumSegmentsKernel<double>, dim3(grid), dim3(256), 0, stream, s->dGroups, s->numGroups, s->dSrcOff, s->numRowsGlobal, (double const *)s->dGather, (double *)dY, scalarsPerRow);
+        rc = hipFailS(hipGetLastError(), "segment sum launch");
+      }
+    } else if (!rc && s->numSegs) {
       // unit = the largest power of two <= 16 bytes dividing a row; buffers are 16-byte aligned
       size_t unit = 16;
       while (rowBytes % unit) unit /= 2;

@@ -94,13 +94,80 @@ def row_partition(desc, world, root=None):
     return [int(c) for c in cuts], [int(v) for v in loads]
 
 
+def rowsum_partition(desc, world):
+    """Whole block rows where they fit, a column share of a block row where they do not: every rank gets whole top-level
+    block rows (largest first, least-loaded rank) as long as its load stays within the mean; each remaining block row
+    is split by COLUMNS -- its (row, col) blocks dealt, largest first, to the k least-loaded ranks, k = 2 unless that
+    leaves the busiest rank more than 3 % over the mean.  No leaf is replicated (unlike row ranges) and the loads match
+    to the size of the smallest blocks; the price is that a shared block row's result is the sum of k partials, added in
+    rank order after the one all-gather (deterministic; equal to one GPU to rounding, not bit for bit).
+    Returns (owner per top-level child, load per rank, segments [(block row, rank)] in list order)."""
+    bw = block_weights(desc)
+    trb = list(desc.top_row_block)
+    nrows = len(desc.meta["top_rows"])
+    total = sum(bw)
+    row_w = [0] * nrows
+    for c, rb in enumerate(trb):
+        row_w[rb] += bw[c]
+    best = None
+    for k in (2, 3, 4, world):
+        k = min(k, world)
+        loads = [0] * world
+        owner = [-1] * len(bw)
+        whole, split = {}, []
+        for rb in sorted(range(nrows), key=lambda i: (-row_w[i], i)):
+            q = min(range(world), key=lambda r: (loads[r], r))
+            if loads[q] + row_w[rb] <= total / world * 1.0001:
+                whole[rb] = q
+                loads[q] += row_w[rb]
+            else:
+                split.append(rb)
+        for c, rb in enumerate(trb):
+            if rb in whole:
+                owner[c] = whole[rb]
+        for rb in split:
+            cand = sorted(range(world), key=lambda r: (loads[r], r))[:k]
+            cols = sorted((c for c in range(len(bw)) if trb[c] == rb), key=lambda c: (-bw[c], c))
+            if k == 2 and len(cols) <= 16:
+                # two ranks, at most 16 blocks: the best of all 2^n column splits (the larger of the two resulting loads)
+                a, b = cand
+                best_mask, best_val = 0, None
+                for mask in range(1 << len(cols)):
+                    wa = sum(bw[c] for i, c in enumerate(cols) if mask >> i & 1)
+                    val = max(loads[a] + wa, loads[b] + row_w[rb] - wa)
+                    if best_val is None or val < best_val:
+                        best_mask, best_val = mask, val
+                for i, c in enumerate(cols):
+                    q = a if best_mask >> i & 1 else b
+                    owner[c] = q
+                    loads[q] += bw[c]
+                continue
+            for c in cols:
+                q = min(cand, key=lambda r: (loads[r], r))
+                owner[c] = q
+                loads[q] += bw[c]
+        if best is None or max(loads) < best[1]:
+            best = (owner, max(loads), loads)
+        if max(loads) <= 1.03 * total / world:
+            break
+    owner, _, loads = best
+    segs = []
+    for rb in range(nrows):
+        for r in sorted({owner[c] for c in range(len(bw)) if trb[c] == rb}):
+            segs.append((rb, r))
+    return owner, loads, segs
+
+
 def choose_mode(desc, world, requested="auto"):
     """How the operator is dealt to `world` ranks:
     'rows'      contiguous row RANGES from row_partition (balanced to a few % at any world size; ONE all-gather;
                 bit-identical to one GPU) -- the default;
     'rowblocks' whole top-level block rows by LPT (round 2's "rows": 12 blocks on a circle bound 8 ranks at 6.2x);
-    'blocks'    top-level (row, col) blocks by LPT + ONE all-reduce (equal to one GPU to rounding only)."""
-    if requested in ("rows", "rowblocks", "blocks"):
+    'blocks'    top-level (row, col) blocks by LPT + ONE all-reduce (equal to one GPU to rounding only);
+    'rowsum'    whole block rows + column shares of the rest (rowsum_partition): no replication, balanced to ~1 %, ONE
+                all-gather, the partials of a shared row added in rank order afterwards (deterministic; equal to one
+                GPU to rounding)."""
+    if requested in ("rows", "rowblocks", "blocks", "rowsum"):
         return requested
     return "rows"
 
@@ -109,12 +176,27 @@ class ShardLayout:
     """Who owns which rows, and where each global row lands in the gathered
     (rank-major, padded) buffer."""
 
-    def __init__(self, top_rows, owner, world):
+    def __init__(self, top_rows, owner, world, segments=None):
+        """segments (rowsum): [(block row, rank)] in list order -- a block row may appear under several ranks, each
+        contributing a partial result for it; top_rows / owner then describe the block rows (owner unused)."""
         self.top_rows = list(top_rows)
         self.owner = list(owner)
         self.world = world
         self.row_offsets = np.concatenate([[0], np.cumsum(self.top_rows)]).astype(np.int64)
         self.n = int(self.row_offsets[-1])
+        self.segments = None
+        if segments is not None:
+            self.segments = [(int(rb), int(r)) for rb, r in segments]
+            self.blocks_of = [[rb for rb, r in self.segments if r == q] for q in range(world)]
+            self.rows_of = [sum(self.top_rows[rb] for rb in blks) for blks in self.blocks_of]
+            self.max_rows = max(self.rows_of) if self.rows_of else 0
+            pos = [q * self.max_rows for q in range(world)]
+            self.seg_src = []                      # gather-buffer row of each segment's first row
+            for rb, r in self.segments:
+                self.seg_src.append(pos[r])
+                pos[r] += self.top_rows[rb]
+            self.gather_index = None
+            return
         self.blocks_of = [[rb for rb in range(len(owner)) if owner[rb] == r] for r in range(world)]
         self.rows_of = [sum(self.top_rows[rb] for rb in blks) for blks in self.blocks_of]
         self.max_rows = max(self.rows_of) if self.rows_of else 0
@@ -147,7 +229,7 @@ class ShardedApply:
         self.y_local = torch.empty((self.local_rows,) + tail, dtype=dtype, device=device)
         self.pad = torch.zeros((layout.max_rows,) + tail, dtype=dtype, device=device)
         self.gathered = torch.empty((layout.world * layout.max_rows,) + tail, dtype=dtype, device=device)
-        self.index = torch.from_numpy(layout.gather_index).to(device)
+        self.index = torch.from_numpy(layout.gather_index).to(device) if layout.gather_index is not None else None
 
     def __call__(self, x):
         import torch.distributed as dist
@@ -165,6 +247,18 @@ class ShardedApply:
         src = torch.view_as_real(self.pad) if self.pad.is_complex() else self.pad
         dst = torch.view_as_real(self.gathered) if self.gathered.is_complex() else self.gathered
         dist.all_gather_into_tensor(dst, src, group=self.group)
+        if self.layout.segments is not None:
+            # rowsum: the partials of a block row, in list (rank) order
+            y = torch.zeros((self.layout.n,) + tuple(self.gathered.shape[1:]), dtype=self.gathered.dtype, device=self.gathered.device)
+            seen = set()
+            for (rb, r), s0 in zip(self.layout.segments, self.layout.seg_src):
+                g0, m = int(self.layout.row_offsets[rb]), self.layout.top_rows[rb]
+                if rb in seen:
+                    y[g0:g0 + m] += self.gathered[s0:s0 + m]
+                else:
+                    y[g0:g0 + m] = self.gathered[s0:s0 + m]
+                    seen.add(rb)
+            return y
         return self.gathered.index_select(0, self.index)
 
 
@@ -195,8 +289,14 @@ class RcclShardedApply:
         spec.structSize = C.sizeof(spec)
         spec.mode = _capi.SHARD_BLOCKS if mode == "blocks" else _capi.SHARD_ROWS      # "rows" and "rowblocks": all-gather of row segments
         spec.numRowsGlobal = layout.n
-        self._seg_rows = np.ascontiguousarray(layout.top_rows, dtype=np.uint64)
-        self._seg_owner = np.ascontiguousarray(layout.owner, dtype=np.uint32)
+        if layout.segments is not None:
+            self._seg_rows = np.ascontiguousarray([layout.top_rows[rb] for rb, _ in layout.segments], dtype=np.uint64)
+            self._seg_owner = np.ascontiguousarray([r for _, r in layout.segments], dtype=np.uint32)
+            self._seg_off = np.ascontiguousarray([layout.row_offsets[rb] for rb, _ in layout.segments], dtype=np.uint64)
+            spec.segGlobalOff = self._seg_off.ctypes.data
+        else:
+            self._seg_rows = np.ascontiguousarray(layout.top_rows, dtype=np.uint64)
+            self._seg_owner = np.ascontiguousarray(layout.owner, dtype=np.uint32)
         if mode != "blocks":
             spec.numSegments = len(self._seg_rows)
             spec.segRows, spec.segOwner = self._seg_rows.ctypes.data, self._seg_owner.ctypes.data

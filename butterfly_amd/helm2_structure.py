@@ -485,6 +485,25 @@ def shard_desc_blocks(desc: Desc, child_indices):
     return desc.add(NODE_BLOCK, desc.rows[desc.root], desc.cols[desc.root], ch, BF_TYPE_BLOCK_DENSE)
 
 
+def shard_desc_children(desc: Desc, child_indices):
+    """Restrict a multilevel descriptor to a subset of its top-level (row, col) blocks and compact the rows: the block
+    rows those blocks touch, in global order, stacked without gaps.  The result maps the full x to this rank's PARTIAL
+    rows -- complete for a block row it owns whole, a partial sum for one it shares by columns with other ranks (their
+    partials are added after the all-gather: dist.py "rowsum").  Returns (new root id, [touched block rows], rows)."""
+    keep = sorted(set(child_indices))
+    ch_all = desc.children[desc.root]
+    trb = desc.top_row_block
+    touched = sorted({trb[i] for i in keep})
+    top_rows = desc.meta["top_rows"]
+    orig_off = np.concatenate([[0], np.cumsum(top_rows)])
+    base, acc = {}, 0
+    for rb in touched:
+        base[rb] = acc
+        acc += top_rows[rb]
+    ch = [(ch_all[i][0], ch_all[i][1] - int(orig_off[trb[i]]) + base[trb[i]], ch_all[i][2]) for i in keep]
+    return desc.add(NODE_BLOCK, acc, desc.cols[desc.root], ch, BF_TYPE_BLOCK_DENSE), touched, acc
+
+
 # --------------------------------------------------------------------------
 # array-backed descriptor: what the native layout (bfhip_layout.c) returns
 # --------------------------------------------------------------------------

@@ -221,11 +221,19 @@ typedef struct BfhipShardSpec {
   uint32_t structSize;      /* = sizeof(BfhipShardSpec) */
   uint32_t mode;            /* BFHIP_SHARD_* */
   uint64_t numRowsGlobal;   /* rows of the whole operator = length of y */
-  uint32_t numSegments;     /* ROWS: consecutive row segments of y, in global order (top-level block rows) */
+  uint32_t numSegments;     /* ROWS: row segments of y (top-level block rows, row ranges) */
   uint32_t reserved;
   const uint64_t *segRows;  /* [numSegments] rows of each segment */
   const uint32_t *segOwner; /* [numSegments] rank that computes it */
+  /* ROWS, optional (round 3; NULL or a struct of the shorter round-2 size: segments are consecutive in global order,
+   * each row computed by exactly one rank).  [numSegments] first global row of each segment.  Several segments may then
+   * cover the SAME rows (identical ranges only): ranks that share a block row by columns each send a partial result
+   * for it, and after the one all-gather every rank adds the partials of a range in LIST order -- a fixed order, so the
+   * result is the same on every rank and from run to run (to rounding the one-GPU result, not bit for bit: that is the
+   * price of splitting a row's sum).  A rank's operator yields its segments in list order, compacted. */
+  const uint64_t *segGlobalOff;
 } BfhipShardSpec;
+#define BFHIP_SHARDSPEC_SIZE_V1 40u   /* sizeof(BfhipShardSpec) before segGlobalOff */
 int bfhipCommGetUniqueId(void *id128);                                       /* ncclGetUniqueId: 128 bytes */
 int bfhipCommInitRank(const void *id128, int nranks, int rank, int device, BfhipComm **out);
 void bfhipCommDestroy(BfhipComm **comm);

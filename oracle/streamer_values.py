@@ -215,9 +215,9 @@ def sphere_lbo_problem(n, lmax):
     return pts, np.stack(cols, axis=1), np.asarray(freqs)
 
 
-def stream_columns(pts, phi, freqs, wmax, freq_depth, tol=1e-3, record=None, min_rows=20, min_cols=20, max_cols=None):
+def stream_columns(pts, phi, freqs, wmax, freq_depth, tol=1e-3, record=None, min_rows=20, min_cols=20, max_cols=None, wmin=0.0):
     """The streaming loop of examples/covariance/lbo_cov.c:139-143 + src/lbo.c:70-150: feed, leaf by leaf of
-    the frequency tree over [0, wmax], the columns whose frequency falls in the leaf's bracket
+    the frequency tree over [wmin, wmax], the columns whose frequency falls in the leaf's bracket
     ([a, b), open-ended at both ends of the tree: src/lbo.c:41-68); stop when the tree is exhausted or, as
     lbo_cov.c:141 does with `numEigs`, once `max_cols` columns went in.  Rows of phi in file order.
     Returns (streamer, Phi in tree order restricted to the streamed columns)."""
@@ -228,7 +228,7 @@ def stream_columns(pts, phi, freqs, wmax, freq_depth, tol=1e-3, record=None, min
     J = phi.shape[1]
     while not st.is_done():
         leaf = st.current_col_node()
-        a, b, left, right = st.cols.leaf_interval(leaf, 0.0, wmax)
+        a, b, left, right = st.cols.leaf_interval(leaf, wmin, wmax)        # bfIntervalTreeInitEmpty(tree, a, b, 2, depth)
         lo = -np.inf if left else a
         hi = np.inf if right else b
         j1 = j0

@@ -44,6 +44,12 @@ def _worker(rank, world, port, n, k, nrhs, out_dir, mode, native=False):
         cuts, loads = row_partition(desc, world)
         layout = ShardLayout([cuts[r + 1] - cuts[r] for r in range(world)], list(range(world)), world)
         row_range = (cuts[rank], cuts[rank + 1])
+    elif mode == "rowsum":
+        from butterfly_amd.dist import rowsum_partition
+        bowner, loads, segs = rowsum_partition(desc, world)
+        layout = ShardLayout(desc.meta["top_rows"], [0] * len(desc.meta["top_rows"]), world, segments=segs)
+        shard_root, touched, rows = hs.shard_desc_children(desc, [i for i in range(len(bowner)) if bowner[i] == rank])
+        assert rows == layout.rows_of[rank] and touched == layout.blocks_of[rank]
     elif mode == "rowblocks":
         weights = row_block_weights(desc)
         owner, loads = assign_row_blocks(weights, world)
@@ -63,7 +69,7 @@ def _worker(rank, world, port, n, k, nrhs, out_dir, mode, native=False):
     rng = np.random.default_rng(5)
     shape = (n,) if nrhs == 1 else (n, nrhs)
     x = torch.from_numpy(rng.standard_normal(shape) + 1j * rng.standard_normal(shape))
-    step = ShardedApply(layout, rank, local_apply, torch.device("cpu"), torch.complex128, nrhs=nrhs, mode=mode)
+    step = ShardedApply(layout, rank, local_apply, torch.device("cpu"), torch.complex128, nrhs=nrhs, mode="rows" if mode == "rowsum" else mode)
     y = step(x)
     # every rank ends with the full, row-ordered result
     np.save(os.path.join(out_dir, f"y{rank}.npy"), y.numpy().copy())
@@ -76,7 +82,8 @@ def _worker(rank, world, port, n, k, nrhs, out_dir, mode, native=False):
 
 @pytest.mark.parametrize("nrhs,mode,native,world", [(1, "rows", False, 2), (2, "rows", False, 2), (1, "rowblocks", False, 2), (2, "rowblocks", False, 2),
                                                     (1, "blocks", False, 2), (2, "blocks", False, 2),
-                                                    (1, "rows", True, 2), (1, "rowblocks", True, 2), (1, "blocks", True, 2), (1, "rows", True, 3)])
+                                                    (1, "rows", True, 2), (1, "rowblocks", True, 2), (1, "blocks", True, 2), (1, "rows", True, 3),
+                                                    (1, "rowsum", True, 3), (2, "rowsum", False, 3), (1, "rowsum", True, 2)])
 def test_two_rank_sharded_apply_matches_full_oracle(tmp_path, nrhs, mode, native, world):
     from butterfly_amd import helm2_structure as hs
     from oracle import bfref

@@ -799,6 +799,58 @@ def test_row_range_shards_are_the_one_gpu_result_bit_for_bit(nrhs):
     op.close()
 
 
+@pytest.mark.parametrize("nrhs", [1, 3])
+def test_shared_row_ranges_are_summed_after_the_gather(nrhs):
+    """"rowsum" sharding (BfhipShardSpec.segGlobalOff): ranks that share a block row by columns each send a partial result
+    for it and every rank adds the partials of a range in list order after the ONE all-gather (bfSumSegmentsKernel).
+    Exercised with a 1-rank communicator whose operator yields block row 0 as TWO partials (even / odd column blocks)
+    stacked on top of the other rows: the summed result equals the plain apply to rounding, is the same run to run, and a
+    range that would not tile the rows is refused."""
+    import torch
+    from butterfly_amd import _capi, helm2_structure as hs
+    from butterfly_amd.dist import RcclShardedApply, ShardLayout, rowsum_partition
+    from butterfly_amd.operator import HipOperator
+    n, k = 8192, 512.0
+    desc, perm = hs.native_multilevel_structure(hs.circle_points(n), k)
+    rng = np.random.default_rng(21)
+    shape = (n,) if nrhs == 1 else (n, nrhs)
+    xd = torch.from_numpy((rng.standard_normal(shape) + 1j * rng.standard_normal(shape)) / np.sqrt(2)).cuda()
+    full = HipOperator.from_desc(desc, None, seed=6, max_rhs=nrhs)
+    want = full.apply_device(xd).clone()
+    full.close()
+    top_rows, trb = desc.meta["top_rows"], desc.top_row_block
+    ch = desc.children[desc.root]
+    m0 = top_rows[0]
+    new, col = [], 0
+    for i, (c, r0, c0) in enumerate(ch):
+        if trb[i] == 0:
+            new.append((c, r0 + (m0 if col % 2 else 0), c0))       # odd column blocks of block row 0: a second partial below the first
+            col += 1
+        else:
+            new.append((c, r0 + m0, c0))                           # every other row moves down by one copy of block row 0
+    root = desc.add(hs.NODE_BLOCK, n + m0, n, new, hs.BF_TYPE_BLOCK_DENSE)
+    op = HipOperator.from_desc(desc, None, root=root, seed=6, max_rhs=nrhs)
+    segs = [(0, 0), (0, 0)] + [(rb, 0) for rb in range(1, len(top_rows))]
+    step = RcclShardedApply(ShardLayout(top_rows, [0] * len(top_rows), 1, segments=segs), 0, op, 0, nrhs=nrhs, mode="rowsum")
+    got = step(xd).clone()
+    torch.cuda.synchronize()
+    assert rel(got.cpu().numpy(), want.cpu().numpy()) <= 1e-14
+    assert torch.equal(got[m0:], want[m0:])                        # rows with one owner are copied, not summed
+    assert torch.equal(step(xd), got)                              # fixed order of additions: reproducible
+    step.close()
+    # the partition bench.py deals to 8 ranks: every block row whole or shared by two ranks, loads within 3 % of the mean
+    bowner, loads, rsegs = rowsum_partition(desc, 8)
+    assert max(loads) <= 1.035 * sum(loads) / 8 and len(rsegs) <= 2 * len(top_rows)
+    # ranges that do not tile the rows are refused at create time
+    bad = ShardLayout(top_rows, [0] * len(top_rows), 1, segments=segs)
+    bad.row_offsets = bad.row_offsets.copy()
+    bad.row_offsets[2] += 1                                        # block row 2 would start one row late: a gap and an overlap
+    with pytest.raises(_capi.BfhipError) as e:
+        RcclShardedApply(bad, 0, op, 0, nrhs=nrhs, mode="rowsum")
+    assert e.value.code == 1
+    op.close()
+
+
 @pytest.mark.parametrize("dtype,demote", [(0, False), (1, False), (1, True)])
 def test_long_contractions_on_gpu(dtype, demote):
     """Row groups cut into several groups (private slots + reduce) because their contraction is long: a

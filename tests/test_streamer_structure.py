@@ -49,6 +49,70 @@ def lbo_case():
     return _CACHE["lbo"]
 
 
+def sphere_fixture_case():
+    """The data the reference's own tests hold next to this path (tests/sphere_Phi.txt, sphere_Lam.txt, the vertices of
+    sphere.obj; copied as numbers by tests/golden/make_sphere_phi_fixture.py): 500 mesh vertices x 32 FEM Laplace-Beltrami
+    eigenvectors, eigenvalues in [50, 100] -- two eigenspaces of the sphere (degrees 8 and 9, 15 + 17 columns).  Streamed as
+    examples/covariance/lbo_cov.c:120-143 does: tol 1e-3, minNumRows = minNumCols = 20, a frequency tree of depth 1 over the
+    eigenvalues' range so that each leaf band is one eigenspace."""
+    if "sphere" not in _CACHE:
+        from butterfly_amd import streamer_structure as ss
+        from oracle import streamer_values as sv
+        z = np.load(os.path.join(HERE, "golden", "sphere_phi_500x32.npz"))
+        freqs = np.sqrt(z["lam"])                                   # src/lbo.c:20-30
+        st, a_phi = sv.stream_columns(z["points"], z["phi"], freqs, float(freqs[-1] * 1.0001), 1, wmin=float(freqs[0] * 0.9999))
+        A = st.get_mat()
+        desc, vals = ss.to_desc(A)
+        _CACHE["sphere"] = (st, a_phi, A, desc, vals)
+    return _CACHE["sphere"]
+
+
+def test_reference_held_sphere_eigenvectors_stream_to_the_tolerance():
+    """The streamer's own acceptance check (src/fac_streamer.c:286-301: || Phi_BF x - Phi x || / || Phi x || against the
+    tolerance) on the reference-held eigenvector matrix, through three appliers: the numpy recursion, the C oracle's
+    bfMatMulVec / bfMatRmulVec on the flat descriptor, and the engine's plan (numpy interpreter; the GPU test below runs
+    the kernels).  The structure is a golden too: 2 feeds, 1 merge, numW = 2, 32 row nodes."""
+    import plan_emulator
+    from butterfly_amd import _capi, streamer_structure as ss
+    from butterfly_amd.operator import HipOperator
+    from oracle import bfref, streamer_values as sv
+    st, phi, A, desc, vals = sphere_fixture_case()
+    assert phi.shape == (500, 32)
+    gs = ss.graph_stats(A)
+    assert st.stats == dict(svds=9, merges=1, feeds=2) and [len(f.W) for f in st.partial] == [2] and [len(f.row_nodes) for f in st.partial] == [32]
+    assert (gs["denseReal"], gs["identity"], gs["maxNest"], gs["leafBytes"]) == (64, 30, 5, 157760)
+    rng = np.random.default_rng(0)
+    x, v = rng.standard_normal(32), rng.standard_normal(500)
+    want, want_t = phi @ x, phi.T @ v
+    assert rel(sv.apply(A, x), want) <= 1e-3                        # 2.0e-4: the tolerance the SVDs were cut at
+    M = bfref.from_desc(desc, vals)
+    y, zt = bfref.mat_mul_vec(M, x), bfref.mat_rmul_vec(M, v)
+    assert rel(y, want) <= 1e-3 and rel(zt, want_t) <= 1e-3 and rel(y, sv.apply(A, x)) <= 1e-13
+    op = HipOperator.from_desc(desc, vals, flags=_capi.FLAG_PLAN_ONLY | _capi.FLAG_ADJOINT)
+    assert rel(plan_emulator.run_plan(op, x), y) <= 1e-13 and rel(plan_emulator.run_plan(op, v, transpose=True), zt) <= 1e-13
+
+
+@pytest.mark.gpu
+def test_reference_held_sphere_eigenvectors_on_gpu():
+    """HIP vs the oracle on the butterfly of the reference-held eigenvector matrix: fp64 <= 1e-12, fp32 <= 2e-5, forward and
+    transposed, and cov_matvec's product Phi Gamma^2 Phi^T v against the dense matrix within the factorization's tolerance."""
+    from butterfly_amd import _capi
+    from butterfly_amd.operator import HipOperator
+    from oracle import bfref
+    st, phi, A, desc, vals = sphere_fixture_case()
+    rng = np.random.default_rng(1)
+    x, v = rng.standard_normal(32), rng.standard_normal(500)
+    M = bfref.from_desc(desc, vals)
+    y_ref, z_ref = bfref.mat_mul_vec(M, x), bfref.mat_rmul_vec(M, v)
+    for demote, tol in ((False, 1e-12), (True, 2e-5)):
+        op = HipOperator.from_desc(desc, vals, flags=_capi.FLAG_ADJOINT, demote_to_f32=demote)
+        assert rel(op.apply_host(x), y_ref) <= tol and rel(op.apply_transpose_host(v), z_ref) <= tol
+        gam = np.exp(-0.02 * np.arange(32))
+        cov = op.apply_host(gam * gam * op.apply_transpose_host(v))
+        assert rel(cov, phi @ (gam * gam * (phi.T @ v))) <= 2e-3
+        op.close()
+
+
 def test_streamer_restatement_reproduces_the_survey_probe():
     """Every count the survey's walk of the reference's object graph printed:
     3656 DenseReal / 2454 Identity leaves in 5332 BlockDense / 2558 BlockCoo / 1834 BlockDiag nodes nested 9

@@ -54,7 +54,9 @@ def family_per_apply(fetch, write, prefix, applies_json):
         w = sum(v["WRITE_SIZE"]["sum"] for k, v in out[write].items() if k.startswith(prefix)) * 1024
         nf = sum(v["FETCH_SIZE"]["dispatches"] for k, v in out[fetch].items() if k.startswith(prefix))
         b = json.load(open(f"{src}/{applies_json}.json"))
-        applies = b["steps"] + 2 + 1          # bench.py --adjoint: 2 warm-up applies + `steps` timed + 1 for the transpose identity
+        # bench.py --adjoint: 2 warm-up transposed applies + `steps` timed ones; on the streamed operand also cov_matvec
+        # (2 warm-up + `steps` timed products + 1 checked against the separate applies: one transposed apply each)
+        applies = b["steps"] + 2 + ((b["steps"] + 3) if "cov_matvec" in b else 0)
         if not nf:
             return None
         return {"fetch_bytes_corrected": f / applies, "write_bytes": w / applies, "hbm_bytes": (f + w) / applies, "dispatches": nf, "applies": applies,
