@@ -41,7 +41,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable copy)
 FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X dense FP64 matrix peak = FP64 vector peak = 1/2 of the 157.3 TFLOP/s FP32 rate
-PROFILE_ROUND = "r2"      # which committed rocprofv3 summaries the `traffic` figure is read from
+PROFILE_ROUND = "r3"      # which committed rocprofv3 summaries the `traffic` figure is read from
 
 
 def log(*a):
@@ -584,11 +584,12 @@ def main():
         for rnd in (PROFILE_ROUND, "r1"):
             prof = os.path.join(ROOT, "profiles", f"{rnd}_pmc_summary.json")
             helm_cfg = (not streamer and n == 262144 and abs(k - 16384) < 1e-9 and args.nrhs in (1, 64) and not real)
+            cfg2 = (not streamer and n == 65536 and abs(k - 4096) < 1e-9 and args.nrhs == 1 and not real)
             strm_cfg = (streamer and n == 1048576 and args.lmax == 255 and dtype == "f32" and args.nrhs == 1 and args.freq_depth is None)
-            if not (world == 1 and (helm_cfg or strm_cfg) and args.emulate_world <= 1 and os.path.exists(prof)):
+            if not (world == 1 and (helm_cfg or strm_cfg or cfg2) and args.emulate_world <= 1 and os.path.exists(prof)) or one_launch:
                 continue
             try:
-                key = ("bfStageKernelReal_f32_streamer_per_launch" if strm_cfg else
+                key = ("bfStageKernelReal_f32_streamer_per_launch" if strm_cfg else "bfStageKernelC128_n65536_per_launch" if cfg2 else
                        "bfStageKernelC128_per_launch" if args.nrhs == 1 else "bfStageKernelC128Mfma_per_launch")
                 pm = json.load(open(prof))[key]
                 roofline["traffic"] = pm["hbm_bytes"]
@@ -652,7 +653,18 @@ def main():
             torch.cuda.synchronize()
             adj_ms = (time.perf_counter() - t1) / args.steps * 1e3
             out["adjoint"] = {"ms_per_apply": adj_ms, "matvec_per_s": args.nrhs / (adj_ms / 1e3),
-                              "hbm_gbs": st["leafBytes"] / 1e9 / (adj_ms / 1e3)}
+                              "hbm_gbs": st["leafBytes"] / 1e9 / (adj_ms / 1e3), "frac_of_hbm_peak": st["leafBytes"] / 1e9 / (adj_ms / 1e3) / HBM_PEAK_GBS,
+                              "traffic_per_apply": None}
+            try:        # HBM bytes per transposed apply from the committed --pmc passes of this command (all bfStageKernelT launches of one apply)
+                pm = json.load(open(os.path.join(ROOT, "profiles", f"{PROFILE_ROUND}_pmc_summary.json")))
+                akey = ("bfStageKernelT_f32_streamer_adjoint_per_apply" if (streamer and n == 1048576 and args.lmax == 255 and dtype == "f32") else
+                        "bfStageKernelT_c128_adjoint_per_apply" if (not streamer and n == 262144 and not real and abs(k - 16384) < 1e-9) else None)
+                if akey and pm.get(akey) and args.nrhs == 1:
+                    out["adjoint"]["traffic_per_apply"] = pm[akey]["hbm_bytes"]
+                    out["adjoint"]["traffic_ratio"] = pm[akey]["ratio"]
+                    out["adjoint"]["traffic_source"] = f"profiles/{PROFILE_ROUND}_pmc_summary.json [{akey}]: committed rocprofv3 --pmc passes, not measured in this run"
+            except Exception:
+                pass
             # <A x, v> = <x, A^T v>: ties the two plans together on the full-size operand
             yx = op.apply_device(x)
             lhs = torch.sum(yx.to(torch.complex128 if not real else torch.float64) * xt.to(torch.complex128 if not real else torch.float64))
@@ -748,6 +760,17 @@ def main():
                              "roofline": {"bound": "mfma", "achieved": tf, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP64_MFMA_PEAK_TFLOPS,
                                           "kernel": "bfStageKernelC128Mfma", "kernel_ms_per_apply": float(ms64.sum()) / reps,
                                           "algorithmic_flops_per_apply": flops}}
+            try:        # the matrix pipe's share of the cycles and the clock the chip sustained under this kernel (committed --pmc pass)
+                pm = json.load(open(os.path.join(ROOT, "profiles", f"{PROFILE_ROUND}_pmc_summary.json")))
+                clk = pm["mfma_sustained_clock"]
+                out["nrhs64"]["roofline"].update({
+                    "sustained_clock_ghz": clk["ghz"], "peak_clock_ghz": clk["peak_ghz"], "mfma_busy_fraction": clk["mfma_busy_fraction"],
+                    "frac_at_sustained_clock": (tf / FP64_MFMA_PEAK_TFLOPS) / (clk["ghz"] / clk["peak_ghz"]),
+                    "traffic": pm["bfStageKernelC128Mfma_per_launch"]["hbm_bytes"],
+                    "clock_source": f"profiles/{PROFILE_ROUND}_pmc_summary.json [mfma_sustained_clock]: GRBM_GUI_ACTIVE / kernel time of the committed --pmc pass of "
+                                    "`bench.py --nrhs 64`, NOT measured in this run; peak 78.6 TFLOP/s assumes 2.4 GHz"})
+            except Exception:
+                pass
             o64.close()
         except Exception as e:
             out["nrhs64"] = {"error": repr(e)}

@@ -28,7 +28,7 @@ def test_two_ranks_start_agree_and_report():
 
 
 def test_three_ranks_get_unequal_but_balanced_ranges():
-    p = run(["--gpus", "3", "--npoints", "16384", "--shard", "rows"], {})
+    p = run(["--gpus", "3", "--npoints", "16384", "--shard", "rows"], {})          # (auto would pick rowsum here: 12 block rows on 3 ranks divide, but not their bytes)
     assert p.returncode == 0, p.stderr[-2000:]
     d = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
     assert d["n_gpus"] == 3 and len(d["cuts"]) == 4 and d["cuts"][0] == 0 and d["cuts"][-1] == 16384

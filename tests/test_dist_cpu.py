@@ -119,7 +119,8 @@ def test_row_partition_balances_eight_ranks():
     desc, perm = hs.native_multilevel_structure(hs.circle_points(65536), 4096.0)
     w = row_block_weights(desc)
     total = sum(w)
-    assert choose_mode(desc, 8) == "rows" and choose_mode(desc, 8, "blocks") == "blocks"
+    assert choose_mode(desc, 2) == "rows" and choose_mode(desc, 4) == "rows" and choose_mode(desc, 8, "rows") == "rows"
+    assert choose_mode(desc, 8) == "rowsum" and choose_mode(desc, 8, "blocks") == "blocks"      # 8 ranks share 4 block rows: by columns, not by replication
     for world in (2, 4):
         cuts, loads = row_partition(desc, world)
         assert cuts[0] == 0 and cuts[-1] == 65536 and sum(loads) == total and max(loads) <= 1.001 * total / world

@@ -27,7 +27,7 @@ def shard():
     if torch.cuda.get_device_properties(0).total_memory < 200e9:
         pytest.skip("needs the 288 GB of an MI355X")
     desc, _ = hs.native_multilevel_structure(hs.circle_points(N), N / 16.0)
-    assert choose_mode(desc, WORLD) == "rows"
+    assert choose_mode(desc, WORLD) == "rowsum" and choose_mode(desc, WORLD, "rows") == "rows"      # this module holds the ROWS shard: the bit-identical one
     bw = block_weights(desc)
     cuts, loads = row_partition(desc, WORLD)
     # 12 top-level row blocks on 8 ranks: 4 block rows are split, their first-applied factors held twice

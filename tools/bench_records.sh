@@ -9,7 +9,7 @@ O=$R/gpurun_out/records_$TAG
 mkdir -p $O
 cd $R
 B="timeout -k 10 400 python bench.py"
-run() { local name=$1; shift; "$@" > $O/$name.json 2> $O/$name.err; echo "$name exit=$?"; }
+run() { local name=$1; shift; "$@" > $O/$name.json 2> $O/$name.err; echo "$name exit=$?"; }      # (an env assignment in front of `run` reaches the command)
 run ${TAG}_bench_n262144                 $B --pcie
 run ${TAG}_bench_n262144_nrhs64          $B --nrhs 64
 run ${TAG}_bench_n65536                  $B --npoints 65536
@@ -17,8 +17,12 @@ run ${TAG}_bench_n65536_nrhs64           $B --npoints 65536 --nrhs 64 --no-cpu-b
 run ${TAG}_bench_n262144_adjoint         $B --adjoint --no-cpu-baseline --no-extra
 run ${TAG}_bench_n262144_rccl_1rank      $B --force-collective --no-cpu-baseline --no-extra
 # every rank's shard of a 2 / 4 / 8-GPU job, one after another on this GPU (the slowest bounds the job)
-for w in 2 4 8; do run ${TAG}_bench_n262144_shards${w}_emulated $B --emulate-world $w --emulate-rank -1 --steps 10; done
-run ${TAG}_bench_n1048576_shards8_emulated    $B --npoints 1048576 --emulate-world 8 --emulate-rank -1 --steps 10
+for w in 2 4 8; do run ${TAG}_bench_n262144_shards${w}_emulated $B --emulate-world $w --emulate-rank -1 --steps 20 --no-cpu-baseline --no-extra; done
+for m in rows rowsum blocks; do run ${TAG}_bench_n262144_shards8_${m}_emulated $B --emulate-world 8 --emulate-rank -1 --steps 20 --shard $m --no-cpu-baseline --no-extra; done
+run ${TAG}_bench_n1048576_shards8_emulated    $B --npoints 1048576 --emulate-world 8 --emulate-rank -1 --steps 10 --no-cpu-baseline --no-extra
+# the experimental one-launch executor (BFHIP_FLAG_FLOW) next to the staged launches
+BFHIP_FLOW=1 run ${TAG}_bench_n65536_flow $B --npoints 65536 --no-cpu-baseline --no-extra
+BFHIP_FLOW=1 run ${TAG}_bench_n262144_flow $B --no-cpu-baseline --no-extra
 # BASELINE configs[4]: the streamed real butterfly (fac_streamer structure, rank model), fp32 and fp64
 S="timeout -k 10 900 python bench.py --workload streamer"
 run ${TAG}_bench_streamer_n1048576_f32   $S --adjoint --steps 10

@@ -30,8 +30,16 @@ for m in ("rows", "blocks"):
         print(m, "failed", ex)
 PY
              }
+shards8sum() { step shards8_rowsum 600 $B --emulate-world 8 --emulate-rank -1 --steps 20 --no-extra --no-cpu-baseline --shard rowsum;
+               python - <<PY
+import json
+d = json.load(open("$O/shards8_rowsum.out")); e = d["emulated_shard"]
+print("rowsum slowest", round(e["slowest_ms"], 4), [(round(t["leaf_gb"], 2), round(t["ms_per_apply"], 4)) for t in e["all_ranks"]])
+PY
+             }
 shard0()     { step shard0_rows 300 $B --emulate-world 8 --emulate-rank 3 --steps 50 --no-extra --no-cpu-baseline --shard rows; grep "stage " $O/shard0_rows.err; }
 lanes()      { step lanes_n65536 300 python tools/exp_lanes.py --n 65536 --lanes 2 3 4; cat $O/lanes_n65536.out;
                step lanes_shard8 400 python tools/exp_lanes.py --n 262144 --world 8 --lanes 2 3; cat $O/lanes_shard8.out; }
 headline()   { step bench_default 900 $B --steps 20 --warmup 5 "$@"; cat $O/bench_default.out | cut -c1-1500; grep "stage " $O/bench_default.err; }
+newtests()   { step pytest_new 900 python -m pytest tests -m gpu -x -q -k "shared_row_ranges or sphere or rccl or sharded"; tail -4 $O/pytest_new.out; }
 for s in "$@"; do $s; done
