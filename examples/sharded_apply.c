@@ -12,7 +12,8 @@
  * The operand is a small block matrix of dense leaves with seeded synthetic values (leafData == NULL);
  * every rank compiles only the block rows it owns (BfhipOptions.rowBlockBegin/End wants a contiguous
  * run, so ownership here is by runs of block rows) and the result is checked against the unsharded
- * operator on rank 0's GPU.  Exit code 0 iff both shard modes reproduce it bit for bit. */
+ * operator on rank 0's GPU; a third pass deals the ranks contiguous row RANGES (bfhipRowPartition +
+ * BfhipOptions.rowBegin/rowEnd).  Exit code 0 iff all three reproduce it bit for bit. */
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -134,6 +135,30 @@ int main(int argc, char **argv) {
   if (bad2) fprintf(stderr, "rank %d: blocks mode differs from the unsharded apply\n", rank);
   printf("rank %d/%d blocks mode: local %.3f ms, collective %.3f ms, %s\n", rank, nranks, localMs, collMs, bad2 ? "MISMATCH" : "bit-identical");
   bfhipShardedFree(&sh);
+
+  /* row RANGES (round 3): balanced cuts from the library, one contiguous range per rank; the rank's operator keeps
+   * exactly what its rows depend on (BfhipOptions.rowBegin / rowEnd) and produces them bit for bit */
+  uint64_t cuts[NBR + 1], segRows2[NBR];
+  uint32_t segOwner2[NBR];
+  CHECK(bfhipRowPartition(&d, (uint32_t)nranks, cuts, NULL));
+  for (int r = 0; r < nranks; ++r) { segRows2[r] = cuts[r + 1] - cuts[r]; segOwner2[r] = (uint32_t)r; }
+  o.rowBlockBegin = o.rowBlockEnd = 0;
+  o.rowBegin = cuts[rank]; o.rowEnd = cuts[rank + 1];
+  BfhipOperator *range = NULL;
+  CHECK(bfhipCompileDesc(&d, &o, &range));
+  o.rowBegin = o.rowEnd = 0;
+  spec.mode = BFHIP_SHARD_ROWS; spec.numSegments = (uint32_t)nranks; spec.segRows = segRows2; spec.segOwner = segOwner2;
+  CHECK(bfhipShardedCreate(range, comm, &spec, (uint32_t)nrhs, &sh));
+  CHECK(bfhipShardedApplyDevice(sh, dX, nrhs, dY, NULL));
+  CHECK(bfhipShardedLastTimes(sh, &localMs, &collMs));
+  if (hipMemcpy(y, dY, m * nrhs * 16, 2)) return 4;
+  int bad3 = memcmp(y, yRef, m * nrhs * 16) != 0;
+  if (bad3) fprintf(stderr, "rank %d: row-range mode differs from the unsharded apply\n", rank);
+  printf("rank %d/%d row ranges [%llu, %llu): local %.3f ms, collective %.3f ms, %s\n", rank, nranks, (unsigned long long)cuts[rank],
+         (unsigned long long)cuts[rank + 1], localMs, collMs, bad3 ? "MISMATCH" : "bit-identical");
+  bfhipShardedFree(&sh);
+  bfhipFree(&range);
+  bad |= bad3;
 
   /* error behaviour: a spec that does not cover the operator is refused, nothing aborts */
   spec.mode = BFHIP_SHARD_ROWS; spec.numSegments = NBR - 1; spec.segRows = rowsOf; spec.segOwner = owner;

@@ -663,7 +663,7 @@ def test_adjoint_never_reads_past_a_short_column_block():
 def test_sharded_apply_from_plain_c(tmp_path):
     """examples/sharded_apply.c: the multi-GPU step of include/bfhip.h (RCCL communicator, local stages,
     in-place ncclAllGather + segment reordering / ncclAllReduce) driven from plain C with a 1-rank
-    communicator; exits 0 iff both shard modes reproduce the unsharded apply bit for bit."""
+    communicator; exits 0 iff all three shard modes reproduce the unsharded apply bit for bit."""
     import os
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -674,7 +674,7 @@ def test_sharded_apply_from_plain_c(tmp_path):
                            f"-Wl,-rpath,{lib}", "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
     p = subprocess.run([exe, "1", "0"], capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stdout + p.stderr
-    assert p.stdout.count("bit-identical") == 2, p.stdout
+    assert p.stdout.count("bit-identical") == 3, p.stdout          # block rows, (row, col) blocks, row ranges
 
 
 @pytest.mark.parametrize("mode", ["rows", "blocks"])
