@@ -8,7 +8,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libbfhip.so")
+LIB_PATH = os.environ.get("BFHIP_LIB_PATH") or os.path.join(_HERE, "csrc", "libbfhip.so")      # (the override is for A/B builds of the kernels)
 
 BFHIP_C128, BFHIP_F64, BFHIP_F32 = 0, 1, 2
 FLAG_PROFILE = 1

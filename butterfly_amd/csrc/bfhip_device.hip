@@ -238,11 +238,15 @@ struct FlowParams {
   uint32_t epoch;                // 1-based apply number since the counters were last cleared
   uint32_t queueBase;            // ticket value of item 0 in this apply
   uint32_t spinLimit;            // a wait gives up after this many polls
+  uint32_t debugMode;            // experiments only (BFHIP_FLOW_DEBUGMODE): 1 plain loads / stores for the intermediates, 2 never wait (results then wrong)
   void const *x;
   void *y;
   void *temp;
 };
 
+#ifndef BF_FLOW_BATCH
+#define BF_FLOW_BATCH 2u      /* measured at N = 65536: 1 -> 1.56 ms, 2 -> 1.36, 4 -> 1.64, 8 -> 2.26 (staged launches: 1.09) */
+#endif
 #define BF_FLOW_SPIN_LIMIT (1u << 21)     // x ~0.5 us: about a second (a legitimate wait is micro- to milliseconds), then the wait gives up and raises `error` instead of hanging the GPU
 
 // Nothing in the launch branches on "lane == 0": a lane-invariant condition inside the item loop invites the compiler to
@@ -306,18 +310,86 @@ __device__ __forceinline__ void bfFlowWait(FlowParams const &p, uint32_t dep, ui
   }
 }
 
+// The launch is software-pipelined one item ahead.  What an item costs on top of its streaming is a chain of dependent
+// round trips -- ticket, item record, piece descriptors, counter polls -- that the staged kernels pay once per launch
+// (as ramp) and a naive persistent kernel pays per item (measured: 1.56 ms against 1.09 ms at N = 65536).  Here the
+// chain of item k + 1 runs underneath item k:
+//   top of item k         the ticket drawn one item ago becomes item k + 1; its record is requested; the ticket of
+//                         item k + 2 is drawn
+//   piece 0 is gathered   the first 64 piece descriptors of item k + 1 are requested (one vector load, 24 bytes a lane)
+//   piece 0 has streamed  they go to the wavefront's second LDS window; the counters of the vectors they read are polled
+//   item k is stored      the poll answers say which of them still have to be waited for (none, in the steady state)
+// Piece descriptors then come from LDS (broadcast reads), not from a scalar load per piece.  Tickets are drawn with a
+// data-dependent increment (lane 0 adds 1, the others 0: the compiler's atomic optimizer turns that into one
+// single-lane atomic) so that nothing in the loop branches on the lane number.
+struct BfFlowWin { uint2 a[64], b[64], c[64]; };     // 64 piece descriptors, 8-byte thirds apart (conflict-free lane-wise writes)
+
+__device__ __forceinline__ BfDevPiece bfFlowWinGet(BfFlowWin const *w, uint32_t i) {
+  uint2 const a = w->a[i], b = w->b[i], c = w->c[i];            // same address in every lane: broadcast
+  BfDevPiece pc;
+  pc.dataOff = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)a.x) | ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)a.y) << 32);
+  pc.inOff = (uint32_t)__builtin_amdgcn_readfirstlane((int)b.x);
+  pc.ncols = (uint32_t)__builtin_amdgcn_readfirstlane((int)b.y);
+  pc.flags = (uint32_t)__builtin_amdgcn_readfirstlane((int)c.x);
+  pc.ld = (uint32_t)__builtin_amdgcn_readfirstlane((int)c.y);
+  return pc;
+}
+
 __global__ __launch_bounds__(BF_WAVES_PER_WG * 64) void bfFlowKernelC128(FlowParams p) {
   __shared__ __attribute__((aligned(16))) double2 lds[BF_WAVES_PER_WG][BF_XCAP];
+  __shared__ __attribute__((aligned(16))) BfFlowWin wins[BF_WAVES_PER_WG][2];
   int const wave = threadIdx.x >> 6;
   int const lane = threadIdx.x & 63;
   double2 *xs = lds[wave];
   double2 const *arena = (double2 const *)p.arena;
   uint32_t const nrhs = p.nrhs;
+  // Tickets are drawn BF_FLOW_BATCH items at a time: every wavefront of the chip draws from ONE counter, and same-address
+  // atomics retire at ~19 ns each device-wide -- with one ticket per item the launch takes items x 19 ns whatever else is
+  // hidden (81 k items at N = 65536: 1.5 ms).  Larger batches trade that for imbalance (consecutive items of the big-first
+  // list are of similar size).  A wavefront works through its batch in order: it still only ever waits for smaller items.
+  uint32_t const one = lane == 0 ? BF_FLOW_BATCH : 0u;
+
+  // ---- prologue: the first item, fetched the slow way
+  uint32_t tk = __hip_atomic_fetch_add(p.queue, one, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  uint32_t cur = (uint32_t)__builtin_amdgcn_readfirstlane((int)tk);
+  if (cur >= p.numItems) return;
+  uint32_t batchEnd = cur + BF_FLOW_BATCH;
+  uint32_t tkNext = __hip_atomic_fetch_add(p.queue, one, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // the next batch, in flight
+  BfDevItem it = p.items[cur];
+  uint32_t od = (uint32_t)__builtin_amdgcn_readfirstlane((int)p.itemOut[cur]);
+  uint32_t cw = 0;
+  uint64_t pending = 0;            // bit i: piece i of the current window reads a vector that was incomplete when polled
+  {
+    BfFlowWin *w = &wins[wave][0];
+    uint32_t const np = it.numPieces < 64u ? it.numPieces : 64u;
+    uint32_t seen = ~0u, want = 0;
+    if ((uint32_t)lane < np) {
+      uint2 const *src = (uint2 const *)(p.pieces + it.pieceBegin + lane);
+      uint2 const a = src[0], b = src[1], c = src[2];
+      w->a[lane] = a; w->b[lane] = b; w->c[lane] = c;
+      if (c.y) { want = (c.x >> 8) * p.epoch; seen = __hip_atomic_load(p.counters + c.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    }
+    pending = __ballot(seen < want);
+    waveSync();
+  }
+
   for (;;) {
-    uint32_t const item = bfFlowTicket(p.queue) - p.queueBase;
-    if (item >= p.numItems) return;
-    BfDevItem const it = p.items[item];
-    uint32_t const od = (uint32_t)__builtin_amdgcn_readfirstlane((int)p.itemOut[item]);
+    // ---- top of item `cur`: the next item is the next of this batch, or the first of the batch drawn a batch ago
+    bool const lastOfBatch = cur + 1 == batchEnd;
+    uint32_t const nxt = lastOfBatch ? (uint32_t)__builtin_amdgcn_readfirstlane((int)tkNext) : cur + 1;
+    bool const haveNext = nxt < p.numItems;
+    BfDevItem itN = it;
+    uint32_t odN = 0;
+    if (haveNext) {
+      itN = p.items[nxt];
+      odN = (uint32_t)__builtin_amdgcn_readfirstlane((int)p.itemOut[nxt]);
+      if (lastOfBatch) tkNext = __hip_atomic_fetch_add(p.queue, one, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // the batch after the next
+    }
+    uint2 wa = make_uint2(0, 0), wb = wa, wc = wa;       // next item's piece descriptors on their way to LDS
+    uint32_t seenN = ~0u, wantN = 0;
+    int stageN = haveNext ? 0 : 3;                       // 0: nothing requested, 1: descriptors requested, 2: in LDS + polled, 3: done / none
+
+    BfFlowWin const *w = &wins[wave][cw];
     uint32_t const mr = it.mrFlags & 0xffffu;
     uint32_t const g = 64u / mr;
     uint32_t const G = g * mr;
@@ -326,35 +398,32 @@ __global__ __launch_bounds__(BF_WAVES_PER_WG * 64) void bfFlowKernelC128(FlowPar
     uint32_t const c = lc / mr;
     uint32_t const r = lc - c * mr;
     double2 *out = (it.mrFlags & BF_ITEM_OUT_Y) ? (double2 *)p.y : (double2 *)p.temp;
-    uint32_t ready = 0;          // the vector this wavefront last saw complete (consecutive pieces often read the same one)
     for (uint32_t q = 0; q < nrhs; ++q) {
       double accr = 0.0, acci = 0.0;
       for (uint32_t pi = 0; pi < it.numPieces; ++pi) {
-        BfDevPiece const pc = p.pieces[it.pieceBegin + pi];
-        uint32_t const dep = (uint32_t)__builtin_amdgcn_readfirstlane((int)pc.ld);
-        uint32_t const want = (uint32_t)__builtin_amdgcn_readfirstlane((int)(pc.flags >> 8)) * p.epoch;      // writers of `dep` ride in the flag word
+        BfDevPiece pc;
+        bool wait;
+        if (pi < 64u) { pc = bfFlowWinGet(w, pi); wait = (pending >> pi) & 1u; }
+        else { pc = p.pieces[it.pieceBegin + pi]; wait = pc.ld != 0; }       // (items of more than 64 pieces: the rest the slow way)
+        uint32_t const dep = pc.ld;
         double2 const *xin = (pc.flags & BF_PIECE_IN_X) ? (double2 const *)p.x : (double2 const *)p.temp;
         xin += (uint64_t)pc.inOff * nrhs + q;
         uint32_t const n = pc.ncols;
+        if (wait && !(p.debugMode & 2u)) bfFlowWait(p, dep, (pc.flags >> 8) * p.epoch);              // seen complete BEFORE the vector is asked for
         if (pc.flags & BF_PIECE_IDENTITY) {
-          if (dep && dep != ready) { bfFlowWait(p, dep, want); ready = dep; }
           if (c == 0 && active) {
             double2 v = dep ? bfLoadCoherent(xin + (uint64_t)r * nrhs) : xin[(uint64_t)r * nrhs];
             accr += v.x; acci += v.y;
           }
           continue;
         }
-        // the input sub-vector: requested together with the poll of its vector's counter -- the producers of all but the
-        // most recent vectors are long done, so the poll almost always confirms what was loaded and costs no round trip
         waveSync();   // previous piece's reads are done before overwriting
-        if (dep) {
-          // the counter is seen complete BEFORE the vector is asked for: two loads of one wavefront to different
-          // addresses may sample memory in either order, so asking for both at once (tried: it hides the poll's round
-          // trip) can pair a complete counter with data from before the last writer -- GMRES stopped converging on it
-          if (dep != ready) { bfFlowWait(p, dep, want); ready = dep; }
-          for (uint32_t j = lane; j < n; j += 64) xs[j] = bfLoadCoherent(xin + (uint64_t)j * nrhs);
-        } else {
-          for (uint32_t j = lane; j < n; j += 64) xs[j] = xin[(uint64_t)j * nrhs];
+        if (dep && !(p.debugMode & 1u)) { for (uint32_t j = lane; j < n; j += 64) xs[j] = bfLoadCoherent(xin + (uint64_t)j * nrhs); }
+        else { for (uint32_t j = lane; j < n; j += 64) xs[j] = xin[(uint64_t)j * nrhs]; }
+        if (stageN == 0) {       // under this piece's stream: the next item's piece descriptors
+          uint32_t const np = itN.numPieces < 64u ? itN.numPieces : 64u;
+          if ((uint32_t)lane < np) { uint2 const *src = (uint2 const *)(p.pieces + itN.pieceBegin + lane); wa = src[0]; wb = src[1]; wc = src[2]; }
+          stageN = 1;
         }
         waveSync();
         double2 const *ap = arena + pc.dataOff + lc;
@@ -376,6 +445,15 @@ __global__ __launch_bounds__(BF_WAVES_PER_WG * 64) void bfFlowKernelC128(FlowPar
           accr = fma(a.x, xv.x, accr); accr = fma(-a.y, xv.y, accr);
           acci = fma(a.x, xv.y, acci); acci = fma(a.y, xv.x, acci);
         }
+        if (stageN == 1) {       // the descriptors have arrived long ago: to the other window, and poll what they read
+          BfFlowWin *wn = &wins[wave][cw ^ 1u];
+          uint32_t const np = itN.numPieces < 64u ? itN.numPieces : 64u;
+          if ((uint32_t)lane < np) {
+            wn->a[lane] = wa; wn->b[lane] = wb; wn->c[lane] = wc;
+            if (wc.y) { wantN = (wc.x >> 8) * p.epoch; seenN = __hip_atomic_load(p.counters + wc.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+          }
+          stageN = 2;
+        }
       }
       waveSync();
       xs[lane] = make_double2(accr, acci);
@@ -384,10 +462,25 @@ __global__ __launch_bounds__(BF_WAVES_PER_WG * 64) void bfFlowKernelC128(FlowPar
         double sr = 0.0, si = 0.0;
         for (uint32_t cc = 0; cc < g; ++cc) { double2 v = xs[cc * mr + lane]; sr += v.x; si += v.y; }
         double2 *dst = out + ((uint64_t)it.outOff + lane) * nrhs + q;
-        if (od) bfStoreCoherent(dst, make_double2(sr, si)); else *dst = make_double2(sr, si);      // later items read it / a later kernel does
+        if (od && !(p.debugMode & 1u)) bfStoreCoherent(dst, make_double2(sr, si)); else *dst = make_double2(sr, si);      // later items read it / a later kernel does
       }
     }
     if (od) bfFlowBump(p.counters + od);      // waits for this wavefront's stores (vmcnt) before the counter moves
+    if (!haveNext) return;
+    // ---- items without a dense piece never reached the hooks: catch up
+    if (stageN < 2) {
+      BfFlowWin *wn = &wins[wave][cw ^ 1u];
+      uint32_t const np = itN.numPieces < 64u ? itN.numPieces : 64u;
+      if ((uint32_t)lane < np) {
+        if (stageN == 0) { uint2 const *src = (uint2 const *)(p.pieces + itN.pieceBegin + lane); wa = src[0]; wb = src[1]; wc = src[2]; }
+        wn->a[lane] = wa; wn->b[lane] = wb; wn->c[lane] = wc;
+        if (wc.y) { wantN = (wc.x >> 8) * p.epoch; seenN = __hip_atomic_load(p.counters + wc.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+      }
+    }
+    pending = __ballot(seenN < wantN);
+    waveSync();       // the other window is written: every lane may read it
+    if (lastOfBatch) batchEnd = nxt + BF_FLOW_BATCH;
+    it = itN; od = odN; cur = nxt; cw ^= 1u;
   }
 }
 
@@ -1583,11 +1676,15 @@ int bfdevLaunchFlow(BfFlowArgs const *a, void *stream) {
   p.counters = (uint32_t *)a->counters;
   p.queue = (uint32_t *)a->counters;            // slot 0: vector id 0 (x) has no counter of its own
   p.error = (uint32_t *)a->counters + 1;        // slot 1: vector id 1 (y) neither
-  p.numItems = a->numItems; p.nrhs = a->nrhs; p.epoch = a->epoch; p.queueBase = a->queueBase;
+  p.numItems = a->numItems; p.nrhs = a->nrhs; p.epoch = a->epoch; p.queueBase = 0;
   static uint32_t spinLimit = 0;
   if (!spinLimit) { char const *e = getenv("BFHIP_FLOW_SPIN"); spinLimit = e ? (uint32_t)strtoul(e, NULL, 10) : BF_FLOW_SPIN_LIMIT; if (!spinLimit) spinLimit = BF_FLOW_SPIN_LIMIT; }
   p.spinLimit = spinLimit;
+  { char const *e = getenv("BFHIP_FLOW_DEBUGMODE"); p.debugMode = e ? (uint32_t)strtoul(e, NULL, 10) : 0u; }
   p.x = a->x; p.y = a->y; p.temp = a->temp;
+  // tickets are drawn one item ahead, so how many an apply draws is not fixed: the queue starts from zero every time
+  hipError_t e = hipMemsetAsync(a->counters, 0, 4, (hipStream_t)stream);
+  if (e != hipSuccess) return hipFail(e, "flow queue reset");
   hipLaunchKernelGGL(bfFlowKernelC128, dim3(a->gridWorkgroups), dim3(BF_WAVES_PER_WG * 64), 0, (hipStream_t)stream, p);
   return hipFail(hipGetLastError(), "flow launch");
 }

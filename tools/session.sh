@@ -42,4 +42,9 @@ lanes()      { step lanes_n65536 300 python tools/exp_lanes.py --n 65536 --lanes
                step lanes_shard8 400 python tools/exp_lanes.py --n 262144 --world 8 --lanes 2 3; cat $O/lanes_shard8.out; }
 headline()   { step bench_default 900 $B --steps 20 --warmup 5 "$@"; cat $O/bench_default.out | cut -c1-1500; grep "stage " $O/bench_default.err; }
 newtests()   { step pytest_new 900 python -m pytest tests -m gpu -x -q -k "shared_row_ranges or sphere or rccl or sharded"; tail -4 $O/pytest_new.out; }
+flow()       { step flow_debug 120 python tools/debug_flow.py; tail -8 $O/flow_debug.out; tail -4 $O/flow_debug.err;
+               step flow_test 300 python -m pytest tests -m gpu -x -q -k "dependency_driven or stage_profile"; tail -3 $O/flow_test.out;
+               BFHIP_FLOW=1 step flow_n65536 200 $B --npoints 65536 --steps 50 --warmup 5 --no-cpu-baseline --no-extra; grep "stage " $O/flow_n65536.err;
+               BFHIP_FLOW=1 step flow_shard 200 $B --emulate-world 8 --emulate-rank 3 --shard blocks --steps 50 --no-extra --no-cpu-baseline; grep "stage " $O/flow_shard.err;
+               BFHIP_FLOW=1 step flow_head 200 $B --steps 20 --no-extra --no-cpu-baseline; grep "stage " $O/flow_head.err; }
 for s in "$@"; do $s; done
