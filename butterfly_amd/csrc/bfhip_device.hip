@@ -130,7 +130,14 @@ __device__ __forceinline__ void waveSync() {
 // ---------------------------------------------------------------------------
 // complex128 stage kernel
 // ---------------------------------------------------------------------------
+#ifndef BF_C128_UNROLL
+#define BF_C128_UNROLL 8
+#endif
+#ifdef BF_C128_WAVES
+__global__ __launch_bounds__(BF_WAVES_PER_WG * 64) __attribute__((amdgpu_waves_per_eu(BF_C128_WAVES, BF_C128_WAVES))) void bfStageKernelC128(StageParams p) {
+#else
 __global__ __launch_bounds__(BF_WAVES_PER_WG * 64) void bfStageKernelC128(StageParams p) {
+#endif
   __shared__ __attribute__((aligned(16))) double2 lds[BF_WAVES_PER_WG][BF_XCAP];
   int const wave = threadIdx.x >> 6;
   int const lane = threadIdx.x & 63;
@@ -171,7 +178,7 @@ __global__ __launch_bounds__(BF_WAVES_PER_WG * 64) void bfStageKernelC128(StageP
       uint32_t const nfull = n / g;
       uint32_t j = c;
       uint32_t s = 0;
-#pragma unroll 8
+#pragma unroll BF_C128_UNROLL
       for (; s < nfull; ++s) {
         double2 a = bfLoadStream(ap + (uint64_t)s * G);
         double2 xv = xs[j];
@@ -335,7 +342,16 @@ __device__ __forceinline__ BfDevPiece bfFlowWinGet(BfFlowWin const *w, uint32_t 
   return pc;
 }
 
-__global__ __launch_bounds__(BF_WAVES_PER_WG * 64) void bfFlowKernelC128(FlowParams p) {
+#ifndef BF_FLOW_UNROLL
+#define BF_FLOW_UNROLL 4
+#endif
+#ifndef BF_FLOW_WAVES
+#define BF_FLOW_WAVES 5
+#endif
+// (the path is latency x concurrency bound: at 4 wavefronts per SIMD the stage kernel itself runs 1.40 ms instead of 1.06 at
+// N = 65536, while 5, 6 or 8 wavefronts with a shorter unroll measure the same -- so the pipelined state is paid for with unroll
+// depth, not with occupancy)
+__global__ __launch_bounds__(BF_WAVES_PER_WG * 64) __attribute__((amdgpu_waves_per_eu(BF_FLOW_WAVES, BF_FLOW_WAVES))) void bfFlowKernelC128(FlowParams p) {
   __shared__ __attribute__((aligned(16))) double2 lds[BF_WAVES_PER_WG][BF_XCAP];
   __shared__ __attribute__((aligned(16))) BfFlowWin wins[BF_WAVES_PER_WG][2];
   int const wave = threadIdx.x >> 6;
@@ -430,7 +446,7 @@ __global__ __launch_bounds__(BF_WAVES_PER_WG * 64) void bfFlowKernelC128(FlowPar
         uint32_t const nfull = n / g;
         uint32_t j = c;
         uint32_t s = 0;
-#pragma unroll 8
+#pragma unroll BF_FLOW_UNROLL
         for (; s < nfull; ++s) {
           double2 a = bfLoadStream(ap + (uint64_t)s * G);
           double2 xv = xs[j];
