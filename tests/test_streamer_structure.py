@@ -323,3 +323,40 @@ def test_rank_model_operand_synthetic_values_on_gpu():
         op = HipOperator.from_desc(desc, None, seed=7, flags=_capi.FLAG_ADJOINT, demote_to_f32=demote)
         assert rel(op.apply_host(x), y_ref) <= tol and rel(op.apply_transpose_host(v), z_ref) <= tol
         op.close()
+
+
+@pytest.mark.gpu
+def test_streamed_operand_shards_by_row_ranges_on_gpu():
+    """Row-range sharding is not tied to a block-matrix root: the streamed butterfly is ONE product, yet the rows a rank
+    owns determine, factor by factor, what it has to hold (backward liveness in the planner).  Four ranks' shards of the
+    rank-model operand at N = 32768, f64 and f32, each equal bit for bit to its rows of the unsharded apply; together
+    they hold more than the operator (the column-side factors are needed by every rank) but each holds less than it."""
+    import torch
+    from butterfly_amd import streamer_structure as ss
+    from butterfly_amd.dist import row_partition
+    from butterfly_amd.operator import HipOperator
+    n, lmax = 32768, 31
+    pts = ss.fibonacci_sphere(n)
+    fd = ss.octree_depth(pts) - 3
+    wmax = float(np.sqrt(lmax * (lmax + 1.0)) * 1.0001)
+    counts, _ = ss.sphere_band_columns(wmax, fd)
+    desc, perm, stats = ss.native_stream_structure(pts, wmax, fd, counts)
+    cuts, loads = row_partition(desc, 4)
+    assert cuts[0] == 0 and cuts[-1] == n and max(loads) <= 1.10 * sum(loads) / 4
+    rng = np.random.default_rng(4)
+    x64 = torch.from_numpy(rng.standard_normal(stats["numCols"])).cuda()
+    for demote in (False, True):
+        x = x64.float() if demote else x64
+        full = HipOperator.from_desc(desc, None, seed=8, demote_to_f32=demote)
+        y = full.apply_device(x).clone()
+        total = full.stats()["leafElems"]
+        full.close()
+        kept = 0
+        for r in range(4):
+            op = HipOperator.from_desc(desc, None, seed=8, demote_to_f32=demote, row_range=(cuts[r], cuts[r + 1]))
+            st = op.stats()
+            assert st["numRows"] == cuts[r + 1] - cuts[r] and st["leafElems"] == loads[r] < total
+            kept += st["leafElems"]
+            assert torch.equal(op.apply_device(x), y[cuts[r]:cuts[r + 1]]), (demote, r)
+            op.close()
+        assert kept >= total

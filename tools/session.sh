@@ -47,4 +47,11 @@ flow()       { step flow_debug 120 python tools/debug_flow.py; tail -8 $O/flow_d
                BFHIP_FLOW=1 step flow_n65536 200 $B --npoints 65536 --steps 50 --warmup 5 --no-cpu-baseline --no-extra; grep "stage " $O/flow_n65536.err;
                BFHIP_FLOW=1 step flow_shard 200 $B --emulate-world 8 --emulate-rank 3 --shard blocks --steps 50 --no-extra --no-cpu-baseline; grep "stage " $O/flow_shard.err;
                BFHIP_FLOW=1 step flow_head 200 $B --steps 20 --no-extra --no-cpu-baseline; grep "stage " $O/flow_head.err; }
+streamshards() { step st_shards8 600 $B --workload streamer --emulate-world 8 --emulate-rank -1 --steps 20 --no-extra --no-cpu-baseline;
+               python - <<PY
+import json
+d = json.load(open("$O/st_shards8.out")); e = d["emulated_shard"]
+print("streamer rows slowest", round(e["slowest_ms"], 4), "full", round(d["ms_per_step"], 4), [(round(t["leaf_gb"], 2), round(t["ms_per_apply"], 4)) for t in e["all_ranks"]])
+PY
+               step st_test 600 python -m pytest tests -m gpu -x -q -k "shards_by_row_ranges"; tail -3 $O/st_test.out; }
 for s in "$@"; do $s; done
