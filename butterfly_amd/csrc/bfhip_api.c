@@ -1319,13 +1319,31 @@ void *bfhipMatMulFunc(void const *rhsV, void *opV) {
   BfAbiMatDenseComplex const *x = (BfAbiMatDenseComplex const *)rhs;
   if (rhs->numRows != op->plan.numCols)
     SHIM_FAIL(BFABI_ERROR_INCOMPATIBLE_SHAPES, "operator has %llu columns, right-hand side %llu rows", (unsigned long long)op->plan.numCols, (unsigned long long)rhs->numRows);
-  if (x->colStride != 1) SHIM_FAIL(BFABI_ERROR_NOT_IMPLEMENTED, "right-hand side with colStride != 1");
   BfAbiLikeFn emptyLike = (BfAbiLikeFn)rhs->vtbl->slot[BFABI_SLOT_EmptyLike];
   if (!emptyLike) SHIM_FAIL(BFABI_ERROR_INVALID_ARGUMENTS, "right-hand side has no EmptyLike");
+  /* a column-strided right-hand side (a view of every k-th column, a column range of a wider matrix:
+   * bfMatDenseComplexGetColRange leaves colStride as it is, src/mat_dense_complex.c:648-672) is gathered into a packed
+   * copy first -- cblas_zgemm in the reference cannot take it either (it passes ldb = rowStride and assumes unit column
+   * stride, :1754), so this is more than the reference does, not less */
+  void *packed = NULL;
+  void const *xdata = x->data;
+  size_t xld = x->rowStride;
+  if (x->colStride != 1) {
+    if (x->colStride == 0) SHIM_FAIL(BFABI_ERROR_INVALID_ARGUMENTS, "right-hand side with colStride 0");
+    size_t const nr = rhs->numRows, nc = rhs->numCols;
+    packed = malloc((nr && nc ? nr * nc : 1) * 16);
+    if (!packed) SHIM_FAIL(BFABI_ERROR_MEMORY_ERROR, "host OOM");
+    for (size_t i = 0; i < nr; ++i)
+      for (size_t q = 0; q < nc; ++q) memcpy((char *)packed + (i * nc + q) * 16, (char const *)x->data + (i * x->rowStride + q * x->colStride) * 16, 16);
+    xdata = packed; xld = nc;
+  }
   BfAbiMat *res = emptyLike(rhs, op->plan.numRows, rhs->numCols);
-  if (!res) SHIM_FAIL(BFABI_ERROR_MEMORY_ERROR, "EmptyLike failed");
+  if (!res) { free(packed); SHIM_FAIL(BFABI_ERROR_MEMORY_ERROR, "EmptyLike failed"); }
   BfAbiMatDenseComplex *y = (BfAbiMatDenseComplex *)res;
-  int rc = bfhipApply(op, x->data, x->rowStride, rhs->numCols, y->data, y->rowStride);
+  int rc;
+  if (y->colStride != 1) rc = bfhipFail(BFABI_ERROR_NOT_IMPLEMENTED, "EmptyLike returned a result with colStride != 1");
+  else rc = bfhipApply(op, xdata, xld, rhs->numCols, y->data, y->rowStride);
+  free(packed);
   if (rc) {
     BfAbiDeleteFn del = (BfAbiDeleteFn)res->vtbl->slot[BFABI_SLOT_Delete];
     if (del) del(&res);

@@ -65,6 +65,37 @@ def test_dropin_vtable_shim(helm2_cases):
     op.close()
 
 
+def test_shim_takes_a_column_strided_right_hand_side(helm2_cases):
+    """A BfMatDenseComplex whose colStride is not 1 (every other column of a wider matrix: what a column-range view of
+    the reference looks like, src/mat_dense_complex.c:648-672) through the shim's Mul slot: gathered, applied, and
+    returned as a fresh packed matrix -- the refusal SURVEY section 8(a) A9 suggested is no longer needed."""
+    from butterfly_amd.operator import HipOperator
+    from oracle import bfref, helm2_build as hb
+    n, k, nrhs = 4096, 100, 3
+    desc, tp, vals = helm2_cases(n, k)
+    A = bfref.from_desc(desc, vals)
+    op = HipOperator.from_bfmat(A.ptr.value)
+    a_hip = op.as_bfmat()
+    lib = bfref.load()
+    rng = np.random.default_rng(8)
+    wide = rng.standard_normal((n, 2 * nrhs)) + 1j * rng.standard_normal((n, 2 * nrhs))
+    X = bfref.dense_complex(wide)
+    # BfMatDenseComplex: numCols at byte 24, rowStride at 32, colStride at 40 (include/bfhip_abi.h; tests/test_abi_layout.py)
+    base = X.ptr if isinstance(X.ptr, int) else X.ptr.value
+    C.c_size_t.from_address(base + 24).value = nrhs
+    C.c_size_t.from_address(base + 40).value = 2
+    r = lib.bfMatMul(a_hip, X.ptr)
+    assert r
+    Y = bfref.Mat(r)
+    assert Y.shape == (n, nrhs)
+    assert rel(Y.to_numpy(), bfref.mat_mul(A, np.ascontiguousarray(wide[:, ::2]))) <= TOL
+    C.c_size_t.from_address(base + 24).value = 2 * nrhs        # restore before the oracle frees it
+    C.c_size_t.from_address(base + 40).value = 1
+    p = C.c_void_p(a_hip)
+    lib.bfMatDelete(C.byref(p))
+    op.close()
+
+
 def test_synthetic_operand_matches_oracle():
     """Structure-exact, value-synthetic operand: the device generates the same
     values the oracle builds on the host (include/bfhip_synth.h)."""
