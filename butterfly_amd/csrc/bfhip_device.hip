@@ -734,15 +734,17 @@ __device__ __forceinline__ void bfRowMajorPiece(void const *rowpV, uint32_t upr,
 // are stored ROW-major like the wide few-row leaves (rows end on the lane granule, nothing else is padded: 5 rows take
 // 5/8 of what the column-major layout reads): group lane gl owns 16-byte column units gl and gl + 16 of every row, x
 // comes straight from global memory, the rows are summed inside the 16 lanes by a fixed butterfly.  No LDS.
+// (like the other stage kernels the body is a function of the block index: bfStageKernelRealBoth runs it next to the
+// one-item-per-wavefront body in one launch)
 template <int DT>
-__global__ __launch_bounds__(BF_WAVES_PER_WG * 64) __attribute__((amdgpu_waves_per_eu(4, 8))) void bfStageKernelSmall(StageParams p) {
+__device__ __forceinline__ void bfStageBodySmall(StageParams const &p, uint32_t const bid) {
   using S = typename Traits<DT>::S;
   constexpr int EPL = Traits<DT>::EPL;
   constexpr int RMAX = 2 * EPL;
   struct __attribute__((aligned(16))) V { S v[EPL]; };
   int const wave = threadIdx.x >> 6;
   int const lane = threadIdx.x & 63;
-  uint32_t const item0 = __builtin_amdgcn_readfirstlane((blockIdx.x * BF_WAVES_PER_WG + wave) * 4u);
+  uint32_t const item0 = __builtin_amdgcn_readfirstlane((bid * BF_WAVES_PER_WG + wave) * 4u);
   if (item0 >= p.numItems) return;
   uint32_t const gid = (uint32_t)lane >> 4, gl = (uint32_t)lane & 15u;
   uint32_t const idx = item0 + gid;
@@ -815,18 +817,22 @@ __global__ __launch_bounds__(BF_WAVES_PER_WG * 64) __attribute__((amdgpu_waves_p
   }
 }
 
+template <int DT>
+__global__ __launch_bounds__(BF_WAVES_PER_WG * 64) __attribute__((amdgpu_waves_per_eu(4, 8))) void bfStageKernelSmall(StageParams p) {
+  bfStageBodySmall<DT>(p, blockIdx.x);
+}
+
 // ---------------------------------------------------------------------------
 // real stage kernel (f64: 2 rows per lane, f32: 4 rows per lane)
 // ---------------------------------------------------------------------------
 template <int DT>
-__global__ __launch_bounds__(BF_WAVES_PER_WG * 64) void bfStageKernelReal(StageParams p) {
+__device__ __forceinline__ void bfStageBodyReal(StageParams const &p, uint32_t const bid, unsigned char (*ldsRaw)[BF_WAVE_LDS_BYTES]) {
   using S = typename Traits<DT>::S;
   constexpr int EPL = Traits<DT>::EPL;
   struct __attribute__((aligned(16))) V { S v[EPL]; };
-  __shared__ __attribute__((aligned(16))) unsigned char ldsRaw[BF_WAVES_PER_WG][BF_WAVE_LDS_BYTES];
   int const wave = threadIdx.x >> 6;
   int const lane = threadIdx.x & 63;
-  uint32_t item = __builtin_amdgcn_readfirstlane(blockIdx.x * BF_WAVES_PER_WG + wave);
+  uint32_t item = __builtin_amdgcn_readfirstlane(bid * BF_WAVES_PER_WG + wave);
   if (item >= p.numItems) return;
   S *xs = (S *)ldsRaw[wave];
   V const *arena = (V const *)p.arena;
@@ -1020,6 +1026,23 @@ __global__ __launch_bounds__(BF_WAVES_PER_WG * 64) void bfStageKernelReal(StageP
   }
 }
 
+template <int DT>
+__global__ __launch_bounds__(BF_WAVES_PER_WG * 64) void bfStageKernelReal(StageParams p) {
+  __shared__ __attribute__((aligned(16))) unsigned char ldsRaw[BF_WAVES_PER_WG][BF_WAVE_LDS_BYTES];
+  bfStageBodyReal<DT>(p, blockIdx.x, ldsRaw);
+}
+
+// The two item families of a real stage in ONE launch: workgroups [0, gridReal) take one item per wavefront, the rest
+// four small items per wavefront.  The two write disjoint rows.  As two launches every inner stage of a streamed
+// butterfly ended with a 55 - 85 us kernel of ~10^4 short workgroups that ran at a fraction of the memory rate behind the
+// tail of the first; in one launch the small items fill that tail.  Both bodies fit 4 wavefronts per SIMD already.
+template <int DT>
+__global__ __launch_bounds__(BF_WAVES_PER_WG * 64) __attribute__((amdgpu_waves_per_eu(4, 8))) void bfStageKernelRealBoth(StageParams pr, StageParams ps, uint32_t gridReal) {
+  __shared__ __attribute__((aligned(16))) unsigned char ldsRaw[BF_WAVES_PER_WG][BF_WAVE_LDS_BYTES];
+  if (blockIdx.x < gridReal) bfStageBodyReal<DT>(pr, blockIdx.x, ldsRaw);
+  else bfStageBodySmall<DT>(ps, blockIdx.x - gridReal);
+}
+
 
 // ---------------------------------------------------------------------------
 // transposed stage kernel: y = A^T x on the forward plan's packed pieces
@@ -1043,6 +1066,18 @@ __global__ __launch_bounds__(BF_WAVES_PER_WG * 64) void bfStageKernelReal(StageP
 #ifndef BF_T_WIDE_NT
 #define BF_T_WIDE_NT 0
 #endif
+// Measured on the streamed N = 1M fp32 operand (transposed apply 8.63 ms): two row blocks requested
+// before the first is used (8 KB per wavefront in flight, 126 VGPRs, still 4 wavefronts per SIMD) -> 8.82 ms; 8 row lanes
+// x 8 loads (BF_T_WIDE_R 8: 155 VGPRs, 3 wavefronts per SIMD) -> 9.65 ms; the same loads at consecutive addresses (wrong
+// results, timing only) -> no change.  Neither bytes in flight nor the 64-byte-per-column pattern bounds this kernel: its
+// wavefronts issue 12 VALU instructions per vector load (SQ counters, profiles/), so it is the instruction count per
+// byte and the resident wavefronts that pay -- hence the single-right-hand-side instantiations below (fp32: 111 -> 92
+// VGPRs, 5 wavefronts per SIMD, 8.63 -> 8.34 ms).  Forcing 6 or 7 wavefronts with amdgpu_waves_per_eu spills 12 / 24
+// VGPRs to scratch: 9.02 / 10.47 ms.
+// row lanes of the 64-column tiling (= its loads in flight: R row lanes x 64 / R columns per load, R loads per item width)
+#ifndef BF_T_WIDE_R
+#define BF_T_WIDE_R 4
+#endif
 
 // R = row lanes per column, C = 64 / R columns per load instruction, NQ loads in flight per block: an
 // item is up to NQ * C columns of A.
@@ -1051,8 +1086,11 @@ __global__ __launch_bounds__(BF_WAVES_PER_WG * 64) void bfStageKernelReal(StageP
 //     16-byte units): with 16 row lanes a 10-unit piece keeps 10 of 16 row lanes busy and a 36-column
 //     remainder 9 of 16 quads; with 4 row lanes a block covers 4 units x 16 columns, the row waste drops
 //     to the last 4-unit step and items are 4x larger.
-template <int DT, int R, int NQ, bool COOP>
-__global__ __launch_bounds__(BF_WAVES_PER_WG * 64) void bfStageKernelT(StageParams p) {
+// (the body is a function of the block index so that one launch can run two tilings side by side: bfStageKernelTBoth)
+// ONE: a single right-hand side, known at compile time -- the 64-bit row * nrhs products of every x address (quarter-rate
+// v_mad_u64_u32, four per block step of the fp32 tiling) fold away.
+template <int DT, int R, int NQ, bool COOP, bool ONE, typename CoopBuf>
+__device__ __forceinline__ void bfStageBodyT(StageParams const &p, uint32_t const bid, CoopBuf &coopBuf) {
   constexpr int C = 64 / R;                          // columns per load instruction
   using S = typename Traits<DT>::S;
   constexpr int EPL = Traits<DT>::EPL;              // rows per 16-byte unit (complex: 1)
@@ -1064,9 +1102,8 @@ __global__ __launch_bounds__(BF_WAVES_PER_WG * 64) void bfStageKernelT(StagePara
   // the first coopItems items (the big ones: the list is sorted) get a workgroup each: wavefront w takes pieces
   // w, w + 4, ... and the four partial results are added in LDS in a fixed order; the rest run one per wavefront
   // (COOP = false: the stage has no such items and the kernel is the plain one-item-per-wavefront one)
-  __shared__ S coopBuf[COOP ? BF_WAVES_PER_WG : 1][COOP ? NQ * C : 1][NC];
-  bool const coop = COOP && blockIdx.x < p.coopItems;
-  uint32_t item = __builtin_amdgcn_readfirstlane(coop ? blockIdx.x : p.coopItems + (blockIdx.x - p.coopItems) * BF_WAVES_PER_WG + wave);
+  bool const coop = COOP && bid < p.coopItems;
+  uint32_t item = __builtin_amdgcn_readfirstlane(coop ? bid : p.coopItems + (bid - p.coopItems) * BF_WAVES_PER_WG + wave);
   if (item >= p.numItems) return;
   uint32_t const wsel = coop ? (uint32_t)wave : 0u, wmask = coop ? BF_WAVES_PER_WG - 1u : 0u;
   BfDevItem const it = p.items[item];
@@ -1076,7 +1113,7 @@ __global__ __launch_bounds__(BF_WAVES_PER_WG * 64) void bfStageKernelT(StagePara
 #pragma unroll                                       // the duplicates are summed but never stored
   for (int cq = 0; cq < NQ; ++cq) jcol[cq] = c4 + C * cq < mr ? c4 + C * cq : mr - 1;
   U const *arena = (U const *)p.arena;               // 16-byte units
-  uint32_t const nrhs = p.nrhs;
+  uint32_t const nrhs = ONE ? 1u : p.nrhs;
   S *out = (it.mrFlags & BF_ITEM_OUT_Y) ? (S *)p.y : (S *)p.temp;
   uint32_t const nq = (mr + C - 1) / C;              // load instructions that touch a column of this item
 
@@ -1178,12 +1215,13 @@ __global__ __launch_bounds__(BF_WAVES_PER_WG * 64) void bfStageKernelT(StagePara
           uint32_t const ru = rb + r < units ? rb + r : units - 1;
           U a[NQ];
 #pragma unroll
-          for (int cq = 0; cq < NQ; ++cq) if ((uint32_t)cq < nq) a[cq] = (R >= 8 || BF_T_WIDE_NT) ? bfLoadStreamV(src + jcol[cq] * stride + ru) : src[jcol[cq] * stride + ru];   // nq: wave-uniform
+          for (int cq = 0; cq < NQ; ++cq) if ((uint32_t)cq < nq) a[cq] = (R >= 16 || BF_T_WIDE_NT) ? bfLoadStreamV(src + jcol[cq] * stride + ru) : src[jcol[cq] * stride + ru];   // nq: wave-uniform
           S xv[UNIT];
 #pragma unroll
           for (int e = 0; e < EPL; ++e) {
             // unconditional loads at a clamped row, zeroed by a select: a load under `row < n ? ... : 0`
             // becomes a branch with its own wait, and the 2 - 4 x loads of a block then run one after another
+            // (one 16-byte load for the blocks whose rows all exist was tried for nrhs = 1: no change)
             uint32_t const row = (rb + r) * EPL + e;
             uint32_t const rowc = row < n ? row : n - 1;
 #pragma unroll
@@ -1261,6 +1299,27 @@ __global__ __launch_bounds__(BF_WAVES_PER_WG * 64) void bfStageKernelT(StagePara
           for (int k = 0; k < NC; ++k) out[(((uint64_t)it.outOff + c4 + C * cq) * nrhs + q) * NC + k] = acc[cq][k];
     }
   }
+}
+
+template <int DT, int R, int NQ, bool COOP, bool ONE>
+__global__ __launch_bounds__(BF_WAVES_PER_WG * 64) void bfStageKernelT(StageParams p) {
+  using S = typename Traits<DT>::S;
+  constexpr int NC = Traits<DT>::CPLX ? 2 : 1;
+  __shared__ S coopBuf[COOP ? BF_WAVES_PER_WG : 1][COOP ? NQ * (64 / R) : 1][NC];
+  bfStageBodyT<DT, R, NQ, COOP, ONE>(p, blockIdx.x, coopBuf);
+}
+
+// Both tilings of a transposed stage in ONE launch (real operands): workgroups [0, gridNarrow) run the 16-row-lane
+// tiling on the 16-column items of tall leaves, the rest the 4-row-lane tiling on the 64-column items.  As two launches a
+// stage of a streamed butterfly paid the ramp and the tail of a 0.15 - 0.6 ms kernel twice and the two item families could
+// not fill each other's tails; both kernels already run at 4 wavefronts per SIMD with the shared-item code, so nothing is
+// lost by giving them one register allocation.
+template <int DT, bool ONE>
+__global__ __launch_bounds__(BF_WAVES_PER_WG * 64) void bfStageKernelTBoth(StageParams pn, StageParams pw, uint32_t gridNarrow) {
+  using S = typename Traits<DT>::S;
+  __shared__ S coopBuf[BF_WAVES_PER_WG][64][1];
+  if (blockIdx.x < gridNarrow) bfStageBodyT<DT, 16, 4, true, ONE>(pn, blockIdx.x, coopBuf);
+  else bfStageBodyT<DT, BF_T_WIDE_R, BF_T_WIDE_R, true, ONE>(pw, blockIdx.x - gridNarrow, coopBuf);
 }
 
 // ---------------------------------------------------------------------------
@@ -1632,6 +1691,23 @@ int bfdevLaunchStage(BfLaunchArgs const *a, void *stream) {
     // 16-column kernel, which needs 98 VGPRs with the shared-item code (4 wavefronts per SIMD instead of 5) and loses
     // 5 % on fac_helm2's adjoint.
     uint64_t const numNarrow = a->numNarrow < a->numItems ? a->numNarrow : a->numItems;
+    if (a->dtype != BFHIP_C128 && numNarrow && numNarrow < a->numItems && a->maxRowsRest > 16) {
+      // real operands with both item families: one launch (bfStageKernelTBoth)
+      StageParams pn = p, pw = p;
+      uint64_t const cntW = a->numItems - numNarrow;
+      uint64_t ncN = a->numCoopNarrow < numNarrow ? a->numCoopNarrow : numNarrow, ncW = a->numCoop < cntW ? a->numCoop : cntW;
+      pn.items = (BfDevItem const *)a->items; pn.numItems = (uint32_t)numNarrow; pn.coopItems = (uint32_t)ncN;
+      pw.items = (BfDevItem const *)a->items + numNarrow; pw.numItems = (uint32_t)cntW; pw.coopItems = (uint32_t)ncW;
+      uint32_t const gridN = (uint32_t)(ncN + (numNarrow - ncN + BF_WAVES_PER_WG - 1) / BF_WAVES_PER_WG);
+      uint32_t const gridW = (uint32_t)(ncW + (cntW - ncW + BF_WAVES_PER_WG - 1) / BF_WAVES_PER_WG);
+#define BF_LAUNCH_TBOTH(DT) do { if (a->nrhs == 1) hipLaunchKernelGGL((bfStageKernelTBoth<DT, true>), dim3(gridN + gridW), dim3(BF_WAVES_PER_WG * 64), 0, s, pn, pw, gridN); \
+                                 else hipLaunchKernelGGL((bfStageKernelTBoth<DT, false>), dim3(gridN + gridW), dim3(BF_WAVES_PER_WG * 64), 0, s, pn, pw, gridN); } while (0)
+      if (a->dtype == BFHIP_F64) BF_LAUNCH_TBOTH(BFHIP_F64);
+      else if (a->dtype == BFHIP_F32) BF_LAUNCH_TBOTH(BFHIP_F32);
+      else return bfhipFail(BFABI_ERROR_TYPE_ERROR, "unknown dtype %u", a->dtype);
+#undef BF_LAUNCH_TBOTH
+      return hipFail(hipGetLastError(), "transposed stage launch");
+    }
     for (int range = 0; range < 2; ++range) {
       uint64_t const first = range ? numNarrow : 0, count = range ? a->numItems - numNarrow : numNarrow;
       if (!count) continue;
@@ -1643,15 +1719,17 @@ int bfdevLaunchStage(BfLaunchArgs const *a, void *stream) {
       p.numItems = (uint32_t)count;
       p.coopItems = (uint32_t)nc;
       grid = (uint32_t)(nc + (count - nc + BF_WAVES_PER_WG - 1) / BF_WAVES_PER_WG);
-#define BF_LAUNCH_T(DT) do { if (wide && nc) hipLaunchKernelGGL((bfStageKernelT<DT, 4, 4, true>), dim3(grid), dim3(BF_WAVES_PER_WG * 64), 0, s, p); \
-                             else if (wide) hipLaunchKernelGGL((bfStageKernelT<DT, 4, 4, false>), dim3(grid), dim3(BF_WAVES_PER_WG * 64), 0, s, p); \
-                             else if (nc) hipLaunchKernelGGL((bfStageKernelT<DT, 16, 4, true>), dim3(grid), dim3(BF_WAVES_PER_WG * 64), 0, s, p); \
-                             else hipLaunchKernelGGL((bfStageKernelT<DT, 16, 4, false>), dim3(grid), dim3(BF_WAVES_PER_WG * 64), 0, s, p); } while (0)
+#define BF_LAUNCH_T1(DT, ONE) do { if (wide && nc) hipLaunchKernelGGL((bfStageKernelT<DT, BF_T_WIDE_R, BF_T_WIDE_R, true, ONE>), dim3(grid), dim3(BF_WAVES_PER_WG * 64), 0, s, p); \
+                             else if (wide) hipLaunchKernelGGL((bfStageKernelT<DT, BF_T_WIDE_R, BF_T_WIDE_R, false, ONE>), dim3(grid), dim3(BF_WAVES_PER_WG * 64), 0, s, p); \
+                             else if (nc) hipLaunchKernelGGL((bfStageKernelT<DT, 16, 4, true, ONE>), dim3(grid), dim3(BF_WAVES_PER_WG * 64), 0, s, p); \
+                             else hipLaunchKernelGGL((bfStageKernelT<DT, 16, 4, false, ONE>), dim3(grid), dim3(BF_WAVES_PER_WG * 64), 0, s, p); } while (0)
+#define BF_LAUNCH_T(DT) do { if (a->nrhs == 1) BF_LAUNCH_T1(DT, true); else BF_LAUNCH_T1(DT, false); } while (0)
       if (a->dtype == BFHIP_C128) BF_LAUNCH_T(BFHIP_C128);
       else if (a->dtype == BFHIP_F64) BF_LAUNCH_T(BFHIP_F64);
       else if (a->dtype == BFHIP_F32) BF_LAUNCH_T(BFHIP_F32);
       else return bfhipFail(BFABI_ERROR_TYPE_ERROR, "unknown dtype %u", a->dtype);
 #undef BF_LAUNCH_T
+#undef BF_LAUNCH_T1
     }
     return hipFail(hipGetLastError(), "transposed stage launch");
   }
@@ -1664,6 +1742,15 @@ int bfdevLaunchStage(BfLaunchArgs const *a, void *stream) {
     uint64_t const numSmall = a->numItems - firstSmall;
     p.numItems = (uint32_t)firstSmall;
     grid = (uint32_t)((firstSmall + BF_WAVES_PER_WG - 1) / BF_WAVES_PER_WG);
+    if (grid && numSmall) {
+      StageParams ps = p;
+      ps.items = (BfDevItem const *)a->items + firstSmall;
+      ps.numItems = (uint32_t)numSmall;
+      uint32_t const gridSmall = (uint32_t)((numSmall + 4 * BF_WAVES_PER_WG - 1) / (4 * BF_WAVES_PER_WG));
+      if (a->dtype == BFHIP_F64) hipLaunchKernelGGL(bfStageKernelRealBoth<BFHIP_F64>, dim3(grid + gridSmall), dim3(BF_WAVES_PER_WG * 64), 0, s, p, ps, grid);
+      else hipLaunchKernelGGL(bfStageKernelRealBoth<BFHIP_F32>, dim3(grid + gridSmall), dim3(BF_WAVES_PER_WG * 64), 0, s, p, ps, grid);
+      return hipFail(hipGetLastError(), "stage launch");
+    }
     if (grid) {
       if (a->dtype == BFHIP_F64) hipLaunchKernelGGL(bfStageKernelReal<BFHIP_F64>, dim3(grid), dim3(BF_WAVES_PER_WG * 64), 0, s, p);
       else hipLaunchKernelGGL(bfStageKernelReal<BFHIP_F32>, dim3(grid), dim3(BF_WAVES_PER_WG * 64), 0, s, p);

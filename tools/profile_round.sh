@@ -1,6 +1,6 @@
 #!/bin/bash
 # Collects the rocprofv3 evidence committed under profiles/ (run on the GPU box via gpurun).
-#   usage: tools/profile_round.sh <round-tag> [helm2|streamer|all]      e.g. r2 helm2
+#   usage: tools/profile_round.sh <round-tag> [helm2|streamer|streamerT|all]      e.g. r2 helm2
 # (every pass lays its operand out and synthesizes it again: ~25 s for the headline operand, ~40 s for the streamed one)
 # Each PMC set is its own pass with --kernel-trace only (no --stats / sys-trace with --pmc).
 set -u
@@ -16,7 +16,7 @@ run() { # name, rocprof args..., -- bench args
   rocprofv3 "${rp[@]}" --output-format csv -d $OUT/$name -- python3 $R/bench.py "$@" --no-cpu-baseline --no-extra > $OUT/$name.json 2> $OUT/$name.log
   echo "$name exit=$?"
 }
-if [ "$PART" != "streamer" ]; then
+if [ "$PART" != "streamer" ] && [ "$PART" != "streamerT" ]; then
 # headline: N=262144, nrhs=1
 run stats_r1   --kernel-trace --stats -- --steps 10 --warmup 2
 run fetch_r1   --kernel-trace --pmc FETCH_SIZE -- --steps 3 --warmup 1
@@ -36,14 +36,20 @@ run stats_adj  --kernel-trace --stats -- --adjoint --steps 5 --warmup 1
 run fetch_adj  --kernel-trace --pmc FETCH_SIZE -- --adjoint --steps 3 --warmup 1
 run write_adj  --kernel-trace --pmc WRITE_SIZE -- --adjoint --steps 3 --warmup 1
 fi
-if [ "$PART" != "helm2" ]; then
+SQSET="SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VALU SQ_BUSY_CYCLES GRBM_GUI_ACTIVE"
+if [ "$PART" != "helm2" ] && [ "$PART" != "streamerT" ]; then
 # BASELINE configs[4]: streamed real butterfly, N = 1M fp32 (bfStageKernelReal<f32>)
 run stats_st   --kernel-trace --stats -- --workload streamer --steps 5 --warmup 1
 run fetch_st   --kernel-trace --pmc FETCH_SIZE -- --workload streamer --steps 2 --warmup 1
 run write_st   --kernel-trace --pmc WRITE_SIZE -- --workload streamer --steps 2 --warmup 1
-# its transposed apply (bfStageKernelT<f32>: 16- and 64-column kernels, shared items)
+run sq_st      --kernel-trace --pmc $SQSET -- --workload streamer --steps 2 --warmup 1
+fi
+if [ "$PART" != "helm2" ]; then
+# its transposed apply (bfStageKernelT<f32>: the 16- and the 64-column tiling of a stage in one launch, shared items)
 run stats_stT  --kernel-trace --stats -- --workload streamer --adjoint --steps 5 --warmup 1
 run fetch_stT  --kernel-trace --pmc FETCH_SIZE -- --workload streamer --adjoint --steps 2 --warmup 1
 run write_stT  --kernel-trace --pmc WRITE_SIZE -- --workload streamer --adjoint --steps 2 --warmup 1
+# where the wavefronts' cycles go (parked on memory / issuing): the transposed kernels next to the forward ones in the same pass
+run sq_stT     --kernel-trace --pmc $SQSET -- --workload streamer --adjoint --steps 2 --warmup 1
 fi
 ls $OUT

@@ -54,4 +54,19 @@ d = json.load(open("$O/st_shards8.out")); e = d["emulated_shard"]
 print("streamer rows slowest", round(e["slowest_ms"], 4), "full", round(d["ms_per_step"], 4), [(round(t["leaf_gb"], 2), round(t["ms_per_apply"], 4)) for t in e["all_ranks"]])
 PY
                step st_test 600 python -m pytest tests -m gpu -x -q -k "shards_by_row_ranges"; tail -3 $O/st_test.out; }
+stadj()      { step pytest_T 900 python -m pytest tests -m gpu -x -q -k "transpose or adjoint or streamer or rmul"; tail -3 $O/pytest_T.out;
+               step st_adj 600 $B --workload streamer --adjoint --steps 10 --warmup 2 --no-cpu-baseline --no-extra;
+               python - <<PY
+import json
+d = json.load(open("$O/st_adj.out")); print("streamer", d["value"], d["ms_per_step"], d["roofline"]["frac"], "adjoint", d["adjoint"])
+PY
+               grep "stage " $O/st_adj.err | tail -24; }
+traceT()     { ( cd /tmp && export TMPDIR=/tmp && timeout -k 10 600 rocprofv3 --kernel-trace --output-format csv -d $O/traceT -- python3 $R/bench.py --workload streamer --adjoint --steps 3 --warmup 1 --no-cpu-baseline --no-extra > $O/traceT.json 2> $O/traceT.log ); echo "traceT exit=$?";
+               python tools/trace_apply.py $O/traceT 120 > $O/traceT.txt; find $O/traceT -name "*.csv" -size +2M -delete; tail -60 $O/traceT.txt; }
+streamer()   { step st_fwd 600 $B --workload streamer --adjoint --steps 10 --warmup 2 --no-cpu-baseline;
+               python - <<PY
+import json
+d = json.load(open("$O/st_fwd.out")); print("streamer", d["value"], d["ms_per_step"], d["roofline"]["frac"], "adjoint", d["adjoint"]["ms_per_apply"], d["adjoint"]["frac_of_hbm_peak"], "cov", d.get("cov_matvec"))
+PY
+               grep "stage " $O/st_fwd.err | tail -12; }
 for s in "$@"; do $s; done

@@ -13,8 +13,14 @@ src = f"gpurun_out/prof_{tag}"
 os.makedirs("profiles", exist_ok=True)
 
 
+def newest(pattern):
+    """A pass directory may hold an earlier run of the same pass (files are named by pid): only the newest run counts."""
+    files = sorted(glob.glob(pattern), key=os.path.getmtime)
+    return files[-1:]
+
+
 def counters(name):
-    files = glob.glob(f"{src}/{name}/*/*_counter_collection.csv")
+    files = newest(f"{src}/{name}/*/*_counter_collection.csv")
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     if not files:
         return {}
@@ -27,19 +33,19 @@ def counters(name):
 out = {"tag": tag, "note": "FETCH_SIZE/WRITE_SIZE in KiB; on gfx950 FETCH_SIZE counts half the bytes of a 16-B/lane streaming read "
        "(MI355X_MICROARCH.md, HBM): fetch bytes = FETCH_SIZE*1024*2; WRITE_SIZE exact.  SQ_* are summed over SEs/XCDs as rocprofv3 reports them."}
 for name in ("stats_r1", "stats_r64", "stats_st", "stats_n65536", "stats_adj", "stats_stT"):
-    for f in glob.glob(f"{src}/{name}/*/*_kernel_stats.csv"):
+    for f in newest(f"{src}/{name}/*/*_kernel_stats.csv"):
         shutil.copy(f, f"profiles/{tag}_{name}_kernel_stats.csv")
     if os.path.exists(f"{src}/{name}.json"):
         shutil.copy(f"{src}/{name}.json", f"profiles/{tag}_{name}_bench_under_rocprof.json")
 for name in ("fetch_r1", "write_r1", "lds_r1", "mfma_r64", "fetch_r64", "write_r64", "fetch_st", "write_st", "fetch_n65536", "write_n65536",
-             "fetch_adj", "write_adj", "fetch_stT", "write_stT"):
+             "fetch_adj", "write_adj", "fetch_stT", "write_stT", "sq_st", "sq_stT"):
     out[name] = counters(name)
 
 
 def kernel_seconds(name, prefix):
     """Sum of (end - start) over the dispatches of kernels whose name starts with `prefix`, from the kernel trace of pass `name`."""
     tot, cnt = 0.0, 0
-    for f in glob.glob(f"{src}/{name}/*/*_kernel_trace.csv"):
+    for f in newest(f"{src}/{name}/*/*_kernel_trace.csv"):
         for r in csv.DictReader(open(f)):
             if r["Kernel_Name"].split("(")[0].startswith(prefix):
                 tot += (float(r["End_Timestamp"]) - float(r["Start_Timestamp"])) * 1e-9
@@ -89,6 +95,30 @@ for nm, key in (("stats_r1", "bfStageKernelC128_per_launch"), ("stats_r64", "bfS
         if "algorithmic_bytes_per_apply" in rl:
             out[key]["algorithmic_bytes"] = rl["algorithmic_bytes_per_apply"] / rl["launches_per_apply"]
             out[key]["ratio"] = out[key]["hbm_bytes"] / out[key]["algorithmic_bytes"]
+
+
+def wave_cycles(name, prefix):
+    """Where the wavefronts of the kernels starting with `prefix` spent their cycles (SQ counters, quad-cycles summed over the chip):
+    parked on s_waitcnt (memory), stalled at issue, issuing; vector-memory and VALU instructions per 1 KB streamed."""
+    ks = {k: v for k, v in out.get(name, {}).items() if k.startswith(prefix) and "SQ_WAVE_CYCLES" in v}
+    if not ks:
+        return None
+    tot = lambda c: sum(v[c]["sum"] for v in ks.values())
+    wc = tot("SQ_WAVE_CYCLES")
+    secs, cnt = kernel_seconds(name, prefix)
+    r = {"kernels": sorted(ks), "dispatches": cnt, "wait_any_frac": tot("SQ_WAIT_ANY") / wc, "wait_inst_any_frac": tot("SQ_WAIT_INST_ANY") / wc,
+         "active_inst_any_frac": tot("SQ_ACTIVE_INST_ANY") / wc, "insts_vmem_rd": tot("SQ_INSTS_VMEM_RD"), "insts_valu": tot("SQ_INSTS_VALU"),
+         "valu_per_vmem_rd": tot("SQ_INSTS_VALU") / max(tot("SQ_INSTS_VMEM_RD"), 1)}
+    if secs > 0:
+        # mean resident wavefronts per SIMD = wave quad-cycles * 4 / (active cycles per XCD * 1024 SIMDs)
+        gui = tot("GRBM_GUI_ACTIVE") / 8
+        r["sustained_clock_ghz"] = gui / secs * 1e-9
+        r["mean_waves_per_simd"] = wc * 4 / (gui * 1024)
+    return r
+
+
+out["bfStageKernelReal_f32_streamer_wave_cycles"] = wave_cycles("sq_stT", "void bfStageKernelReal") or wave_cycles("sq_st", "void bfStageKernelReal")
+out["bfStageKernelT_f32_streamer_wave_cycles"] = wave_cycles("sq_stT", "void bfStageKernelT")
 try:
     m = out["mfma_r64"]["bfStageKernelC128Mfma"]
     busy, gui = m["SQ_VALU_MFMA_BUSY_CYCLES"]["sum"], m["GRBM_GUI_ACTIVE"]["sum"]
@@ -104,4 +134,4 @@ try:
 except KeyError:
     pass
 json.dump(out, open(f"profiles/{tag}_pmc_summary.json", "w"), indent=1)
-print(json.dumps({k: out[k] for k in out if k.endswith("per_launch") or k.endswith("per_apply") or k.startswith("mfma_")}, indent=1))
+print(json.dumps({k: out[k] for k in out if k.endswith("per_launch") or k.endswith("per_apply") or k.endswith("wave_cycles") or k.startswith("mfma_")}, indent=1))
