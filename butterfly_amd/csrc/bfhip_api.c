@@ -91,6 +91,7 @@ static void freeDevicePlanOf(BfPlan *plan) {
     BfStage *st = &plan->stages[s];
     bfdevFree(st->dItems); st->dItems = NULL;
     bfdevFree(st->dPieces); st->dPieces = NULL;
+    bfdevFree(st->dTickets); st->dTickets = NULL;
     for (uint64_t r = 0; r < st->numReduce; ++r) {
       bfdevFree(st->reduce[r].dRowInterval); bfdevFree(st->reduce[r].dIvBegin); bfdevFree(st->reduce[r].dSrcBias);
       st->reduce[r].dRowInterval = st->reduce[r].dIvBegin = st->reduce[r].dSrcBias = NULL;
@@ -683,6 +684,14 @@ static int runPlan(BfhipOperator *op, BfPlan *plan, void const *dX, size_t nrhs,
     a.arena = op->dArena; a.items = st->dItems; a.pieces = st->dPieces; a.numItems = st->numItems; a.firstSmall = st->firstSmall; a.numCoop = st->numCoop; a.numNarrow = st->numNarrow; a.numCoopNarrow = st->numCoopNarrow; a.maxRowsRest = st->maxRowsRest;
     a.x = dX; a.y = dY; a.temp = op->dTemp; a.zero = op->dZero; a.nrhs = (uint32_t)nrhs; a.dtype = plan->dtype; a.maxRows = st->maxRows;
     a.transposed = plan->transposed;
+    a.tickets = NULL;
+    if (plan->dtype == BFHIP_C128 && !plan->transposed && nrhs < 3) {
+      if (!st->dTickets) {        /* first apply: the stage's ticket counters (one-time, not stream-ordered) */
+        if ((rc = bfdevMalloc(&st->dTickets, BF_TICKET_POOLS * BF_TICKET_STRIDE * 4))) goto out;
+        if ((rc = bfdevMemset(st->dTickets, 0, BF_TICKET_POOLS * BF_TICKET_STRIDE * 4))) goto out;
+      }
+      a.tickets = st->dTickets;
+    }
     if (prof && (rc = bfdevEventRecord(op->evStart[evBase + s], stream))) goto out;
     if ((rc = bfdevLaunchStage(&a, stream))) goto out;
     if (prof && (rc = bfdevEventRecord(op->evStop[evBase + s], stream))) goto out;

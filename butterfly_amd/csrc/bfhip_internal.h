@@ -131,6 +131,9 @@ typedef struct BfStage {
   uint32_t *itemBuf;         /* [numItems] */
   /* device copies */
   void *dItems, *dPieces;
+  /* persistent launches of a stage with more items than wavefront slots (bfStageKernelC128P): BF_TICKET_POOLS ticket
+   * counters, zero between launches (the wavefront that draws a pool's last ticket of a launch puts it back to zero) */
+  void *dTickets;
 } BfStage;
 
 typedef struct BfPlan {
@@ -239,7 +242,10 @@ typedef struct BfLaunchArgs {
   uint32_t dtype;
   uint32_t maxRows;
   int transposed;        /* pieces carry `ld`: lanes own columns of the forward pieces */
+  void *tickets;         /* NULL, or BF_TICKET_POOLS x BF_TICKET_STRIDE uint32 owned by this stage, zero between launches (see BfStage.dTickets) */
 } BfLaunchArgs;
+#define BF_TICKET_POOLS 64u
+#define BF_TICKET_STRIDE 64u      /* uint32 between two pools' counters: a 256-byte block each -- counters that share a cache line share its atomic unit (measured: 64 packed counters behaved like one) */
 int bfdevLaunchStage(BfLaunchArgs const *a, void *stream);
 
 /* dependency-driven launch of a whole forward complex128 plan (bfFlowKernelC128): see bfhip_device.hip */

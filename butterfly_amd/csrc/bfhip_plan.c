@@ -524,6 +524,8 @@ void bfPlanFree(BfPlan *plan) {
 }
 
 /* target upper bound on the leaf bytes one item (one wavefront) streams */
+/* (measured round 3, A/B on one box: 16 / 32 / 64 / 128 KiB here, and 64 ... 1024 KiB for the contraction cap below, give
+ * the same times at N = 65536 and on a 1/8 shard to 1 %; the headline is 3 - 5 % slower with caps below 1 MiB) */
 #define BF_ITEM_BYTES (128u << 10)
 
 /* vector-arena allocator: 4-element alignment keeps every segment 16-byte
@@ -694,9 +696,10 @@ int bfPlanBuild(BfIr const *ir, BfPlanOptions const *po, BfPlan *plan) {
       itemRows = (10 * slots4 < 8 * slots16) ? 64 : 16;
     }
     uint64_t const stageElems = fullStageElems[s];
+    uint64_t const itemBytes = BF_ITEM_BYTES;
     uint64_t capBytes = 1u << 20;
     if (stageElems * plan->elemSize / 4096 < capBytes) capBytes = stageElems * plan->elemSize / 4096;
-    if (capBytes < BF_ITEM_BYTES) capBytes = BF_ITEM_BYTES;
+    if (capBytes < itemBytes) capBytes = itemBytes;
     uint64_t const floorRowsCap = T ? itemRows : (uint64_t)(po->minChunkRows ? po->minChunkRows : 16) * plan->epl;
     uint64_t capColsCls[2];
     capColsCls[0] = capBytes / (floorRowsCap * plan->elemSize);
@@ -850,7 +853,7 @@ int bfPlanBuild(BfIr const *ir, BfPlanOptions const *po, BfPlan *plan) {
       if (!T && gr->colsSum) {
         uint64_t const gran = 16 * plan->epl;
         uint64_t const floorRows = (po->minChunkRows ? po->minChunkRows : 16) * plan->epl;
-        uint64_t want = (BF_ITEM_BYTES / plan->elemSize) / gr->colsSum / gran * gran;
+        uint64_t want = (itemBytes / plan->elemSize) / gr->colsSum / gran * gran;
         if (want < floorRows) want = floorRows;
         if (want < chunk) chunk = want;
       }

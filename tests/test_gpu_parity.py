@@ -8,6 +8,7 @@ Tolerance (north_star "stated fp64 tolerance"):
   is the butterfly's own truncation error, <= 1e-9.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -15,6 +16,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 TOL = 1e-12
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def rel(a, b):
@@ -946,3 +948,60 @@ def _check_against_dense(d, vals, dense, rng, demote, nrhs):
     z = op.apply_transpose_host(v)
     assert rel(y, dense @ x) <= tol and rel(z, dense.T @ v) <= tol
     op.close()
+
+
+_PERSISTENT_CHILD = r"""
+import hashlib, json, os, sys
+import numpy as np, torch
+sys.path.insert(0, os.environ["BF_REPO"])
+from butterfly_amd import helm2_structure as hs
+from butterfly_amd.operator import HipOperator
+n, k = 65536, 4096.0
+desc, perm = hs.native_multilevel_structure(hs.circle_points(n), k)
+op = HipOperator.from_desc(desc, None, seed=9, max_rhs=2)
+rng = np.random.default_rng(5)
+out = {}
+for nrhs in (1, 2):
+    shape = (n,) if nrhs == 1 else (n, nrhs)
+    x = torch.from_numpy((rng.standard_normal(shape) + 1j * rng.standard_normal(shape)) / np.sqrt(2)).cuda()
+    y = op.apply_device(x).clone()
+    for i in range(50):                                    # the ticket counters must come back to zero after every launch
+        assert torch.equal(op.apply_device(x), y), i
+    z = op.apply_device(torch.roll(x, 7, 0) * 1.5).clone()
+    torch.cuda.synchronize()
+    out[str(nrhs)] = [hashlib.sha256(y.cpu().numpy().tobytes()).hexdigest(), hashlib.sha256(z.cpu().numpy().tobytes()).hexdigest()]
+tl = os.environ.get("BFHIP_TIMELINE_FILE")
+if tl:
+    head = [l for l in open(tl).read().split("\n") if l.startswith("launch")]
+    out["timeline_launches"] = len(head)
+    out["timeline_items"] = sum(int(l.split()[1]) for l in head)
+print("RESULT " + json.dumps(out))
+"""
+
+
+def _run_child(env_extra):
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, BF_REPO=ROOT, **env_extra)
+    r = subprocess.run([sys.executable, "-c", _PERSISTENT_CHILD], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return json.loads([l for l in r.stdout.split("\n") if l.startswith("RESULT ")][-1][7:])
+
+
+def test_persistent_ticket_launch_and_item_timeline_are_bit_identical_to_the_plain_launches(tmp_path):
+    """BFHIP_PERSISTENT=1 (experimental): stages with more items than wavefront slots run as one persistent grid whose
+    wavefronts draw pooled tickets (bfStageKernelC128P); BFHIP_TIMELINE_FILE: the diagnostic launch that records every
+    item's start and end.  Both read the environment once per process, hence the child processes.  Same items, same
+    arithmetic: the results are bit-identical to the plain launches', apply after apply (the last draw of a launch
+    resets its pool)."""
+    plain = _run_child({"BFHIP_PERSISTENT": "0"})
+    persistent = _run_child({"BFHIP_PERSISTENT": "1"})
+    assert persistent["1"] == plain["1"] and persistent["2"] == plain["2"]
+    tl = str(tmp_path / "items.timeline")
+    for mode in ("0", "1"):
+        if os.path.exists(tl):
+            os.remove(tl)
+        traced = _run_child({"BFHIP_PERSISTENT": mode, "BFHIP_TIMELINE_FILE": tl})
+        assert traced["1"] == plain["1"] and traced["2"] == plain["2"]
+        assert traced["timeline_launches"] > 0 and traced["timeline_items"] > 100000

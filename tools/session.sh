@@ -69,4 +69,11 @@ import json
 d = json.load(open("$O/st_fwd.out")); print("streamer", d["value"], d["ms_per_step"], d["roofline"]["frac"], "adjoint", d["adjoint"]["ms_per_apply"], d["adjoint"]["frac_of_hbm_peak"], "cov", d.get("cov_matvec"))
 PY
                grep "stage " $O/st_fwd.err | tail -12; }
+three()      { step t_shard3 300 $B --emulate-world 8 --emulate-rank 3 --steps 50 --no-extra --no-cpu-baseline --shard rows
+               python -c "import json; d = json.load(open('$O/t_shard3.out')); print('shard 3/8', d['ms_per_step'], d['roofline']['frac'])"
+               step t_n65536 200 $B --npoints 65536 --steps 50 --warmup 5 --no-cpu-baseline --no-extra
+               python -c "import json; d = json.load(open('$O/t_n65536.out')); print('N=65536', d['ms_per_step'], d['roofline']['frac'])"
+               step t_head 300 $B --steps 20 --warmup 3 --no-cpu-baseline --no-extra
+               python -c "import json; d = json.load(open('$O/t_head.out')); print('headline', d['ms_per_step'], d['roofline']['frac'])"; }
+c128tests()  { step pytest_c 900 python -m pytest tests -m gpu -x -q -k "parity or fullsize or config4 or gmres or decor"; tail -3 $O/pytest_c.out; }
 for s in "$@"; do $s; done
