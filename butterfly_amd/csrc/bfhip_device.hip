@@ -35,11 +35,11 @@
 #include <stdlib.h>
 
 #include "bfhip_internal.h"
+#include "bfhip_stage_c128.h"
 #include "../../include/bfhip_abi.h"
 #include "../../include/bfhip_synth.h"
 
 #define BF_WAVES_PER_WG 4
-#define BF_XCAP 256            /* must equal BfPlan.xcap */
 #define BF_WAVE_LDS_BYTES (BF_XCAP * 16)
 
 static int hipFail(hipError_t e, char const *what) {
@@ -55,35 +55,6 @@ template <int DT> struct Traits;
 template <> struct Traits<BFHIP_C128> { using S = double; static constexpr int EPL = 1; static constexpr bool CPLX = true; };
 template <> struct Traits<BFHIP_F64> { using S = double; static constexpr int EPL = 2; static constexpr bool CPLX = false; };
 template <> struct Traits<BFHIP_F32> { using S = float; static constexpr int EPL = 4; static constexpr bool CPLX = false; };
-
-struct StageParams {
-  void const *arena;
-  BfDevItem const *items;
-  BfDevPiece const *pieces;
-  uint32_t numItems;
-  uint32_t nrhs;
-  uint32_t coopItems;    // transposed: items [0, coopItems) get a workgroup each, its 4 wavefronts share the pieces
-  uint32_t pad;
-  void const *x;
-  void *y;
-  void *temp;
-  void const *zero;   // >= 1 KiB of zeros (X fragments of out-of-range columns)
-};
-
-// Leaf data is read exactly once per apply: stream it with the non-temporal
-// policy so it does not displace the (re-read) vectors from L2 / Infinity Cache.
-#ifndef BF_STREAM_NT
-#define BF_STREAM_NT 1
-#endif
-typedef double bf_d2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ double2 bfLoadStream(double2 const *p) {
-#if BF_STREAM_NT
-  bf_d2 v = __builtin_nontemporal_load((bf_d2 const *)p);
-  return make_double2(v.x, v.y);
-#else
-  return *p;
-#endif
-}
 
 typedef unsigned int bf_u4 __attribute__((ext_vector_type(4)));
 template <typename V> __device__ __forceinline__ V bfLoadStreamV(V const *p) {
@@ -120,166 +91,17 @@ __device__ __forceinline__ BfDevPiece bfPieceWinGet(BfPieceWin const &win, uint3
   return pc;
 }
 
-__device__ __forceinline__ void waveSync() {
-  // LDS traffic of one wave is issued in order; this only stops the compiler
-  // from moving LDS accesses across the hand-off between lanes.
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
 // ---------------------------------------------------------------------------
 // complex128 stage kernel
 // ---------------------------------------------------------------------------
-#ifndef BF_C128_UNROLL
-#define BF_C128_UNROLL 8
-#endif
-// Wavefronts per workgroup of this kernel.  A wavefront slot is refilled only when a whole workgroup's worth of slots is
-// free on its CU: with 4-wavefront workgroups of unequal items, per-item timelines (tools/timeline.py) show 10 - 15 % of
-// the slots empty through the second half of a short launch -- 3 - 5 us between the end of an item and the start of its
-// replacement -- and this kernel's bandwidth is proportional to the wavefronts that stream.
-#ifndef BF_C128_WG_WAVES
-#define BF_C128_WG_WAVES 1
-#endif
-// (TL: the diagnostic instantiation records when every item started and ended, BFHIP_TIMELINE_FILE in bfdevLaunchStage)
-// Index tables are read-only for the whole launch: loaded through the constant address space so that a wave-uniform
-// load stays a scalar load (s_load, scalar cache) even in a kernel that stores and draws tickets before it -- after a
-// store that may alias, hipcc otherwise turns every such load into a vector load + readfirstlane, a trip through the
-// vector memory pipe that is busy streaming.  (Only there: in the one-item kernel the loads are scalar anyway, and with
-// this form hipcc schedules its column loop for 54 VGPRs instead of 88 -- 8 wavefronts per SIMD with fewer loads in
-// flight each, 20 - 60 % slower.)
-template <typename T>
-__device__ __forceinline__ T bfConstLoad(T const *q) {
-  static_assert(sizeof(T) % 4 == 0, "dword-sized records");
-  typedef uint32_t const __attribute__((address_space(4))) *CP;
-  CP const w = (CP)(uintptr_t)q;
-  union { T v; uint32_t u[sizeof(T) / 4]; } r;
-#pragma unroll
-  for (unsigned k = 0; k < sizeof(T) / 4; ++k) r.u[k] = w[k];
-  return r.v;
-}
-
-template <bool TL, bool PERSIST>
-__device__ __forceinline__ void bfItemC128(StageParams const &p, uint32_t const item, double2 *xs, int const lane, uint64_t *timeline) {
-  uint64_t tlStart = 0;
-  if (TL) tlStart = wall_clock64();
-  BfDevItem const it = PERSIST ? bfConstLoad(p.items + item) : p.items[item];
-  uint32_t const mr = it.mrFlags & 0xffffu;
-  uint32_t const g = 64u / mr;
-  uint32_t const G = g * mr;
-  bool const active = (uint32_t)lane < G;
-  uint32_t const lc = active ? (uint32_t)lane : G - 1;   // clamped lane: inactive lanes recompute the last slot
-  uint32_t const c = lc / mr;
-  uint32_t const r = lc - c * mr;
-  double2 const *arena = (double2 const *)p.arena;
-  uint32_t const nrhs = p.nrhs;
-  double2 *out = (it.mrFlags & BF_ITEM_OUT_Y) ? (double2 *)p.y : (double2 *)p.temp;
-
-  // (Measured and set aside, round 3: the descriptor of piece pi + 1 requested while piece pi streams, and x gathered
-  // first with the first 3 - 4 loads of the piece already in flight behind it -- ISA as intended, same times at N = 65536,
-  // on a 1/8 shard and at the headline size: the round trips at the head of a piece are not what the short launches lose.)
-  for (uint32_t q = 0; q < nrhs; ++q) {
-    double accr = 0.0, acci = 0.0;
-    for (uint32_t pi = 0; pi < it.numPieces; ++pi) {
-      BfDevPiece const pc = PERSIST ? bfConstLoad(p.pieces + it.pieceBegin + pi) : p.pieces[it.pieceBegin + pi];
-      double2 const *xin = (pc.flags & BF_PIECE_IN_X) ? (double2 const *)p.x : (double2 const *)p.temp;
-      xin += (uint64_t)pc.inOff * nrhs + q;
-      uint32_t const n = pc.ncols;
-      if (pc.flags & BF_PIECE_IDENTITY) {
-        if (c == 0 && active) {
-          double2 v = xin[(uint64_t)r * nrhs];
-          accr += v.x; acci += v.y;
-        }
-        continue;
-      }
-      // gather the input sub-vector into LDS
-      waveSync();   // previous piece's reads are done before overwriting
-      for (uint32_t j = lane; j < n; j += 64) xs[j] = xin[(uint64_t)j * nrhs];
-      waveSync();
-      double2 const *ap = arena + pc.dataOff + lc;
-      uint32_t const nfull = n / g;
-      uint32_t j = c;
-      uint32_t s = 0;
-#pragma unroll BF_C128_UNROLL
-      for (; s < nfull; ++s) {
-        double2 a = bfLoadStream(ap + (uint64_t)s * G);
-        double2 xv = xs[j];
-        accr = fma(a.x, xv.x, accr); accr = fma(-a.y, xv.y, accr);
-        acci = fma(a.x, xv.y, acci); acci = fma(a.y, xv.x, acci);
-        j += g;
-      }
-      uint32_t const rem = n - nfull * g;
-      if (active && c < rem) {
-        double2 a = bfLoadStream(ap + (uint64_t)nfull * G);
-        double2 xv = xs[j];
-        accr = fma(a.x, xv.x, accr); accr = fma(-a.y, xv.y, accr);
-        acci = fma(a.x, xv.y, acci); acci = fma(a.y, xv.x, acci);
-      }
-    }
-    // combine the g column groups (fixed order) and store
-    waveSync();
-    xs[lane] = make_double2(accr, acci);
-    waveSync();
-    if ((uint32_t)lane < mr) {
-      double sr = 0.0, si = 0.0;
-      for (uint32_t cc = 0; cc < g; ++cc) { double2 v = xs[cc * mr + lane]; sr += v.x; si += v.y; }
-      out[((uint64_t)it.outOff + lane) * nrhs + q] = make_double2(sr, si);
-    }
-  }
-  if (TL) {
-    __builtin_amdgcn_s_waitcnt(0);       // the item's stores have been issued and its loads have returned
-    if (lane == 0) { timeline[2 * (uint64_t)item] = tlStart; timeline[2 * (uint64_t)item + 1] = wall_clock64(); }
-  }
-}
-
-// (5 wavefronts per SIMD is where this kernel is fastest -- 4: 30 % slower, 6 - 8 with a shorter unroll: the same; the loads
-// requested ahead of the x gather would otherwise cost the fifth: 100 VGPRs unconstrained, 74 with the bound, no spills)
 template <bool TL>
 __device__ __forceinline__ void bfStageBodyC128(StageParams const &p, double2 (*lds)[BF_XCAP], uint64_t *timeline) {
   int const wave = threadIdx.x >> 6;
   int const lane = threadIdx.x & 63;
   uint32_t const item = __builtin_amdgcn_readfirstlane(blockIdx.x * BF_C128_WG_WAVES + wave);
   if (item >= p.numItems) return;
-  bfItemC128<TL, false>(p, item, lds[wave], lane, timeline);
-}
-
-// Persistent form, for a stage with more items than the chip has wavefront slots (experimental, BFHIP_PERSISTENT=1).  With
-// one item per wavefront a slot stands empty for 3 - 5 us between the end of an item and the start of the workgroup that
-// replaces it (per-item timelines, tools/timeline.py: 5 - 10 % of the slots through the second half of a short launch), and
-// this kernel's bandwidth is proportional to the wavefronts that stream.  Here the grid is the chip's slots (one-wavefront
-// workgroups); wavefront w takes item w, then draws tickets for the items past the grid.  One ticket counter would be the
-// flow launch's mistake again (same-address atomics retire at ~19 ns device-wide): there are BF_TICKET_POOLS counters, 256
-// bytes apart (packed into two cache lines they behaved like one counter: the first items of a launch took 25 % longer),
-// pool p owning items grid + p, grid + p + POOLS, ... (the list is sorted big-first, so every pool sees the same sizes)
-// and drawn from by the wavefronts (w >> 3) % POOLS == p -- eight consecutive workgroups, one per XCD.  Nothing depends on
-// which workgroups are resident.  A launch draws exactly valid(p) + wavefronts(p) tickets from pool p (every wavefront ends
-// on one failed draw); whoever draws the last one puts the counter back to zero for the next launch: no host state, no
-// memset, safe to replay from a captured graph.  Same items, same arithmetic: bit-identical to the plain launch.
-// MEASURED (N = 65536): 1.135 ms against 1.08 ms plain.  The ticket's round trip takes the place of the dispatch gap: hipcc
-// waits for a returning atomic where it is issued (its wave-reduction needs the result), so the draw cannot ride under the
-// item's stream, and an asm atomic whose result the compiler does not know to be in flight is not safe to keep in a
-// register across the item.  Dealing the items out statically instead (no atomics: every wavefront streams 99.5 % of the
-// time against 94 %) loses more at the end of the launch, where nothing evens out the wavefronts' different speeds
-// (1.112 ms).  Kept as the tested starting point, like the flow launch.
-template <bool TL>
-__device__ __forceinline__ void bfStageBodyC128P(StageParams const &p, double2 *xs, uint32_t *tickets, uint64_t *timeline) {
-  int const lane = threadIdx.x & 63;
-  uint32_t const w = blockIdx.x, G = gridDim.x;           // G: a multiple of 8 * BF_TICKET_POOLS, < numItems
-  uint32_t const pool = (w >> 3) % BF_TICKET_POOLS;
-  uint32_t const dyn = p.numItems - G;
-  uint32_t const valid = dyn / BF_TICKET_POOLS + (pool < dyn % BF_TICKET_POOLS ? 1u : 0u);
-  uint32_t const draws = valid + G / BF_TICKET_POOLS;      // of this pool, per launch
-  uint32_t const one = lane == 0 ? 1u : 0u;               // (a data-dependent increment, not a branch on the lane: see bfFlowKernelC128)
-  uint32_t item = w;
-  uint32_t t;
-  for (;;) {
-    uint32_t const tk = __hip_atomic_fetch_add(tickets + pool * BF_TICKET_STRIDE, one, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    bfItemC128<TL, true>(p, item, xs, lane, timeline);
-    t = (uint32_t)__builtin_amdgcn_readfirstlane((int)tk);
-    if (t >= valid) break;
-    item = G + t * BF_TICKET_POOLS + pool;
-  }
-  if (t + 1 == draws) __hip_atomic_store(tickets + pool * BF_TICKET_STRIDE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // the pool's last draw of this launch
+  BfDevItem const it = p.items[item];
+  bfItemC128<TL, false>(p, it, item, lds[wave], lane, timeline, BfNoHook());
 }
 
 #ifdef BF_C128_WAVES
@@ -291,19 +113,10 @@ __global__ __launch_bounds__(BF_C128_WG_WAVES * 64) BF_C128_ATTR void bfStageKer
   __shared__ __attribute__((aligned(16))) double2 lds[BF_C128_WG_WAVES][BF_XCAP];
   bfStageBodyC128<false>(p, lds, nullptr);
 }
-__global__ __launch_bounds__(BF_C128_WG_WAVES * 64) void bfStageKernelC128Timeline(StageParams p, uint64_t *timeline) {
+__global__ __launch_bounds__(BF_C128_WG_WAVES * 64) BF_C128_ATTR void bfStageKernelC128Timeline(StageParams p, uint64_t *timeline) {
   __shared__ __attribute__((aligned(16))) double2 lds[BF_C128_WG_WAVES][BF_XCAP];
   bfStageBodyC128<true>(p, lds, timeline);
 }
-__global__ __launch_bounds__(64) BF_C128_ATTR void bfStageKernelC128P(StageParams p, uint32_t *tickets) {
-  __shared__ __attribute__((aligned(16))) double2 lds[BF_XCAP];
-  bfStageBodyC128P<false>(p, lds, tickets, nullptr);
-}
-__global__ __launch_bounds__(64) void bfStageKernelC128PTimeline(StageParams p, uint32_t *tickets, uint64_t *timeline) {
-  __shared__ __attribute__((aligned(16))) double2 lds[BF_XCAP];
-  bfStageBodyC128P<true>(p, lds, tickets, timeline);
-}
-
 
 // ---------------------------------------------------------------------------
 // Dependency-driven launch of a whole complex128 plan ("flow"): ONE persistent
@@ -1767,38 +1580,21 @@ int bfdevSynthFill(void *arena, uint32_t dtype, BfSynthPiece const *hostPieces, 
 }
 
 // Diagnostic (BFHIP_TIMELINE_FILE=path, complex128 stages with nrhs < 3): the launch is synchronous and appends, per launch,
-// a header line "launch <numItems> <numPieces>" and per item "<start> <end> <rows> <columns summed over its dense pieces>"
+// a header line "launch <numItems> <numPieces>" and per item "<start> <end> <rows> <columns summed over its dense pieces>
+// <pieces> <first descriptor here> <first x gathered> <first piece streamed> <all pieces done>"
 // (wall_clock64 ticks: 100 MHz) to the file -- where inside a launch the time goes (tools/timeline.py).
-// wavefront slots of the device for the complex128 stage kernel (5 per SIMD), rounded down to what the ticket pools need.
-// The persistent launches are OFF unless BFHIP_PERSISTENT=1: measured slower than the plain launches (see below).
-static uint32_t bfPersistentGrid() {
-  static int cached = -1;
-  if (cached < 0) {
-    int dev = 0, cus = 0;
-    char const *e = getenv("BFHIP_PERSISTENT");
-    if (!(e && e[0] == '1') || hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cached = 0;
-    else {
-      int occ = 0;
-      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, bfStageKernelC128P, 64, 0) != hipSuccess || occ <= 0) occ = 20;
-      uint64_t const slots = (uint64_t)cus * (uint64_t)occ;
-      cached = (int)(slots / (8u * BF_TICKET_POOLS) * (8u * BF_TICKET_POOLS));
-    }
-  }
-  return (uint32_t)cached;
-}
-
 static int bfTimelineLaunch(BfLaunchArgs const *a, StageParams const &p, uint32_t grid, uint32_t pgrid, hipStream_t s) {
   uint64_t const n = a->numItems;
   uint64_t *dev = nullptr;
-  if (hipMalloc((void **)&dev, (n ? n : 1) * 16) != hipSuccess) return bfhipFail(BFABI_ERROR_MEMORY_ERROR, "timeline buffer");
-  (void)hipMemsetAsync(dev, 0, (n ? n : 1) * 16, s);
-  if (pgrid) hipLaunchKernelGGL(bfStageKernelC128PTimeline, dim3(pgrid), dim3(64), 0, s, p, (uint32_t *)a->tickets, dev);
+  if (hipMalloc((void **)&dev, (n ? n : 1) * 64) != hipSuccess) return bfhipFail(BFABI_ERROR_MEMORY_ERROR, "timeline buffer");
+  (void)hipMemsetAsync(dev, 0, (n ? n : 1) * 64, s);
+  if (pgrid) (void)bfdevLaunchPersistC128(&p, pgrid, a->tickets, dev, s);
   else hipLaunchKernelGGL(bfStageKernelC128Timeline, dim3(grid), dim3(BF_C128_WG_WAVES * 64), 0, s, p, dev);
   int rc = hipFail(hipStreamSynchronize(s), "timeline launch");
   if (!rc && n) {
-    std::vector<uint64_t> t(2 * n);
+    std::vector<uint64_t> t(8 * n);
     std::vector<BfDevItem> items(n);
-    (void)hipMemcpy(t.data(), dev, n * 16, hipMemcpyDeviceToHost);
+    (void)hipMemcpy(t.data(), dev, n * 64, hipMemcpyDeviceToHost);
     (void)hipMemcpy(items.data(), a->items, n * sizeof(BfDevItem), hipMemcpyDeviceToHost);
     uint64_t np = 0;
     for (uint64_t i = 0; i < n; ++i) if ((uint64_t)items[i].pieceBegin + items[i].numPieces > np) np = (uint64_t)items[i].pieceBegin + items[i].numPieces;
@@ -1810,7 +1606,8 @@ static int bfTimelineLaunch(BfLaunchArgs const *a, StageParams const &p, uint32_
       for (uint64_t i = 0; i < n; ++i) {
         uint64_t cols = 0;
         for (uint32_t k = 0; k < items[i].numPieces; ++k) if (!(pieces[items[i].pieceBegin + k].flags & BF_PIECE_IDENTITY)) cols += pieces[items[i].pieceBegin + k].ncols;
-        fprintf(f, "%llu %llu %u %llu %u\n", (unsigned long long)t[2 * i], (unsigned long long)t[2 * i + 1], items[i].mrFlags & 0xffffu, (unsigned long long)cols, items[i].numPieces);
+        fprintf(f, "%llu %llu %u %llu %u %llu %llu %llu %llu\n", (unsigned long long)t[8 * i], (unsigned long long)t[8 * i + 5], items[i].mrFlags & 0xffffu, (unsigned long long)cols, items[i].numPieces,
+                (unsigned long long)t[8 * i + 1], (unsigned long long)t[8 * i + 2], (unsigned long long)t[8 * i + 3], (unsigned long long)t[8 * i + 4]);
       }
       fclose(f);
     }
@@ -1887,11 +1684,11 @@ int bfdevLaunchStage(BfLaunchArgs const *a, void *stream) {
   if (a->dtype == BFHIP_C128 && a->nrhs >= BF_MFMA_MIN_RHS) hipLaunchKernelGGL(bfStageKernelC128Mfma, dim3(grid), dim3(BF_WAVES_PER_WG * 64), 0, s, p);
   else if (a->dtype == BFHIP_C128) {
     grid = (uint32_t)((a->numItems + BF_C128_WG_WAVES - 1) / BF_C128_WG_WAVES);
-    uint32_t const slots = bfPersistentGrid();
+    uint32_t const slots = bfdevPersistentGrid();
     uint32_t const pgrid = (a->tickets && slots && a->numItems > slots) ? slots : 0;        /* 0: every item has a slot of its own anyway */
     if (getenv("BFHIP_TIMELINE_FILE")) return bfTimelineLaunch(a, p, grid, pgrid, s);
-    if (pgrid) hipLaunchKernelGGL(bfStageKernelC128P, dim3(pgrid), dim3(64), 0, s, p, (uint32_t *)a->tickets);
-    else hipLaunchKernelGGL(bfStageKernelC128, dim3(grid), dim3(BF_C128_WG_WAVES * 64), 0, s, p);
+    if (pgrid) return bfdevLaunchPersistC128(&p, pgrid, a->tickets, nullptr, s);
+    hipLaunchKernelGGL(bfStageKernelC128, dim3(grid), dim3(BF_C128_WG_WAVES * 64), 0, s, p);
   }
   else if (a->dtype == BFHIP_F64 || a->dtype == BFHIP_F32) {
     // items [firstSmall, numItems) are small (BF_ITEM_SMALL): their own launch, four to a wavefront; the two launches

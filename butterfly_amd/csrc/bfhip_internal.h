@@ -247,6 +247,9 @@ typedef struct BfLaunchArgs {
 #define BF_TICKET_POOLS 64u
 #define BF_TICKET_STRIDE 64u      /* uint32 between two pools' counters: a 256-byte block each -- counters that share a cache line share its atomic unit (measured: 64 packed counters behaved like one) */
 int bfdevLaunchStage(BfLaunchArgs const *a, void *stream);
+/* bfhip_persist.hip (experimental persistent launch of the complex128 stage kernel) */
+uint32_t bfdevPersistentGrid(void);
+int bfdevLaunchPersistC128(void const *stageParams, uint32_t grid, void *tickets, void *timeline, void *stream);
 
 /* dependency-driven launch of a whole forward complex128 plan (bfFlowKernelC128): see bfhip_device.hip */
 typedef struct BfFlowArgs {

@@ -1,7 +1,7 @@
 """Where inside a launch the time goes: runs one apply with BFHIP_TIMELINE_FILE set (bfhip_device.hip: every complex128
 stage launch records when each item started and ended, 100 MHz ticks) and prints, per launch, the bytes, the span, the
 rate, how long the launch took to reach half / 90 % of its peak concurrency, how long the tail below 50 % concurrency
-lasted, and the bytes moved in 10 us bins.
+lasted, the share of the items' lifetime spent before / between / after streaming, and (--bins) the bytes moved in 10 us bins.
   python tools/timeline.py --npoints 65536 [--emulate-world 8 --emulate-rank 3]"""
 import argparse, json, os, sys, tempfile
 import numpy as np
@@ -44,7 +44,7 @@ def main():
             i += 1
             continue
         ni = int(lines[i].split()[1])
-        a = np.array([[int(v) for v in lines[i + 1 + j].split()] for j in range(ni)], dtype=np.int64).reshape(ni, 5)
+        a = np.array([[int(v) for v in lines[i + 1 + j].split()] for j in range(ni)], dtype=np.int64).reshape(ni, 9)
         i += 1 + ni
         raws[f"launch{len(out)}"] = a
         t0, t1 = a[:, 0] * 10e-3, a[:, 1] * 10e-3                    # us
@@ -63,6 +63,13 @@ def main():
                "us_to_half_peak": t_half, "us_to_90pct_peak": t_90, "tail_below_half_us": span - last_above_half,
                "item_us_median": float(np.median(t1 - t0)), "item_us_max": float((t1 - t0).max()), "item_kb_median": float(np.median(nb)) / 1e3,
                "item_kb_max": float(nb.max()) / 1e3, "first_item_end_us": float(t1.min())}
+        # inside the items (100 MHz stamps; items with a dense piece): record + first descriptor, first x gather, streaming, reduce + store
+        ok = (a[:, 5] > 0) & (a[:, 6] > 0) & (a[:, 8] > 0)
+        if ok.any():
+            td, tx, te = a[ok, 5] * 10e-3 - base, a[ok, 6] * 10e-3 - base, a[ok, 8] * 10e-3 - base
+            life = (t1 - t0)[ok].sum()
+            rec["share_of_item_time"] = {"record_and_descriptor": float((td - t0[ok]).sum() / life), "first_x_gather": float((tx - td).sum() / life),
+                                         "pieces": float((te - tx).sum() / life), "reduce_and_store": float((t1[ok] - te).sum() / life)}
         if args.bins:
             # bytes attributed uniformly over each item's lifetime, 10 us bins
             edges = np.arange(0, span + 10, 10.0)
