@@ -572,7 +572,7 @@ def main():
         else:
             roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                        "kernel": ("bfFlowKernelC128" if one_launch else "bfStageKernelC128") if not real else f"bfStageKernelReal<{dtype}>",
+                        "kernel": ("bfFlowKernelC128" if one_launch else "bfStageKernelC128") if not real else f"bfStageKernelRealBoth<{dtype}>",
                         "launches_per_apply": per_apply,
                         **({"rank": prof_rank, "note": "the slowest rank's stage kernels (it bounds the step); bytes = that rank's shard"} if multi else {}),
                         "avg_launch_ms": avg_launch_ms, "algorithmic_bytes_per_launch": bytes_per_apply / max(per_apply, 1),
@@ -601,12 +601,14 @@ def main():
                 pass
         # context for `frac` (informational; `peak` stays the guide's figure): what a pure stream of
         # non-temporal reads / a bare loop of these MFMAs reaches on an MI355X of this pool
-        for key, fn, fld in (("measured_stream_read_gbs", "r2_hbm_peak.json", "read_nt_gbs"), ("measured_mfma_loop_tflops", "r2_mfma_peak.json", "fp64_mfma_16x16x4_tflops")):
+        for key, fn, fld in (("measured_stream_read_gbs", "hbm_peak.json", "read_nt_gbs"), ("measured_mfma_loop_tflops", "mfma_peak.json", "fp64_mfma_16x16x4_tflops")):
             if (roofline["bound"] == "hbm") == (fld == "read_nt_gbs"):
-                try:
-                    roofline[key] = json.load(open(os.path.join(ROOT, "profiles", fn)))[fld]
-                except Exception:
-                    pass
+                for rnd in (PROFILE_ROUND, "r2"):
+                    try:
+                        roofline[key] = json.load(open(os.path.join(ROOT, "profiles", f"{rnd}_{fn}")))[fld]
+                        break
+                    except Exception:
+                        pass
         if args.pcie:
             # host-buffer path (bfhipApply): H2D of x, all stages, D2H of y -- never the headline value
             t1 = time.perf_counter()

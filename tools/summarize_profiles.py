@@ -85,7 +85,24 @@ out["bfStageKernelC128Mfma_per_launch"] = per_launch("fetch_r64", "write_r64", "
 out["bfStageKernelC128_n65536_per_launch"] = per_launch("fetch_n65536", "write_n65536", "bfStageKernelC128")
 out["bfStageKernelT_c128_adjoint_per_apply"] = family_per_apply("fetch_adj", "write_adj", "void bfStageKernelT", "fetch_adj")
 out["bfStageKernelT_f32_streamer_adjoint_per_apply"] = family_per_apply("fetch_stT", "write_stT", "void bfStageKernelT", "fetch_stT")
-out["bfStageKernelReal_f32_streamer_per_launch"] = next((v for v in (per_launch("fetch_st", "write_st", k) for k in list(out.get("fetch_st", {})) if "bfStageKernelReal" in k) if v), None)
+
+
+def family_per_launch(fetch, write, prefixes):
+    """Mean HBM bytes per launch over a family of kernels (a real stage is ONE launch of bfStageKernelRealBoth, or of
+    bfStageKernelReal / bfStageKernelSmall alone when it has one kind of item only)."""
+    try:
+        sel = lambda d, c: [v[c] for k, v in d.items() if any(k.startswith(q) for q in prefixes) and c in v]
+        ff, ww = sel(out[fetch], "FETCH_SIZE"), sel(out[write], "WRITE_SIZE")
+        n = sum(v["dispatches"] for v in ff)
+        if not n or n != sum(v["dispatches"] for v in ww):
+            return None
+        f, w = sum(v["sum"] for v in ff) * 1024 * 2 / n, sum(v["sum"] for v in ww) * 1024 / n
+        return {"fetch_bytes_corrected": f, "write_bytes": w, "hbm_bytes": f + w, "dispatches": n}
+    except KeyError:
+        return None
+
+
+out["bfStageKernelReal_f32_streamer_per_launch"] = family_per_launch("fetch_st", "write_st", ("void bfStageKernelReal", "void bfStageKernelSmall"))
 for nm, key in (("stats_r1", "bfStageKernelC128_per_launch"), ("stats_r64", "bfStageKernelC128Mfma_per_launch"), ("stats_st", "bfStageKernelReal_f32_streamer_per_launch"),
                 ("stats_n65536", "bfStageKernelC128_n65536_per_launch")):
     p = f"{src}/{nm}.json"
