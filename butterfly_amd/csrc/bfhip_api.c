@@ -689,6 +689,7 @@ static int runPlan(BfhipOperator *op, BfPlan *plan, void const *dX, size_t nrhs,
       if (!st->dTickets) {        /* first apply: the stage's ticket counters (one-time, not stream-ordered) */
         if ((rc = bfdevMalloc(&st->dTickets, BF_TICKET_POOLS * BF_TICKET_STRIDE * 4))) goto out;
         if ((rc = bfdevMemset(st->dTickets, 0, BF_TICKET_POOLS * BF_TICKET_STRIDE * 4))) goto out;
+        if ((rc = bfdevSync(NULL))) goto out;        /* the fill is ordered on the null stream only: done before anything on the caller's stream can draw */
       }
       a.tickets = st->dTickets;
     }

@@ -63,6 +63,13 @@ enum {
                                     not for the previous stage; bit-identical results) instead of one launch per stage.
                                     Measured slower than the staged launches on MI355X: off by default */
 };
+/* Environment variables read by the library (diagnostics and experiments; none is needed for normal use):
+ *   BFHIP_FLOW=1            as BFHIP_FLAG_FLOW for every operator compiled in the process
+ *   BFHIP_PERSISTENT=1      complex128 stages with more items than wavefront slots run as a persistent grid that draws
+ *                           pooled tickets (bfhip_persist.hip; bit-identical results, measured equal to slower; read once)
+ *   BFHIP_TIMELINE_FILE=p   every complex128 stage launch (1 - 2 right-hand sides) becomes a synchronous diagnostic launch
+ *                           that appends each item's start / end stamps to file p (tools/timeline.py; same results)
+ *   BFHIP_JACOBI_GLOBAL=1   builder: every SVD problem through the global-memory fallback kernel (test hook) */
 
 typedef struct BfhipOptions {
   uint32_t structSize;      /* = sizeof(BfhipOptions) */
