@@ -416,6 +416,7 @@ int bfhipCompileIrFill(BfIr *ir, BfhipOptions const *opts, BfFillFn fill, void *
     if (ir->dtype != BFHIP_F64) { rc = bfhipFail(BFABI_ERROR_TYPE_ERROR, "demoteToF32 applies to real operands only"); goto done; }
     po.storeDtype = BFHIP_F32;
   }
+  po.groupByInput = o.maxRhs >= 3;
   po.minChunkRows = o.maxRhs >= 3 ? 32 : 16;   /* operators compiled for RHS blocks run on the matrix-core kernel */
   po.rowBlockBegin = o.rowBlockBegin;
   po.rowAlignBytes = 128;      /* rows of row-major pieces on 128-byte lines: the forward kernel gains 1 - 3 % on them, the transposed one 3 % */

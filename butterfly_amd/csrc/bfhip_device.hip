@@ -411,165 +411,7 @@ __global__ __launch_bounds__(BF_WAVES_PER_WG * 64) __attribute__((amdgpu_waves_p
   }
 }
 
-// ---------------------------------------------------------------------------
-// complex128 stage kernel for blocks of right-hand sides (nrhs >= 3): the same
-// items and the same packed pieces, contracted on the FP64 matrix cores.
-//
-// One wavefront per item; per 16-row slab and per chunk of <= 64 RHS it keeps
-// 4 (RHS tiles) x 2 (re, im) accumulators of v_mfma_f64_16x16x4_f64.  Per
-// k-step (4 leaf columns) one 16-byte load per lane fetches the A fragment
-// (lane l: row l&15, column l>>4 -- contiguous in the column-major piece) and
-// one per RHS tile the X fragment (lane l: X row l>>4, RHS l&15); a complex
-// multiply-accumulate is 4 real MFMAs (re += Ar*Br - Ai*Bi, im += Ar*Bi + Ai*Br).
-// Arithmetic intensity at nrhs = 64 is 32 flop per leaf byte, above the
-// ~10 flop/B ridge: this kernel is bound by the FP64 MFMA rate (78.6 TFLOP/s),
-// tile quantization (rows to 16, columns to 4) costs a few % at 16 points per
-// wavelength where blocks are 17..770 wide.
-// f64 fragment maps (cdna_hip_programming.md section 3): A[i = l&15][k = l>>4],
-// B[k = l>>4][j = l&15], D reg v of lane l = D[i = 4v + (l>>4)][j = l&15].
-// ---------------------------------------------------------------------------
-typedef double bf_d4 __attribute__((ext_vector_type(4)));
-
-// One pass = MS 16-row slabs x NT 16-RHS tiles of one item, over all its pieces.
-// The k-loop of a piece is one basic block: the fragments of k-step kk+1 are
-// requested (clamped, always-valid addresses) before the 4*MS*NT MFMAs of
-// k-step kk issue, so with two waves per SIMD one wave's MFMAs cover the
-// other's loads.  Columns past the piece end (last k-step when n % 4 != 0) are
-// neutralised by zeroing the X fragment with a select; RHS past nrhs only
-// produce columns that are never stored.  Identity pieces are added at store.
-template <int NT, int MS>
-__device__ __forceinline__ void bfMfmaPass(StageParams const &p, BfDevItem const &it, uint32_t mr, uint32_t s0,
-                                           uint32_t q0, uint32_t li, uint32_t lk) {
-  uint32_t const nrhs = p.nrhs;
-  double2 const *arena = (double2 const *)p.arena;
-  double2 *out = (it.mrFlags & BF_ITEM_OUT_Y) ? (double2 *)p.y : (double2 *)p.temp;
-  bf_d4 accr[MS][NT], acci[MS][NT];
-#pragma unroll
-  for (int m = 0; m < MS; ++m)
-#pragma unroll
-    for (int t = 0; t < NT; ++t) { accr[m][t] = (bf_d4){0, 0, 0, 0}; acci[m][t] = (bf_d4){0, 0, 0, 0}; }
-  uint32_t arow[MS];
-#pragma unroll
-  for (int m = 0; m < MS; ++m) arow[m] = min(s0 + 16u * m + li, mr - 1);   // clamped: rows past the item end are never stored
-  uint32_t const qmax = nrhs - 1 - q0;
-  uint32_t qoff[NT];
-#pragma unroll
-  for (int t = 0; t < NT; ++t) qoff[t] = (16u * t + li <= qmax) ? 16u * t : 0u;
-  bool hasIdentity = false;
-
-  for (uint32_t pi = 0; pi < it.numPieces; ++pi) {
-    BfDevPiece const pc = p.pieces[it.pieceBegin + pi];
-    if (pc.flags & BF_PIECE_IDENTITY) { hasIdentity = true; continue; }
-    double2 const *xin = (pc.flags & BF_PIECE_IN_X) ? (double2 const *)p.x : (double2 const *)p.temp;
-    xin += (uint64_t)pc.inOff * nrhs + q0 + li;
-    uint32_t const n = pc.ncols;
-    double2 const *ap = arena + pc.dataOff;
-    uint32_t const ksteps = (n + 3) / 4;
-    uint32_t const nlast = n - 1;
-    double2 aCur[MS], bCur[NT];
-    {
-      uint32_t const c0 = min(lk, nlast);
-      double2 const *a0 = ap + (uint64_t)c0 * mr, *x0 = xin + (uint64_t)c0 * nrhs;
-#pragma unroll
-      for (int m = 0; m < MS; ++m) aCur[m] = bfLoadStream(a0 + arow[m]);
-#pragma unroll
-      for (int t = 0; t < NT; ++t) bCur[t] = x0[qoff[t]];
-    }
-    for (uint32_t kk = 0; kk < ksteps; ++kk) {
-      uint32_t const cn = min(4 * (kk + 1) + lk, nlast);
-      bool const cvalid = 4 * kk + lk < n;
-      double2 const *a1 = ap + (uint64_t)cn * mr, *x1 = xin + (uint64_t)cn * nrhs;
-      double2 aNxt[MS], bNxt[NT];
-#pragma unroll
-      for (int m = 0; m < MS; ++m) aNxt[m] = bfLoadStream(a1 + arow[m]);
-#pragma unroll
-      for (int t = 0; t < NT; ++t) bNxt[t] = x1[qoff[t]];
-      // keep the requests above the MFMAs of this step ...
-      __builtin_amdgcn_sched_barrier(0);
-      double bx[NT], by[NT];
-#pragma unroll
-      for (int t = 0; t < NT; ++t) { bx[t] = cvalid ? bCur[t].x : 0.0; by[t] = cvalid ? bCur[t].y : 0.0; }
-#pragma unroll
-      for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int m = 0; m < MS; ++m) {
-          accr[m][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(aCur[m].x, bx[t], accr[m][t], 0, 0, 0);
-          acci[m][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(aCur[m].x, by[t], acci[m][t], 0, 0, 0);
-        }
-#pragma unroll
-      for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int m = 0; m < MS; ++m) {
-          accr[m][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(-aCur[m].y, by[t], accr[m][t], 0, 0, 0);
-          acci[m][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(aCur[m].y, bx[t], acci[m][t], 0, 0, 0);
-        }
-      // ... and their completion wait below them: hipcc otherwise rotates the
-      // loop so that each step's MFMAs wait for the loads issued just before
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int m = 0; m < MS; ++m) { asm volatile("" : "+v"(aNxt[m].x), "+v"(aNxt[m].y)); aCur[m] = aNxt[m]; }
-#pragma unroll
-      for (int t = 0; t < NT; ++t) { asm volatile("" : "+v"(bNxt[t].x), "+v"(bNxt[t].y)); bCur[t] = bNxt[t]; }
-    }
-  }
-#pragma unroll
-  for (int m = 0; m < MS; ++m)
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-      for (int v = 0; v < 4; ++v) {
-        uint32_t const row = s0 + 16u * m + 4 * v + lk;
-        if (row < mr && 16u * t + li <= qmax) {
-          double re = accr[m][t][v], im = acci[m][t][v];
-          if (hasIdentity) {      // rare (real-operand zoo; complex operands have none)
-            for (uint32_t pi = 0; pi < it.numPieces; ++pi) {
-              BfDevPiece const pc = p.pieces[it.pieceBegin + pi];
-              if (!(pc.flags & BF_PIECE_IDENTITY)) continue;
-              double2 const *xin = (pc.flags & BF_PIECE_IN_X) ? (double2 const *)p.x : (double2 const *)p.temp;
-              double2 xv = xin[((uint64_t)pc.inOff + row) * nrhs + q0 + 16 * t + li];
-              re += xv.x; im += xv.y;
-            }
-          }
-          out[((uint64_t)it.outOff + row) * nrhs + q0 + 16 * t + li] = make_double2(re, im);
-        }
-      }
-}
-
-#define BF_MFMA_PASS bfMfmaPass
-#define BF_MFMA_WAVES_PER_SIMD 2
-#ifndef BF_MFMA_MIN_RHS
-#define BF_MFMA_MIN_RHS 3
-#endif
-
-template <int MS>
-__device__ __forceinline__ void bfMfmaDispatch(uint32_t nt, StageParams const &p, BfDevItem const &it, uint32_t mr,
-                                               uint32_t s0, uint32_t q0, uint32_t li, uint32_t lk) {
-  switch (nt) {
-  case 4: BF_MFMA_PASS<4, MS>(p, it, mr, s0, q0, li, lk); break;
-  case 3: BF_MFMA_PASS<3, MS>(p, it, mr, s0, q0, li, lk); break;
-  case 2: BF_MFMA_PASS<2, MS>(p, it, mr, s0, q0, li, lk); break;
-  default: BF_MFMA_PASS<1, MS>(p, it, mr, s0, q0, li, lk); break;
-  }
-}
-
-__global__ __launch_bounds__(BF_WAVES_PER_WG * 64, BF_MFMA_WAVES_PER_SIMD) void bfStageKernelC128Mfma(StageParams p) {
-  int const wave = threadIdx.x >> 6;
-  int const lane = threadIdx.x & 63;
-  uint32_t item = __builtin_amdgcn_readfirstlane(blockIdx.x * BF_WAVES_PER_WG + wave);
-  if (item >= p.numItems) return;
-  BfDevItem const it = p.items[item];
-  uint32_t const mr = it.mrFlags & 0xffffu;
-  uint32_t const nrhs = p.nrhs;
-  uint32_t const li = lane & 15, lk = lane >> 4;
-  for (uint32_t q0 = 0; q0 < nrhs; q0 += 64) {
-    uint32_t const nt = (nrhs - q0 >= 64) ? 4u : (nrhs - q0 + 15u) / 16u;
-    uint32_t s0 = 0;
-    while (s0 < mr) {
-      if (mr - s0 > 16) { bfMfmaDispatch<2>(nt, p, it, mr, s0, q0, li, lk); s0 += 32; }
-      else { bfMfmaDispatch<1>(nt, p, it, mr, s0, q0, li, lk); s0 += 16; }
-    }
-  }
-}
+#include "bfhip_stage_mfma.h"
 
 // One row-major piece of MR rows (see the row-major branch of bfStageKernelReal): lane owns 16-byte units u = lane,
 // lane + 64, ... of every row; UNR units are in flight at once, so (MR + 1) * UNR independent loads per lane.  All
@@ -1681,7 +1523,7 @@ int bfdevLaunchStage(BfLaunchArgs const *a, void *stream) {
     }
     return hipFail(hipGetLastError(), "transposed stage launch");
   }
-  if (a->dtype == BFHIP_C128 && a->nrhs >= BF_MFMA_MIN_RHS) hipLaunchKernelGGL(bfStageKernelC128Mfma, dim3(grid), dim3(BF_WAVES_PER_WG * 64), 0, s, p);
+  if (a->dtype == BFHIP_C128 && a->nrhs >= BF_MFMA_MIN_RHS) hipLaunchKernelGGL(bfStageKernelC128Mfma, dim3((uint32_t)a->numItems), dim3(64), 0, s, p);      /* one wavefront per workgroup */
   else if (a->dtype == BFHIP_C128) {
     grid = (uint32_t)((a->numItems + BF_C128_WG_WAVES - 1) / BF_C128_WG_WAVES);
     uint32_t const slots = bfdevPersistentGrid();

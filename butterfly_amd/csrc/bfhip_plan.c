@@ -489,6 +489,8 @@ typedef struct Group {
 
 typedef struct ItemTmp {
   uint64_t cost;
+  uint64_t sortCost;             /* what the list is ordered by: cost, or its bucket when neighbours are to share their input (cmpItemCost) */
+  uint64_t inKey;                /* (input buffer, first input element) of the group's first task; 0 unless sortCost is a bucket */
   uint64_t group;
   uint32_t rowBegin, rows;       /* chunk inside the group */
   uint32_t small, narrow;        /* small: runs four to a wavefront, sorted behind everything else; narrow: 16-column transposed item, sorted first */
@@ -498,7 +500,9 @@ static int cmpItemCost(void const *pa, void const *pb) {
   ItemTmp const *a = pa, *b = pb;
   if (a->small != b->small) return a->small < b->small ? -1 : 1;
   if (a->narrow != b->narrow) return a->narrow > b->narrow ? -1 : 1;
-  if (a->cost != b->cost) return a->cost > b->cost ? -1 : 1;      /* big first */
+  if (a->sortCost != b->sortCost) return a->sortCost > b->sortCost ? -1 : 1;      /* big first */
+  if (a->inKey != b->inKey) return a->inKey < b->inKey ? -1 : 1;
+  if (a->cost != b->cost) return a->cost > b->cost ? -1 : 1;
   if (a->group != b->group) return a->group < b->group ? -1 : 1;
   return a->rowBegin < b->rowBegin ? -1 : (a->rowBegin > b->rowBegin);
 }
@@ -876,6 +880,19 @@ int bfPlanBuild(BfIr const *ir, BfPlanOptions const *po, BfPlan *plan) {
         uint64_t rows = m - r0 < chunk ? m - r0 : chunk;
         tmp[ni].group = g; tmp[ni].rowBegin = (uint32_t)r0; tmp[ni].rows = (uint32_t)rows;
         tmp[ni].cost = rows * colsSum;
+        tmp[ni].sortCost = tmp[ni].cost;
+        tmp[ni].inKey = 0;
+        if (po->groupByInput && !T) {
+          /* Items that read the same input rows -- the row chunks of a group, and the sibling groups of a radix-4
+           * butterfly stage, which read the same column blocks (src/fac_helm2.c:277-318) -- become list neighbours, so
+           * that the RHS-block kernel runs them side by side on one XCD and their X panel is fetched into ONE L2 once:
+           * the list is big-first by cost BUCKET (quarter octaves), by input inside a bucket. */
+          uint64_t c = tmp[ni].cost ? tmp[ni].cost : 1;
+          uint32_t pbit = 63u - (uint32_t)__builtin_clzll(c);
+          tmp[ni].sortCost = (uint64_t)pbit * 4u + (pbit >= 2 ? (c >> (pbit - 2)) & 3u : 0u);
+          Task const *t0 = &b.tasks[groups[g].taskBegin];
+          tmp[ni].inKey = ((uint64_t)t0->inBuf << 40) | (t0->inOff & 0xffffffffffull);
+        }
         /* colsSum < 128 also means "not row-major" */
         tmp[ni].small = !T && plan->dtype != BFHIP_C128 && rows <= 2 * plan->epl && colsSum < BF_SMALL_COLS && piecesPerChunk <= BF_SMALL_PIECES;
         tmp[ni].narrow = groups[g].cls;

@@ -1,0 +1,279 @@
+// bfhip_stage_mfma.h -- complex128 stage kernel for blocks of right-hand sides (nrhs >= 3): the same items and the
+// same packed pieces as bfStageKernelC128, contracted on the FP64 matrix cores (v_mfma_f64_16x16x4_f64).  It replaces
+// the cblas_zgemm of every leaf of a level (reference src/mat_dense_complex.c:1704-1765) and the view / accumulate
+// passes around it (src/mat_block_coo.c:404-418, src/mat_block_diag.c:387-399).  Included by bfhip_device.hip only.
+//
+// Shape of the work.  An item is <= 64 rows of one output row group; its dense pieces are stored back to back,
+// column-major with the item's row count as the column stride, so the item's leaf data is ONE column-major
+// mr x C matrix (C = the sum of the pieces' widths) -- a *segment* -- whose column c multiplies one row of the
+// input vector.  The kernel writes tab[] (that row's byte offset, 32 bits per column) into LDS once per segment and then runs
+// one flat k-loop over the segment: piece boundaries do not exist inside the loop.  (A segment ends where the next
+// piece is not contiguous, reads another vector (x / intermediates), or the table is full; fac_helm2 items are one
+// segment, two in the last stage.)
+//
+// One pass = MS 16-row slabs x NT 16-RHS tiles: 4 * MS * NT MFMAs per k-step (4 leaf columns).  Fragment maps
+// (cdna_hip_programming.md section 3): A[i = l & 15][k = l >> 4], B[k = l >> 4][j = l & 15], D reg v of lane l =
+// D[i = 4 v + (l >> 4)][j = l & 15]; a complex multiply-accumulate is 4 real MFMAs, the -Ai*Bi term through the NEG
+// bit of the instruction (blgp bit 0 negates A on the f64 MFMA: tools/mfma_probe.hip).
+//
+// What the inner loop is made of, and why (tools/mfma_probe.hip, profiles/r4_mfma_probe.json):
+//   * ONE wavefront cannot keep the FP64 matrix pipe busy (0.75 of peak with 16 independent accumulators), two or more
+//     can (0.99): every cycle a wavefront spends on anything else costs a quarter of the pipe, so the loop holds no
+//     VALU address arithmetic, no selects and no register copies.  Fragments come through buffer loads -- a loop
+//     invariant VGPR offset, the k-step advance in an SGPR, columns / rows past the end of the segment returned as
+//     zeros by the range check (which includes the SGPR offset) instead of clamps + selects.
+//   * ONE set of fragment registers: a fragment is requested again right after the last MFMA that reads it (A of slab
+//     0 after the first half of the k-step, X tile t inside the second half, A of slab 1 at the end), half a k-step
+//     ahead of its next use; 128 accumulator + 24 fragment registers leave room for THREE wavefronts per SIMD, so a
+//     wavefront between items (table, stores) leaves two on the pipe.
+//   * The loads are asm statements and the waits are placed by hand: hipcc's wait insertion treats every load pending
+//     at a loop header as one lump (s_waitcnt vmcnt(0) at the top: the fragment requested last would be waited for
+//     first).  Loads return in order, so vmcnt(n) = "all but the n youngest have arrived".
+//   * One wavefront per workgroup: a slot is refilled as soon as its item ends.
+#ifndef BFHIP_STAGE_MFMA_H
+#define BFHIP_STAGE_MFMA_H
+
+#define BF_MF_TABCAP 2304u          /* columns of one segment: 9 KiB of LDS per wavefront, 12 wavefronts per CU */
+#define BF_MF_TABPAD 24u
+#define BF_MF_SPAN_BYTES (1u << 31) /* a segment's input rows span less than this many bytes (32-bit buffer offsets) */
+#ifndef BF_MFMA_WAVES_PER_SIMD
+#define BF_MFMA_WAVES_PER_SIMD 2
+#endif
+#ifndef BF_MF_XCD_RUN
+#define BF_MF_XCD_RUN 1u
+#endif
+#ifndef BF_MFMA_MIN_RHS
+#define BF_MFMA_MIN_RHS 3
+#endif
+
+typedef double bf_d4 __attribute__((ext_vector_type(4)));
+typedef int bf_i4 __attribute__((ext_vector_type(4)));
+union BfFrag { bf_u4 u; double d[2]; };
+
+// a raw buffer descriptor in SGPRs: 48-bit base, stride 0, num_records in bytes
+__device__ __forceinline__ bf_i4 bfMakeRsrc(void const *base, uint32_t bytes) {
+  uint64_t const b = (uint64_t)base;
+  bf_i4 r;
+  r.x = __builtin_amdgcn_readfirstlane((int)(uint32_t)b);
+  r.y = __builtin_amdgcn_readfirstlane((int)((uint32_t)(b >> 32) & 0xffffu));
+  r.z = __builtin_amdgcn_readfirstlane((int)bytes);
+  r.w = 0x00020000;
+  return r;
+}
+template <int STREAM, int OFF> __device__ __forceinline__ void bfFragLoad(BfFrag &f, uint32_t voff, bf_i4 rsrc, uint32_t soff) {
+  if (STREAM) asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:%4 nt" : "=v"(f.u) : "v"(voff), "s"(rsrc), "s"(soff), "n"(OFF));
+  else asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:%4" : "=v"(f.u) : "v"(voff), "s"(rsrc), "s"(soff), "n"(OFF));
+}
+template <int N> __device__ __forceinline__ void bfFragWait(BfFrag &f) { asm volatile("s_waitcnt vmcnt(%1)" : "+v"(f.u) : "n"(N)); }
+template <int N> __device__ __forceinline__ void bfFragWait(BfFrag &f, BfFrag &g) { asm volatile("s_waitcnt vmcnt(%2)" : "+v"(f.u), "+v"(g.u) : "n"(N)); }
+
+__device__ __forceinline__ void bfCmac(bf_d4 &accr, bf_d4 &acci, BfFrag const &a, BfFrag const &x) {
+  accr = __builtin_amdgcn_mfma_f64_16x16x4f64(a.d[0], x.d[0], accr, 0, 0, 0);
+  acci = __builtin_amdgcn_mfma_f64_16x16x4f64(a.d[0], x.d[1], acci, 0, 0, 0);
+  accr = __builtin_amdgcn_mfma_f64_16x16x4f64(a.d[1], x.d[1], accr, 0, 0, 1);      // - Ai * Bi
+  acci = __builtin_amdgcn_mfma_f64_16x16x4f64(a.d[1], x.d[0], acci, 0, 0, 0);
+}
+
+// What a segment's k-loop needs besides the table.
+struct BfMfSeg {
+  bf_i4 ra, rx;          // leaf matrix (mr x cols, column-major), input rows [minRow, maxRow] x the pass's RHS
+  uint32_t voffA;        // lane: (column lk of a k-step, row s0 + li); slab 1 is +256 bytes
+  uint32_t cX;           // lane: li * 16; + tab[column] = byte offset of the lane's X fragment
+  uint32_t stepA;        // 4 columns = 4 * mr * 16 bytes
+  uint32_t ksteps;
+};
+
+// The k-loop of one segment: MS slabs x NT tiles, two sets of fragment registers.  While the MFMAs of k-step ks read
+// set 0, the requests of k-step ks + 1 fill set 1, and the other way round in the second half of the (twice
+// unrolled) loop body, so nothing is ever copied.  Issue order of a k-step's requests: A0 (A1) X0 .. X(NT-1); the
+// wait in front of tile t lets the NT - 1 - t younger requests of its own set and the whole next set stay pending.
+// An odd number of k-steps ends with a k-step of zeros (the leaf fragments past the end of the segment).
+template <int NT, int MS, int SET>
+__device__ __forceinline__ void bfMfmaRequest(BfFrag (&a)[2][2], BfFrag (&x)[2][4], BfMfSeg const &sg, uint32_t soffA, uint32_t voffX) {
+  bfFragLoad<1, 0>(a[SET][0], sg.voffA, sg.ra, soffA);
+  if (MS > 1) bfFragLoad<1, 256>(a[SET][1], sg.voffA, sg.ra, soffA);
+  bfFragLoad<0, 0>(x[SET][0], voffX, sg.rx, 0);
+  if (NT > 1) bfFragLoad<0, 256>(x[SET][1], voffX, sg.rx, 0);
+  if (NT > 2) bfFragLoad<0, 512>(x[SET][2], voffX, sg.rx, 0);
+  if (NT > 3) bfFragLoad<0, 768>(x[SET][3], voffX, sg.rx, 0);
+}
+template <int NT, int MS, int SET, int T>
+__device__ __forceinline__ void bfMfmaTile(bf_d4 (&accr)[2][4], bf_d4 (&acci)[2][4], BfFrag (&a)[2][2], BfFrag (&x)[2][4]) {
+  if (T < NT) {
+    constexpr int pending = (NT - 1 - T) + NT + MS;
+    if (T == 0 && MS > 1) asm volatile("s_waitcnt vmcnt(%3)" : "+v"(a[SET][0].u), "+v"(a[SET][1].u), "+v"(x[SET][0].u) : "n"(pending));
+    else if (T == 0) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a[SET][0].u), "+v"(x[SET][0].u) : "n"(pending));
+    else asm volatile("s_waitcnt vmcnt(%1)" : "+v"(x[SET][T < NT ? T : 0].u) : "n"(pending));
+    bfCmac(accr[0][T], acci[0][T], a[SET][0], x[SET][T < NT ? T : 0]);
+    if (MS > 1) bfCmac(accr[1][T], acci[1][T], a[SET][1], x[SET][T < NT ? T : 0]);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+template <int NT, int MS>
+__device__ __forceinline__ void bfMfmaSegment(bf_d4 (&accr)[2][4], bf_d4 (&acci)[2][4], BfMfSeg const &sg, uint32_t const *tab, uint32_t lk) {
+  BfFrag a[2][2], x[2][4];
+  uint32_t ti = lk;
+  uint32_t soffA = 0;
+  bfMfmaRequest<NT, MS, 0>(a, x, sg, soffA, tab[ti] + sg.cX);
+  uint32_t t1 = tab[ti + 4], t2 = tab[ti + 8];      // read an iteration ahead of their use
+  ti += 12;
+  for (uint32_t ks = 0; ks < sg.ksteps; ks += 2) {
+    uint32_t const v1 = t1 + sg.cX, v2 = t2 + sg.cX;
+    t1 = tab[ti];                                    // the table is padded past the last k-step (BF_MF_TABPAD)
+    t2 = tab[ti + 4];
+    ti += 8;
+    soffA += sg.stepA;
+    __builtin_amdgcn_sched_barrier(0);
+    bfMfmaRequest<NT, MS, 1>(a, x, sg, soffA, v1);
+    __builtin_amdgcn_sched_barrier(0);
+    bfMfmaTile<NT, MS, 0, 0>(accr, acci, a, x);
+    bfMfmaTile<NT, MS, 0, 1>(accr, acci, a, x);
+    bfMfmaTile<NT, MS, 0, 2>(accr, acci, a, x);
+    bfMfmaTile<NT, MS, 0, 3>(accr, acci, a, x);
+    soffA += sg.stepA;
+    bfMfmaRequest<NT, MS, 0>(a, x, sg, soffA, v2);
+    __builtin_amdgcn_sched_barrier(0);
+    bfMfmaTile<NT, MS, 1, 0>(accr, acci, a, x);
+    bfMfmaTile<NT, MS, 1, 1>(accr, acci, a, x);
+    bfMfmaTile<NT, MS, 1, 2>(accr, acci, a, x);
+    bfMfmaTile<NT, MS, 1, 3>(accr, acci, a, x);
+  }
+  // the requests of the k-step past the end (zeros from the range check / a padded table row) must land before the
+  // registers are used again
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(a[0][0].u), "+v"(a[0][MS > 1 ? 1 : 0].u), "+v"(x[0][0].u), "+v"(x[0][NT > 1 ? 1 : 0].u), "+v"(x[0][NT > 2 ? 2 : 0].u), "+v"(x[0][NT > 3 ? 3 : 0].u));
+}
+
+// One pass = rows [s0, s0 + 16 MS) x RHS [q0, q0 + 16 NT) of one item, over all its segments.
+template <int NT, int MS>
+__device__ __forceinline__ void bfMfmaPass(StageParams const &p, BfDevItem const &it, uint32_t mr, uint32_t s0, uint32_t q0, uint32_t *tab, int lane) {
+  uint32_t const nrhs = p.nrhs;
+  uint32_t const li = lane & 15, lk = lane >> 4;
+  bf_d4 accr[2][4], acci[2][4];
+#pragma unroll
+  for (int m = 0; m < MS; ++m)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) { accr[m][t] = (bf_d4){0, 0, 0, 0}; acci[m][t] = (bf_d4){0, 0, 0, 0}; }
+  bool hasIdentity = false;
+  uint32_t const np = it.numPieces;
+  uint32_t const spanRows = BF_MF_SPAN_BYTES / (nrhs * 16u);
+  uint32_t pi = 0;
+  while (pi < np) {
+    // ---- the next segment: its row table into LDS, its extent into scalars.  (The descriptor window is loaded
+    // again for every segment: six registers that must not stay live across the k-loop.)
+    uint32_t cols = 0, minRow = 0, maxRow = 0, inX = 0;
+    uint64_t aOff = 0, expect = 0;
+    bool started = false;
+    BfPieceWin win;
+    uint32_t wbase = 0xffffff00u;
+    while (pi < np) {
+      if (pi - wbase >= 64u) {
+        wbase = pi;
+        win = bfPieceWinLoad(p.pieces + it.pieceBegin + wbase, np - wbase < 64u ? np - wbase : 64u, lane);
+      }
+      BfDevPiece const pc = bfPieceWinGet(win, pi - wbase);
+      if (pc.flags & BF_PIECE_IDENTITY) { hasIdentity = true; ++pi; continue; }
+      uint32_t const px = pc.flags & BF_PIECE_IN_X, last = pc.inOff + pc.ncols - 1;
+      uint32_t lo = pc.inOff, hi = last;
+      if (started) {
+        if (pc.dataOff != expect || px != inX || cols + pc.ncols > BF_MF_TABCAP) break;
+        lo = minRow < lo ? minRow : lo;
+        hi = maxRow > hi ? maxRow : hi;
+        if (hi - lo >= spanRows) break;
+      } else {
+        started = true;
+        aOff = pc.dataOff;
+        inX = px;
+      }
+      minRow = lo;
+      maxRow = hi;
+      for (uint32_t j = (uint32_t)lane; j < pc.ncols; j += 64u) tab[cols + j] = pc.inOff + j;
+      cols += pc.ncols;
+      expect = pc.dataOff + (uint64_t)mr * pc.ncols;
+      ++pi;
+    }
+    if (!cols) break;                      // identity pieces only
+    // columns past the end: the leaf fragment is zero there (range check), any row of the segment will do
+    if ((uint32_t)lane < BF_MF_TABPAD) tab[cols + lane] = minRow;
+    waveSync();
+    // rows -> byte offsets from the segment's first row (fits 32 bits: spanRows)
+    for (uint32_t j = (uint32_t)lane; j < cols + BF_MF_TABPAD; j += 64u) tab[j] = (tab[j] - minRow) * (nrhs * 16u);
+    waveSync();
+    BfMfSeg sg;
+    sg.stepA = 4u * mr * 16u;
+    sg.ksteps = (cols + 3u) / 4u;
+    sg.ra = bfMakeRsrc((double2 const *)p.arena + aOff, mr * cols * 16u);
+    char const *xin = inX ? (char const *)p.x : (char const *)p.temp;
+    // the last row ends with this pass's RHS (lanes past nrhs read zeros there, the next row's values elsewhere:
+    // columns of the product that are never stored)
+    sg.rx = bfMakeRsrc(xin + ((uint64_t)minRow * nrhs + q0) * 16u, ((maxRow - minRow) * nrhs + (nrhs - q0)) * 16u);
+    sg.voffA = (lk * mr + s0 + li) * 16u;          // rows past the item's end alias the next column: rows of the product that are never stored
+    sg.cX = li * 16u;
+    bfMfmaSegment<NT, MS>(accr, acci, sg, tab, lk);
+    waveSync();                                      // the table is rewritten by the next segment
+  }
+  double2 *out = (it.mrFlags & BF_ITEM_OUT_Y) ? (double2 *)p.y : (double2 *)p.temp;
+  uint32_t const qmax = nrhs - 1 - q0;
+  // (the lane's coordinates are derived again from an opaque copy: hipcc otherwise computes the store addresses
+  // before the k-loop and carries them through it, which costs the third wavefront per SIMD)
+  uint32_t lane2 = (uint32_t)lane;
+  asm volatile("" : "+v"(lane2));
+  uint32_t const li2 = lane2 & 15u, lk2 = lane2 >> 4;
+#pragma unroll
+  for (int m = 0; m < MS; ++m)
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        uint32_t const row = s0 + 16u * m + 4 * v + lk2;
+        if (row < mr && 16u * t + li2 <= qmax) {
+          double re = accr[m][t][v], im = acci[m][t][v];
+          if (hasIdentity) {      // rare (real-operand zoo; complex operands have none)
+            for (uint32_t k = 0; k < np; ++k) {
+              BfDevPiece const pc = p.pieces[it.pieceBegin + k];
+              if (!(pc.flags & BF_PIECE_IDENTITY)) continue;
+              double2 const *xin = (pc.flags & BF_PIECE_IN_X) ? (double2 const *)p.x : (double2 const *)p.temp;
+              double2 xv = xin[((uint64_t)pc.inOff + row) * nrhs + q0 + 16 * t + li2];
+              re += xv.x; im += xv.y;
+            }
+          }
+          out[((uint64_t)it.outOff + row) * nrhs + q0 + 16 * t + li2] = make_double2(re, im);
+        }
+      }
+  // stores and fragment requests share vmcnt: nothing of this pass may be pending when the next one counts
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+template <int MS>
+__device__ __forceinline__ void bfMfmaDispatch(uint32_t nt, StageParams const &p, BfDevItem const &it, uint32_t mr, uint32_t s0, uint32_t q0, uint32_t *tab, int lane) {
+  switch (nt) {
+  case 4: bfMfmaPass<4, MS>(p, it, mr, s0, q0, tab, lane); break;
+  case 3: bfMfmaPass<3, MS>(p, it, mr, s0, q0, tab, lane); break;
+  case 2: bfMfmaPass<2, MS>(p, it, mr, s0, q0, tab, lane); break;
+  default: bfMfmaPass<1, MS>(p, it, mr, s0, q0, tab, lane); break;
+  }
+}
+
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BF_MFMA_WAVES_PER_SIMD, BF_MFMA_WAVES_PER_SIMD))) void bfStageKernelC128Mfma(StageParams p) {
+  __shared__ uint32_t tab[BF_MF_TABCAP + BF_MF_TABPAD];
+  int const lane = threadIdx.x;
+  // Workgroups are dealt to the 8 XCDs round robin; neighbours in the item list (the row chunks of one row group:
+  // same cost, same input rows) are to meet in ONE L2, so runs of BF_MF_XCD_RUN list neighbours go to one XCD.
+  uint32_t item = blockIdx.x;
+  if (BF_MF_XCD_RUN > 1) {
+    uint32_t const blk = 8u * BF_MF_XCD_RUN;
+    if (item < p.numItems / blk * blk) { uint32_t const r = item % blk; item = item - r + (r % 8u) * BF_MF_XCD_RUN + r / 8u; }
+  }
+  if (item >= p.numItems) return;
+  BfDevItem const it = p.items[item];
+  uint32_t const mr = it.mrFlags & 0xffffu;
+  uint32_t const nrhs = p.nrhs;
+  for (uint32_t q0 = 0; q0 < nrhs; q0 += 64) {
+    uint32_t const nt = (nrhs - q0 >= 64) ? 4u : (nrhs - q0 + 15u) / 16u;
+    uint32_t s0 = 0;
+    while (s0 < mr) {
+      if (mr - s0 > 16) { bfMfmaDispatch<2>(nt, p, it, mr, s0, q0, tab, lane); s0 += 32; }
+      else { bfMfmaDispatch<1>(nt, p, it, mr, s0, q0, tab, lane); s0 += 16; }
+    }
+  }
+}
+#endif

@@ -76,4 +76,27 @@ three()      { step t_shard3 300 $B --emulate-world 8 --emulate-rank 3 --steps 5
                step t_head 300 $B --steps 20 --warmup 3 --no-cpu-baseline --no-extra
                python -c "import json; d = json.load(open('$O/t_head.out')); print('headline', d['ms_per_step'], d['roofline']['frac'])"; }
 c128tests()  { step pytest_c 900 python -m pytest tests -m gpu -x -q -k "parity or fullsize or config4 or gmres or decor"; tail -3 $O/pytest_c.out; }
+probe()      { step mfma_probe 300 tools/mfma_probe.bin; cat $O/mfma_probe.out; }
+diag64()     { for v in base NOA NOX NOAX; do
+                 if [ $v = base ]; then unset BFHIP_LIB_PATH; else export BFHIP_LIB_PATH=$R/butterfly_amd/csrc/exp/libbfhip_$v.so; fi
+                 step r64_$v 300 $B --nrhs 64 --steps 5 --warmup 2 --no-cpu-baseline --no-extra
+                 python -c "import json; d = json.load(open('$O/r64_$v.out')); print('$v', d['ms_per_step'], d['roofline']['achieved'])"; grep "stage " $O/r64_$v.err
+               done; unset BFHIP_LIB_PATH; }
+r64()        { step pytest_r64 600 python -m pytest tests -m gpu -x -q -k "rhs_block or dropin or nested or fullsize or linear or random"; tail -5 $O/pytest_r64.out;
+               step r64_n65536 300 $B --npoints 65536 --nrhs 64 --steps 10 --warmup 2 --no-cpu-baseline --no-extra
+               python -c "import json; d = json.load(open('$O/r64_n65536.out')); print('n65536', d['ms_per_step'], d['roofline']['achieved'], d['roofline']['frac'])"; grep "stage " $O/r64_n65536.err
+               step r64_head 300 $B --nrhs 64 --steps 5 --warmup 2 --no-extra
+               python -c "import json; d = json.load(open('$O/r64_head.out')); print('n262144', d['ms_per_step'], d['roofline']['achieved'], d['roofline']['frac'], d['cpu_baseline'].get('parity_rel_l2'))"; grep "stage " $O/r64_head.err; }
+xcd()        { for v in ${XCD_VARIANTS:-base X4 X8 X16}; do
+                 if [ $v = base ]; then unset BFHIP_LIB_PATH; else export BFHIP_LIB_PATH=$R/butterfly_amd/csrc/exp/libbfhip_$v.so; fi
+                 step x64_$v 300 $B --nrhs 64 --steps 5 --warmup 2 --no-cpu-baseline --no-extra
+                 python -c "import json; d = json.load(open('$O/x64_$v.out')); print('$v', d['ms_per_step'], d['roofline']['achieved'], d['roofline']['frac'])"; grep "stage " $O/x64_$v.err | tail -5
+               done; unset BFHIP_LIB_PATH; }
+pmc64()      { ( cd /tmp && export TMPDIR=/tmp
+                 for v in ${PMC_VARIANTS:-base}; do
+                   if [ $v = base ]; then unset BFHIP_LIB_PATH; else export BFHIP_LIB_PATH=$R/butterfly_amd/csrc/exp/libbfhip_$v.so; fi
+                   timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/fetch_$v -- python3 $R/bench.py --nrhs 64 --steps 2 --warmup 1 --no-cpu-baseline --no-extra > $O/fetch_$v.json 2> $O/fetch_$v.log; echo "fetch_$v exit=$?"
+                   timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/mfma_$v -- python3 $R/bench.py --nrhs 64 --steps 2 --warmup 1 --no-cpu-baseline --no-extra > $O/mfma_$v.json 2> $O/mfma_$v.log; echo "mfma_$v exit=$?"
+                   python3 $R/tools/pmc_quick.py $O/fetch_$v $O/mfma_$v
+                 done ) }
 for s in "$@"; do $s; done
