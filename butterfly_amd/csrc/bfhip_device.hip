@@ -1523,7 +1523,7 @@ int bfdevLaunchStage(BfLaunchArgs const *a, void *stream) {
     }
     return hipFail(hipGetLastError(), "transposed stage launch");
   }
-  if (a->dtype == BFHIP_C128 && a->nrhs >= BF_MFMA_MIN_RHS) hipLaunchKernelGGL(bfStageKernelC128Mfma, dim3((uint32_t)a->numItems), dim3(64), 0, s, p);      /* one wavefront per workgroup */
+  if (a->dtype == BFHIP_C128 && a->nrhs >= BF_MFMA_MIN_RHS) hipLaunchKernelGGL(bfStageKernelC128Mfma, dim3((uint32_t)((a->numItems + BF_MF_WG_WAVES - 1) / BF_MF_WG_WAVES)), dim3(64 * BF_MF_WG_WAVES), 0, s, p);
   else if (a->dtype == BFHIP_C128) {
     grid = (uint32_t)((a->numItems + BF_C128_WG_WAVES - 1) / BF_C128_WG_WAVES);
     uint32_t const slots = bfdevPersistentGrid();

@@ -29,7 +29,6 @@
 //   * The loads are asm statements and the waits are placed by hand: hipcc's wait insertion treats every load pending
 //     at a loop header as one lump (s_waitcnt vmcnt(0) at the top: the fragment requested last would be waited for
 //     first).  Loads return in order, so vmcnt(n) = "all but the n youngest have arrived".
-//   * One wavefront per workgroup: a slot is refilled as soon as its item ends.
 #ifndef BFHIP_STAGE_MFMA_H
 #define BFHIP_STAGE_MFMA_H
 
@@ -40,7 +39,10 @@
 #define BF_MFMA_WAVES_PER_SIMD 2
 #endif
 #ifndef BF_MF_XCD_RUN
-#define BF_MF_XCD_RUN 1u
+#define BF_MF_XCD_RUN 32u           /* workgroups */
+#endif
+#ifndef BF_MF_WG_WAVES
+#define BF_MF_WG_WAVES 1u
 #endif
 #ifndef BF_MFMA_MIN_RHS
 #define BF_MFMA_MIN_RHS 3
@@ -253,16 +255,22 @@ __device__ __forceinline__ void bfMfmaDispatch(uint32_t nt, StageParams const &p
   }
 }
 
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BF_MFMA_WAVES_PER_SIMD, BF_MFMA_WAVES_PER_SIMD))) void bfStageKernelC128Mfma(StageParams p) {
-  __shared__ uint32_t tab[BF_MF_TABCAP + BF_MF_TABPAD];
-  int const lane = threadIdx.x;
-  // Workgroups are dealt to the 8 XCDs round robin; neighbours in the item list (the row chunks of one row group:
-  // same cost, same input rows) are to meet in ONE L2, so runs of BF_MF_XCD_RUN list neighbours go to one XCD.
-  uint32_t item = blockIdx.x;
+__global__ __launch_bounds__(64 * BF_MF_WG_WAVES) __attribute__((amdgpu_waves_per_eu(BF_MFMA_WAVES_PER_SIMD, BF_MFMA_WAVES_PER_SIMD))) void bfStageKernelC128Mfma(StageParams p) {
+  __shared__ uint32_t tabs[BF_MF_WG_WAVES][BF_MF_TABCAP + BF_MF_TABPAD];
+  int const lane = threadIdx.x & 63;
+  uint32_t const wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  uint32_t *tab = tabs[wave];
+  // The wavefronts of a workgroup take neighbours of the item list: row chunks of one row group and of its sibling
+  // groups (same cost, same input rows: the planner's order for RHS-block operators).  They start together and run at
+  // the same rate, so a row of X is fetched into the L2 once for all of them.  Workgroups are dealt to the 8 XCDs round
+  // robin: runs of BF_MF_XCD_RUN workgroups that are neighbours in the list go to ONE XCD for the same reason.
+  uint32_t wg = blockIdx.x;
+  uint32_t const numWg = (p.numItems + BF_MF_WG_WAVES - 1u) / BF_MF_WG_WAVES;
   if (BF_MF_XCD_RUN > 1) {
     uint32_t const blk = 8u * BF_MF_XCD_RUN;
-    if (item < p.numItems / blk * blk) { uint32_t const r = item % blk; item = item - r + (r % 8u) * BF_MF_XCD_RUN + r / 8u; }
+    if (wg < numWg / blk * blk) { uint32_t const r = wg % blk; wg = wg - r + (r % 8u) * BF_MF_XCD_RUN + r / 8u; }
   }
+  uint32_t const item = wg * BF_MF_WG_WAVES + wave;
   if (item >= p.numItems) return;
   BfDevItem const it = p.items[item];
   uint32_t const mr = it.mrFlags & 0xffffu;

@@ -99,4 +99,9 @@ pmc64()      { ( cd /tmp && export TMPDIR=/tmp
                    timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/mfma_$v -- python3 $R/bench.py --nrhs 64 --steps 2 --warmup 1 --no-cpu-baseline --no-extra > $O/mfma_$v.json 2> $O/mfma_$v.log; echo "mfma_$v exit=$?"
                    python3 $R/tools/pmc_quick.py $O/fetch_$v $O/mfma_$v
                  done ) }
+r64small()   { for v in ${XCD_VARIANTS:-base}; do
+                 if [ $v = base ]; then unset BFHIP_LIB_PATH; else export BFHIP_LIB_PATH=$R/butterfly_amd/csrc/exp/libbfhip_$v.so; fi
+                 step s64_$v 300 $B --npoints 65536 --nrhs 64 --steps 10 --warmup 2 --no-cpu-baseline --no-extra
+                 python -c "import json; d = json.load(open('$O/s64_$v.out')); print('n65536 $v', d['ms_per_step'], d['roofline']['achieved'], d['roofline']['frac'])"
+               done; unset BFHIP_LIB_PATH; }
 for s in "$@"; do $s; done
