@@ -3,6 +3,7 @@
 all: lib oracle
 lib:
 	$(MAKE) -C butterfly_amd/csrc
+	$(MAKE) -C butterfly_amd/csrc experimental
 oracle:
 	$(MAKE) -C oracle
 test: all

@@ -50,7 +50,7 @@ def log(*a):
 
 def parse_args(argv):
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None, help="ranks = GPUs of one node (default: the launcher's WORLD_SIZE, else 1)")
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", choices=["helm2", "streamer"], default="helm2")
@@ -79,7 +79,10 @@ def parse_args(argv):
                     help="multi-GPU: rows = balanced contiguous row ranges (bfhipRowPartition) + ONE all-gather, bit-identical to one GPU (default); "
                          "rowblocks = whole top-level block rows by LPT + all-gather; blocks = top-level (row, col) blocks by LPT + ONE all-reduce; "
                          "rowsum = whole block rows + column shares of the rest, ONE all-gather, shared rows' partials added in rank order (no replication)")
-    return ap.parse_args(argv)
+    args = ap.parse_args(argv)
+    if args.gpus is None:          # started by torch.distributed.run without --gpus: the launcher's world size is the job's
+        args.gpus = int(os.environ.get("WORLD_SIZE", "1"))
+    return args
 
 
 def free_port():
@@ -112,6 +115,44 @@ def launch_ranks(args, argv):
 
 
 # ---------------------------------------------------------------------------------------------------
+# What a multi-rank run checks about itself (same code on GPUs over RCCL and in the CPU dry run over gloo)
+# ---------------------------------------------------------------------------------------------------
+def ranks_max_abs_diff(dist, y, use_pg):
+    """max over ranks r of max |y_r - y_0|: after the closing collective every rank must hold the same y."""
+    import torch
+    if not use_pg:
+        return 0.0
+    ref = y.detach().clone()
+    view = torch.view_as_real(ref) if ref.is_complex() else ref
+    dist.broadcast(view, src=0)
+    d = (y - ref).abs().max().to(torch.float64).reshape(1) if y.numel() else torch.zeros(1, dtype=torch.float64, device=y.device)
+    dist.all_reduce(d, op=dist.ReduceOp.MAX)
+    return float(d.item())
+
+
+def all_ranks_ok(dist, ok, text, use_pg):
+    """(every rank succeeded, [(rank, error text) of those that did not]): a collective decision, so that either every
+    rank keeps libbfhip's own RCCL communicator or every rank falls back to torch.distributed."""
+    if not use_pg:
+        return bool(ok), ([] if ok else [(0, text)])
+    box = [None] * dist.get_world_size()
+    dist.all_gather_object(box, (bool(ok), str(text)[:300]))
+    bad = [(r, t) for r, (o, t) in enumerate(box) if not o]
+    return not bad, bad
+
+
+def pad_to_common_length(dist, vec, use_pg):
+    """ranks may have compiled plans of different depth (blocks / rowsum shards): pad a per-stage vector with zeros to the
+    longest before it is all-gathered"""
+    import torch
+    if not use_pg:
+        return vec
+    m = torch.tensor([vec.numel()], dtype=torch.int64, device=vec.device)
+    dist.all_reduce(m, op=dist.ReduceOp.MAX)
+    return torch.cat([vec, torch.zeros(int(m.item()) - vec.numel(), dtype=vec.dtype, device=vec.device)])
+
+
+# ---------------------------------------------------------------------------------------------------
 # CPU baselines (the oracle as the checker and as the stated baseline; never the thing shipped)
 # ---------------------------------------------------------------------------------------------------
 def _blas_one_thread():
@@ -126,14 +167,16 @@ def _blas_one_thread():
     return blas
 
 
-def cpu_baseline_helm2(desc, seed, total_leaf_elems, weights, budget_bytes, nrhs, x, y_gpu_full, row_offsets):
+def cpu_baseline_helm2(desc, seed, total_leaf_elems, weights, budget_bytes, nrhs, x, y_gpu_full, row_offsets, first=()):
     """Oracle (port of the reference bfMatMul) on a bounded sample: the top-level block rows, smallest
-    first, that fit in `budget_bytes` of leaf data; extrapolated to the whole operand by leaf bytes."""
+    first, that fit in `budget_bytes` of leaf data; extrapolated to the whole operand by leaf bytes.
+    `first`: block rows the sample must start with (multi-GPU rowsum mode: a block row whose result is the sum
+    of two ranks' partials, so that the parity figure of the line covers the shared path)."""
     import numpy as np
     from butterfly_amd import helm2_structure as hs
     from oracle import bfref
     blas = _blas_one_thread()
-    order = np.argsort(weights)
+    order = [int(rb) for rb in first] + [int(rb) for rb in np.argsort(weights) if int(rb) not in set(first)]
     chosen, acc = [], 0
     for rb in order:
         if weights[rb] == 0:
@@ -278,7 +321,7 @@ def main():
     import torch
     import torch.distributed as dist
     from butterfly_amd import _capi, helm2_structure as hs
-    from butterfly_amd.dist import (RcclShardedApply, ShardLayout, assign_row_blocks, block_weights, choose_mode,
+    from butterfly_amd.dist import (RcclShardedApply, ShardedApply, ShardLayout, assign_row_blocks, block_weights, choose_mode,
                                     row_block_weights, row_partition, rowsum_partition)
     from butterfly_amd.operator import HipOperator
 
@@ -310,6 +353,10 @@ def main():
         sys.exit(2)
 
     streamer = args.workload == "streamer"
+    # the default line (headline operand, one GPU) also times the adjoint apply of the same operand
+    if (not streamer and world == 1 and args.n in (None, 262144) and args.k is None and args.nrhs == 1 and args.dtype in (None, "c128")
+            and not args.no_extra and args.emulate_world <= 1 and not dry):
+        args.adjoint = True
     dtype = args.dtype or ("f32" if streamer else "c128")
     if streamer and dtype == "c128":
         raise SystemExit("the streamed operand is real: --dtype f32 or f64")
@@ -417,18 +464,39 @@ def main():
             sigs = [None] * world
             dist.all_gather_object(sigs, mine_sig)
             same = all(sg == sigs[0] for sg in sigs)
+        # the checks a real multi-rank run makes about itself, on CPU tensors over gloo: (a) every rank ends with the same
+        # y (BENCH_DRY_PERTURB_RANK=r makes rank r's copy differ), (b) the collective decision between libbfhip's own RCCL
+        # communicator and torch.distributed (BENCH_DRY_FAIL_RCCL_RANK=r: creation "fails" on rank r only)
+        yd = torch.arange(1000, dtype=torch.float64).to(torch.complex128) * (1 + 2j)
+        if os.environ.get("BENCH_DRY_PERTURB_RANK") == str(rank):
+            yd[17] += 1e-3
+        ydiff = ranks_max_abs_diff(dist, yd, use_pg)
+        fail_rank = os.environ.get("BENCH_DRY_FAIL_RCCL_RANK")
+        ok_all, bad = all_ranks_ok(dist, fail_rank != str(rank), "simulated bfhipCommInitRank failure", use_pg)
+        prof_len = int(pad_to_common_length(dist, torch.zeros(3 * (5 + rank)), use_pg).numel())
+        rows_alt = None
+        if world > 1 and mode != "rows" and not streamer:
+            c2, l2 = row_partition(desc, world)
+            rows_alt = {"cuts": [int(c) for c in c2], "replication": sum(l2) / total_leaf, "imbalance": max(l2) / (sum(l2) / len(l2))}
         if rank == 0:
             real_stdout.write(json.dumps({"dry_run": True, "n_gpus": world, "mode": mode, "cuts": [int(c) for c in cuts],
                                           "rank_leaf_gb": [l * esz / 1e9 for l in loads], "imbalance": max(loads) / (sum(loads) / len(loads)),
-                                          "replication": sum(loads) / total_leaf, "ranks_agree": same, "workload": workload}) + "\n")
+                                          "replication": sum(loads) / total_leaf, "ranks_agree": same, "workload": workload,
+                                          "multi_gpu": {"ranks_max_abs_diff": ydiff, "ranks_agree": ydiff == 0.0,
+                                                        "collective_impl": "libbfhip (RCCL)" if ok_all else "torch.distributed",
+                                                        "collective_fallback_reason": bad, "padded_profile_len": prof_len,
+                                                        "also_timed": ({"mode": "rows", **rows_alt} if rows_alt else None),
+                                                        "shared_block_rows": sorted({rb for rb, _ in rsegs if sum(1 for b2, _ in rsegs if b2 == rb) > 1}) if mode == "rowsum" else []}}) + "\n")
             real_stdout.flush()
         if use_pg:
             dist.barrier()
             dist.destroy_process_group()
-        sys.exit(0 if same else 3)
+        sys.exit(0 if same and ydiff == 0.0 else 3)
 
-    def compile_shard(r, max_rhs):
-        """The operator rank r of an `sworld`-rank job holds."""
+    def compile_shard(r, max_rhs, mode=None, cuts=None):
+        """The operator rank r of an `sworld`-rank job holds (mode / cuts: another way to deal it than the line's own)."""
+        mode = mode or mode_main
+        cuts = cuts or cuts_main
         rr = None
         if sworld == 1:
             root, rows = desc.root, n
@@ -446,6 +514,7 @@ def main():
                                   demote_to_f32=(dtype == "f32"), row_range=rr)
         return o, rows
 
+    mode_main, cuts_main = mode, cuts
     t0 = time.time()
     op, local_rows = compile_shard(srank, args.nrhs)
     torch.cuda.synchronize()
@@ -464,16 +533,76 @@ def main():
         x_host = (rng.standard_normal(shape) + 1j * rng.standard_normal(shape)) / np.sqrt(2)
     x = torch.from_numpy(x_host).to(dev).to(tdtype)
 
-    sharded = None
-    if (world > 1 or args.force_collective) and args.emulate_world <= 1:
-        layout = (ShardLayout(top_rows, owner, world, segments=rsegs) if mode == "rowsum" else
-                  ShardLayout(seg_rows if not streamer else top_rows, owner, world))
+    class TorchStep:
+        """The same step with the closing collective issued by torch.distributed (still RCCL over xGMI on GPUs): the
+        fallback when libbfhip's own communicator cannot be created on some rank.  Times its two halves with events."""
+        def __init__(self, the_op, layout_, mode_):
+            self.inner = ShardedApply(layout_, rank, lambda xin, out: the_op.apply_device(xin, out), dev, tdtype, nrhs=args.nrhs, mode=mode_,
+                                      force_collective=args.force_collective)
+            self.timing, self.ev = False, [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+            inner_apply = self.inner.local_apply
+
+            def timed_local(xin, out):
+                r_ = inner_apply(xin, out)
+                if self.timing:
+                    self.ev[1].record()
+                return r_
+            self.inner.local_apply = timed_local
+
+        def __call__(self, xin):
+            if self.timing:
+                self.ev[0].record()
+            y_ = self.inner(xin)
+            if self.timing:
+                self.ev[2].record()
+            return y_
+
+        def set_timing(self, on):
+            self.timing = bool(on)
+
+        def last_times(self):
+            torch.cuda.synchronize()
+            return self.ev[0].elapsed_time(self.ev[1]), self.ev[1].elapsed_time(self.ev[2])
+
+        def close(self):
+            pass
+
+    def make_layout(mode_, cuts_):
+        if mode_ == "rowsum":
+            return ShardLayout(top_rows, owner, world, segments=rsegs)
+        if mode_ == "rows" and not streamer:
+            return ShardLayout([cuts_[r + 1] - cuts_[r] for r in range(world)], list(range(world)), world)
+        return ShardLayout(seg_rows if not streamer else top_rows, owner, world)
+
+    def make_sharded(the_op, mode_, cuts_):
+        """(step, which implementation issues the collective, [(rank, why)] if libbfhip's communicator was given up).
+        Every rank takes the same branch: the outcome of the attempt is agreed on through torch's process group."""
+        layout_ = make_layout(mode_, cuts_)
 
         def bcast(payload):
             box = [payload]
             dist.broadcast_object_list(box, src=0)
             return box[0]
-        sharded = RcclShardedApply(layout, rank, op, local_rank, nrhs=args.nrhs, mode=mode, bcast=bcast if world > 1 else None)
+        sh_, err = None, ""
+        if os.environ.get("BENCH_FORCE_TORCH_COLLECTIVE") == "1":
+            err = "BENCH_FORCE_TORCH_COLLECTIVE=1"
+        else:
+            try:
+                sh_ = RcclShardedApply(layout_, rank, the_op, local_rank, nrhs=args.nrhs, mode=mode_, bcast=bcast if world > 1 else None)
+            except Exception as e:        # a rank that cannot create its communicator must not leave the others waiting in a collective
+                err = repr(e)
+        ok_all, bad = all_ranks_ok(dist, sh_ is not None, err, use_pg)
+        if ok_all:
+            return sh_, "libbfhip (RCCL, dlopen)", []
+        if sh_ is not None:
+            sh_.close()
+        if rank == 0:
+            log("bench.py: libbfhip's RCCL communicator unavailable on", bad, "-> the collective goes through torch.distributed")
+        return TorchStep(the_op, layout_, mode_), "torch.distributed", bad
+
+    sharded, coll_impl, coll_bad = None, None, []
+    if (world > 1 or args.force_collective) and args.emulate_world <= 1:
+        sharded, coll_impl, coll_bad = make_sharded(op, mode, cuts)
         step = sharded
     else:
         y_buf = torch.empty((local_rows,) + shape[1:], dtype=tdtype, device=dev)
@@ -524,7 +653,10 @@ def main():
         # roofline is the SLOWEST rank's, the one that bounds the step
         per_apply_ms = float(ms.sum()) / max(float(launches.max()), 1.0)
         v = torch.tensor([float(np.median(loc)), float(np.median(coll)), st["leafBytes"] / 1e9, per_apply_ms], dtype=torch.float64, device=dev)
-        prof = torch.tensor(np.concatenate([ms, launches.astype(np.float64), sbytes.astype(np.float64)]), dtype=torch.float64, device=dev)
+        # (ranks may have compiled plans of different depth: each of the three per-stage vectors is padded to the longest)
+        parts = [pad_to_common_length(dist, torch.tensor(np.asarray(a_, dtype=np.float64), dtype=torch.float64, device=dev), use_pg)
+                 for a_ in (ms, launches, sbytes)]
+        prof = torch.cat(parts)
         if use_pg:
             allv = [torch.zeros_like(v) for _ in range(world)]
             dist.all_gather(allv, v)
@@ -535,8 +667,10 @@ def main():
         allv = torch.stack(allv).cpu().numpy()
         allp = torch.stack(allp).cpu().numpy()
         prof_rank = int(np.argmax(allv[:, 3]))
-        S_ = len(ms)
+        S_ = int(parts[0].numel())
         ms, launches, sbytes = allp[prof_rank, :S_], allp[prof_rank, S_:2 * S_].astype(np.uint64), allp[prof_rank, 2 * S_:].astype(np.uint64)
+        # every rank must have ended with the same y
+        ydiff = ranks_max_abs_diff(dist, step(x), use_pg)
         gb = allv[:, 2]
         multi = {"mode": mode, "collective": "ncclAllReduce (sum)" if mode == "blocks" else "ncclAllGather (in place) + segment reorder",
                  "rank_leaf_gb": [round(float(g), 3) for g in gb], "imbalance": float(gb.max() / gb.mean()),
@@ -544,7 +678,41 @@ def main():
                  "rank_local_ms": [round(float(r[0]), 4) for r in allv], "rank_kernel_ms": [round(float(r[3]), 4) for r in allv],
                  "max_local_ms": float(allv[:, 0].max()), "collective_ms_per_rank": [round(float(r[1]), 4) for r in allv],
                  "max_collective_ms": float(allv[:, 1].max()), "collective_bytes": int(n * args.nrhs * esz),
-                 "roofline_rank": prof_rank, "bit_identical_to_one_gpu": mode in ("rows", "rowblocks")}
+                 "roofline_rank": prof_rank, "bit_identical_to_one_gpu": mode in ("rows", "rowblocks"),
+                 "ranks_max_abs_diff": ydiff, "ranks_agree": ydiff == 0.0,
+                 "collective_impl": coll_impl, "collective_fallback_reason": coll_bad}
+        # The default at this world size is not the bit-identical row-range shard (8 ranks: rowsum): time that one too
+        if world > 1 and mode != "rows" and args.shard == "auto" and not streamer:
+            try:
+                cuts2, loads2 = row_partition(desc, world)
+                sharded.close()
+                op.close()
+                op, _rows2 = compile_shard(rank, args.nrhs, mode="rows", cuts=cuts2)
+                sharded, impl2, bad2 = make_sharded(op, "rows", cuts2)
+                step = sharded
+                sharded.set_timing(False)
+                op.set_profile_sampling(1 << 30)
+                for _ in range(max(args.warmup, 2)):
+                    step(x)
+                torch.cuda.synchronize()
+                if use_pg:
+                    dist.barrier()
+                t1 = time.perf_counter()
+                for _ in range(args.steps):
+                    y2 = step(x)
+                torch.cuda.synchronize()
+                if use_pg:
+                    dist.barrier()
+                el2 = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev)
+                if use_pg:
+                    dist.all_reduce(el2, op=dist.ReduceOp.MAX)
+                d2 = ranks_max_abs_diff(dist, y2, use_pg)
+                multi["also_timed"] = {"mode": "rows", "bit_identical_to_one_gpu": True, "ms_per_step": float(el2.item()) / args.steps * 1e3,
+                                       "value": args.steps * args.nrhs / float(el2.item()), "unit": "matvec/s",
+                                       "replication": float(sum(loads2) / total_leaf), "imbalance": float(max(loads2) / (sum(loads2) / len(loads2))),
+                                       "ranks_max_abs_diff": d2, "ranks_agree": d2 == 0.0, "collective_impl": impl2}
+            except Exception as e:
+                multi["also_timed"] = {"mode": "rows", "error": repr(e)[:300]}
 
     if rank == 0:
         kern_ms = float(ms.sum())
@@ -706,8 +874,13 @@ def main():
                 if streamer:
                     out["cpu_baseline"] = cpu_baseline_streamer(desc, args.seed, args.cpu_budget_gb * 1e9)
                 elif not real:
+                    # rowsum mode: the sample starts with a block row that two ranks share (its result is a sum of partials)
+                    shared_rb = (sorted({rb for rb, _ in rsegs if sum(1 for b2, _ in rsegs if b2 == rb) > 1}, key=lambda rb: weights[rb])[:1]
+                                 if (multi and mode == "rowsum") else [])
                     out["cpu_baseline"] = cpu_baseline_helm2(desc, args.seed, total_leaf, weights, args.cpu_budget_gb * 1e9, args.nrhs, x_host,
-                                                             y_full.cpu().numpy(), row_offsets)
+                                                             y_full.cpu().numpy(), row_offsets, first=shared_rb)
+                    if shared_rb:
+                        out["cpu_baseline"]["parity_covers_shared_block_row"] = int(shared_rb[0])
             except Exception as e:  # the baseline must never take the measurement down
                 out["cpu_baseline"] = {"value": None, "unit": "matvec/s", "cores": 1, "kind": "port", "sample": f"failed: {e!r}"}
 
@@ -777,10 +950,27 @@ def main():
         except Exception as e:
             out["nrhs64"] = {"error": repr(e)}
 
+        # BASELINE configs[1] (N = 65536, k = 4096, one right-hand side: launches of ~1 GB) in a child process: its own line
+        try:
+            torch.cuda.empty_cache()
+            cmd = [sys.executable, os.path.abspath(__file__), "--npoints", "65536", "--steps", "50", "--warmup", "5", "--no-extra",
+                   "--seed", str(args.seed), "--cpu-budget-gb", "4.0"]
+            env = dict(os.environ)
+            for k_ in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+                env.pop(k_, None)
+            pr = subprocess.run(cmd, capture_output=True, text=True, timeout=240, env=env)
+            line = [ln for ln in pr.stdout.splitlines() if ln.startswith("{")]
+            if pr.returncode != 0 or not line:
+                raise RuntimeError(f"child exit {pr.returncode}: {pr.stderr[-300:]}")
+            c = json.loads(line[-1])
+            out["n65536"] = {"config": "BASELINE configs[1]: " + c["config"]["workload"], "value": c["value"], "unit": c["unit"], "dtype": c["dtype"],
+                             "steps": c["steps"], "ms_per_step": c["ms_per_step"], "roofline": c["roofline"], "cpu_baseline": c.get("cpu_baseline")}
+        except Exception as e:
+            out["n65536"] = {"error": repr(e)[:400]}
+
         # BASELINE configs[4] rides along too: the streamed real butterfly at N = 1M x 65536 columns, fp32, in a child
         # process of its own (the C layout needs seconds; bounded at 4.5 minutes, after which the key holds the error)
         if not args.no_streamer:
-            import subprocess
             try:
                 torch.cuda.empty_cache()
                 cmd = [sys.executable, os.path.abspath(__file__), "--workload", "streamer", "--steps", "10", "--warmup", "2", "--adjoint",

@@ -299,6 +299,7 @@ static void dropPlanMirrors(BfPlan *plan) {
 }
 
 
+#ifdef BFHIP_EXPERIMENTAL      /* the dependency-driven launch lives in `make experimental` builds only (bfhip_experimental.hip) */
 /* Flat index tables for the dependency-driven launch (bfFlowKernelC128): all stages' items in stage order with global
  * piece indices, pieces carrying the id of the vector they read, per item the vector it writes, per vector its number
  * of writers, and the counters.  Needs the host mirrors of the plan. */
@@ -375,6 +376,7 @@ done:
   free(items); free(pieces); free(itemOut);
   return rc;
 }
+#endif
 
 static int ensureTemp(BfhipOperator *op, uint32_t nrhs) {
   if (op->dTemp && op->tempRhs >= nrhs) return 0;
@@ -403,6 +405,12 @@ int bfhipCompileIrFill(BfIr *ir, BfhipOptions const *opts, BfFillFn fill, void *
   int const planOnly = (o.flags & BFHIP_FLAG_PLAN_ONLY) != 0;
   op->flags = o.flags;
   op->seed = o.seed;
+#ifndef BFHIP_EXPERIMENTAL
+  if (o.flags & BFHIP_FLAG_FLOW) {
+    rc = bfhipFail(BFABI_ERROR_NOT_IMPLEMENTED, "BFHIP_FLAG_FLOW: this library was built without the experimental executors (make -C butterfly_amd/csrc experimental)");
+    goto done;
+  }
+#endif
   if (!planOnly) {
     bfdevGetDevice(&prevDev);
     if ((rc = bfdevSetDevice(o.device))) goto done;
@@ -440,7 +448,9 @@ int bfhipCompileIrFill(BfIr *ir, BfhipOptions const *opts, BfFillFn fill, void *
     op->hasTplan = 1;
   }
   if (planOnly) {
+#ifdef BFHIP_EXPERIMENTAL
     if (op->plan.dtype == BFHIP_C128 && op->plan.flowOk && (o.flags & BFHIP_FLAG_FLOW) && (rc = buildFlow(op, 1))) goto done;
+#endif
     /* keep the IR (with its borrowed leaf pointers) for bfhipPlanPackArena */
     op->ir = malloc(sizeof *op->ir);
     if (!op->ir) { rc = bfhipFail(BFABI_ERROR_MEMORY_ERROR, "host OOM"); goto done; }
@@ -457,10 +467,22 @@ int bfhipCompileIrFill(BfIr *ir, BfhipOptions const *opts, BfFillFn fill, void *
   if (op->hasTplan && (rc = uploadPlanMeta(op, &op->tplan))) goto done;
   /* leaf values: computed on the device by the caller's builder, or packed / synthesized from the IR */
   if ((rc = fill ? fill(&op->plan, ir, op->dArena, fillCtx) : packLeaves(op, ir, o.seed, NULL))) goto done;
+#ifdef BFHIP_EXPERIMENTAL
   {
     char const *envFlow = getenv("BFHIP_FLOW");         /* A/B switch for whole programs; BFHIP_FLAG_FLOW is the per-operator one */
     if (op->plan.dtype == BFHIP_C128 && op->plan.flowOk && ((o.flags & BFHIP_FLAG_FLOW) || (envFlow && envFlow[0] == '1')) && (rc = buildFlow(op, 0))) goto done;
   }
+  /* the persistent ticket launch (BFHIP_PERSISTENT=1): every stage's counters exist before the first apply, so that an
+   * apply never allocates or synchronises (a sharded step must not fail on ONE rank after its peers entered the collective) */
+  if (op->plan.dtype == BFHIP_C128 && bfdevPersistentGrid()) {
+    for (uint64_t s_ = 0; s_ < op->plan.numStages; ++s_) {
+      BfStage *st_ = &op->plan.stages[s_];
+      if ((rc = bfdevMalloc(&st_->dTickets, BF_TICKET_POOLS * BF_TICKET_STRIDE * 4))) goto done;
+      if ((rc = bfdevMemset(st_->dTickets, 0, BF_TICKET_POOLS * BF_TICKET_STRIDE * 4))) goto done;
+    }
+    if ((rc = bfdevSync(NULL))) goto done;
+  }
+#endif
   /* host mirrors of the bulky per-piece arrays are no longer needed */
   dropPlanMirrors(&op->plan);
   dropPlanMirrors(&op->tplan);
@@ -632,6 +654,7 @@ static int runPlan(BfhipOperator *op, BfPlan *plan, void const *dX, size_t nrhs,
   if (prof && op->evIssued - op->evHarvested >= BF_EV_POOL && (rc = harvestEvents(op, op->evIssued - BF_EV_POOL + 1))) goto out;
   uint64_t const evBase = prof ? (op->evIssued % BF_EV_POOL) * plan->numStages : 0;
   if (prof) op->evFlow[op->evIssued % BF_EV_POOL] = 0;
+#ifdef BFHIP_EXPERIMENTAL
   if (op->flow && plan == &op->plan && nrhs <= 2) {
     /* the whole plan as ONE dependency-driven launch (bfFlowKernelC128), then the reduce passes into y */
     uint32_t const perApply = op->flowNumItems + op->flowGrid * 4u;      /* tickets an apply consumes: every wavefront draws one past the end */
@@ -679,6 +702,7 @@ static int runPlan(BfhipOperator *op, BfPlan *plan, void const *dX, size_t nrhs,
     if (prof) { ++op->evIssued; op->lastNrhs = (uint32_t)nrhs; }
     goto out;
   }
+#endif
   for (uint64_t s = 0; s < plan->numStages; ++s) {
     BfStage *st = &plan->stages[s];
     BfLaunchArgs a;
@@ -686,14 +710,7 @@ static int runPlan(BfhipOperator *op, BfPlan *plan, void const *dX, size_t nrhs,
     a.x = dX; a.y = dY; a.temp = op->dTemp; a.zero = op->dZero; a.nrhs = (uint32_t)nrhs; a.dtype = plan->dtype; a.maxRows = st->maxRows;
     a.transposed = plan->transposed;
     a.tickets = NULL;
-    if (plan->dtype == BFHIP_C128 && !plan->transposed && nrhs < 3) {
-      if (!st->dTickets) {        /* first apply: the stage's ticket counters (one-time, not stream-ordered) */
-        if ((rc = bfdevMalloc(&st->dTickets, BF_TICKET_POOLS * BF_TICKET_STRIDE * 4))) goto out;
-        if ((rc = bfdevMemset(st->dTickets, 0, BF_TICKET_POOLS * BF_TICKET_STRIDE * 4))) goto out;
-        if ((rc = bfdevSync(NULL))) goto out;        /* the fill is ordered on the null stream only: done before anything on the caller's stream can draw */
-      }
-      a.tickets = st->dTickets;
-    }
+    if (plan->dtype == BFHIP_C128 && !plan->transposed && nrhs < 3) a.tickets = st->dTickets;      /* NULL unless this is an EXPERIMENTAL build run with BFHIP_PERSISTENT=1 (allocated at compile time) */
     if (prof && (rc = bfdevEventRecord(op->evStart[evBase + s], stream))) goto out;
     if ((rc = bfdevLaunchStage(&a, stream))) goto out;
     if (prof && (rc = bfdevEventRecord(op->evStop[evBase + s], stream))) goto out;

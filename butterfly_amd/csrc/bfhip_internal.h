@@ -262,6 +262,8 @@ typedef struct BfFlowArgs {
   void *y, *temp;
 } BfFlowArgs;
 int bfdevLaunchFlow(BfFlowArgs const *a, void *stream);
+/* EXPERIMENTAL builds: timeline / persistent launch of a complex128 stage (bfhip_experimental.hip); *handled = 0 -> the caller launches it */
+int bfdevLaunchStageExperimental(BfLaunchArgs const *a, void const *stageParams, uint32_t grid, void *stream, int *handled);
 int bfdevFlowGrid(uint64_t numItems, uint32_t *grid);
 int bfdevMemsetAsync(void *dst, int value, size_t bytes, void *stream);
 

@@ -49,6 +49,35 @@ def test_product_does_not_link_the_oracle():
     assert "bfMatMul" not in syms and "bfref" not in syms
 
 
+def test_product_holds_no_experimental_executor():
+    """The one-launch ("flow") executor, the persistent ticket launch and the timeline instantiation -- spin-waiting
+    kernels and getenv-switched code paths -- are built into libbfhip_exp.so only (make experimental); the product
+    library neither defines their symbols nor reads their environment variables, and refuses BFHIP_FLAG_FLOW."""
+    import subprocess
+    from butterfly_amd import _capi
+    prod = os.path.join(ROOT, "butterfly_amd", "csrc", "libbfhip.so")
+    syms = subprocess.check_output(["nm", "-D", "--defined-only", prod], text=True)
+    for name in ("bfFlowKernelC128", "bfdevLaunchFlow", "bfdevFlowGrid", "bfdevPersistentGrid", "bfdevLaunchPersistC128", "bfStageKernelC128P",
+                 "bfStageKernelC128Timeline", "bfdevLaunchStageExperimental"):
+        assert name not in syms, name
+    blob = open(prod, "rb").read()
+    for env in (b"BFHIP_FLOW", b"BFHIP_PERSISTENT", b"BFHIP_TIMELINE_FILE", b"BFHIP_FLOW_SPIN"):
+        assert env not in blob, env
+    exp = os.path.join(ROOT, "butterfly_amd", "csrc", "libbfhip_exp.so")
+    if os.path.exists(exp):
+        esyms = subprocess.check_output(["nm", "-D", "--defined-only", exp], text=True)
+        assert "bfdevLaunchFlow" in esyms and "bfdevPersistentGrid" in esyms
+    if os.path.basename(_capi.LIB_PATH) == "libbfhip.so":
+        import numpy as np
+        from butterfly_amd import helm2_structure as hs
+        from butterfly_amd.operator import HipOperator
+        import pytest
+        desc, _ = hs.native_multilevel_structure(hs.circle_points(1024), 64.0)
+        with pytest.raises(_capi.BfhipError) as ei:
+            HipOperator.from_desc(desc, None, flags=_capi.FLAG_PLAN_ONLY | _capi.FLAG_FLOW)
+        assert ei.value.code == 3
+
+
 def test_builder_structs_match_the_header_and_arguments_are_checked(tmp_path):
     """ctypes / numpy mirrors of include/bfhip_build.h have the C sizes; bad
     arguments are refused before any device is touched."""

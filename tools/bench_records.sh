@@ -27,10 +27,12 @@ run ${TAG}_bench_n1048576_shards8_emulated    $B --npoints 1048576 --emulate-wor
 fi
 if [ "$PART" = all ] || [ "$PART" = streamer ]; then
 # the experimental one-launch executor (BFHIP_FLAG_FLOW) and the persistent ticket launch next to the staged launches
-BFHIP_FLOW=1 run ${TAG}_bench_n65536_flow $B --npoints 65536 --no-cpu-baseline --no-extra
-BFHIP_FLOW=1 run ${TAG}_bench_n262144_flow $B --no-cpu-baseline --no-extra
-BFHIP_PERSISTENT=1 run ${TAG}_bench_n65536_persistent $B --npoints 65536 --no-cpu-baseline --no-extra
-BFHIP_PERSISTENT=1 run ${TAG}_bench_n262144_persistent $B --no-cpu-baseline --no-extra
+# (they live in libbfhip_exp.so only: make -C butterfly_amd/csrc experimental)
+EXPLIB=$(pwd)/butterfly_amd/csrc/libbfhip_exp.so
+BFHIP_LIB_PATH=$EXPLIB BFHIP_FLOW=1 run ${TAG}_bench_n65536_flow $B --npoints 65536 --no-cpu-baseline --no-extra
+BFHIP_LIB_PATH=$EXPLIB BFHIP_FLOW=1 run ${TAG}_bench_n262144_flow $B --no-cpu-baseline --no-extra
+BFHIP_LIB_PATH=$EXPLIB BFHIP_PERSISTENT=1 run ${TAG}_bench_n65536_persistent $B --npoints 65536 --no-cpu-baseline --no-extra
+BFHIP_LIB_PATH=$EXPLIB BFHIP_PERSISTENT=1 run ${TAG}_bench_n262144_persistent $B --no-cpu-baseline --no-extra
 # BASELINE configs[4]: the streamed real butterfly (fac_streamer structure, rank model), fp32 and fp64
 S="timeout -k 10 900 python bench.py --workload streamer"
 run ${TAG}_bench_streamer_n1048576_f32   $S --adjoint --steps 10

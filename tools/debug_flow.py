@@ -3,6 +3,8 @@
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+# the executors this tool drives live in the experimental build only (make -C butterfly_amd/csrc experimental)
+os.environ.setdefault("BFHIP_LIB_PATH", os.path.join(ROOT, "butterfly_amd", "csrc", "libbfhip_exp.so"))
 os.environ.setdefault("BFHIP_FLOW_DEBUG", "1")
 os.environ.setdefault("BFHIP_FLOW_SPIN", "2000")
 def say(*a):

@@ -7,6 +7,8 @@ import argparse, json, os, sys, tempfile
 import numpy as np
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+# the executors this tool drives live in the experimental build only (make -C butterfly_amd/csrc experimental)
+os.environ.setdefault("BFHIP_LIB_PATH", os.path.join(os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."), "butterfly_amd", "csrc", "libbfhip_exp.so"))
 
 
 def main():
