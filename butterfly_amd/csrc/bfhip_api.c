@@ -1286,6 +1286,7 @@ typedef struct BfhipMat {
   BfAbiMat super;             /* must be first: this IS a BfMat */
   BfhipOperator *op;
   int ownsOperator;
+  int transposed;             /* bfMatTranspose has been applied an odd number of times: Mul / MulVec run the adjoint plan */
 } BfhipMat;
 
 /* Failures surface the way the reference's own Mul failures do: the global error code is set
@@ -1307,8 +1308,10 @@ static void shimRaise(int code) {
 }
 #define SHIM_FAIL(code, ...) do { shimRaise(bfhipFail((code), __VA_ARGS__)); return NULL; } while (0)
 
-static size_t shimGetNumRows(BfAbiMat const *m) { return bfhipGetNumRows(((BfhipMat const *)m)->op); }
-static size_t shimGetNumCols(BfAbiMat const *m) { return bfhipGetNumCols(((BfhipMat const *)m)->op); }
+/* shape of what the object currently stands for: A, or A^T after bfMatTranspose (the reference's transposed product
+ * answers with its reversed, transposed factors' shapes: src/mat_product.c:146-192, 409-420) */
+static size_t shimGetNumRows(BfAbiMat const *m) { BfhipMat const *s = (BfhipMat const *)m; return s->transposed ? bfhipGetNumCols(s->op) : bfhipGetNumRows(s->op); }
+static size_t shimGetNumCols(BfAbiMat const *m) { BfhipMat const *s = (BfhipMat const *)m; return s->transposed ? bfhipGetNumRows(s->op) : bfhipGetNumCols(s->op); }
 static int shimGetType(BfAbiMat const *m) { (void)m; return BFABI_TYPE_MAT_FUNC; }
 static size_t shimNumBytes(BfAbiMat const *m) { return bfhipNumBytes(((BfhipMat const *)m)->op); }
 static void shimDelete(BfAbiMat **m) {
@@ -1335,18 +1338,19 @@ static BfAbiMat *shimGetView(BfAbiMat *m) {
 /* Y = A X for a reference dense RHS; the result is allocated through the
  * RHS's own EmptyLike slot so the reference owns and frees it
  * (bfMatBlockCooMul does the same with ZerosLike, mat_block_coo.c:401). */
-void *bfhipMatMulFunc(void const *rhsV, void *opV) {
-  BfhipOperator *op = opV;
+static void *shimMulImpl(void const *rhsV, BfhipOperator *op, int transpose) {
   BfAbiMat const *rhs = rhsV;
   if (!op || !rhs || !rhs->vtbl) SHIM_FAIL(BFABI_ERROR_INVALID_ARGUMENTS, "NULL operand");
+  if (transpose && !op->hasTplan) SHIM_FAIL(BFABI_ERROR_NOT_IMPLEMENTED, "Mul on a transposed operator needs BFHIP_FLAG_ADJOINT");
+  uint64_t const inLen = transpose ? op->plan.numRows : op->plan.numCols, outLen = transpose ? op->plan.numCols : op->plan.numRows;
   BfAbiGetTypeFn getType = (BfAbiGetTypeFn)rhs->vtbl->slot[BFABI_SLOT_GetType];
   if (!getType || getType(rhs) != BFABI_TYPE_MAT_DENSE_COMPLEX || op->srcDtype != BFHIP_C128)
     /* same restriction as bfMatDenseComplexMul's switch (mat_dense_complex.c:1036-1047) */
     SHIM_FAIL(BFABI_ERROR_NOT_IMPLEMENTED, "Mul needs a complex operator and a BfMatDenseComplex right-hand side");
   if (rhs->props & (BFABI_MAT_PROPS_TRANS | BFABI_MAT_PROPS_CONJ)) SHIM_FAIL(BFABI_ERROR_NOT_IMPLEMENTED, "transposed right-hand side");
   BfAbiMatDenseComplex const *x = (BfAbiMatDenseComplex const *)rhs;
-  if (rhs->numRows != op->plan.numCols)
-    SHIM_FAIL(BFABI_ERROR_INCOMPATIBLE_SHAPES, "operator has %llu columns, right-hand side %llu rows", (unsigned long long)op->plan.numCols, (unsigned long long)rhs->numRows);
+  if (rhs->numRows != inLen)
+    SHIM_FAIL(BFABI_ERROR_INCOMPATIBLE_SHAPES, "operator has %llu columns, right-hand side %llu rows", (unsigned long long)inLen, (unsigned long long)rhs->numRows);
   BfAbiLikeFn emptyLike = (BfAbiLikeFn)rhs->vtbl->slot[BFABI_SLOT_EmptyLike];
   if (!emptyLike) SHIM_FAIL(BFABI_ERROR_INVALID_ARGUMENTS, "right-hand side has no EmptyLike");
   /* a column-strided right-hand side (a view of every k-th column, a column range of a wider matrix:
@@ -1365,12 +1369,12 @@ void *bfhipMatMulFunc(void const *rhsV, void *opV) {
       for (size_t q = 0; q < nc; ++q) memcpy((char *)packed + (i * nc + q) * 16, (char const *)x->data + (i * x->rowStride + q * x->colStride) * 16, 16);
     xdata = packed; xld = nc;
   }
-  BfAbiMat *res = emptyLike(rhs, op->plan.numRows, rhs->numCols);
+  BfAbiMat *res = emptyLike(rhs, outLen, rhs->numCols);
   if (!res) { free(packed); SHIM_FAIL(BFABI_ERROR_MEMORY_ERROR, "EmptyLike failed"); }
   BfAbiMatDenseComplex *y = (BfAbiMatDenseComplex *)res;
   int rc;
   if (y->colStride != 1) rc = bfhipFail(BFABI_ERROR_NOT_IMPLEMENTED, "EmptyLike returned a result with colStride != 1");
-  else rc = bfhipApply(op, xdata, xld, rhs->numCols, y->data, y->rowStride);
+  else rc = applyHost(op, transpose, xdata, xld, rhs->numCols, y->data, y->rowStride);
   free(packed);
   if (rc) {
     BfAbiDeleteFn del = (BfAbiDeleteFn)res->vtbl->slot[BFABI_SLOT_Delete];
@@ -1381,8 +1385,24 @@ void *bfhipMatMulFunc(void const *rhsV, void *opV) {
   return res;
 }
 
+void *bfhipMatMulFunc(void const *rhsV, void *opV) { return shimMulImpl(rhsV, opV, 0); }
+
 static BfAbiMat *shimMul(BfAbiMat const *lhs, BfAbiMat const *rhs) {
-  return bfhipMatMulFunc(rhs, ((BfhipMat const *)lhs)->op);
+  return shimMulImpl(rhs, ((BfhipMat const *)lhs)->op, ((BfhipMat const *)lhs)->transposed);
+}
+
+/* bfMatTranspose (slot 63, src/mat.c:271-273): in place, as bfMatProductTranspose reverses and transposes its factors
+ * (src/mat_product.c:409-420).  The adjoint plan over the same packed leaves exists already (BFHIP_FLAG_ADJOINT), so the
+ * object only changes which of its two plans Mul / MulVec / RmulVec run and what GetNumRows / GetNumCols answer; twice
+ * is the identity.  A plain transpose (no conjugation), like the reference's.  The slot returns nothing: without an
+ * adjoint plan the reference's error state is raised (NOT_IMPLEMENTED) and the object is left as it was. */
+static void shimTranspose(BfAbiMat *m) {
+  BfhipMat *s = (BfhipMat *)m;
+  if (!s->op->hasTplan) { shimRaise(bfhipFail(BFABI_ERROR_NOT_IMPLEMENTED, "Transpose needs an operator compiled with BFHIP_FLAG_ADJOINT")); return; }
+  s->transposed = !s->transposed;
+  size_t const r = s->super.numRows;
+  s->super.numRows = s->super.numCols;
+  s->super.numCols = r;
 }
 
 /* y = A x (transpose == 0) or z = x^T A as a vector (bfMatRmulVec) for a reference BfVecReal; real
@@ -1393,14 +1413,15 @@ static BfAbiMat *shimMul(BfAbiMat const *lhs, BfAbiMat const *rhs) {
  * vtable, so that the reference's bfVecDelete -> bfVecRealDeinitAndDealloc frees data and struct with
  * free() (src/vec_real.c:661-676, src/mem.c:65-67).  Rectangular operators are the normal case:
  * cov_matvec applies the N x m operator Phi both ways (examples/covariance/lbo_cov.c:48-60). */
-static BfAbiVec *shimApplyVec(BfAbiMat const *lhs, BfAbiVec const *vec, int transpose) {
+static BfAbiVec *shimApplyVec(BfAbiMat const *lhs, BfAbiVec const *vec, int rmul) {
   BfhipOperator *op = ((BfhipMat const *)lhs)->op;
-  char const *const what = transpose ? "RmulVec" : "MulVec";
+  char const *const what = rmul ? "RmulVec" : "MulVec";
+  int const transpose = rmul != ((BfhipMat const *)lhs)->transposed;          /* x^T (A^T) = (A x)^T */
   if (!vec || !vec->vtbl) SHIM_FAIL(BFABI_ERROR_INVALID_ARGUMENTS, "%s: NULL vector", what);
   BfAbiVecGetTypeFn getType = (BfAbiVecGetTypeFn)vec->vtbl->slot[BFABI_VSLOT_GetType];
   if (!getType || getType(vec) != BFABI_TYPE_VEC_REAL || op->srcDtype != BFHIP_F64)
     SHIM_FAIL(BFABI_ERROR_NOT_IMPLEMENTED, "%s needs a real operator and a BfVecReal", what);
-  if (transpose && !op->hasTplan) SHIM_FAIL(BFABI_ERROR_NOT_IMPLEMENTED, "RmulVec needs an operator compiled with BFHIP_FLAG_ADJOINT");
+  if (transpose && !op->hasTplan) SHIM_FAIL(BFABI_ERROR_NOT_IMPLEMENTED, "%s needs an operator compiled with BFHIP_FLAG_ADJOINT", what);
   uint64_t const inLen = transpose ? op->plan.numRows : op->plan.numCols;
   uint64_t const outLen = transpose ? op->plan.numCols : op->plan.numRows;
   if (vec->size != inLen)
@@ -1431,6 +1452,7 @@ static BfAbiMatVtable ShimVtable = {.slot = {
   [BFABI_SLOT_GetNumCols] = (void *)shimGetNumCols,
   [BFABI_SLOT_Mul] = (void *)shimMul,
   [BFABI_SLOT_MulVec] = (void *)shimMulVec,
+  [BFABI_SLOT_Transpose] = (void *)shimTranspose,
 }};
 
 void *bfhipMatNew(BfhipOperator *op, int ownsOperator) {

@@ -250,6 +250,7 @@ typedef int    (*BfAbiGetTypeFn)(BfAbiMat const *);
 typedef size_t (*BfAbiGetSizeFn)(BfAbiMat const *);
 typedef BfAbiMat *(*BfAbiLikeFn)(BfAbiMat const *, size_t, size_t);
 typedef void   (*BfAbiDeleteFn)(BfAbiMat **);
+typedef void   (*BfAbiTransposeFn)(BfAbiMat *);            /* slot 63: in place, reference src/mat.c:271-273 */
 typedef BfAbiMat *(*BfAbiMulFn)(BfAbiMat const *, BfAbiMat const *);
 typedef BfAbiVec *(*BfAbiMulVecFn)(BfAbiMat const *, BfAbiVec const *);
 typedef int    (*BfAbiVecGetTypeFn)(BfAbiVec const *);

@@ -90,6 +90,9 @@ BfVec *bfMatRmulVec(BfMat const *lhs, BfVec const *rhs) {
 void bfMatDelete(BfMat **mat) {
   if (mat && *mat) SLOT(*mat, BFABI_SLOT_Delete, BfAbiDeleteFn)(mat);
 }
+/* src/mat.c:271-273: in-place transposition is one more virtual call (the types restated here do not fill the slot;
+ * the dispatcher is what a foreign operator behind the vtable is driven through) */
+void bfMatTranspose(BfMat *mat) { SLOT(mat, BFABI_SLOT_Transpose, BfAbiTransposeFn)(mat); }
 size_t bfMatGetNumRows(BfMat const *mat) { return SLOT(mat, BFABI_SLOT_GetNumRows, BfAbiGetSizeFn)(mat); }
 size_t bfMatGetNumCols(BfMat const *mat) { return SLOT(mat, BFABI_SLOT_GetNumCols, BfAbiGetSizeFn)(mat); }
 int bfMatGetType(BfMat const *mat) { return SLOT(mat, BFABI_SLOT_GetType, BfAbiGetTypeFn)(mat); }

@@ -41,6 +41,7 @@ def load():
     lib.bfMatMulVec.argtypes = [vp, vp]; lib.bfMatMulVec.restype = vp
     lib.bfMatRmulVec.argtypes = [vp, vp]; lib.bfMatRmulVec.restype = vp
     lib.bfMatDelete.argtypes = [C.POINTER(vp)]; lib.bfMatDelete.restype = None
+    lib.bfMatTranspose.argtypes = [vp]; lib.bfMatTranspose.restype = None
     lib.bfVecDelete.argtypes = [C.POINTER(vp)]; lib.bfVecDelete.restype = None
     for f in ("bfMatGetNumRows", "bfMatGetNumCols", "bfMatNumBytes"):
         getattr(lib, f).argtypes = [vp]; getattr(lib, f).restype = sz

@@ -593,6 +593,75 @@ def test_rectangular_cov_matvec_through_the_shim(m, n):
     op.close()
 
 
+@pytest.mark.parametrize("m,n", [(300, 70), (96, 96)])
+def test_transpose_slot_flips_the_shim_between_its_two_plans(m, n):
+    """bfMatTranspose (slot 63, reference src/mat.c:271-273) on the shim, driven by the oracle's dispatcher: in place, like
+    bfMatProductTranspose (src/mat_product.c:409-420).  Afterwards bfMatMulVec is what the oracle's bfMatRmulVec gives on
+    the original operator and the other way round, GetNumRows / GetNumCols answer for A^T, and twice is the identity."""
+    import randgraph
+    from butterfly_amd import _capi
+    from butterfly_amd.operator import HipOperator
+    from oracle import bfref
+    rng = np.random.default_rng(4242 + m)
+    desc, vals = randgraph.random_operand(rng, depth=4, size_hint=120, cplx=False, m=m, n=n)
+    A = bfref.from_desc(desc, vals)
+    v, w = rng.standard_normal(m), rng.standard_normal(n)
+    lib = bfref.load()
+    op = HipOperator.from_bfmat(A.ptr.value, flags=_capi.FLAG_ADJOINT)
+    a_hip = C.c_void_p(op.as_bfmat())
+    assert (lib.bfMatGetNumRows(a_hip), lib.bfMatGetNumCols(a_hip)) == (m, n)
+    lib.bfMatTranspose(a_hip)
+    assert (lib.bfMatGetNumRows(a_hip), lib.bfMatGetNumCols(a_hip)) == (n, m)
+    ht = _handle(a_hip, (n, m))
+    assert rel(bfref.mat_mul_vec(ht, v), bfref.mat_rmul_vec(A, v)) <= TOL           # A^T v
+    assert rel(bfref.mat_rmul_vec(ht, w), bfref.mat_mul_vec(A, w)) <= TOL           # w^T A^T = (A w)^T
+    lib.bfClearError()
+    with pytest.raises(RuntimeError, match="BfError 8"):                              # shapes are those of A^T now
+        bfref.mat_mul_vec(ht, np.zeros(m + 1))
+    # a view taken of the transposed object is transposed too (GetView is a shallow copy)
+    lib.bfMatTranspose(a_hip)
+    assert (lib.bfMatGetNumRows(a_hip), lib.bfMatGetNumCols(a_hip)) == (m, n)
+    h = _handle(a_hip, (m, n))
+    assert rel(bfref.mat_mul_vec(h, w), bfref.mat_mul_vec(A, w)) <= TOL
+    assert rel(bfref.mat_rmul_vec(h, v), bfref.mat_rmul_vec(A, v)) <= TOL
+    lib.bfMatDelete(C.byref(a_hip))
+    op.close()
+    # without an adjoint plan the slot raises the reference's error state and leaves the object as it was
+    op = HipOperator.from_bfmat(A.ptr.value)
+    a_hip = C.c_void_p(op.as_bfmat())
+    lib.bfClearError()
+    lib.bfMatTranspose(a_hip)
+    assert lib.bfGetError() == 3                                                      # BF_ERROR_NOT_IMPLEMENTED
+    lib.bfClearError()
+    assert (lib.bfMatGetNumRows(a_hip), lib.bfMatGetNumCols(a_hip)) == (m, n)
+    assert rel(bfref.mat_mul_vec(_handle(a_hip, (m, n)), w), bfref.mat_mul_vec(A, w)) <= TOL
+    lib.bfMatDelete(C.byref(a_hip))
+    op.close()
+
+
+def test_transposed_complex_shim_multiplies_by_the_plain_transpose(helm2_cases):
+    """bfMatTranspose on a complex operator: bfMatMul(A_hip, X) is then A^T X (no conjugation, as in the reference),
+    checked against the dense A^T obtained column by column from the oracle."""
+    from butterfly_amd import _capi
+    from butterfly_amd.operator import HipOperator
+    from oracle import bfref, helm2_build as hb
+    n, k = 1024, 64
+    desc, tp, vals = helm2_cases(n, k)
+    A = bfref.from_desc(desc, vals)
+    dense = bfref.mat_mul(A, np.eye(n, dtype=np.complex128))
+    x = hb.complex_randn(n * 3, 5).reshape(n, 3)
+    lib = bfref.load()
+    op = HipOperator.from_desc(desc, vals, flags=_capi.FLAG_ADJOINT, max_rhs=3)
+    a_hip = C.c_void_p(op.as_bfmat())
+    h = _handle(a_hip, (n, n))
+    lib.bfMatTranspose(a_hip)
+    assert rel(bfref.mat_mul(h, x), dense.T @ x) <= 1e-11
+    lib.bfMatTranspose(a_hip)
+    assert rel(bfref.mat_mul(h, x), dense @ x) <= 1e-11
+    lib.bfMatDelete(C.byref(a_hip))
+    op.close()
+
+
 @pytest.mark.parametrize("demote", [False, True])
 def test_fused_covariance_products_match_the_oracle_sequence(demote):
     """sample_z and cov_matvec of examples/covariance/lbo_cov.c:36-60 as ONE device call each
