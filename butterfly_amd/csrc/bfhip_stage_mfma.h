@@ -69,13 +69,6 @@ template <int STREAM, int OFF> __device__ __forceinline__ void bfFragLoad(BfFrag
 template <int N> __device__ __forceinline__ void bfFragWait(BfFrag &f) { asm volatile("s_waitcnt vmcnt(%1)" : "+v"(f.u) : "n"(N)); }
 template <int N> __device__ __forceinline__ void bfFragWait(BfFrag &f, BfFrag &g) { asm volatile("s_waitcnt vmcnt(%2)" : "+v"(f.u), "+v"(g.u) : "n"(N)); }
 
-__device__ __forceinline__ void bfCmac(bf_d4 &accr, bf_d4 &acci, BfFrag const &a, BfFrag const &x) {
-  accr = __builtin_amdgcn_mfma_f64_16x16x4f64(a.d[0], x.d[0], accr, 0, 0, 0);
-  acci = __builtin_amdgcn_mfma_f64_16x16x4f64(a.d[0], x.d[1], acci, 0, 0, 0);
-  accr = __builtin_amdgcn_mfma_f64_16x16x4f64(a.d[1], x.d[1], accr, 0, 0, 1);      // - Ai * Bi
-  acci = __builtin_amdgcn_mfma_f64_16x16x4f64(a.d[1], x.d[0], acci, 0, 0, 0);
-}
-
 // What a segment's k-loop needs besides the table.
 struct BfMfSeg {
   bf_i4 ra, rx;          // leaf matrix (mr x cols, column-major), input rows [minRow, maxRow] x the pass's RHS
@@ -85,38 +78,67 @@ struct BfMfSeg {
   uint32_t ksteps;
 };
 
-// The k-loop of one segment: MS slabs x NT tiles, two sets of fragment registers.  While the MFMAs of k-step ks read
-// set 0, the requests of k-step ks + 1 fill set 1, and the other way round in the second half of the (twice
-// unrolled) loop body, so nothing is ever copied.  Issue order of a k-step's requests: A0 (A1) X0 .. X(NT-1); the
-// wait in front of tile t lets the NT - 1 - t younger requests of its own set and the whole next set stay pending.
+// The k-loop of one segment: MS slabs x NT tiles.
+//
+// Complex products by Gauss's three multiplications: with T1 = Ar Xr, T2 = Ai Xi, T3 = (Ar + Ai)(Xr + Xi) summed over
+// the segment, Re = T1 - T2 and Im = T3 - T1 - T2 -- 3 real MFMAs per complex multiply-accumulate instead of 4, paid
+// for with MS + NT v_add_f64 per k-step (the fragment sums) and a third accumulator per tile (24 x 8 = 192 VGPRs: two
+// wavefronts per SIMD still fit).  The kernel is power-bound, not issue-bound (MFMA-busy x clock is
+// constant across every variant of this loop), so a quarter fewer MFMAs is a quarter less time.  Normwise as accurate as
+// the four-multiplication form (the imaginary part loses relative accuracy only where it is small next to |A||X|).
+//
+// Registers and requests.  A fragments (streamed from HBM, the long latency) have TWO sets: the A of k-step ks + 1 is
+// requested at the top of k-step ks.  X fragments (L2) have ONE set: tile t is requested again right after the 3 MS
+// MFMAs that read it, 3 MS (NT - 1) MFMAs before its next use (tile-outer, slab-inner order).  Requests return in order,
+// so in front of every tile "all but the NT - 1 + MS youngest have arrived" is the wait (s_waitcnt vmcnt).
 // An odd number of k-steps ends with a k-step of zeros (the leaf fragments past the end of the segment).
-template <int NT, int MS, int SET>
-__device__ __forceinline__ void bfMfmaRequest(BfFrag (&a)[2][2], BfFrag (&x)[2][4], BfMfSeg const &sg, uint32_t soffA, uint32_t voffX) {
+template <int MS, int SET>
+__device__ __forceinline__ void bfMfmaRequestA(BfFrag (&a)[2][2], BfMfSeg const &sg, uint32_t soffA) {
   bfFragLoad<1, 0>(a[SET][0], sg.voffA, sg.ra, soffA);
   if (MS > 1) bfFragLoad<1, 256>(a[SET][1], sg.voffA, sg.ra, soffA);
-  bfFragLoad<0, 0>(x[SET][0], voffX, sg.rx, 0);
-  if (NT > 1) bfFragLoad<0, 256>(x[SET][1], voffX, sg.rx, 0);
-  if (NT > 2) bfFragLoad<0, 512>(x[SET][2], voffX, sg.rx, 0);
-  if (NT > 3) bfFragLoad<0, 768>(x[SET][3], voffX, sg.rx, 0);
+}
+template <int T>
+__device__ __forceinline__ void bfMfmaRequestX(BfFrag (&x)[4], BfMfSeg const &sg, uint32_t voffX) {
+  bfFragLoad<0, 256 * T>(x[T], voffX, sg.rx, 0);
 }
 template <int NT, int MS, int SET, int T>
-__device__ __forceinline__ void bfMfmaTile(bf_d4 (&accr)[2][4], bf_d4 (&acci)[2][4], BfFrag (&a)[2][2], BfFrag (&x)[2][4]) {
+__device__ __forceinline__ void bfMfmaTile(bf_d4 (&acc)[3][2][4], BfFrag (&a)[2][2], BfFrag (&x)[4], double (&as)[2], BfMfSeg const &sg, uint32_t voffXnext) {
   if (T < NT) {
-    constexpr int pending = (NT - 1 - T) + NT + MS;
-    if (T == 0 && MS > 1) asm volatile("s_waitcnt vmcnt(%3)" : "+v"(a[SET][0].u), "+v"(a[SET][1].u), "+v"(x[SET][0].u) : "n"(pending));
-    else if (T == 0) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a[SET][0].u), "+v"(x[SET][0].u) : "n"(pending));
-    else asm volatile("s_waitcnt vmcnt(%1)" : "+v"(x[SET][T < NT ? T : 0].u) : "n"(pending));
-    bfCmac(accr[0][T], acci[0][T], a[SET][0], x[SET][T < NT ? T : 0]);
-    if (MS > 1) bfCmac(accr[1][T], acci[1][T], a[SET][1], x[SET][T < NT ? T : 0]);
+    constexpr int TT = T < NT ? T : 0;
+    constexpr int pending = NT - 1 + MS;
+    if (T == 0 && MS > 1) asm volatile("s_waitcnt vmcnt(%3)" : "+v"(a[SET][0].u), "+v"(a[SET][1].u), "+v"(x[0].u) : "n"(pending));
+    else if (T == 0) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a[SET][0].u), "+v"(x[0].u) : "n"(pending));
+    else asm volatile("s_waitcnt vmcnt(%1)" : "+v"(x[TT].u) : "n"(pending));
+    if (T == 0) {
+      as[0] = a[SET][0].d[0] + a[SET][0].d[1];
+      if (MS > 1) as[1] = a[SET][1].d[0] + a[SET][1].d[1];
+    }
+    double const xs = x[TT].d[0] + x[TT].d[1];
+#pragma unroll
+    for (int m = 0; m < MS; ++m) {
+      acc[0][m][TT] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[SET][m].d[0], x[TT].d[0], acc[0][m][TT], 0, 0, 0);
+      acc[1][m][TT] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[SET][m].d[1], x[TT].d[1], acc[1][m][TT], 0, 0, 0);
+      acc[2][m][TT] = __builtin_amdgcn_mfma_f64_16x16x4f64(as[m], xs, acc[2][m][TT], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    bfMfmaRequestX<TT>(x, sg, voffXnext);
     __builtin_amdgcn_sched_barrier(0);
   }
 }
 template <int NT, int MS>
-__device__ __forceinline__ void bfMfmaSegment(bf_d4 (&accr)[2][4], bf_d4 (&acci)[2][4], BfMfSeg const &sg, uint32_t const *tab, uint32_t lk) {
-  BfFrag a[2][2], x[2][4];
+__device__ __forceinline__ void bfMfmaSegment(bf_d4 (&acc)[3][2][4], BfMfSeg const &sg, uint32_t const *tab, uint32_t lk) {
+  BfFrag a[2][2], x[4];
+  double as[2];
   uint32_t ti = lk;
   uint32_t soffA = 0;
-  bfMfmaRequest<NT, MS, 0>(a, x, sg, soffA, tab[ti] + sg.cX);
+  {
+    uint32_t const v0 = tab[ti] + sg.cX;
+    bfMfmaRequestA<MS, 0>(a, sg, soffA);
+    bfMfmaRequestX<0>(x, sg, v0);
+    if (NT > 1) bfMfmaRequestX<1>(x, sg, v0);
+    if (NT > 2) bfMfmaRequestX<2>(x, sg, v0);
+    if (NT > 3) bfMfmaRequestX<3>(x, sg, v0);
+  }
   uint32_t t1 = tab[ti + 4], t2 = tab[ti + 8];      // read an iteration ahead of their use
   ti += 12;
   for (uint32_t ks = 0; ks < sg.ksteps; ks += 2) {
@@ -126,23 +148,23 @@ __device__ __forceinline__ void bfMfmaSegment(bf_d4 (&accr)[2][4], bf_d4 (&acci)
     ti += 8;
     soffA += sg.stepA;
     __builtin_amdgcn_sched_barrier(0);
-    bfMfmaRequest<NT, MS, 1>(a, x, sg, soffA, v1);
+    bfMfmaRequestA<MS, 1>(a, sg, soffA);
     __builtin_amdgcn_sched_barrier(0);
-    bfMfmaTile<NT, MS, 0, 0>(accr, acci, a, x);
-    bfMfmaTile<NT, MS, 0, 1>(accr, acci, a, x);
-    bfMfmaTile<NT, MS, 0, 2>(accr, acci, a, x);
-    bfMfmaTile<NT, MS, 0, 3>(accr, acci, a, x);
+    bfMfmaTile<NT, MS, 0, 0>(acc, a, x, as, sg, v1);
+    bfMfmaTile<NT, MS, 0, 1>(acc, a, x, as, sg, v1);
+    bfMfmaTile<NT, MS, 0, 2>(acc, a, x, as, sg, v1);
+    bfMfmaTile<NT, MS, 0, 3>(acc, a, x, as, sg, v1);
     soffA += sg.stepA;
-    bfMfmaRequest<NT, MS, 0>(a, x, sg, soffA, v2);
+    bfMfmaRequestA<MS, 0>(a, sg, soffA);
     __builtin_amdgcn_sched_barrier(0);
-    bfMfmaTile<NT, MS, 1, 0>(accr, acci, a, x);
-    bfMfmaTile<NT, MS, 1, 1>(accr, acci, a, x);
-    bfMfmaTile<NT, MS, 1, 2>(accr, acci, a, x);
-    bfMfmaTile<NT, MS, 1, 3>(accr, acci, a, x);
+    bfMfmaTile<NT, MS, 1, 0>(acc, a, x, as, sg, v2);
+    bfMfmaTile<NT, MS, 1, 1>(acc, a, x, as, sg, v2);
+    bfMfmaTile<NT, MS, 1, 2>(acc, a, x, as, sg, v2);
+    bfMfmaTile<NT, MS, 1, 3>(acc, a, x, as, sg, v2);
   }
-  // the requests of the k-step past the end (zeros from the range check / a padded table row) must land before the
+  // the requests of the k-steps past the end (zeros from the range check / a padded table row) must land before the
   // registers are used again
-  asm volatile("s_waitcnt vmcnt(0)" : "+v"(a[0][0].u), "+v"(a[0][MS > 1 ? 1 : 0].u), "+v"(x[0][0].u), "+v"(x[0][NT > 1 ? 1 : 0].u), "+v"(x[0][NT > 2 ? 2 : 0].u), "+v"(x[0][NT > 3 ? 3 : 0].u));
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(a[0][0].u), "+v"(a[0][MS > 1 ? 1 : 0].u), "+v"(x[0].u), "+v"(x[NT > 1 ? 1 : 0].u), "+v"(x[NT > 2 ? 2 : 0].u), "+v"(x[NT > 3 ? 3 : 0].u));
 }
 
 // One pass = rows [s0, s0 + 16 MS) x RHS [q0, q0 + 16 NT) of one item, over all its segments.
@@ -150,11 +172,13 @@ template <int NT, int MS>
 __device__ __forceinline__ void bfMfmaPass(StageParams const &p, BfDevItem const &it, uint32_t mr, uint32_t s0, uint32_t q0, uint32_t *tab, int lane) {
   uint32_t const nrhs = p.nrhs;
   uint32_t const li = lane & 15, lk = lane >> 4;
-  bf_d4 accr[2][4], acci[2][4];
+  bf_d4 acc[3][2][4];            // T1 = sum Ar Xr, T2 = sum Ai Xi, T3 = sum (Ar + Ai)(Xr + Xi)
 #pragma unroll
-  for (int m = 0; m < MS; ++m)
+  for (int g = 0; g < 3; ++g)
 #pragma unroll
-    for (int t = 0; t < NT; ++t) { accr[m][t] = (bf_d4){0, 0, 0, 0}; acci[m][t] = (bf_d4){0, 0, 0, 0}; }
+    for (int m = 0; m < MS; ++m)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[g][m][t] = (bf_d4){0, 0, 0, 0};
   bool hasIdentity = false;
   uint32_t const np = it.numPieces;
   uint32_t const spanRows = BF_MF_SPAN_BYTES / (nrhs * 16u);
@@ -210,7 +234,7 @@ __device__ __forceinline__ void bfMfmaPass(StageParams const &p, BfDevItem const
     sg.rx = bfMakeRsrc(xin + ((uint64_t)minRow * nrhs + q0) * 16u, ((maxRow - minRow) * nrhs + (nrhs - q0)) * 16u);
     sg.voffA = (lk * mr + s0 + li) * 16u;          // rows past the item's end alias the next column: rows of the product that are never stored
     sg.cX = li * 16u;
-    bfMfmaSegment<NT, MS>(accr, acci, sg, tab, lk);
+    bfMfmaSegment<NT, MS>(acc, sg, tab, lk);
     waveSync();                                      // the table is rewritten by the next segment
   }
   double2 *out = (it.mrFlags & BF_ITEM_OUT_Y) ? (double2 *)p.y : (double2 *)p.temp;
@@ -228,7 +252,7 @@ __device__ __forceinline__ void bfMfmaPass(StageParams const &p, BfDevItem const
       for (int v = 0; v < 4; ++v) {
         uint32_t const row = s0 + 16u * m + 4 * v + lk2;
         if (row < mr && 16u * t + li2 <= qmax) {
-          double re = accr[m][t][v], im = acci[m][t][v];
+          double re = acc[0][m][t][v] - acc[1][m][t][v], im = acc[2][m][t][v] - acc[0][m][t][v] - acc[1][m][t][v];
           if (hasIdentity) {      // rare (real-operand zoo; complex operands have none)
             for (uint32_t k = 0; k < np; ++k) {
               BfDevPiece const pc = p.pieces[it.pieceBegin + k];

@@ -104,4 +104,10 @@ r64small()   { for v in ${XCD_VARIANTS:-base}; do
                  step s64_$v 300 $B --npoints 65536 --nrhs 64 --steps 10 --warmup 2 --no-cpu-baseline --no-extra
                  python -c "import json; d = json.load(open('$O/s64_$v.out')); print('n65536 $v', d['ms_per_step'], d['roofline']['achieved'], d['roofline']['frac'])"
                done; unset BFHIP_LIB_PATH; }
+inline64()   { step def1 600 $B --steps 20 --warmup 5 --no-streamer
+               python -c "import json; d = json.load(open('$O/def1.out')); print('default line: headline', d['roofline']['frac'], 'nrhs64', d['nrhs64']['roofline']['frac'], d['nrhs64']['ms_per_apply'], 'n65536', d['n65536']['roofline']['frac'])"
+               step alone64 300 $B --nrhs 64 --steps 10 --warmup 3 --no-cpu-baseline --no-extra
+               python -c "import json; d = json.load(open('$O/alone64.out')); print('standalone nrhs64', d['ms_per_step'], d['roofline']['frac'])"
+               step alone64b 300 $B --nrhs 64 --steps 30 --warmup 10 --no-cpu-baseline --no-extra
+               python -c "import json; d = json.load(open('$O/alone64b.out')); print('standalone nrhs64 (30 steps)', d['ms_per_step'], d['roofline']['frac'])"; }
 for s in "$@"; do $s; done
