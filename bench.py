@@ -736,6 +736,9 @@ def main():
                         "launches_per_apply": per_apply, "avg_launch_ms": avg_launch_ms,
                         "algorithmic_flops_per_apply": flops_per_apply, "hbm_gbs_algorithmic": achieved,
                         "kernel_ms_per_apply": kern_ms / max(launches.max(), 1),
+                        "executed_mfma_flops_per_apply": 6.0 * args.nrhs * st["leafElems"],
+                        "note": "algorithmic flops = 8 nrhs sum(m n) (SURVEY 8(d)); the kernel forms each complex product with Gauss's 3 real "
+                                "multiplications: 6 nrhs sum(m n) MFMA flops issued (+ tile padding)",
                         "event_sampling": f"HIP events around every launch of 1 apply in {ev_every} of the timed region"}
         else:
             roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -917,11 +920,12 @@ def main():
             o64, _ = compile_shard(0, nr)
             x64 = torch.from_numpy((rng.standard_normal((n, nr)) + 1j * rng.standard_normal((n, nr))) / np.sqrt(2)).to(dev)
             y64 = torch.empty((n, nr), dtype=tdtype, device=dev)
-            for _ in range(3):          # (one warm-up apply measured 3 % low: the clock settles over the first ~100 ms of MFMA load)
+            for _ in range(8):          # (the clock settles over the first few hundred ms of matrix-core load: early applies measure 1 - 3 % low)
                 o64.apply_device(x64, y64)
             torch.cuda.synchronize()
             o64.stage_profile(reset=True)
-            reps = 10
+            o64.set_profile_sampling(4)        # events around every launch of one apply in four
+            reps = 20
             t1 = time.perf_counter()
             for _ in range(reps):
                 o64.apply_device(x64, y64)
@@ -929,18 +933,21 @@ def main():
             dt = (time.perf_counter() - t1) / reps
             ms64, l64, _ = o64.stage_profile()
             flops = 8.0 * nr * o64.stats()["leafElems"]
-            tf = flops * reps / 1e12 / (float(ms64.sum()) / 1e3)
+            sampled = max(int(l64.max()), 1)
+            tf = flops * sampled / 1e12 / (float(ms64.sum()) / 1e3)
             out["nrhs64"] = {"config": "BASELINE configs[2]: the same operand, 64 right-hand sides (bfStageKernelC128Mfma)", "steps": reps,
                              "matvec_per_s": nr / dt, "ms_per_apply": dt * 1e3,
                              "roofline": {"bound": "mfma", "achieved": tf, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP64_MFMA_PEAK_TFLOPS,
-                                          "kernel": "bfStageKernelC128Mfma", "kernel_ms_per_apply": float(ms64.sum()) / reps,
-                                          "algorithmic_flops_per_apply": flops}}
+                                          "kernel": "bfStageKernelC128Mfma", "kernel_ms_per_apply": float(ms64.sum()) / sampled,
+                                          "algorithmic_flops_per_apply": flops,
+                                          "executed_mfma_flops_per_apply": 6.0 * nr * o64.stats()["leafElems"],
+                                          "note": "algorithmic flops = 8 nrhs sum(m n) (4 real multiply-adds per complex one, SURVEY 8(d)); the kernel forms each "
+                                                  "complex product with Gauss's 3 real multiplications, i.e. issues 6 nrhs sum(m n) MFMA flops (+ tile padding)"}}
             try:        # the matrix pipe's share of the cycles and the clock the chip sustained under this kernel (committed --pmc pass)
                 pm = json.load(open(os.path.join(ROOT, "profiles", f"{PROFILE_ROUND}_pmc_summary.json")))
                 clk = pm["mfma_sustained_clock"]
                 out["nrhs64"]["roofline"].update({
                     "sustained_clock_ghz": clk["ghz"], "peak_clock_ghz": clk["peak_ghz"], "mfma_busy_fraction": clk["mfma_busy_fraction"],
-                    "frac_at_sustained_clock": (tf / FP64_MFMA_PEAK_TFLOPS) / (clk["ghz"] / clk["peak_ghz"]),
                     "traffic": pm["bfStageKernelC128Mfma_per_launch"]["hbm_bytes"],
                     "clock_source": f"profiles/{PROFILE_ROUND}_pmc_summary.json [mfma_sustained_clock]: GRBM_GUI_ACTIVE / kernel time of the committed --pmc pass of "
                                     "`bench.py --nrhs 64`, NOT measured in this run; peak 78.6 TFLOP/s assumes 2.4 GHz"})

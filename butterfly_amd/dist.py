@@ -175,9 +175,16 @@ def choose_mode(desc, world, requested="auto"):
     # row ranges are free where the top-level block rows divide evenly (2 and 4 ranks on a closed curve: no leaf is
     # replicated); where a block row has to be shared (8 ranks: +6 % leaves for the replicated first-applied factors)
     # the column split of rowsum is the cheaper way to share it
-    cuts, loads = row_partition(desc, world)
+    has_blocks = getattr(desc, "top_row_block", None) is not None
+    try:
+        cuts, loads = row_partition(desc, world)
+    except Exception:
+        # fewer clean cut positions than ranks (small or tall-leaf operands): no row ranges -- share block rows instead
+        if not has_blocks:
+            raise
+        return "rowsum"
     total = int(desc.subtree_leaf_elems()[desc.root]) if hasattr(desc, "subtree_leaf_elems") else sum(row_block_weights(desc))
-    return "rows" if sum(loads) <= 1.005 * total or getattr(desc, "top_row_block", None) is None else "rowsum"
+    return "rows" if sum(loads) <= 1.005 * total or not has_blocks else "rowsum"
 
 
 class ShardLayout:
