@@ -105,8 +105,9 @@ __device__ __forceinline__ uint32_t bfFlowTicket(uint32_t *queue) {
 }
 __device__ __forceinline__ void bfFlowBump(uint32_t *counter) {
   uint64_t saved;
-  // (the release fence before this call ends in buffer_wbl2; the writeback is complete when vmcnt drains -- the
-  // compiler cannot know that the asm below is the atomic the fence orders, so the wait is spelled out here)
+  // Ordering: there is NO fence before this call.  The item's rows were written with agent-scope (sc1) stores -- written
+  // through this XCD's L2 -- and vmcnt counts them until they are acknowledged there; the counter moves only after
+  // vmcnt has drained (the wait below), and readers use agent-scope loads.  That is the whole argument.
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\t"
                "s_mov_b64 %0, exec\n\t"
                "s_mov_b64 exec, 1\n\t"
@@ -398,7 +399,9 @@ int bfdevLaunchFlow(BfFlowArgs const *a, void *stream) {
   static uint32_t spinLimit = 0;
   if (!spinLimit) { char const *e = getenv("BFHIP_FLOW_SPIN"); spinLimit = e ? (uint32_t)strtoul(e, NULL, 10) : BF_FLOW_SPIN_LIMIT; if (!spinLimit) spinLimit = BF_FLOW_SPIN_LIMIT; }
   p.spinLimit = spinLimit;
-  { char const *e = getenv("BFHIP_FLOW_DEBUGMODE"); p.debugMode = e ? (uint32_t)strtoul(e, NULL, 10) : 0u; }
+  static int debugMode = -1;                     // read once, like the spin limit
+  if (debugMode < 0) { char const *e = getenv("BFHIP_FLOW_DEBUGMODE"); debugMode = e ? (int)strtoul(e, NULL, 10) : 0; }
+  p.debugMode = (uint32_t)debugMode;
   p.x = a->x; p.y = a->y; p.temp = a->temp;
   // tickets are drawn one item ahead, so how many an apply draws is not fixed: the queue starts from zero every time
   hipError_t e = hipMemsetAsync(a->counters, 0, 4, (hipStream_t)stream);

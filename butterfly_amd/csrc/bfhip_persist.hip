@@ -79,22 +79,24 @@ __global__ __launch_bounds__(64) void bfStageKernelC128PTimeline(StageParams p, 
 // wavefront slots of the device for this kernel (5 per SIMD), rounded down to what the ticket pools need; 0 unless
 // BFHIP_PERSISTENT=1
 extern "C" uint32_t bfdevPersistentGrid(void) {
-  static int cached = -1;
-  if (cached < 0) {
-    int dev = 0, cus = 0;
-    char const *e = getenv("BFHIP_PERSISTENT");
-    if (!(e && e[0] == '1') || hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cached = 0;
-    else {
-      int occ = 0;
-      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, bfStageKernelC128P, 64, 0) != hipSuccess || occ <= 0) occ = 20;
-      uint64_t const slots = (uint64_t)cus * (uint64_t)occ;
-      cached = (int)(slots / (8u * BF_TICKET_POOLS) * (8u * BF_TICKET_POOLS));
-    }
+  static int enabled = -1;                         // the environment is read once
+  static int cached[16];                           // per device ordinal: CU counts may differ (0: not asked yet)
+  if (enabled < 0) { char const *e = getenv("BFHIP_PERSISTENT"); enabled = e && e[0] == '1'; }
+  if (!enabled) return 0;
+  int dev = 0, cus = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return 0;
+  if (!cached[dev]) {
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+    int occ = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, bfStageKernelC128P, 64, 0) != hipSuccess || occ <= 0) occ = 20;
+    uint64_t const slots = (uint64_t)cus * (uint64_t)occ;
+    cached[dev] = (int)(slots / (8u * BF_TICKET_POOLS) * (8u * BF_TICKET_POOLS));
   }
-  return (uint32_t)cached;
+  return (uint32_t)cached[dev];
 }
 
-// stageParams: the StageParams of bfdevLaunchStage; grid from bfdevPersistentGrid, < numItems; timeline NULL or 2 x numItems uint64
+// stageParams: the StageParams of bfdevLaunchStage; grid from bfdevPersistentGrid, < numItems; timeline NULL or
+// 8 x numItems uint64 (64 bytes per item: bfItemC128<TL> stamps timeline[8 * item + 0 .. 5])
 extern "C" int bfdevLaunchPersistC128(void const *stageParams, uint32_t grid, void *tickets, void *timeline, void *stream) {
   StageParams const &p = *(StageParams const *)stageParams;
   if (!grid || grid >= p.numItems || grid % (8u * BF_TICKET_POOLS) || !tickets) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "persistent launch: bad grid");

@@ -110,4 +110,13 @@ inline64()   { step def1 600 $B --steps 20 --warmup 5 --no-streamer
                python -c "import json; d = json.load(open('$O/alone64.out')); print('standalone nrhs64', d['ms_per_step'], d['roofline']['frac'])"
                step alone64b 300 $B --nrhs 64 --steps 30 --warmup 10 --no-cpu-baseline --no-extra
                python -c "import json; d = json.load(open('$O/alone64b.out')); print('standalone nrhs64 (30 steps)', d['ms_per_step'], d['roofline']['frac'])"; }
+adjab()      { for v in ${ADJ_VARIANTS:-T0 base}; do
+                 if [ $v = base ]; then unset BFHIP_LIB_PATH; else export BFHIP_LIB_PATH=$R/butterfly_amd/csrc/exp/libbfhip_$v.so; fi
+                 step adj_$v 300 $B --adjoint --steps 10 --warmup 2 --no-cpu-baseline --no-extra
+                 python -c "import json; d = json.load(open('$O/adj_$v.out')); print('$v c128 adjoint', d['adjoint']['ms_per_apply'], d['adjoint']['frac_of_hbm_peak'], d['adjoint']['transpose_identity_rel'])"
+                 step adjs_$v 300 $B --npoints 65536 --adjoint --steps 30 --warmup 3 --no-cpu-baseline --no-extra
+                 python -c "import json; d = json.load(open('$O/adjs_$v.out')); print('$v n65536 adjoint', d['adjoint']['ms_per_apply'], d['adjoint']['frac_of_hbm_peak'])"
+                 step stadj_$v 400 $B --workload streamer --adjoint --steps 10 --warmup 2 --no-cpu-baseline --no-extra
+                 python -c "import json; d = json.load(open('$O/stadj_$v.out')); print('$v streamer fwd', d['ms_per_step'], d['roofline']['frac'], 'adjoint', d['adjoint']['ms_per_apply'], d['adjoint']['frac_of_hbm_peak'], d['adjoint']['transpose_identity_rel'])"
+               done; unset BFHIP_LIB_PATH; }
 for s in "$@"; do $s; done
