@@ -41,7 +41,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable copy)
 FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X dense FP64 matrix peak = FP64 vector peak = 1/2 of the 157.3 TFLOP/s FP32 rate
-PROFILE_ROUND = "r3"      # which committed rocprofv3 summaries the `traffic` figure is read from
+PROFILE_ROUND = "r4"      # which committed rocprofv3 summaries the `traffic` figure is read from
 
 
 def log(*a):
@@ -395,13 +395,13 @@ def main():
         ncols = int(desc.cols[desc.root])
         total_leaf = gstats["leafBytes"] // 8
         workload = (f"fac_streamer butterfly of the N x J Laplace-Beltrami eigenvector matrix of a sphere (examples/covariance): N={n} octree rows, "
-                    f"J={ncols} columns (lmax={args.lmax}), frequency tree depth {fd}, tol=1e-3 rank model, minNumRows=minNumCols=20, nrhs={args.nrhs}")
+                    f"J={ncols} columns (lmax={args.lmax}), frequency tree depth {fd}, tol=1e-3 rank model (rank-model structure, NOT the reference's SVD-driven structure: DESIGN.md section 12), minNumRows=minNumCols=20, nrhs={args.nrhs}")
         config = {"workload": workload, "n": n, "num_cols": ncols, "lmax": args.lmax, "freq_depth": fd, "nrhs": args.nrhs,
                   "leaf_bytes": total_leaf * esz, "num_w": num_w,
                   "graph": {k: gstats[k] for k in ("denseReal", "identity", "blockCoo", "blockDense", "blockDiag", "maxNest")},
                   "dense_bytes": n * ncols * esz, "sharding": "none",
                   "layout": "python restatement" if args.python_layout else "native (bfhipStreamerLayoutCreate)"}
-        data = "synthetic (block structure laid out by the fac_streamer merge-and-split recursion under the fitted rank model; seeded values generated in HBM)"
+        data = "synthetic (block structure laid out by the fac_streamer merge-and-split recursion under the fitted rank model -- not what the reference's truncated SVDs would give at this size; seeded values generated in HBM)"
         metric = "butterfly matvecs/sec (streamed real butterfly apply, examples/covariance)"
         top_rows, weights, row_offsets = [n], [total_leaf], np.array([0, n])
         sworld, srank = (args.emulate_world, max(args.emulate_rank, 0)) if args.emulate_world > 1 else (world, rank)
@@ -752,7 +752,7 @@ def main():
         # `traffic` = HBM bytes PER LAUNCH (like `achieved`), from the COMMITTED rocprofv3 --pmc profile of this
         # very command (FETCH_SIZE / WRITE_SIZE in separate passes, gfx950 x2 FETCH correction): counters cannot
         # be read from inside the process, so it is not measured in this run and other configurations report null.
-        for rnd in (PROFILE_ROUND, "r1"):
+        for rnd in (PROFILE_ROUND, "r3"):
             prof = os.path.join(ROOT, "profiles", f"{rnd}_pmc_summary.json")
             helm_cfg = (not streamer and n == 262144 and abs(k - 16384) < 1e-9 and args.nrhs in (1, 64) and not real)
             cfg2 = (not streamer and n == 65536 and abs(k - 4096) < 1e-9 and args.nrhs == 1 and not real)
@@ -774,7 +774,7 @@ def main():
         # non-temporal reads / a bare loop of these MFMAs reaches on an MI355X of this pool
         for key, fn, fld in (("measured_stream_read_gbs", "hbm_peak.json", "read_nt_gbs"), ("measured_mfma_loop_tflops", "mfma_peak.json", "fp64_mfma_16x16x4_tflops")):
             if (roofline["bound"] == "hbm") == (fld == "read_nt_gbs"):
-                for rnd in (PROFILE_ROUND, "r2"):
+                for rnd in (PROFILE_ROUND, "r3"):
                     try:
                         roofline[key] = json.load(open(os.path.join(ROOT, "profiles", f"{rnd}_{fn}")))[fld]
                         break
