@@ -58,18 +58,24 @@ enum {
                                     for inspecting the flattened layout (bfhipPlan* below) */
   BFHIP_FLAG_ADJOINT = 1u << 2,  /* also build the plan of A^T (bfhipApplyTranspose*, RmulVec of the shim):
                                     index metadata only, the packed leaf data is shared */
-  BFHIP_FLAG_FLOW = 1u << 3      /* EXPERIMENTAL, complex128 operators applied to 1 - 2 right-hand sides: the whole plan as ONE
-                                    dependency-driven persistent launch (items wait for the intermediate vectors they read,
-                                    not for the previous stage; bit-identical results) instead of one launch per stage.
-                                    Measured slower than the staged launches on MI355X: off by default */
+  BFHIP_FLAG_FLOW = 1u << 3      /* EXPERIMENTAL BUILDS ONLY (libbfhip_exp.so, `make -C butterfly_amd/csrc experimental`): complex128
+                                    operators applied to 1 - 2 right-hand sides run the whole plan as ONE dependency-driven
+                                    persistent launch (items wait for the intermediate vectors they read, not for the previous
+                                    stage; bit-identical results).  Measured slower than the staged launches on MI355X
+                                    (DESIGN.md section 15).  The product library (libbfhip.so) does not contain that executor
+                                    and refuses the flag with BF_ERROR_NOT_IMPLEMENTED */
 };
-/* Environment variables read by the library (diagnostics and experiments; none is needed for normal use):
+/* Environment variables.  The product library reads three, all test / diagnosis hooks:
+ *   BFHIP_JACOBI_GLOBAL=1   builder: every SVD problem through the global-memory fallback kernel (test hook)
+ *   BFHIP_ALLOW_UNCONVERGED_SVD=1   builder: keep an operator whose Jacobi SVDs hit the sweep limit (diagnosis)
+ *   BFHIP_GMRES_MGS=1       GMRES: the reference's modified Gram-Schmidt order instead of batched CGS2 (as the per-call option)
+ * The experimental build (libbfhip_exp.so) additionally reads, once per process:
  *   BFHIP_FLOW=1            as BFHIP_FLAG_FLOW for every operator compiled in the process
  *   BFHIP_PERSISTENT=1      complex128 stages with more items than wavefront slots run as a persistent grid that draws
- *                           pooled tickets (bfhip_persist.hip; bit-identical results, measured equal to slower; read once)
+ *                           pooled tickets (bfhip_persist.hip; bit-identical results, measured equal to slower)
  *   BFHIP_TIMELINE_FILE=p   every complex128 stage launch (1 - 2 right-hand sides) becomes a synchronous diagnostic launch
  *                           that appends each item's start / end stamps to file p (tools/timeline.py; same results)
- *   BFHIP_JACOBI_GLOBAL=1   builder: every SVD problem through the global-memory fallback kernel (test hook) */
+ *   BFHIP_FLOW_SPIN, BFHIP_FLOW_DEBUG, BFHIP_FLOW_DEBUGMODE   diagnostics of the one-launch executor */
 
 typedef struct BfhipOptions {
   uint32_t structSize;      /* = sizeof(BfhipOptions) */
@@ -382,7 +388,7 @@ void bfhipFree(BfhipOperator **op);
 
 /* ---- reference-vtable shim ----------------------------------------------- */
 
-/* A `BfMat *` whose vtable implements Mul, MulVec, RmulVec, GetView, GetNumRows,
+/* A `BfMat *` whose vtable implements Mul, MulVec, RmulVec, Transpose, GetView, GetNumRows,
  * GetNumCols, GetType (-> BF_TYPE_MAT_FUNC), NumBytes and Delete on top of
  * `op`, so that unmodified reference code (bfSolveGMRES src/linalg.c:125,155;
  * cov_matvec examples/covariance/lbo_cov.c:48-60; an enclosing BfMatBlockDense,
@@ -391,8 +397,15 @@ void bfhipFree(BfhipOperator **op);
  * slot 8) so that the reference's bfMatDelete frees them
  * (mat_dense_complex.c:2164-2187); MulVec / RmulVec results are malloc'd
  * BfVecReal of the operator's row / column count carrying the argument's
- * vtable (rectangular operators are fine).  Delete releases the shim and, if
- * `ownsOperator`, the operator; a GetView copy never owns it. */
+ * vtable (rectangular operators are fine).  Transpose (slot 63, bfMatTranspose,
+ * src/mat.c:271-273) works in place like bfMatProductTranspose
+ * (src/mat_product.c:409-420): the object switches between the forward and the
+ * adjoint plan of `op` (BFHIP_FLAG_ADJOINT; without it the slot raises
+ * BF_ERROR_NOT_IMPLEMENTED and changes nothing), GetNumRows / GetNumCols answer
+ * for A^T, Mul / MulVec multiply by A^T and RmulVec by A; twice is the
+ * identity; the transpose is plain (no conjugation), as in the reference.
+ * Delete releases the shim and, if `ownsOperator`, the operator; a GetView copy
+ * never owns it (and is transposed if its source was). */
 void *bfhipMatNew(BfhipOperator *op, int ownsOperator);
 
 /* Failures of the shim's Mul / MulVec / RmulVec / GetView return NULL and, by default, also raise
