@@ -735,6 +735,7 @@ def main():
                         "frac": tf / FP64_MFMA_PEAK_TFLOPS, "traffic": None, "kernel": "bfStageKernelC128Mfma",
                         "launches_per_apply": per_apply, "avg_launch_ms": avg_launch_ms,
                         "algorithmic_flops_per_apply": flops_per_apply, "hbm_gbs_algorithmic": achieved,
+                        "algorithmic_bytes_per_apply": bytes_per_apply,
                         "kernel_ms_per_apply": kern_ms / max(launches.max(), 1),
                         "executed_mfma_flops_per_apply": 6.0 * args.nrhs * st["leafElems"],
                         "note": "algorithmic flops = 8 nrhs sum(m n) (SURVEY 8(d)); the kernel forms each complex product with Gauss's 3 real "

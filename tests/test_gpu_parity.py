@@ -258,6 +258,35 @@ def test_wide_tall_leaves_and_zero_fill_on_gpu():
     op.close()
 
 
+@pytest.mark.parametrize("nrhs", [3, 17, 64, 80])
+def test_rhs_block_kernel_segments(nrhs):
+    """The matrix-core kernel runs an item as one or more *segments* (contiguous leaf columns reading one vector, at most
+    2304 of them): an operator compiled for ONE right-hand side has 16-row items of up to 4096 columns, so applying it
+    to a block of right-hand sides splits items at the table capacity; a product under a dense block mixes pieces that
+    read x with pieces that read an intermediate in one row group; 37- and 150-row groups leave ragged slabs, 17 and 80
+    right-hand sides ragged tiles and a second 64-wide pass.  All against numpy."""
+    from butterfly_amd import helm2_structure as hs
+    from butterfly_amd.operator import HipOperator
+    rng = np.random.default_rng(70 + nrhs)
+    cz = lambda m, n: (rng.standard_normal((m, n)) + 1j * rng.standard_normal((m, n))) / np.sqrt(n)
+    d = hs.Desc(dtype=0)
+    vals = {}
+    wide = d.add(hs.NODE_DENSE, 37, 6000); vals[wide] = cz(37, 6000)           # one row group, 6000 columns of x
+    a = d.add(hs.NODE_DENSE, 150, 300); vals[a] = cz(150, 300)
+    b = d.add(hs.NODE_DENSE, 300, 500); vals[b] = cz(300, 500)
+    prod = d.add(hs.NODE_PRODUCT, 150, 500, [(a, 0, 0), (b, 0, 0)])
+    near = d.add(hs.NODE_DENSE, 150, 700); vals[near] = cz(150, 700)           # same rows as the product's last factor: reads x
+    d.root = d.add(hs.NODE_BLOCK, 187, 6000, [(wide, 0, 0), (prod, 37, 100), (near, 37, 900)], hs.BF_TYPE_BLOCK_COO)
+    x = rng.standard_normal((6000, nrhs)) + 1j * rng.standard_normal((6000, nrhs))
+    want = np.zeros((187, nrhs), dtype=complex)
+    want[:37] = vals[wide] @ x
+    want[37:] = vals[a] @ (vals[b] @ x[100:600]) + vals[near] @ x[900:1600]
+    for max_rhs in (1, nrhs):
+        op = HipOperator.from_desc(d, vals, max_rhs=max_rhs)
+        assert rel(op.apply_host(x), want) <= TOL, max_rhs
+        op.close()
+
+
 def test_row_sharded_operators_on_gpu(helm2_cases):
     from butterfly_amd import helm2_structure as hs
     from butterfly_amd.operator import HipOperator

@@ -109,8 +109,11 @@ for nm, key in (("stats_r1", "bfStageKernelC128_per_launch"), ("stats_r64", "bfS
     if os.path.exists(p) and out.get(key):
         b = json.load(open(p))
         rl = b["roofline"]
-        if "algorithmic_bytes_per_apply" in rl:
-            out[key]["algorithmic_bytes"] = rl["algorithmic_bytes_per_apply"] / rl["launches_per_apply"]
+        per_apply = rl.get("algorithmic_bytes_per_apply")
+        if per_apply is None and "hbm_gbs_algorithmic" in rl:       # RHS-block lines carry the rate: bytes = rate x kernel time
+            per_apply = rl["hbm_gbs_algorithmic"] * 1e9 * rl["kernel_ms_per_apply"] / 1e3
+        if per_apply is not None:
+            out[key]["algorithmic_bytes"] = per_apply / rl["launches_per_apply"]
             out[key]["ratio"] = out[key]["hbm_bytes"] / out[key]["algorithmic_bytes"]
 
 
