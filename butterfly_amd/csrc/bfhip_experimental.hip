@@ -374,8 +374,9 @@ static int bfTimelineLaunch(BfLaunchArgs const *a, StageParams const &p, uint32_
 int bfdevLaunchStageExperimental(BfLaunchArgs const *a, void const *stageParams, uint32_t grid, void *stream, int *handled) {
   StageParams const &p = *(StageParams const *)stageParams;
   hipStream_t s = (hipStream_t)stream;
-  static int timelineOn = -1;                       // the environment is read once, not per launch
-  if (timelineOn < 0) { char const *e = getenv("BFHIP_TIMELINE_FILE"); timelineOn = e && e[0]; }
+  // (read per launch on purpose: tools/timeline.py switches the diagnostic on for ONE apply after its warm-up)
+  char const *tlEnv = getenv("BFHIP_TIMELINE_FILE");
+  int const timelineOn = tlEnv && tlEnv[0];
   uint32_t const slots = bfdevPersistentGrid();
   uint32_t const pgrid = (a->tickets && slots && a->numItems > slots) ? slots : 0;        /* 0: every item has a slot of its own anyway */
   *handled = 1;
