@@ -68,6 +68,9 @@ def parse_args(argv):
                     help="helm2: c128 (headline); f64 / f32 = the same block layout with real values (a kernel proxy).  "
                          "streamer: f32 (default; the build's extension, configs[4]) or f64 (the reference's type)")
     ap.add_argument("--adjoint", action="store_true", help="also time y = A^T x (RmulVec path) and report it next to the headline")
+    ap.add_argument("--adjoint-shared", action="store_true",
+                    help="with --adjoint: the adjoint plan reads the forward plan's packed leaves through the transposed kernels (BFHIP_FLAG_ADJOINT: no extra "
+                         "leaf memory) instead of a packed copy of its own on the forward kernels (BFHIP_FLAG_ADJOINT_PACKED, the default here: twice the leaf memory)")
     ap.add_argument("--pcie", action="store_true", help="also time the host-buffer path (H2D + apply + D2H)")
     ap.add_argument("--emulate-world", type=int, default=0,
                     help="diagnostic: on ONE GPU, time the shard that rank --emulate-rank of an N-rank job would own (no collective); "
@@ -365,7 +368,10 @@ def main():
     real = dtype != "c128"
     esz = {"c128": 16, "f64": 8, "f32": 4}[dtype]
     tdtype = {"c128": torch.complex128, "f64": torch.float64, "f32": torch.float32}[dtype]
-    flags = _capi.FLAG_PROFILE | (_capi.FLAG_ADJOINT if args.adjoint else 0)
+    if streamer:
+        args.adjoint_shared = True      # the transposed expression of a streamed butterfly (tall-narrow transposed leaves) suits the forward kernels
+                                        # badly: 2x slower than the transposed kernels on the shared leaves
+    flags = _capi.FLAG_PROFILE | ((_capi.FLAG_ADJOINT if args.adjoint_shared else _capi.FLAG_ADJOINT_PACKED) if args.adjoint else 0)
 
     # ---- the operand's block layout -------------------------------------------------------------------
     t0 = time.time()
@@ -828,12 +834,15 @@ def main():
             adj_ms = (time.perf_counter() - t1) / args.steps * 1e3
             out["adjoint"] = {"ms_per_apply": adj_ms, "matvec_per_s": args.nrhs / (adj_ms / 1e3),
                               "hbm_gbs": st["leafBytes"] / 1e9 / (adj_ms / 1e3), "frac_of_hbm_peak": st["leafBytes"] / 1e9 / (adj_ms / 1e3) / HBM_PEAK_GBS,
-                              "traffic_per_apply": None}
+                              "traffic_per_apply": None,
+                              "layout": ("shared: the forward plan's packed leaves read by the transposed kernels (BFHIP_FLAG_ADJOINT)" if args.adjoint_shared else
+                                         "packed: a second copy of the leaves laid out for A^T, applied by the forward kernels (BFHIP_FLAG_ADJOINT_PACKED; "
+                                         f"{2 * st['leafBytes'] / 1e9:.1f} GB of leaves resident)")}
             try:        # HBM bytes per transposed apply from the committed --pmc passes of this command (all bfStageKernelT launches of one apply)
                 pm = json.load(open(os.path.join(ROOT, "profiles", f"{PROFILE_ROUND}_pmc_summary.json")))
                 akey = ("bfStageKernelT_f32_streamer_adjoint_per_apply" if (streamer and n == 1048576 and args.lmax == 255 and dtype == "f32") else
                         "bfStageKernelT_c128_adjoint_per_apply" if (not streamer and n == 262144 and not real and abs(k - 16384) < 1e-9) else None)
-                if akey and pm.get(akey) and args.nrhs == 1:
+                if akey and pm.get(akey) and args.nrhs == 1 and args.adjoint_shared:
                     out["adjoint"]["traffic_per_apply"] = pm[akey]["hbm_bytes"]
                     out["adjoint"]["traffic_ratio"] = pm[akey]["ratio"]
                     out["adjoint"]["traffic_source"] = f"profiles/{PROFILE_ROUND}_pmc_summary.json [{akey}]: committed rocprofv3 --pmc passes, not measured in this run"

@@ -54,6 +54,7 @@ struct BfhipOperator {
   int device;
   uint32_t flags;
   void *dArena;               /* leaf data */
+  void *dArenaT;              /* BFHIP_FLAG_ADJOINT_PACKED: the leaves of A^T packed for tplan, a FORWARD plan of the transposed expression */
   void *dTemp;                /* vector arena: intermediates + partial slots, tempElems * maxRhs */
   void *dZero;                /* 4 KiB of zeros */
   uint32_t tempRhs;
@@ -115,6 +116,7 @@ void bfhipFree(BfhipOperator **pop) {
   free(op->evStart); free(op->evStop); free(op->stageMs); free(op->stageLaunches);
   freeDevicePlan(op);
   bfdevFree(op->dArena);
+  bfdevFree(op->dArenaT);
   bfdevFree(op->dTemp);
   bfdevFree(op->dZero);
   bfdevFree(op->dFlowItems); bfdevFree(op->dFlowPieces); bfdevFree(op->dFlowItemOut); bfdevFree(op->dFlowWriters); bfdevFree(op->dFlowCounters);
@@ -149,7 +151,10 @@ static void packPiece(BfPlan const *pl, BfIr const *ir, BfDevPiece const *pc, Bf
   uint64_t ldr = ir->leafRowStride[node], ldc = ir->leafColStride[node];
   double const *A = (double const *)data;
   double scale = 0;
-  uint64_t vbase = ir->synthBase[node], n = ir->cols[node];
+  /* synthetic leaves: element (i, j) of the ORIGINAL leaf is stream value base + i * n + j, n its column count; the leaves of a
+   * transposed view (bfIrTransposed) hold element (j, i) of it */
+  uint64_t vbase = ir->synthBase[node], n = ir->transposedView ? ir->rows[node] : ir->cols[node];
+  uint64_t const sR = ir->transposedView ? 1 : n, sC = ir->transposedView ? n : 1;
   if (!data) scale = cplx ? sqrt(3.0 / (2.0 * (double)n)) : sqrt(3.0 / (double)n);
   int const rowMajor = (pc->flags & BF_PIECE_ROWMAJOR) != 0;      /* real dtypes only */
   uint32_t const rowsStored = rowMajor ? mr : mrPad;
@@ -162,8 +167,8 @@ static void packPiece(BfPlan const *pl, BfIr const *ir, BfDevPiece const *pc, Bf
           if (cplx && !ir->leafReal[node]) { double const *e = A + 2 * (i * ldr + j * ldc); re = e[0]; im = e[1]; }
           else re = A[i * ldr + j * ldc];
         } else {
-          re = bfhip_synth_value(seed, vbase + i * n + j, 0) * scale;
-          if (cplx) im = bfhip_synth_value(seed, vbase + i * n + j, 1) * scale;
+          re = bfhip_synth_value(seed, vbase + i * sR + j * sC, 0) * scale;
+          if (cplx) im = bfhip_synth_value(seed, vbase + i * sR + j * sC, 1) * scale;
         }
       }
       uint64_t e = rowMajor ? (uint64_t)r * pc->ld + c : (uint64_t)c * mrPad + r;
@@ -197,8 +202,7 @@ static void packPiece(BfPlan const *pl, BfIr const *ir, BfDevPiece const *pc, Bf
  * write everything (synthetic leaves included) to host memory; else upload
  * host-valued leaves through a staging buffer and synthesize the rest on the
  * device. */
-static int packLeaves(BfhipOperator const *op, BfIr const *ir, uint64_t seed, void *hostDst) {
-  BfPlan const *pl = &op->plan;
+static int packLeavesPlan(BfPlan const *pl, void *dArena, BfIr const *ir, uint64_t seed, void *hostDst) {
   size_t const es = pl->elemSize;
   int const cplx = pl->dtype == BFHIP_C128;
   size_t const chunkBytes = (size_t)64 << 20;
@@ -234,11 +238,13 @@ static int packLeaves(BfhipOperator const *op, BfIr const *ir, uint64_t seed, vo
           BfSynthPiece *sp = &synth[numSynth++];
           sp->dataOff = pc->dataOff;
           sp->vbase = ir->synthBase[node];
-          sp->leafCols = (uint32_t)ir->cols[node];
+          uint64_t const ncol = ir->transposedView ? ir->rows[node] : ir->cols[node];      /* columns of the leaf the stream was laid over */
+          sp->strideR = ir->transposedView ? 1u : (uint32_t)ncol;
+          sp->strideC = ir->transposedView ? (uint32_t)ncol : 1u;
           sp->row0 = src->row0; sp->col0 = src->col0;
           sp->mr = mr; sp->mrPad = mrPad; sp->ncols = pc->ncols;
           sp->rowMajor = (pc->flags & BF_PIECE_ROWMAJOR) != 0; sp->ldr = pc->ld;
-          sp->scale = cplx ? sqrt(3.0 / (2.0 * (double)ir->cols[node])) : sqrt(3.0 / (double)ir->cols[node]);
+          sp->scale = cplx ? sqrt(3.0 / (2.0 * (double)ncol)) : sqrt(3.0 / (double)ncol);
           continue;
         }
         if (!stage) {
@@ -248,7 +254,7 @@ static int packLeaves(BfhipOperator const *op, BfIr const *ir, uint64_t seed, vo
         }
         /* pieces are consecutive in the arena except across synthetic ones */
         if (fill && (pc->dataOff != chunkBase + fill / es || fill + bytes > chunkBytes)) {
-          rc = bfdevMemcpyH2D((char *)op->dArena + chunkBase * es, stage, fill);
+          rc = bfdevMemcpyH2D((char *)dArena + chunkBase * es, stage, fill);
           fill = 0;
           if (rc) break;
         }
@@ -259,11 +265,15 @@ static int packLeaves(BfhipOperator const *op, BfIr const *ir, uint64_t seed, vo
       }
     }
   }
-  if (!rc && fill) rc = bfdevMemcpyH2D((char *)op->dArena + chunkBase * es, stage, fill);
+  if (!rc && fill) rc = bfdevMemcpyH2D((char *)dArena + chunkBase * es, stage, fill);
   free(stage);
-  if (!rc && numSynth) rc = bfdevSynthFill(op->dArena, pl->dtype, synth, numSynth, seed);
+  if (!rc && numSynth) rc = bfdevSynthFill(dArena, pl->dtype, synth, numSynth, seed);
   free(synth);
   return rc;
+}
+
+static int packLeaves(BfhipOperator const *op, BfIr const *ir, uint64_t seed, void *hostDst) {
+  return packLeavesPlan(&op->plan, op->dArena, ir, seed, hostDst);
 }
 
 static int uploadPlanMeta(BfhipOperator *op, BfPlan *plan) {
@@ -433,7 +443,20 @@ int bfhipCompileIrFill(BfIr *ir, BfhipOptions const *opts, BfFillFn fill, void *
   po.rowEnd = o.rowEnd;
   if ((rc = bfPlanBuild(ir, &po, &op->plan))) goto done;
   op->leafBytesAlgorithmic = op->plan.leafElems * op->plan.elemSize;
-  if (o.flags & BFHIP_FLAG_ADJOINT) {
+  /* The adjoint plan.  BFHIP_FLAG_ADJOINT_PACKED: a FORWARD plan of the transposed expression over its own packed copy of the
+   * leaves (twice the leaf memory; A^T x then runs on the forward kernels at the forward rate).  Not with a caller-side
+   * value builder (its values exist in the forward arena only) and not plan-only: those get the shared-leaf plan below. */
+  BfIr irT;
+  memset(&irT, 0, sizeof irT);
+  int const packedT = (o.flags & BFHIP_FLAG_ADJOINT_PACKED) && !fill;      /* (plan-only: the plan can be inspected, bfhipPlanPackArena packs the forward arena only) */
+  if (packedT) {
+    if (po.rowEnd > 0 || po.rowBlockEnd > 0) { rc = bfhipFail(BFABI_ERROR_NOT_IMPLEMENTED, "BFHIP_FLAG_ADJOINT_PACKED on a row-sharded operator"); goto done; }
+    if ((rc = bfIrTransposed(ir, &irT))) goto done;
+    BfPlanOptions pt = po;
+    if ((rc = bfPlanBuild(&irT, &pt, &op->tplan))) { bfIrFree(&irT); goto done; }
+    op->hasTplan = 1;
+    if (planOnly) bfIrFree(&irT);
+  } else if (o.flags & (BFHIP_FLAG_ADJOINT | BFHIP_FLAG_ADJOINT_PACKED)) {
     BfFwdPiece *fwd = NULL;
     uint64_t nf = 0;
     if ((rc = bfPlanFwdPieces(&op->plan, &fwd, &nf))) goto done;
@@ -466,7 +489,13 @@ int bfhipCompileIrFill(BfIr *ir, BfhipOptions const *opts, BfFillFn fill, void *
   if ((rc = uploadPlanMeta(op, &op->plan))) goto done;
   if (op->hasTplan && (rc = uploadPlanMeta(op, &op->tplan))) goto done;
   /* leaf values: computed on the device by the caller's builder, or packed / synthesized from the IR */
-  if ((rc = fill ? fill(&op->plan, ir, op->dArena, fillCtx) : packLeaves(op, ir, o.seed, NULL))) goto done;
+  if ((rc = fill ? fill(&op->plan, ir, op->dArena, fillCtx) : packLeaves(op, ir, o.seed, NULL))) { bfIrFree(&irT); goto done; }
+  if (packedT) {
+    rc = bfdevMalloc(&op->dArenaT, (size_t)op->tplan.arenaElems * op->tplan.elemSize + BF_ARENA_SLACK);
+    if (!rc) rc = packLeavesPlan(&op->tplan, op->dArenaT, &irT, o.seed, NULL);
+    bfIrFree(&irT);
+    if (rc) goto done;
+  }
 #ifdef BFHIP_EXPERIMENTAL
   {
     char const *envFlow = getenv("BFHIP_FLOW");         /* A/B switch for whole programs; BFHIP_FLAG_FLOW is the per-operator one */
@@ -706,7 +735,7 @@ static int runPlan(BfhipOperator *op, BfPlan *plan, void const *dX, size_t nrhs,
   for (uint64_t s = 0; s < plan->numStages; ++s) {
     BfStage *st = &plan->stages[s];
     BfLaunchArgs a;
-    a.arena = op->dArena; a.items = st->dItems; a.pieces = st->dPieces; a.numItems = st->numItems; a.firstSmall = st->firstSmall; a.numCoop = st->numCoop; a.numNarrow = st->numNarrow; a.numCoopNarrow = st->numCoopNarrow; a.maxRowsRest = st->maxRowsRest;
+    a.arena = (plan == &op->tplan && op->dArenaT) ? op->dArenaT : op->dArena; a.items = st->dItems; a.pieces = st->dPieces; a.numItems = st->numItems; a.firstSmall = st->firstSmall; a.numCoop = st->numCoop; a.numNarrow = st->numNarrow; a.numCoopNarrow = st->numCoopNarrow; a.maxRowsRest = st->maxRowsRest;
     a.x = dX; a.y = dY; a.temp = op->dTemp; a.zero = op->dZero; a.nrhs = (uint32_t)nrhs; a.dtype = plan->dtype; a.maxRows = st->maxRows;
     a.transposed = plan->transposed;
     a.tickets = NULL;
@@ -907,7 +936,7 @@ int bfhipGetStats(BfhipOperator const *op, BfhipStats *st) {
   }
   st->leafElems = pl->leafElems;
   st->leafBytes = pl->leafElems * pl->elemSize;
-  st->arenaBytes = pl->arenaElems * pl->elemSize;
+  st->arenaBytes = pl->arenaElems * pl->elemSize + (op->dArenaT ? op->tplan.arenaElems * op->tplan.elemSize : 0);      /* both packed copies with BFHIP_FLAG_ADJOINT_PACKED */
   st->tempElems = pl->tempElems;
   st->metaBytes = op->metaBytes;
   return 0;
@@ -1203,6 +1232,7 @@ static int loadPlan(FILE *fp, BfhipOperator *op, BfPlan *pl, FileHeader const *f
 int bfhipSave(BfhipOperator *op, char const *path) {
   if (!op || !path) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "NULL argument");
   if (op->flags & BFHIP_FLAG_PLAN_ONLY) return bfhipFail(BFABI_ERROR_RUNTIME_ERROR, "a plan-only operator has no device data to save");
+  if (op->dArenaT) return bfhipFail(BFABI_ERROR_NOT_IMPLEMENTED, "bfhipSave: operator compiled with BFHIP_FLAG_ADJOINT_PACKED (its second leaf arena is not part of the file format)");
   int prev = -1;
   bfdevGetDevice(&prev);
   int rc = bfdevSetDevice(op->device);

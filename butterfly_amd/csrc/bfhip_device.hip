@@ -855,7 +855,7 @@ __global__ __launch_bounds__(256) void bfSynthKernel(void *arenaV, BfSynthPiece 
     else { col = (uint32_t)(e / pc.mrPad); r = (uint32_t)(e - (uint64_t)col * pc.mrPad); }
     S re = 0, im = 0;
     if (r < pc.mr && col < pc.ncols) {
-      uint64_t idx = pc.vbase + (uint64_t)(pc.row0 + r) * pc.leafCols + (pc.col0 + col);
+      uint64_t idx = pc.vbase + (uint64_t)(pc.row0 + r) * pc.strideR + (uint64_t)(pc.col0 + col) * pc.strideC;
       re = (S)(bfhip_synth_value(seed, idx, 0) * pc.scale);
       if (CPLX) im = (S)(bfhip_synth_value(seed, idx, 1) * pc.scale);
     }
@@ -1108,10 +1108,11 @@ int bfdevSynthFill(void *arena, uint32_t dtype, BfSynthPiece const *hostPieces, 
   if (rc) return rc;
   rc = hipFail(hipMemcpy(d, hostPieces, count * sizeof(BfSynthPiece), hipMemcpyHostToDevice), "hipMemcpy(synth pieces)");
   if (!rc) {
-    // grid.x is limited to 2^31-1; chunk to be safe
+    // a launch's global size (blocks x 256 threads) is a 32-bit count of work-items: at most 2^24 - 1 blocks of 256, or the
+    // launch silently covers a truncated grid (found at 18 M pieces: the packed adjoint of the N = 1M streamed operand)
     uint64_t done = 0;
     while (done < count && !rc) {
-      uint32_t n = (uint32_t)((count - done) > (1u << 30) ? (1u << 30) : (count - done));
+      uint32_t n = (uint32_t)((count - done) > (1u << 23) ? (1u << 23) : (count - done));
       if (dtype == BFHIP_C128) hipLaunchKernelGGL(bfSynthKernel<BFHIP_C128>, dim3(n), dim3(256), 0, 0, arena, d + done, seed);
       else if (dtype == BFHIP_F64) hipLaunchKernelGGL(bfSynthKernel<BFHIP_F64>, dim3(n), dim3(256), 0, 0, arena, d + done, seed);
       else hipLaunchKernelGGL(bfSynthKernel<BFHIP_F32>, dim3(n), dim3(256), 0, 0, arena, d + done, seed);
@@ -1126,6 +1127,8 @@ int bfdevSynthFill(void *arena, uint32_t dtype, BfSynthPiece const *hostPieces, 
 
 int bfdevLaunchStage(BfLaunchArgs const *a, void *stream) {
   if (!a->numItems) return 0;
+  /* a launch's global size is a 32-bit count of work-items; the widest mapping here is one 64-lane wavefront per item */
+  if (a->numItems >= (1ull << 32) / 256) return bfhipFail(BFABI_ERROR_RUNTIME_ERROR, "stage of %llu items exceeds the 32-bit global size of a launch", (unsigned long long)a->numItems);
   StageParams p;
   p.arena = a->arena;
   p.items = (BfDevItem const *)a->items;

@@ -33,6 +33,8 @@ typedef struct BfIr {
   uint64_t *leafColStride;     /* element stride between columns (BfMat graphs may have colStride != 1) */
   uint8_t *leafReal;           /* host values of this leaf are real doubles even in a complex operand (BfMatDiagReal terms) */
   uint64_t *synthBase;         /* per node: base index in the synthetic stream */
+  int transposedView;          /* this IR is the transpose of the one the operator was compiled from (bfIrTransposed): synthetic leaf
+                                * values are stream(base + col * rows + row), i.e. the ORIGINAL leaf's row-major index */
   uint64_t *topRowBlock;       /* per child of root, or NULL */
   uint32_t *depth;             /* stages needed by the subtree */
   /* sparse decorations folded into host-valued dense leaves: value added to leaf element (row, col) when the
@@ -48,6 +50,7 @@ void bfIrFree(BfIr *ir);
 int bfIrFromDesc(BfhipDesc const *desc, BfIr *ir);
 int bfIrFromBfMat(void const *bfMat, BfIr *ir);
 int bfIrFinalize(BfIr *ir);   /* validation, depth, synthetic bases */
+int bfIrTransposed(BfIr const *src, BfIr *dst);   /* dst = the expression of src^T over the same (borrowed) leaf values; src finalized */
 
 /* ------------------------------------------------------------------------
  * Plan: the flattened per-stage layout (host mirror of what lives in HBM)
@@ -219,7 +222,8 @@ void bfdevHostFreePinned(void *p);
 typedef struct BfSynthPiece {
   uint64_t dataOff;     /* element offset in arena */
   uint64_t vbase;       /* synthetic index of leaf element (0,0) */
-  uint32_t leafCols;    /* leaf row length n (row-major virtual index = i*n + j) */
+  uint32_t strideR, strideC;   /* virtual index of leaf element (i, j) = vbase + i * strideR + j * strideC (n, 1 -- or 1, rows of the leaf
+                                * as stored, for the leaves of a transposed view) */
   uint32_t row0, col0;
   uint32_t mr, mrPad, ncols;
   uint32_t rowMajor, ldr;      /* row-major piece: element (r, c) at dataOff + r * ldr + c */

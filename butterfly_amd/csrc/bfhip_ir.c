@@ -33,6 +33,52 @@ static void *dupArray(void const *src, uint64_t count, size_t elt) {
   return p;
 }
 
+static int cmpPatch(void const *pa, void const *pb);
+
+/* The expression of A^T over the same leaf values: every node's shape swapped, a block's children placed at (col0, row0), a
+ * product's factors in reverse order, host-valued leaves read with their strides swapped, synthetic leaves marked
+ * (transposedView) so that element (i, j) of a transposed leaf is the stream value of element (j, i) of the original.  What
+ * bfMatProductTranspose does to a product in place (reference src/mat_product.c:409-420), as a second expression. */
+int bfIrTransposed(BfIr const *src, BfIr *dst) {
+  memset(dst, 0, sizeof *dst);
+  uint64_t const n = src->numNodes, nc = src->numChildren;
+  dst->dtype = src->dtype; dst->numNodes = n; dst->numChildren = nc; dst->root = src->root;
+  dst->capNodes = n; dst->capChildren = nc;
+  dst->transposedView = !src->transposedView;
+  dst->kind = dupArray(src->kind, n, 1);
+  dst->rows = dupArray(src->cols, n, 8);
+  dst->cols = dupArray(src->rows, n, 8);
+  dst->childBegin = dupArray(src->childBegin, n + 1, 8);
+  dst->childNode = dupArray(src->childNode, nc, 8);
+  dst->childRow0 = dupArray(src->childCol0, nc, 8);
+  dst->childCol0 = dupArray(src->childRow0, nc, 8);
+  dst->leafData = dupArray(src->leafData, n, sizeof(void *));
+  dst->leafRowStride = dupArray(src->leafColStride, n, 8);
+  dst->leafColStride = dupArray(src->leafRowStride, n, 8);
+  dst->leafReal = dupArray(src->leafReal, n, 1);
+  dst->synthBase = dupArray(src->synthBase, n, 8);
+  dst->depth = dupArray(src->depth, n, 4);
+  dst->patches = dupArray(src->patches, src->numPatches, sizeof(BfIrPatch));
+  dst->numPatches = dst->capPatches = src->numPatches;
+  if (!dst->kind || !dst->rows || !dst->cols || !dst->childBegin || !dst->childNode || !dst->childRow0 || !dst->childCol0 || !dst->leafData ||
+      !dst->leafRowStride || !dst->leafColStride || !dst->leafReal || !dst->synthBase || !dst->depth || !dst->patches) {
+    bfIrFree(dst);
+    return bfhipFail(BFABI_ERROR_MEMORY_ERROR, "host OOM");
+  }
+  for (uint64_t v = 0; v < n; ++v) {
+    if (src->kind[v] != BFHIP_NODE_PRODUCT) continue;
+    uint64_t const b = src->childBegin[v], e = src->childBegin[v + 1];
+    for (uint64_t c = b; c < e; ++c) {          /* factors in reverse order; a product's children sit at (0, 0) */
+      dst->childNode[c] = src->childNode[e - 1 - (c - b)];
+      dst->childRow0[c] = src->childCol0[e - 1 - (c - b)];
+      dst->childCol0[c] = src->childRow0[e - 1 - (c - b)];
+    }
+  }
+  for (uint64_t k = 0; k < dst->numPatches; ++k) { uint32_t const r = dst->patches[k].row; dst->patches[k].row = dst->patches[k].col; dst->patches[k].col = r; }
+  if (dst->numPatches) qsort(dst->patches, dst->numPatches, sizeof(BfIrPatch), cmpPatch);
+  return 0;
+}
+
 int bfIrFromDesc(BfhipDesc const *d, BfIr *ir) {
   memset(ir, 0, sizeof *ir);
   if (!d || d->structSize < sizeof(BfhipDesc)) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "BfhipDesc.structSize too small");

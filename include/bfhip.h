@@ -58,6 +58,12 @@ enum {
                                     for inspecting the flattened layout (bfhipPlan* below) */
   BFHIP_FLAG_ADJOINT = 1u << 2,  /* also build the plan of A^T (bfhipApplyTranspose*, RmulVec of the shim):
                                     index metadata only, the packed leaf data is shared */
+  BFHIP_FLAG_ADJOINT_PACKED = 1u << 4,  /* as BFHIP_FLAG_ADJOINT, but A^T gets a packed copy of the leaves of its own: the adjoint
+                                    plan is then a FORWARD plan of the transposed expression (factors reversed, every leaf
+                                    transposed -- what bfMatProductTranspose leaves behind, src/mat_product.c:409-420) and
+                                    A^T x runs on the forward kernels at the forward rate, for twice the leaf memory.
+                                    Falls back to the shared-leaf plan with a device value builder / BFHIP_FLAG_PLAN_ONLY;
+                                    such operators cannot be saved (bfhipSave: NOT_IMPLEMENTED) */
   BFHIP_FLAG_FLOW = 1u << 3      /* EXPERIMENTAL BUILDS ONLY (libbfhip_exp.so, `make -C butterfly_amd/csrc experimental`): complex128
                                     operators applied to 1 - 2 right-hand sides run the whole plan as ONE dependency-driven
                                     persistent launch (items wait for the intermediate vectors they read, not for the previous

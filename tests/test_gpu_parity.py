@@ -622,6 +622,44 @@ def test_rectangular_cov_matvec_through_the_shim(m, n):
     op.close()
 
 
+@pytest.mark.parametrize("cplx,values", [(False, True), (False, False), (True, True), (True, False)])
+def test_packed_adjoint_runs_the_transposed_expression_on_the_forward_kernels(cplx, values, tmp_path):
+    """BFHIP_FLAG_ADJOINT_PACKED: A^T gets its own packed copy of the leaves and its plan is a FORWARD plan of the transposed
+    expression (blocks placed at (col0, row0), products reversed, every leaf transposed -- reference
+    src/mat_product.c:409-420).  Same result as the shared-leaf adjoint plan and as the oracle's bfMatRmulVec (real) /
+    the dense transpose (complex), with host-valued and with synthetic leaves, rectangular, several right-hand sides."""
+    import randgraph
+    from butterfly_amd import _capi
+    from butterfly_amd.operator import HipOperator
+    from oracle import bfref
+    rng = np.random.default_rng(900 + 2 * cplx + values)
+    m, n = 260, 190
+    desc, vals = randgraph.random_operand(rng, depth=4, size_hint=110, cplx=cplx, m=m, n=n)
+    if not values:
+        vals = None
+    A = bfref.from_desc(desc, vals, seed=11)
+    packed = HipOperator.from_desc(desc, vals, seed=11, flags=_capi.FLAG_ADJOINT_PACKED)
+    shared = HipOperator.from_desc(desc, vals, seed=11, flags=_capi.FLAG_ADJOINT)
+    assert packed.stats()["arenaBytes"] >= 2 * shared.stats()["leafBytes"] and packed.stats()["leafBytes"] == shared.stats()["leafBytes"]
+    for nrhs in (1, 3):
+        shape = (m,) if nrhs == 1 else (m, nrhs)
+        v = rng.standard_normal(shape) + (1j * rng.standard_normal(shape) if cplx else 0)
+        if cplx:
+            dense = bfref.mat_mul(A, np.eye(n, dtype=np.complex128))
+            want = dense.T @ v
+        else:
+            want = np.stack([bfref.mat_rmul_vec(A, v if nrhs == 1 else v[:, q]) for q in range(nrhs)], axis=-1).reshape((n,) if nrhs == 1 else (n, nrhs))
+        got_p, got_s = packed.apply_transpose_host(v), shared.apply_transpose_host(v)
+        assert rel(got_p, want) <= TOL and rel(got_s, want) <= TOL
+        # the forward apply is untouched by either
+        w = rng.standard_normal((n,) if nrhs == 1 else (n, nrhs)) + (1j * rng.standard_normal((n,) if nrhs == 1 else (n, nrhs)) if cplx else 0)
+        assert np.array_equal(packed.apply_host(w), shared.apply_host(w))
+    with pytest.raises(_capi.BfhipError) as ei:
+        packed.save(tmp_path / "p.bfhip")
+    assert ei.value.code == 3
+    packed.close(); shared.close()
+
+
 @pytest.mark.parametrize("m,n", [(300, 70), (96, 96)])
 def test_transpose_slot_flips_the_shim_between_its_two_plans(m, n):
     """bfMatTranspose (slot 63, reference src/mat.c:271-273) on the shim, driven by the oracle's dispatcher: in place, like

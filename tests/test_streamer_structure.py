@@ -301,8 +301,9 @@ def test_streamed_operand_on_gpu_forward_and_transposed(case):
     x, v = rng.standard_normal(J), rng.standard_normal(n)
     M = bfref.from_desc(desc, vals)
     y_ref, z_ref = bfref.mat_mul_vec(M, x), bfref.mat_rmul_vec(M, v)
-    for demote, tol in ((False, 1e-12), (True, 1e-5)):
-        op = HipOperator.from_desc(desc, vals, flags=_capi.FLAG_ADJOINT, demote_to_f32=demote)
+    for demote, tol, flag in ((False, 1e-12, _capi.FLAG_ADJOINT), (True, 1e-5, _capi.FLAG_ADJOINT), (False, 1e-12, _capi.FLAG_ADJOINT_PACKED),
+                              (True, 1e-5, _capi.FLAG_ADJOINT_PACKED)):      # shared-leaf adjoint plan / its own packed copy on the forward kernels
+        op = HipOperator.from_desc(desc, vals, flags=flag, demote_to_f32=demote)
         y = op.apply_host(x)
         z = op.apply_transpose_host(v)
         assert rel(y, y_ref) <= tol and rel(z, z_ref) <= tol, (demote, rel(y, y_ref), rel(z, z_ref))
@@ -350,9 +351,11 @@ def test_rank_model_operand_synthetic_values_on_gpu():
     rng = np.random.default_rng(2)
     x, v = rng.standard_normal(A.n), rng.standard_normal(n)
     y_ref, z_ref = bfref.mat_mul_vec(M, x), bfref.mat_rmul_vec(M, v)
-    for demote, tol in ((False, 1e-12), (True, 2e-5)):
-        op = HipOperator.from_desc(desc, None, seed=7, flags=_capi.FLAG_ADJOINT, demote_to_f32=demote)
-        assert rel(op.apply_host(x), y_ref) <= tol and rel(op.apply_transpose_host(v), z_ref) <= tol
+    for demote, tol, flag in ((False, 1e-12, _capi.FLAG_ADJOINT), (True, 2e-5, _capi.FLAG_ADJOINT), (False, 1e-12, _capi.FLAG_ADJOINT_PACKED),
+                              (True, 2e-5, _capi.FLAG_ADJOINT_PACKED)):
+        op = HipOperator.from_desc(desc, None, seed=7, flags=flag, demote_to_f32=demote)
+        ey, ez = rel(op.apply_host(x), y_ref), rel(op.apply_transpose_host(v), z_ref)
+        assert ey <= tol and ez <= tol, (demote, flag, ey, ez)
         op.close()
 
 

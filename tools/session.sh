@@ -119,4 +119,13 @@ adjab()      { for v in ${ADJ_VARIANTS:-T0 base}; do
                  step stadj_$v 400 $B --workload streamer --adjoint --steps 10 --warmup 2 --no-cpu-baseline --no-extra
                  python -c "import json; d = json.load(open('$O/stadj_$v.out')); print('$v streamer fwd', d['ms_per_step'], d['roofline']['frac'], 'adjoint', d['adjoint']['ms_per_apply'], d['adjoint']['frac_of_hbm_peak'], d['adjoint']['transpose_identity_rel'])"
                done; unset BFHIP_LIB_PATH; }
+packed()     { step pytest_p 600 python -m pytest tests -m gpu -x -q -k "adjoint or transpose or rmul or cov or save_load"; tail -3 $O/pytest_p.out
+               for v in "" "--adjoint-shared"; do t=$(echo "x$v" | tr -d ' -');
+                 step adj_$t 300 $B --adjoint $v --steps 10 --warmup 2 --no-cpu-baseline --no-extra
+                 python -c "import json; d = json.load(open('$O/adj_$t.out')); print('$t c128 adjoint', d['adjoint']['ms_per_apply'], d['adjoint']['frac_of_hbm_peak'], d['adjoint']['transpose_identity_rel'], 'fwd', d['ms_per_step'])"
+                 step adjs_$t 300 $B --npoints 65536 --adjoint $v --steps 30 --warmup 3 --no-cpu-baseline --no-extra
+                 python -c "import json; d = json.load(open('$O/adjs_$t.out')); print('$t n65536 adjoint', d['adjoint']['ms_per_apply'], d['adjoint']['frac_of_hbm_peak'])"
+                 step stadj_$t 400 $B --workload streamer --adjoint $v --steps 10 --warmup 2 --no-cpu-baseline --no-extra
+                 python -c "import json; d = json.load(open('$O/stadj_$t.out')); print('$t streamer fwd', d['ms_per_step'], d['roofline']['frac'], 'adjoint', d['adjoint']['ms_per_apply'], d['adjoint']['frac_of_hbm_peak'], d['adjoint']['transpose_identity_rel'], 'cov', d['cov_matvec']['ms_per_product'], d['cov_matvec']['rel_vs_separate_applies'])"
+               done; }
 for s in "$@"; do $s; done
