@@ -64,7 +64,7 @@ class BfhipShardSpec(C.Structure):
 
 class BfhipPlanInfo(C.Structure):
     _fields_ = [(n, C.c_uint32) for n in ("structSize", "dtype", "elemSize", "epl", "xcap", "reserved")] + [
-        (n, C.c_uint64) for n in ("numRows", "numCols", "numStages", "arenaElems", "tempElems", "numStagesT", "tempElemsT")]
+        (n, C.c_uint64) for n in ("numRows", "numCols", "numStages", "arenaElems", "tempElems", "numStagesT", "tempElemsT", "arenaElemsT")]
 
 
 class BfhipStageView(C.Structure):
@@ -396,6 +396,8 @@ def load():
     lib.bfhipPlanGetReduce.restype = C.c_int
     lib.bfhipPlanPackArena.argtypes = [vp, vp]
     lib.bfhipPlanPackArena.restype = C.c_int
+    lib.bfhipPlanPackArenaT.argtypes = [vp, vp]
+    lib.bfhipPlanPackArenaT.restype = C.c_int
     lib.bfhipSave.argtypes = [vp, C.c_char_p]
     lib.bfhipSave.restype = C.c_int
     lib.bfhipLoad.argtypes = [C.c_char_p, C.POINTER(BfhipOptions), C.POINTER(vp)]

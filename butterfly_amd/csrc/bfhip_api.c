@@ -73,8 +73,10 @@ struct BfhipOperator {
   uint64_t applyCount;              /* forward applies so far */
   void *dCov;                       /* scratch of the covariance products (2 vectors of the longer side) */
   uint32_t profEvery;               /* events around one apply in profEvery (0, 1: every apply) */
-  /* BFHIP_FLAG_PLAN_ONLY: the IR is kept (borrowed leaf pointers!) for bfhipPlanPackArena */
-  BfIr *ir;
+  /* BFHIP_FLAG_PLAN_ONLY: the IR is kept (borrowed leaf pointers!) for bfhipPlanPackArena; irT: its transposed view when the
+   * adjoint plan has an arena of its own (BFHIP_FLAG_ADJOINT_PACKED), for bfhipPlanPackArenaT */
+  BfIr *ir, *irT;
+  int packedT;
   uint64_t seed;
   /* dependency-driven launch of the forward plan (complex128, nrhs <= 2): flat copies of the index tables */
   int flow;
@@ -128,6 +130,7 @@ void bfhipFree(BfhipOperator **pop) {
   bfPlanFree(&op->plan);
   bfPlanFree(&op->tplan);
   if (op->ir) { bfIrFree(op->ir); free(op->ir); }
+  if (op->irT) { bfIrFree(op->irT); free(op->irT); }
   int const touchedDevice = !(op->flags & BFHIP_FLAG_PLAN_ONLY);
   free(op);
   *pop = NULL;
@@ -455,7 +458,13 @@ int bfhipCompileIrFill(BfIr *ir, BfhipOptions const *opts, BfFillFn fill, void *
     BfPlanOptions pt = po;
     if ((rc = bfPlanBuild(&irT, &pt, &op->tplan))) { bfIrFree(&irT); goto done; }
     op->hasTplan = 1;
-    if (planOnly) bfIrFree(&irT);
+    op->packedT = 1;
+    if (planOnly) {          /* kept for bfhipPlanPackArenaT */
+      op->irT = malloc(sizeof *op->irT);
+      if (!op->irT) { bfIrFree(&irT); rc = bfhipFail(BFABI_ERROR_MEMORY_ERROR, "host OOM"); goto done; }
+      *op->irT = irT;
+      memset(&irT, 0, sizeof irT);
+    }
   } else if (o.flags & (BFHIP_FLAG_ADJOINT | BFHIP_FLAG_ADJOINT_PACKED)) {
     BfFwdPiece *fwd = NULL;
     uint64_t nf = 0;
@@ -958,6 +967,8 @@ int bfhipPlanGetInfo(BfhipOperator const *op, BfhipPlanInfo *info) {
   info->arenaElems = pl->arenaElems; info->tempElems = pl->tempElems;
   info->numStagesT = op->hasTplan ? op->tplan.numStages : 0;
   info->tempElemsT = op->hasTplan ? op->tplan.tempElems : 0;
+  info->reserved = op->packedT ? 1u : 0u;                     /* 1: the adjoint plan is a forward plan over its own arena ... */
+  info->arenaElemsT = op->packedT ? op->tplan.arenaElems : 0;      /* ... of this many elements */
   return 0;
 }
 int bfhipPlanGetStage(BfhipOperator const *op, uint64_t stage, BfhipStageView *v) {
@@ -989,6 +1000,14 @@ int bfhipPlanPackArena(BfhipOperator const *op, void *dst) {
   if (rc) return rc;
   if (!dst) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "NULL destination");
   return packLeaves(op, op->ir, op->seed, dst);
+}
+/* the second arena of a BFHIP_FLAG_ADJOINT_PACKED plan (arenaElemsT elements): the leaves of the transposed expression */
+int bfhipPlanPackArenaT(BfhipOperator const *op, void *dst) {
+  int rc = needPlanOnly(op);
+  if (rc) return rc;
+  if (!dst) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "NULL destination");
+  if (!op->packedT || !op->irT) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "operator was not compiled with BFHIP_FLAG_ADJOINT_PACKED");
+  return packLeavesPlan(&op->tplan, NULL, op->irT, op->seed, dst);
 }
 
 

@@ -353,9 +353,12 @@ int bfhipCovMatvecDevice(BfhipOperator *op, const void *dGammaLam, const uint64_
  * are the START of a stage's list and run on the 16-row-lane kernel).  Piece flags: 1 reads x (else the
  * vector arena), 2 identity (no data: adds the input rows), 4 row-major. */
 typedef struct BfhipPlanInfo {
-  uint32_t structSize, dtype, elemSize, epl, xcap, reserved;
+  uint32_t structSize, dtype, elemSize, epl, xcap;
+  uint32_t reserved;                 /* 1: the adjoint plan is a forward plan of the transposed expression over an arena of its own
+                                        (BFHIP_FLAG_ADJOINT_PACKED): its stages are run like forward stages, on bfhipPlanPackArenaT's data */
   uint64_t numRows, numCols, numStages, arenaElems, tempElems;
   uint64_t numStagesT, tempElemsT;   /* transposed plan (0 without BFHIP_FLAG_ADJOINT) */
+  uint64_t arenaElemsT;              /* elements of the packed adjoint's own arena (0 otherwise) */
 } BfhipPlanInfo;
 typedef struct BfhipStageView {
   uint32_t structSize, reserved;
@@ -378,6 +381,8 @@ int bfhipPlanGetReduce(const BfhipOperator *op, uint64_t stage, uint64_t index, 
  * descriptor's / graph's leaf values must still be alive.  Synthetic leaves
  * are generated with the host copy of the value stream. */
 int bfhipPlanPackArena(const BfhipOperator *op, void *dst);
+/* the second arena of a BFHIP_FLAG_ADJOINT_PACKED plan (BfhipPlanInfo.arenaElemsT elements) */
+int bfhipPlanPackArenaT(const BfhipOperator *op, void *dst);
 
 /* ---- serialization ------------------------------------------------------- */
 /* Write / read a compiled operator (packed leaf arena + per-stage index

@@ -40,18 +40,26 @@ def run_plan(op, x, transpose=False):
     _capi.check(lib.bfhipPlanGetInfo(op.handle, C.byref(info)))
     dt = {0: np.complex128, 1: np.float64, 2: np.float32}[info.dtype]
     epl = info.epl
-    arena = np.zeros(int(info.arenaElems), dtype=dt)
-    _capi.check(lib.bfhipPlanPackArena(op.handle, arena.ctypes.data))
+    # BFHIP_FLAG_ADJOINT_PACKED: the adjoint plan is a FORWARD plan of the transposed expression over an arena of its own --
+    # its stages are run with the forward kernels' semantics on that arena
+    packed = transpose and int(info.reserved) == 1
+    if packed:
+        arena = np.zeros(int(info.arenaElemsT), dtype=dt)
+        _capi.check(lib.bfhipPlanPackArenaT(op.handle, arena.ctypes.data))
+    else:
+        arena = np.zeros(int(info.arenaElems), dtype=dt)
+        _capi.check(lib.bfhipPlanPackArena(op.handle, arena.ctypes.data))
+    tstages, transpose = transpose, transpose and not packed      # from here on `transpose` = "transposed-kernel semantics"
     x = np.asarray(x, dtype=dt)
     one_d = x.ndim == 1
     if one_d:
         x = x[:, None]
     nrhs = x.shape[1]
-    stage0 = int(info.numStages) if transpose else 0
-    nstages = int(info.numStagesT) if transpose else int(info.numStages)
-    if transpose:
+    stage0 = int(info.numStages) if tstages else 0
+    nstages = int(info.numStagesT) if tstages else int(info.numStages)
+    if tstages:
         assert nstages > 0, "operator has no transposed plan (FLAG_ADJOINT)"
-    y = np.full((int(info.numCols if transpose else info.numRows), nrhs), np.nan, dtype=dt)
+    y = np.full((int(info.numCols if tstages else info.numRows), nrhs), np.nan, dtype=dt)
     temp = np.full((int(max(info.tempElems, info.tempElemsT)), nrhs), np.nan, dtype=dt)
     for s in range(stage0, stage0 + nstages):
         sv = _capi.BfhipStageView()

@@ -397,6 +397,35 @@ def test_transposed_plan_random_real_graphs(seed):
         assert rel(plan_emulator.run_plan(op, xf) + 1, bfref.mat_mul_vec(A, xf) + 1) < (2e-5 if demote else 1e-12)
 
 
+ADJP = dict(flags=_capi.FLAG_PLAN_ONLY | _capi.FLAG_ADJOINT_PACKED)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_packed_adjoint_plan_random_graphs(seed):
+    """BFHIP_FLAG_ADJOINT_PACKED: the adjoint plan is a forward plan of the transposed expression (blocks at (col0, row0),
+    products reversed, leaves transposed: reference src/mat_product.c:409-420) over an arena of its own; run by the plan
+    interpreter with forward semantics on that arena, it is the oracle's bfMatRmulVec -- host-valued and synthetic leaves,
+    real (fp64 and demoted) and complex."""
+    rng = np.random.default_rng(8100 + seed)
+    cplx = bool(seed % 2)
+    desc, vals = randgraph.random_operand(rng, depth=int(rng.integers(1, 5)), size_hint=int(rng.integers(8, 260)), cplx=cplx)
+    if seed % 4 >= 2:
+        vals = None                                           # synthetic: the transposed leaves hold the SAME value stream, transposed
+    m, n = desc.rows[desc.root], desc.cols[desc.root]
+    A = bfref.from_desc(desc, vals, seed=5)
+    x = rng.standard_normal(m) + (1j * rng.standard_normal(m) if cplx else 0)
+    if cplx:
+        want = bfref.mat_mul(A, np.eye(n, dtype=np.complex128)).T @ x
+    else:
+        want = bfref.mat_rmul_vec(A, x)
+    for demote in ((False,) if cplx else (False, True)):
+        op = HipOperator.from_desc(desc, vals, seed=5, demote_to_f32=demote, **ADJP)
+        assert rel(plan_emulator.run_plan(op, x, transpose=True) + 1, want + 1) < (2e-5 if demote else 1e-12)
+        xf = rng.standard_normal(n) + (1j * rng.standard_normal(n) if cplx else 0)
+        fwd = bfref.mat_mul(A, xf) if cplx else bfref.mat_mul_vec(A, xf)
+        assert rel(plan_emulator.run_plan(op, xf) + 1, fwd + 1) < (2e-5 if demote else 1e-12)
+
+
 def test_transposed_plan_helm2(helm2_cases):
     n, k = 2048, 128
     desc, tp, vals = helm2_cases(n, k)
