@@ -338,10 +338,15 @@ def main():
     if not dry:
         torch.cuda.set_device(local_rank)
         dev = torch.device("cuda", local_rank)
-    use_pg = world > 1
+    # --force-collective: the multi-rank code path with ONE rank (a rehearsal on a one-GPU box): a 1-rank process group too, so
+    # that everything a real N > 1 run does -- the collective decision, rank agreement, the torch.distributed fallback
+    # (BENCH_FORCE_TORCH_COLLECTIVE=1) and, with BENCH_ALSO_TIME_ROWS=1, the second partition -- runs here as well
+    use_pg = world > 1 or (args.force_collective and not dry)
     if use_pg:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", str(29500 + os.getpid() % 1000))
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if dry:
             dist.init_process_group("gloo")
         else:
@@ -688,7 +693,7 @@ def main():
                  "ranks_max_abs_diff": ydiff, "ranks_agree": ydiff == 0.0,
                  "collective_impl": coll_impl, "collective_fallback_reason": coll_bad}
         # The default at this world size is not the bit-identical row-range shard (8 ranks: rowsum): time that one too
-        if world > 1 and mode != "rows" and args.shard == "auto" and not streamer:
+        if ((world > 1 and args.shard == "auto") or os.environ.get("BENCH_ALSO_TIME_ROWS") == "1") and mode != "rows" and not streamer:
             try:
                 cuts2, loads2 = row_partition(desc, world)
                 sharded.close()

@@ -54,6 +54,32 @@ def test_bench_starts_its_own_ranks(monkeypatch):
     assert m["mode"] == "rows" and len(m["rank_local_ms"]) == 1 and m["max_local_ms"] > 0 and m["max_collective_ms"] >= 0
 
 
+def test_multi_rank_reporting_with_one_rank(monkeypatch):
+    """What a real N > 1 line adds -- rank agreement, which library issued the collective, the torch.distributed fallback,
+    the bit-identical row shard timed next to a default that is not `rows`, the parity sample on a shared block row -- through
+    the same code with ONE rank (--force-collective starts a 1-rank process group)."""
+    monkeypatch.setenv("BENCH_ALSO_TIME_ROWS", "1")
+    d = run_bench("--force-collective", "--shard", "rowsum", "--cpu-budget-gb", "0.05")
+    m = d["multi_gpu"]
+    assert m["mode"] == "rowsum" and m["ranks_agree"] and m["ranks_max_abs_diff"] == 0.0 and m["collective_impl"].startswith("libbfhip")
+    assert m["also_timed"]["mode"] == "rows" and m["also_timed"]["bit_identical_to_one_gpu"] and m["also_timed"]["ranks_agree"] and m["also_timed"]["ms_per_step"] > 0
+    assert d["cpu_baseline"]["parity_rel_l2"] < 1e-12
+    monkeypatch.setenv("BENCH_FORCE_TORCH_COLLECTIVE", "1")
+    d = run_bench("--force-collective", "--shard", "blocks", "--no-cpu-baseline")
+    m = d["multi_gpu"]
+    assert m["collective_impl"] == "torch.distributed" and m["collective_fallback_reason"] == [[0, "BENCH_FORCE_TORCH_COLLECTIVE=1"]]
+    assert m["ranks_agree"] and m["max_local_ms"] > 0 and m["max_collective_ms"] >= 0 and m["also_timed"]["collective_impl"] == "torch.distributed"
+
+
+def test_adjoint_layouts_in_the_bench_line():
+    """--adjoint: a packed copy of the leaves for A^T on the forward kernels (default for fac_helm2 operands) or the shared
+    leaves through the transposed kernels; both tie <A x, v> to <x, A^T v>."""
+    for extra, word in ((("--adjoint",), "packed"), (("--adjoint", "--adjoint-shared"), "shared")):
+        d = run_bench(*extra, "--no-cpu-baseline")
+        a = d["adjoint"]
+        assert a["layout"].startswith(word) and a["transpose_identity_rel"] < 1e-12 and a["ms_per_apply"] > 0
+
+
 def test_bench_fails_loudly_when_a_rank_fails():
     """More ranks than GPUs on the box: a rank cannot get its device; the parent must exit non-zero, no JSON."""
     import torch

@@ -130,4 +130,12 @@ packed()     { step pytest_p 600 python -m pytest tests -m gpu -x -q -k "adjoint
                done; }
 tracePk()    { ( cd /tmp && export TMPDIR=/tmp && export BENCH_STREAMER_PACKED=1 && timeout -k 10 600 rocprofv3 --kernel-trace --output-format csv -d $O/tracePk -- python3 $R/bench.py --workload streamer --adjoint --steps 2 --warmup 1 --no-cpu-baseline --no-extra > $O/tracePk.json 2> $O/tracePk.log ); echo "tracePk exit=$?";
                python tools/trace_apply.py $O/tracePk 70 > $O/tracePk.txt; find $O/tracePk -name "*.csv" -size +2M -delete; grep -v "at::native\|rocclr" $O/tracePk.txt | tail -45; }
+rehearse()   { step rh_rccl 300 $B --force-collective --steps 10 --warmup 2 --no-cpu-baseline --no-extra
+               python -c "import json; d = json.load(open('$O/rh_rccl.out')); m = d['multi_gpu']; print('rccl', d['ms_per_step'], m['collective_impl'], m['ranks_agree'], m['max_local_ms'], m['max_collective_ms'])"
+               BENCH_FORCE_TORCH_COLLECTIVE=1 step rh_torch 300 $B --force-collective --steps 10 --warmup 2 --no-cpu-baseline --no-extra
+               python -c "import json; d = json.load(open('$O/rh_torch.out')); m = d['multi_gpu']; print('torch', d['ms_per_step'], m['collective_impl'], m['collective_fallback_reason'], m['ranks_agree'], m['max_local_ms'], m['max_collective_ms'])"
+               BENCH_ALSO_TIME_ROWS=1 step rh_rowsum 400 $B --force-collective --shard rowsum --steps 10 --warmup 2 --cpu-budget-gb 7
+               python -c "import json; d = json.load(open('$O/rh_rowsum.out')); m = d['multi_gpu']; print('rowsum', d['ms_per_step'], m['mode'], m['ranks_agree'], 'also', m.get('also_timed'), 'parity', d['cpu_baseline'].get('parity_rel_l2'), d['cpu_baseline'].get('parity_covers_shared_block_row'))"
+               BENCH_ALSO_TIME_ROWS=1 BENCH_FORCE_TORCH_COLLECTIVE=1 step rh_blocks 400 $B --force-collective --shard blocks --steps 10 --warmup 2 --no-cpu-baseline --no-extra
+               python -c "import json; d = json.load(open('$O/rh_blocks.out')); m = d['multi_gpu']; print('blocks/torch', d['ms_per_step'], m['mode'], m['collective_impl'], m['ranks_agree'], 'also', m.get('also_timed'))"; }
 for s in "$@"; do $s; done
