@@ -17,6 +17,7 @@ run ${TAG}_bench_n262144_nrhs64          $B --nrhs 64
 run ${TAG}_bench_n65536                  $B --npoints 65536
 run ${TAG}_bench_n65536_nrhs64           $B --npoints 65536 --nrhs 64 --no-cpu-baseline
 run ${TAG}_bench_n262144_adjoint         $B --adjoint --no-cpu-baseline --no-extra
+run ${TAG}_bench_n262144_adjoint_shared  $B --adjoint --adjoint-shared --no-cpu-baseline --no-extra
 run ${TAG}_bench_n262144_rccl_1rank      $B --force-collective --no-cpu-baseline --no-extra
 fi
 if [ "$PART" = all ] || [ "$PART" = shards ]; then

@@ -31,10 +31,10 @@ run write_r64  --kernel-trace --pmc WRITE_SIZE -- --nrhs 64 --steps 2 --warmup 1
 run stats_n65536 --kernel-trace --stats -- --npoints 65536 --steps 20 --warmup 3
 run fetch_n65536 --kernel-trace --pmc FETCH_SIZE -- --npoints 65536 --steps 5 --warmup 1
 run write_n65536 --kernel-trace --pmc WRITE_SIZE -- --npoints 65536 --steps 5 --warmup 1
-# adjoint apply of the headline operand (bfStageKernelT)
-run stats_adj  --kernel-trace --stats -- --adjoint --steps 5 --warmup 1
-run fetch_adj  --kernel-trace --pmc FETCH_SIZE -- --adjoint --steps 3 --warmup 1
-run write_adj  --kernel-trace --pmc WRITE_SIZE -- --adjoint --steps 3 --warmup 1
+# adjoint apply of the headline operand on the shared leaves (bfStageKernelT; bench.py's default, a packed copy for A^T, runs the forward kernels)
+run stats_adj  --kernel-trace --stats -- --adjoint --adjoint-shared --steps 5 --warmup 1
+run fetch_adj  --kernel-trace --pmc FETCH_SIZE -- --adjoint --adjoint-shared --steps 3 --warmup 1
+run write_adj  --kernel-trace --pmc WRITE_SIZE -- --adjoint --adjoint-shared --steps 3 --warmup 1
 fi
 SQSET="SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VALU SQ_BUSY_CYCLES GRBM_GUI_ACTIVE"
 if [ "$PART" != "helm2" ] && [ "$PART" != "streamerT" ]; then
