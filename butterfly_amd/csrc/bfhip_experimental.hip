@@ -80,6 +80,14 @@ struct FlowParams {
   void *temp;
 };
 
+// -DBF_FLOW_STATIC=1: no ticket counter, wavefront slot w takes items w, w + S, ... (round 4).  Measured on one box
+// (N = 65536 / rows shard 3 of 8 / headline): static 1.109 / 1.90 / 10.70 ms, tickets two at a time 1.51 / 2.66 / 11.18,
+// staged launches 1.098 / 1.54 / 10.60; with the inner loop unrolled 8x at 4 wavefronts per SIMD 1.122 / 1.85 / 10.59.
+// Without its tickets the one-launch executor EQUALS the staged launches where items are small and loses where a few
+// 1 MiB items live as long as a launch: the stage boundaries it removes were not what short launches lose.
+#ifndef BF_FLOW_STATIC
+#define BF_FLOW_STATIC 0
+#endif
 #ifndef BF_FLOW_BATCH
 #define BF_FLOW_BATCH 2u      /* measured at N = 65536: 1 -> 1.56 ms, 2 -> 1.36, 4 -> 1.64, 8 -> 2.26 (staged launches: 1.09) */
 #endif
@@ -196,11 +204,23 @@ __global__ __launch_bounds__(BF_WAVES_PER_WG * 64) __attribute__((amdgpu_waves_p
   uint32_t const one = lane == 0 ? BF_FLOW_BATCH : 0u;
 
   // ---- prologue: the first item, fetched the slow way
+#if BF_FLOW_STATIC
+  // static dealing: wavefront slot w of the resident grid takes items w, w + S, w + 2 S, ... (S = slots) of the stage-major,
+  // big-first list -- no ticket counter at all (same-address atomics retire at ~19 ns each device-wide: 81 k items = 1.5 ms).
+  // Still deadlock-free: every slot walks its items in list order, so the smallest unfinished item never waits.
+  (void)one;
+  uint32_t const slotStride = gridDim.x * BF_WAVES_PER_WG;
+  uint32_t cur = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * BF_WAVES_PER_WG + wave));
+  if (cur >= p.numItems) return;
+  uint32_t batchEnd = 0, tkNext = 0;
+  (void)batchEnd; (void)tkNext;
+#else
   uint32_t tk = __hip_atomic_fetch_add(p.queue, one, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   uint32_t cur = (uint32_t)__builtin_amdgcn_readfirstlane((int)tk);
   if (cur >= p.numItems) return;
   uint32_t batchEnd = cur + BF_FLOW_BATCH;
   uint32_t tkNext = __hip_atomic_fetch_add(p.queue, one, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // the next batch, in flight
+#endif
   BfDevItem it = p.items[cur];
   uint32_t od = (uint32_t)__builtin_amdgcn_readfirstlane((int)p.itemOut[cur]);
   uint32_t cw = 0;
@@ -221,8 +241,13 @@ __global__ __launch_bounds__(BF_WAVES_PER_WG * 64) __attribute__((amdgpu_waves_p
 
   for (;;) {
     // ---- top of item `cur`: the next item is the next of this batch, or the first of the batch drawn a batch ago
+#if BF_FLOW_STATIC
+    bool const lastOfBatch = false;
+    uint32_t const nxt = cur + slotStride < cur ? 0xffffffffu : cur + slotStride;
+#else
     bool const lastOfBatch = cur + 1 == batchEnd;
     uint32_t const nxt = lastOfBatch ? (uint32_t)__builtin_amdgcn_readfirstlane((int)tkNext) : cur + 1;
+#endif
     bool const haveNext = nxt < p.numItems;
     BfDevItem itN = it;
     uint32_t odN = 0;

@@ -138,4 +138,17 @@ rehearse()   { step rh_rccl 300 $B --force-collective --steps 10 --warmup 2 --no
                python -c "import json; d = json.load(open('$O/rh_rowsum.out')); m = d['multi_gpu']; print('rowsum', d['ms_per_step'], m['mode'], m['ranks_agree'], 'also', m.get('also_timed'), 'parity', d['cpu_baseline'].get('parity_rel_l2'), d['cpu_baseline'].get('parity_covers_shared_block_row'))"
                BENCH_ALSO_TIME_ROWS=1 BENCH_FORCE_TORCH_COLLECTIVE=1 step rh_blocks 400 $B --force-collective --shard blocks --steps 10 --warmup 2 --no-cpu-baseline --no-extra
                python -c "import json; d = json.load(open('$O/rh_blocks.out')); m = d['multi_gpu']; print('blocks/torch', d['ms_per_step'], m['mode'], m['collective_impl'], m['ranks_agree'], 'also', m.get('also_timed'))"; }
+flowab()     { for v in ${FLOW_VARIANTS:-exp_static exp_tickets}; do export BFHIP_LIB_PATH=$R/butterfly_amd/csrc/exp/libbfhip_$v.so
+                 if [ $v = exp_static ]; then step flowtest_$v 600 python -m pytest tests/experimental_checks.py -m gpu -x -q -k "dependency_driven and not 65536" -p no:cacheprovider; tail -2 $O/flowtest_$v.out; fi
+                 BFHIP_FLOW=1 step fl_n65536_$v 200 $B --npoints 65536 --steps 50 --warmup 5 --no-cpu-baseline --no-extra
+                 python -c "import json; d = json.load(open('$O/fl_n65536_$v.out')); print('$v n65536 flow', d['ms_per_step'], d['roofline']['frac'], d['roofline']['kernel'])"
+                 BFHIP_FLOW=1 step fl_shard_$v 200 $B --emulate-world 8 --emulate-rank 3 --shard rows --steps 50 --no-extra --no-cpu-baseline
+                 python -c "import json; d = json.load(open('$O/fl_shard_$v.out')); print('$v shard3 flow', d['ms_per_step'], d['roofline']['frac'])"
+                 BFHIP_FLOW=1 step fl_head_$v 200 $B --steps 20 --no-extra --no-cpu-baseline
+                 python -c "import json; d = json.load(open('$O/fl_head_$v.out')); print('$v headline flow', d['ms_per_step'], d['roofline']['frac'])"
+               done; unset BFHIP_LIB_PATH
+               step st_n65536 200 $B --npoints 65536 --steps 50 --warmup 5 --no-cpu-baseline --no-extra
+               python -c "import json; d = json.load(open('$O/st_n65536.out')); print('staged n65536', d['ms_per_step'], d['roofline']['frac'])"
+               step st_shard 200 $B --emulate-world 8 --emulate-rank 3 --shard rows --steps 50 --no-extra --no-cpu-baseline
+               python -c "import json; d = json.load(open('$O/st_shard.out')); print('staged shard3', d['ms_per_step'], d['roofline']['frac'])"; }
 for s in "$@"; do $s; done
