@@ -733,12 +733,12 @@ def main():
         bytes_per_apply = int(sbytes.sum())
         avg_launch_ms = kern_ms / max(n_launch, 1)
         achieved = bytes_per_apply * applies / 1e9 / (kern_ms / 1e3) if kern_ms > 0 else 0.0
-        one_launch = (not real) and args.nrhs <= 2 and op is not None and op.flow_status()[0]
+        one_launch = (not real) and args.nrhs < 2 and op is not None and op.flow_status()[0]
         for s in range(len(ms)):
             if launches[s]:
                 log(f"  stage {s}: {ms[s] / max(launches[s], 1):8.3f} ms/launch  {sbytes[s] / 1e9:8.3f} GB  "
                     f"{(sbytes[s] / 1e9) / (ms[s] / max(launches[s], 1) / 1e3) if ms[s] > 0 else 0:8.1f} GB/s" + ("   [all stages: one launch]" if one_launch else ""))
-        if args.nrhs >= 3 and not real:
+        if args.nrhs >= 2 and not real:
             # block of right-hand sides: 8*nrhs flops per leaf element (32 flop/B at nrhs=64) -> FP64-MFMA bound
             flops_per_apply = 8.0 * args.nrhs * st["leafElems"]
             tf = flops_per_apply * applies / 1e12 / (kern_ms / 1e3) if kern_ms > 0 else 0.0

@@ -653,7 +653,7 @@ int bfhipGetStageProfile(BfhipOperator *op, double *ms, uint64_t *launches, uint
   int rc = harvestEvents(op, op->evIssued);
   if (rc) return rc;
   uint32_t const nr = op->lastNrhs ? op->lastNrhs : 1;
-  int const oneLaunch = op->flow && nr <= 2;        /* the whole apply is one launch: its time and bytes are reported under stage 0 */
+  int const oneLaunch = op->flow && nr < 2;        /* the whole apply is one launch: its time and bytes are reported under stage 0 */
   for (uint64_t s = 0; s < op->plan.numStages; ++s) {
     if (ms) ms[s] = op->stageMs[s];
     if (launches) launches[s] = op->stageLaunches[s];
@@ -693,7 +693,7 @@ static int runPlan(BfhipOperator *op, BfPlan *plan, void const *dX, size_t nrhs,
   uint64_t const evBase = prof ? (op->evIssued % BF_EV_POOL) * plan->numStages : 0;
   if (prof) op->evFlow[op->evIssued % BF_EV_POOL] = 0;
 #ifdef BFHIP_EXPERIMENTAL
-  if (op->flow && plan == &op->plan && nrhs <= 2) {
+  if (op->flow && plan == &op->plan && nrhs < 2) {            /* (two and more right-hand sides: the matrix-core kernel, staged) */
     /* the whole plan as ONE dependency-driven launch (bfFlowKernelC128), then the reduce passes into y */
     uint32_t const perApply = op->flowNumItems + op->flowGrid * 4u;      /* tickets an apply consumes: every wavefront draws one past the end */
     if (op->flowEpoch >= 0x7fffffffu / op->flowMaxWriters - 1 || op->flowQueueBase >= 0xffffffffu - 2u * perApply) {
@@ -748,7 +748,7 @@ static int runPlan(BfhipOperator *op, BfPlan *plan, void const *dX, size_t nrhs,
     a.x = dX; a.y = dY; a.temp = op->dTemp; a.zero = op->dZero; a.nrhs = (uint32_t)nrhs; a.dtype = plan->dtype; a.maxRows = st->maxRows;
     a.transposed = plan->transposed;
     a.tickets = NULL;
-    if (plan->dtype == BFHIP_C128 && !plan->transposed && nrhs < 3) a.tickets = st->dTickets;      /* NULL unless this is an EXPERIMENTAL build run with BFHIP_PERSISTENT=1 (allocated at compile time) */
+    if (plan->dtype == BFHIP_C128 && !plan->transposed && nrhs < 2) a.tickets = st->dTickets;      /* NULL unless this is an EXPERIMENTAL build run with BFHIP_PERSISTENT=1 (allocated at compile time) */
     if (prof && (rc = bfdevEventRecord(op->evStart[evBase + s], stream))) goto out;
     if ((rc = bfdevLaunchStage(&a, stream))) goto out;
     if (prof && (rc = bfdevEventRecord(op->evStop[evBase + s], stream))) goto out;

@@ -1192,7 +1192,12 @@ int bfdevLaunchStage(BfLaunchArgs const *a, void *stream) {
     }
     return hipFail(hipGetLastError(), "transposed stage launch");
   }
-  if (a->dtype == BFHIP_C128 && a->nrhs >= BF_MFMA_MIN_RHS) hipLaunchKernelGGL(bfStageKernelC128Mfma, dim3((uint32_t)((a->numItems + BF_MF_WG_WAVES - 1) / BF_MF_WG_WAVES)), dim3(64 * BF_MF_WG_WAVES), 0, s, p);
+  if (a->dtype == BFHIP_C128 && a->nrhs >= BF_MFMA_MIN_RHS) {
+    dim3 const g((uint32_t)((a->numItems + BF_MF_WG_WAVES - 1) / BF_MF_WG_WAVES)), b(64 * BF_MF_WG_WAVES);
+    if (a->nrhs <= 16) hipLaunchKernelGGL(bfStageKernelC128Mfma1, g, b, 0, s, p);            /* one RHS tile: 5 wavefronts per SIMD */
+    else if (a->nrhs <= 32) hipLaunchKernelGGL(bfStageKernelC128Mfma2, g, b, 0, s, p);       /* two: 3 */
+    else hipLaunchKernelGGL(bfStageKernelC128Mfma, g, b, 0, s, p);                           /* up to four per pass: 2 */
+  }
   else if (a->dtype == BFHIP_C128) {
     grid = (uint32_t)((a->numItems + BF_C128_WG_WAVES - 1) / BF_C128_WG_WAVES);
 #ifdef BFHIP_EXPERIMENTAL

@@ -1,4 +1,4 @@
-// bfhip_stage_mfma.h -- complex128 stage kernel for blocks of right-hand sides (nrhs >= 3): the same items and the
+// bfhip_stage_mfma.h -- complex128 stage kernel for blocks of right-hand sides (nrhs >= 2): the same items and the
 // same packed pieces as bfStageKernelC128, contracted on the FP64 matrix cores (v_mfma_f64_16x16x4_f64).  It replaces
 // the cblas_zgemm of every leaf of a level (reference src/mat_dense_complex.c:1704-1765) and the view / accumulate
 // passes around it (src/mat_block_coo.c:404-418, src/mat_block_diag.c:387-399).  Included by bfhip_device.hip only.
@@ -32,7 +32,7 @@
 #ifndef BFHIP_STAGE_MFMA_H
 #define BFHIP_STAGE_MFMA_H
 
-#define BF_MF_TABCAP 2304u          /* columns of one segment: 9 KiB of LDS per wavefront, 12 wavefronts per CU */
+#define BF_MF_TABCAP 1792u          /* columns of one segment: 7.1 KiB of LDS per wavefront -- 20 wavefronts per CU (the 1-tile instantiation) fit 160 KiB */
 #define BF_MF_TABPAD 24u
 #define BF_MF_SPAN_BYTES (1u << 31) /* a segment's input rows span less than this many bytes (32-bit buffer offsets) */
 #ifndef BF_MFMA_WAVES_PER_SIMD
@@ -45,7 +45,7 @@
 #define BF_MF_WG_WAVES 1u
 #endif
 #ifndef BF_MFMA_MIN_RHS
-#define BF_MFMA_MIN_RHS 3
+#define BF_MFMA_MIN_RHS 2
 #endif
 
 typedef double bf_d4 __attribute__((ext_vector_type(4)));
@@ -269,25 +269,28 @@ __device__ __forceinline__ void bfMfmaPass(StageParams const &p, BfDevItem const
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-template <int MS>
+template <int MS, int MAXNT>
 __device__ __forceinline__ void bfMfmaDispatch(uint32_t nt, StageParams const &p, BfDevItem const &it, uint32_t mr, uint32_t s0, uint32_t q0, uint32_t *tab, int lane) {
-  switch (nt) {
-  case 4: bfMfmaPass<4, MS>(p, it, mr, s0, q0, tab, lane); break;
-  case 3: bfMfmaPass<3, MS>(p, it, mr, s0, q0, tab, lane); break;
-  case 2: bfMfmaPass<2, MS>(p, it, mr, s0, q0, tab, lane); break;
-  default: bfMfmaPass<1, MS>(p, it, mr, s0, q0, tab, lane); break;
-  }
+  if (MAXNT >= 4 && nt == 4) bfMfmaPass<4, MS>(p, it, mr, s0, q0, tab, lane);
+  else if (MAXNT >= 3 && nt == 3) bfMfmaPass<3, MS>(p, it, mr, s0, q0, tab, lane);
+  else if (MAXNT >= 2 && nt == 2) bfMfmaPass<2, MS>(p, it, mr, s0, q0, tab, lane);
+  else bfMfmaPass<1, MS>(p, it, mr, s0, q0, tab, lane);
 }
 
-__global__ __launch_bounds__(64 * BF_MF_WG_WAVES) __attribute__((amdgpu_waves_per_eu(BF_MFMA_WAVES_PER_SIMD, BF_MFMA_WAVES_PER_SIMD))) void bfStageKernelC128Mfma(StageParams p) {
-  __shared__ uint32_t tabs[BF_MF_WG_WAVES][BF_MF_TABCAP + BF_MF_TABPAD];
+// MAXNT = the widest pass the launch needs (RHS tiles of 16): the accumulators of 4 tiles x 2 slabs x 3 products leave two
+// wavefronts per SIMD, which is what the matrix pipe needs at 64 RHS -- but with 2 - 32 RHS the kernel is bound by the leaf
+// stream, not by the pipe, and then it is wavefronts (bytes in flight) that count: the 1- and 2-tile instantiations need
+// a third / half of the registers and run WAVES = 5 / 3 wavefronts per SIMD (N = 262144: 2 - 16 RHS 14.3 - 15.9 -> see
+// DESIGN.md section 4).
+template <int MAXNT, int WAVES>
+__device__ __forceinline__ void bfStageBodyC128Mfma(StageParams const &p, uint32_t (*tabs)[BF_MF_TABCAP + BF_MF_TABPAD]) {
   int const lane = threadIdx.x & 63;
   uint32_t const wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   uint32_t *tab = tabs[wave];
   // The wavefronts of a workgroup take neighbours of the item list: row chunks of one row group and of its sibling
-  // groups (same cost, same input rows: the planner's order for RHS-block operators).  They start together and run at
-  // the same rate, so a row of X is fetched into the L2 once for all of them.  Workgroups are dealt to the 8 XCDs round
-  // robin: runs of BF_MF_XCD_RUN workgroups that are neighbours in the list go to ONE XCD for the same reason.
+  // groups (same cost, same input rows: the planner's order for RHS-block operators).  Workgroups are dealt to the 8 XCDs
+  // round robin: runs of BF_MF_XCD_RUN workgroups that are neighbours in the list go to ONE XCD, so that a row of X is
+  // fetched into that L2 once for all of them.
   uint32_t wg = blockIdx.x;
   uint32_t const numWg = (p.numItems + BF_MF_WG_WAVES - 1u) / BF_MF_WG_WAVES;
   if (BF_MF_XCD_RUN > 1) {
@@ -303,9 +306,24 @@ __global__ __launch_bounds__(64 * BF_MF_WG_WAVES) __attribute__((amdgpu_waves_pe
     uint32_t const nt = (nrhs - q0 >= 64) ? 4u : (nrhs - q0 + 15u) / 16u;
     uint32_t s0 = 0;
     while (s0 < mr) {
-      if (mr - s0 > 16) { bfMfmaDispatch<2>(nt, p, it, mr, s0, q0, tab, lane); s0 += 32; }
-      else { bfMfmaDispatch<1>(nt, p, it, mr, s0, q0, tab, lane); s0 += 16; }
+      if (mr - s0 > 16) { bfMfmaDispatch<2, MAXNT>(nt, p, it, mr, s0, q0, tab, lane); s0 += 32; }
+      else { bfMfmaDispatch<1, MAXNT>(nt, p, it, mr, s0, q0, tab, lane); s0 += 16; }
     }
   }
+}
+
+__global__ __launch_bounds__(64 * BF_MF_WG_WAVES) __attribute__((amdgpu_waves_per_eu(BF_MFMA_WAVES_PER_SIMD, BF_MFMA_WAVES_PER_SIMD))) void bfStageKernelC128Mfma(StageParams p) {
+  __shared__ uint32_t tabs[BF_MF_WG_WAVES][BF_MF_TABCAP + BF_MF_TABPAD];
+  bfStageBodyC128Mfma<4, BF_MFMA_WAVES_PER_SIMD>(p, tabs);
+}
+// <= 32 right-hand sides (2 tiles): 3 wavefronts per SIMD
+__global__ __launch_bounds__(64 * BF_MF_WG_WAVES) __attribute__((amdgpu_waves_per_eu(3, 3))) void bfStageKernelC128Mfma2(StageParams p) {
+  __shared__ uint32_t tabs[BF_MF_WG_WAVES][BF_MF_TABCAP + BF_MF_TABPAD];
+  bfStageBodyC128Mfma<2, 3>(p, tabs);
+}
+// <= 16 right-hand sides (1 tile): 5 wavefronts per SIMD
+__global__ __launch_bounds__(64 * BF_MF_WG_WAVES) __attribute__((amdgpu_waves_per_eu(5, 5))) void bfStageKernelC128Mfma1(StageParams p) {
+  __shared__ uint32_t tabs[BF_MF_WG_WAVES][BF_MF_TABCAP + BF_MF_TABPAD];
+  bfStageBodyC128Mfma<1, 5>(p, tabs);
 }
 #endif

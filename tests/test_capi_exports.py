@@ -78,7 +78,7 @@ def test_product_holds_no_experimental_executor():
         assert ei.value.code == 3
 
 
-def test_rhs_block_kernel_has_no_scratch_and_two_wavefronts_per_simd(tmp_path):
+def test_rhs_block_kernels_have_no_scratch_and_keep_their_occupancy(tmp_path):
     """bfStageKernelC128Mfma issues its fragment loads as asm statements and counts them by hand (s_waitcnt vmcnt(n)): a
     register spill inside its k-loop would be a scratch load the count does not know of -- silently wrong results.  The
     compiled kernel must use no scratch, spill nothing and fit two wavefronts per SIMD (<= 256 VGPRs)."""
@@ -92,14 +92,17 @@ def test_rhs_block_kernel_has_no_scratch_and_two_wavefronts_per_simd(tmp_path):
     subprocess.check_call([hipcc, "-O3", "-g", "-fPIC", "--offload-arch=gfx950", "-std=c++17", "-S", "--cuda-device-only", "-o", str(out),
                            os.path.join(ROOT, "butterfly_amd", "csrc", "bfhip_device.hip")], stderr=subprocess.DEVNULL)
     txt = open(out).read()
-    i = txt.index(".name:           _Z21bfStageKernelC128Mfma11StageParams")
-    meta = txt[i:i + 800]
-    get = lambda k: int(re.search(r"\." + k + r":\s+(\d+)", meta).group(1))
-    assert get("private_segment_fixed_size") == 0 and get("vgpr_spill_count") == 0 and get("sgpr_spill_count") == 0
-    assert get("vgpr_count") <= 256
-    body = txt[txt.index("_Z21bfStageKernelC128Mfma11StageParams:"):]
-    body = body[:body.index("s_endpgm")]
-    assert "scratch_" not in body and body.count("v_mfma_f64_16x16x4_f64") >= 96
+    # the 4-tile kernel (2 wavefronts per SIMD) and its 2- and 1-tile instantiations (3 and 5)
+    for sym, vmax, mfmas in (("_Z21bfStageKernelC128Mfma11StageParams", 256, 96), ("_Z22bfStageKernelC128Mfma211StageParams", 168, 48),
+                             ("_Z22bfStageKernelC128Mfma111StageParams", 96, 18)):
+        i = txt.index(".name:           " + sym)
+        meta = txt[i:i + 800]
+        get = lambda k: int(re.search(r"\." + k + r":\s+(\d+)", meta).group(1))
+        assert get("private_segment_fixed_size") == 0 and get("vgpr_spill_count") == 0 and get("sgpr_spill_count") == 0, sym
+        assert get("vgpr_count") <= vmax, (sym, get("vgpr_count"))
+        body = txt[txt.index(sym + ":"):]
+        body = body[:body.index("s_endpgm")]
+        assert "scratch_" not in body and body.count("v_mfma_f64_16x16x4_f64") >= mfmas, sym
 
 
 def test_builder_structs_match_the_header_and_arguments_are_checked(tmp_path):

@@ -151,4 +151,8 @@ flowab()     { for v in ${FLOW_VARIANTS:-exp_static exp_tickets}; do export BFHI
                python -c "import json; d = json.load(open('$O/st_n65536.out')); print('staged n65536', d['ms_per_step'], d['roofline']['frac'])"
                step st_shard 200 $B --emulate-world 8 --emulate-rank 3 --shard rows --steps 50 --no-extra --no-cpu-baseline
                python -c "import json; d = json.load(open('$O/st_shard.out')); print('staged shard3', d['ms_per_step'], d['roofline']['frac'])"; }
+rhssweep()   { for q in 1 2 3 4 8 16 32 48 64; do
+                 step rhs_$q 200 $B --nrhs $q --steps 5 --warmup 2 --no-cpu-baseline --no-extra
+                 python -c "import json; d = json.load(open('$O/rhs_$q.out')); print('nrhs $q', round(d['ms_per_step'], 3), 'ms', d['roofline']['kernel'], round(d['roofline']['frac'], 3))"
+               done; }
 for s in "$@"; do $s; done
