@@ -78,7 +78,7 @@ struct BfhipOperator {
   BfIr *ir, *irT;
   int packedT;
   uint64_t seed;
-  /* dependency-driven launch of the forward plan (complex128, nrhs <= 2): flat copies of the index tables */
+  /* dependency-driven launch of the forward plan (complex128, one right-hand side): flat copies of the index tables */
   int flow;
   void *dFlowItems, *dFlowPieces, *dFlowItemOut, *dFlowWriters, *dFlowCounters;
   uint32_t flowNumItems, flowGrid, flowEpoch, flowQueueBase, flowMaxWriters;
@@ -786,7 +786,7 @@ int bfhipOperatorReserveRhs(BfhipOperator *op, uint32_t nrhs) {
   return rc;
 }
 
-/* Is the forward plan applied as ONE dependency-driven launch (1 - 2 right-hand sides), and has any of its waits ever
+/* Is the forward plan applied as ONE dependency-driven launch (one right-hand side), and has any of its waits ever
  * given up?  (They cannot, by construction; the flag exists so that a broken invariant shows up as an error instead
  * of a hung GPU.)  Synchronizes the device's default stream when the flag is read. */
 int bfhipFlowStatus(BfhipOperator *op, uint32_t *enabled, uint32_t *waitGaveUp) {

@@ -65,7 +65,7 @@ enum {
                                     Falls back to the shared-leaf plan with a device value builder / BFHIP_FLAG_PLAN_ONLY;
                                     such operators cannot be saved (bfhipSave: NOT_IMPLEMENTED) */
   BFHIP_FLAG_FLOW = 1u << 3      /* EXPERIMENTAL BUILDS ONLY (libbfhip_exp.so, `make -C butterfly_amd/csrc experimental`): complex128
-                                    operators applied to 1 - 2 right-hand sides run the whole plan as ONE dependency-driven
+                                    operators applied to ONE right-hand side run the whole plan as ONE dependency-driven
                                     persistent launch (items wait for the intermediate vectors they read, not for the previous
                                     stage; bit-identical results).  Measured slower than the staged launches on MI355X
                                     (DESIGN.md section 15).  The product library (libbfhip.so) does not contain that executor
@@ -79,7 +79,7 @@ enum {
  *   BFHIP_FLOW=1            as BFHIP_FLAG_FLOW for every operator compiled in the process
  *   BFHIP_PERSISTENT=1      complex128 stages with more items than wavefront slots run as a persistent grid that draws
  *                           pooled tickets (bfhip_persist.hip; bit-identical results, measured equal to slower)
- *   BFHIP_TIMELINE_FILE=p   every complex128 stage launch (1 - 2 right-hand sides) becomes a synchronous diagnostic launch
+ *   BFHIP_TIMELINE_FILE=p   every complex128 stage launch (one right-hand side) becomes a synchronous diagnostic launch
  *                           that appends each item's start / end stamps to file p (tools/timeline.py; same results)
  *   BFHIP_FLOW_SPIN, BFHIP_FLOW_DEBUG, BFHIP_FLOW_DEBUGMODE   diagnostics of the one-launch executor */
 
@@ -301,7 +301,7 @@ size_t bfhipGetNumCols(const BfhipOperator *op);
  * (mat_block_coo.c:238-258, mat_dense_complex.c:452-455). */
 size_t bfhipNumBytes(const BfhipOperator *op);
 
-/* Whether applies of 1 - 2 right-hand sides run as one dependency-driven launch (see BFHIP_FLAG_FLOW), and whether
+/* Whether applies of one right-hand side run as one dependency-driven launch (see BFHIP_FLAG_FLOW), and whether
  * one of its waits ever gave up (0 by construction; checked by the test-suite after every flow test). */
 int bfhipFlowStatus(BfhipOperator *op, uint32_t *enabled, uint32_t *waitGaveUp);
 

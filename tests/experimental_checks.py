@@ -39,7 +39,7 @@ def test_stage_profile_of_the_one_launch_executor():
 
 @pytest.mark.parametrize("n,k", [(4096, 100.0), (16384, 1024.0), (65536, 4096.0)])
 def test_one_dependency_driven_launch_equals_the_staged_launches(n, k):
-    """BFHIP_FLAG_FLOW (experimental; complex128 operators at 1 - 2 right-hand sides): the whole plan as ONE persistent
+    """BFHIP_FLAG_FLOW (experimental; complex128 operators at one right-hand side; two and more run the matrix-core kernel, staged): the whole plan as ONE persistent
     launch whose items wait for the intermediate vectors they read (bfFlowKernelC128) instead of one launch per stage.
     Same items, same arithmetic: bit-identical to the staged launches and to itself over hundreds of applies (the
     counters run on from apply to apply), equal to the oracle, and no wait ever gives up."""

@@ -347,9 +347,9 @@ def test_stage_profile_reports_every_stage(helm2_cases):
         op.close()
 
 
-@pytest.mark.parametrize("nrhs", [3, 16, 20, 64, 70])
+@pytest.mark.parametrize("nrhs", [2, 3, 16, 20, 33, 64, 70])
 def test_rhs_block_kernel_matches_oracle(helm2_cases, nrhs):
-    """nrhs >= 3 runs the MFMA (v_mfma_f64_16x16x4_f64) stage kernel; RHS counts
+    """nrhs >= 2 runs the MFMA (v_mfma_f64_16x16x4_f64) stage kernel; RHS counts
     that are not multiples of 16 / 64 exercise its tile masking."""
     from butterfly_amd.operator import HipOperator
     from oracle import bfref
