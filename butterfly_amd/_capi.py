@@ -105,7 +105,7 @@ class BfhipHelm2Problem(C.Structure):
 class BfhipBuildStats(C.Structure):
     _fields_ = [("structSize", C.c_uint32), ("numBatches", C.c_uint32)] + [
         (n, C.c_uint64) for n in ("kernelLeaves", "reexpLeaves", "kernelEvals", "maxSweeps", "notConverged", "truncated", "sumSweeps")] + [
-        ("seconds", C.c_double)]
+        ("seconds", C.c_double), ("qrProblems", C.c_uint64), ("qrColumns", C.c_uint64), ("qrRank", C.c_uint64)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_ if n != "structSize"}

@@ -146,13 +146,27 @@ static int envUpload(BfhipHelm2Problem const *prob, DevEnv *e) {
 }
 
 /* workspace of one re-expansion problem, in complex elements */
-typedef struct ReexpWs { uint64_t zeq, v, zor, t, scale, total; } ReexpWs;
-static ReexpWs reexpWs(BfhipHelm2Recipe const *r) {
+typedef struct ReexpWs { uint64_t zeq, v, x, zor, t, scale, total; } ReexpWs;
+
+/* Problems with at least this many equivalent sources go through the QR preconditioner (bfQrcpKernel) before the
+ * Jacobi kernel: those are the ones whose stacked matrix does not stay in LDS.  BFHIP_JACOBI_QR_MIN overrides the
+ * default (0: every problem, a test hook; a huge value: none). */
+static uint32_t qrMinCols(void) {
+  char const *env = getenv("BFHIP_JACOBI_QR_MIN");
+  if (env && env[0]) return (uint32_t)strtoul(env, NULL, 10);
+  return 65;
+}
+static int usesQr(BfhipHelm2Recipe const *r, uint32_t qrMin) {
+  return r->equiv.count >= qrMin && bfdevQrcpFits(r->tgt.count, r->equiv.count);
+}
+
+static ReexpWs reexpWs(BfhipHelm2Recipe const *r, uint32_t qrMin) {
   uint64_t const mt = r->tgt.count, me = r->equiv.count, n = r->src.count;
   ReexpWs w;
   w.zeq = 0;
   w.v = w.zeq + mt * me;
-  w.zor = w.v + me * me;
+  w.x = w.v + me * me;
+  w.zor = w.x + (usesQr(r, qrMin) ? me * me : 0);
   w.t = w.zor + mt * n;
   w.scale = w.t + me * n;
   w.total = w.scale + (me + 1) / 2;
@@ -161,7 +175,7 @@ static ReexpWs reexpWs(BfhipHelm2Recipe const *r) {
 
 static uint64_t recipeCost(BfhipHelm2Recipe const *r) {
   uint64_t c = (uint64_t)leafRows(r) * r->src.count;
-  if (r->kind == BFHIP_LEAF_REEXP) c += reexpWs(r).total;
+  if (r->kind == BFHIP_LEAF_REEXP) c += reexpWs(r, qrMinCols()).total;
   return c;
 }
 
@@ -178,13 +192,21 @@ static int buildBatch(BfhipHelm2Problem const *prob, uint64_t const *idx, uint64
   uint64_t *prefix = malloc((2 * count + 1) * sizeof *prefix);
   BfSvdProb *probs = malloc((count + 1) * sizeof *probs);
   BfGemmJob *g1 = malloc((count + 1) * sizeof *g1), *g2 = malloc((count + 1) * sizeof *g2);
-  if (!wsOff || !mats || !prefix || !probs || !g1 || !g2) { rc = bfhipFail(BFABI_ERROR_MEMORY_ERROR, "host OOM (builder batch)"); goto done; }
+  BfQrProb *qr = malloc((count + 1) * sizeof *qr);
+  uint64_t *qrOf = malloc((count + 1) * sizeof *qrOf);          /* least-squares problem of the k-th QR problem */
+  uint32_t *qrRank = malloc((count + 1) * sizeof *qrRank);
+  uint32_t const qrMin = qrMinCols();
+  uint64_t nq = 0;
+  if (!wsOff || !mats || !prefix || !probs || !g1 || !g2 || !qr || !qrOf || !qrRank) {
+    rc = bfhipFail(BFABI_ERROR_MEMORY_ERROR, "host OOM (builder batch)");
+    goto done;
+  }
   for (uint64_t i = 0; i < count; ++i) {
     BfhipHelm2Recipe const *r = &prob->recipes[idx[i]];
     storeOff[i] = storeElems;
     storeElems += (uint64_t)leafRows(r) * r->src.count;
     wsOff[i] = wsElems;
-    if (r->kind == BFHIP_LEAF_REEXP) { wsElems += reexpWs(r).total; ++numReexp; }
+    if (r->kind == BFHIP_LEAF_REEXP) { wsElems += reexpWs(r, qrMin).total; ++numReexp; }
   }
   if ((rc = bfdevMalloc(dStore, (size_t)(storeElems ? storeElems : 1) * 16))) goto done;
   if (wsElems && (rc = bfdevMalloc(&dWs, (size_t)wsElems * 16))) goto done;
@@ -203,7 +225,7 @@ static int buildBatch(BfhipHelm2Problem const *prob, uint64_t const *idx, uint64
       st->kernelEvals += (uint64_t)r->tgt.count * r->src.count;
       continue;
     }
-    ReexpWs const w = reexpWs(r);
+    ReexpWs const w = reexpWs(r, qrMin);
     char *base = ws + wsOff[i] * 16;
     uint32_t const mt = r->tgt.count, me = r->equiv.count, n = r->src.count;
     /* re-expansions use the proxy potential; the column weights of the operator scale Z_orig */
@@ -216,7 +238,12 @@ static int buildBatch(BfhipHelm2Problem const *prob, uint64_t const *idx, uint64
     prefix[nm + 1] = prefix[nm] + ((uint64_t)mt * n + BF_EVAL_TILE - 1) / BF_EVAL_TILE;
     ++nm;
     probs[np].a = base + w.zeq * 16; probs[np].v = base + w.v * 16; probs[np].scale = (double *)(base + w.scale * 16);
-    probs[np].mt = mt; probs[np].me = me;
+    probs[np].mt = mt; probs[np].me = me; probs[np].dim = mt > me ? mt : me; probs[np].pad = 0;
+    if (usesQr(r, qrMin)) {
+      qr[nq].a = probs[np].a; qr[nq].b = base + w.zor * 16; qr[nq].x = base + w.x * 16;
+      qr[nq].mt = mt; qr[nq].me = me; qr[nq].n = n; qr[nq].dim = probs[np].dim;
+      qrOf[nq++] = np;
+    }
     /* T = diag(1/sigma^2) (U Sigma)^H Z_orig */
     memset(&g1[np], 0, sizeof g1[np]);
     g1[np].a = probs[np].a; g1[np].b = base + w.zor * 16; g1[np].c = base + w.t * 16; g1[np].scale = probs[np].scale;
@@ -230,6 +257,17 @@ static int buildBatch(BfhipHelm2Problem const *prob, uint64_t const *idx, uint64
     st->kernelEvals += (uint64_t)mt * me + (uint64_t)mt * n;
   }
   if ((rc = bfdevBuildEval(mats, prefix, nm, env))) goto done;
+  /* QR-preconditioned problems: A P = Q R in place, Z_orig <- Q^H Z_orig, and the Jacobi kernel gets X = (R[0:r] P^T)^H
+   * (me x r) instead of A:  X V1 = W  =>  pinv(A) Z_orig = W diag(1/sigma^2) V1^H (Q^H Z_orig)[0:r]  (bfhip_build.hip) */
+  if ((rc = bfdevBuildQrcp(qr, nq, qrRank))) goto done;
+  for (uint64_t k = 0; k < nq; ++k) {
+    uint64_t const q = qrOf[k];
+    uint32_t const me = qr[k].me, rk = qrRank[k];
+    probs[q].a = qr[k].x; probs[q].mt = me; probs[q].me = rk;                     /* V1: rk x rk in the v block */
+    g1[q].a = probs[q].v; g1[q].M = rk; g1[q].K = rk; g1[q].lda = rk;             /* T[0:rk] = diag(1/sigma^2) V1^H (Q^H Z_orig)[0:rk] */
+    g2[q].a = qr[k].x; g2[q].K = rk; g2[q].lda = me;                              /* X = W T[0:rk] */
+    st->qrProblems += 1; st->qrColumns += me; st->qrRank += rk;
+  }
   BfSvdStats ss = {st->maxSweeps, 0, 0, 0};
   if ((rc = bfdevBuildJacobi(probs, np, &ss))) goto done;
   st->maxSweeps = ss.maxSweeps; st->notConverged += ss.notConverged; st->truncated += ss.truncated; st->sumSweeps += ss.sumSweeps;
@@ -239,7 +277,7 @@ static int buildBatch(BfhipHelm2Problem const *prob, uint64_t const *idx, uint64
 done:
   bfdevFree(dWs);
   if (rc) { bfdevFree(*dStore); *dStore = NULL; }
-  free(wsOff); free(mats); free(prefix); free(probs); free(g1); free(g2);
+  free(wsOff); free(mats); free(prefix); free(probs); free(g1); free(g2); free(qr); free(qrOf); free(qrRank);
   return rc;
 }
 

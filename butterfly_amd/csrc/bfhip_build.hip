@@ -21,6 +21,7 @@
 // summation orders, no atomics in any result.
 
 #include <hip/hip_runtime.h>
+#include <time.h>
 #include <stdint.h>
 #include <stdlib.h>
 
@@ -267,7 +268,7 @@ __device__ void bfJacobiFinish(BfSvdProb const &P, BfSvdStats *stats, int sweep,
   }
   __syncthreads();
   double const eps = 2.220446049250313e-16;
-  double const tol = (double)(mt > me ? mt : me) * eps * *sigMaxShared + eps;
+  double const tol = (double)P.dim * eps * *sigMaxShared + eps;
   unsigned long long dropped = 0;
   for (uint32_t j = tid; j < me; j += nthreads) {
     double const s2 = P.scale[j];
@@ -370,7 +371,7 @@ __global__ __launch_bounds__(1024) void bfJacobiKernel(BfSvdProb const *probs, u
   // Columns below the truncation threshold (relative to the largest column norm, a lower bound of
   // sigma_max) are never rotated: they will be dropped, and what they carry is below the rounding
   // error of the matrix.  Left alone they would keep the sweeps busy orthogonalising noise.
-  double const deadRel = (double)(mt > me ? mt : me) * 2.220446049250313e-16;
+  double const deadRel = (double)P.dim * 2.220446049250313e-16;
   double const dead2 = deadRel * deadRel * bfJacobiMaxNorm2<W>(P, &maxNormBits);
   if (resident) loadPair(0, 1, true);
   else {
@@ -443,7 +444,7 @@ __global__ __launch_bounds__(1024) void bfJacobiGlobalKernel(BfSvdProb const *pr
   uint32_t const nthreads = blockDim.x, tid = threadIdx.x;
   uint32_t const groups = nthreads / W, g = tid / W, l = tid % W;
   double const tol2 = (double)mt * 2.220446049250313e-16 * 2.220446049250313e-16;
-  double const deadRel = (double)(mt > me ? mt : me) * 2.220446049250313e-16;
+  double const deadRel = (double)P.dim * 2.220446049250313e-16;
   double const dead2 = deadRel * deadRel * bfJacobiMaxNorm2<W>(P, &maxNormBits);
   for (uint64_t e = tid; e < (uint64_t)me * me; e += nthreads) V[e] = make_double2((e % me == e / me) ? 1.0 : 0.0, 0.0);
   uint32_t const M = me + (me & 1u);
@@ -488,6 +489,207 @@ __global__ __launch_bounds__(1024) void bfJacobiGlobalKernel(BfSvdProb const *pr
     if (converged) break;
   }
   bfJacobiFinish<W>(P, stats, sweep, converged, &sigMax);
+}
+
+// ---------------------------------------------------------------------------
+// Preconditioner of the Jacobi SVD for the problems that do not fit LDS (Drmac & Veselic's
+// scheme, first stage): Householder QR with column pivoting  A P = Q R,  stopped at the first step
+// whose largest remaining column is below the threshold under which the Jacobi kernel never
+// rotates a column (r steps).  The right-hand side B rides along as extra, never pivoted
+// columns and leaves as Q^H B.  What the Jacobi kernel then orthogonalises is
+//   X = (R[0:r, :] P^T)^H      (me x r, rows in the ORIGINAL column order of A),
+// whose columns are already graded and few: X V1 = W (orthogonal columns, norms sigma)  gives
+//   A ~ (Q[:, 0:r] V1) (W^H)  and  pinv(A) B = W diag(1/sigma^2) V1^H (Q^H B)[0:r, :].
+// One workgroup per problem; a column of the trailing matrix per 64-lane group (its segment in
+// registers between the dot product and the update when it has <= 1024 rows); the squared norm
+// of every updated column is accumulated from the updated values themselves, so the pivot
+// choice never sees a downdated norm.  The reflector lives in LDS.  All orders are fixed.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void bfQrcpKernel(BfQrProb const *probs, uint32_t *ranks) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char bfQrLds[];
+  constexpr int W = 64;
+  BfQrProb const P = probs[blockIdx.x];
+  uint32_t const mt = P.mt, me = P.me, n = P.n;
+  double2 *A = (double2 *)P.a, *B = (double2 *)P.b, *X = (double2 *)P.x;
+  double2 *u = (double2 *)bfQrLds;                       // [mt]
+  double *cn = (double *)(u + mt);                       // [me] squared norms of rows j.. of the columns
+  uint32_t *perm = (uint32_t *)(cn + me);                // [me]
+  __shared__ double redVal[16];
+  __shared__ uint32_t redIdx[16];
+  __shared__ double sCoef, sDead2;
+  __shared__ uint32_t sPivot;
+  uint32_t const nthreads = blockDim.x, tid = threadIdx.x;
+  uint32_t const groups = nthreads / W, g = tid / W, l = tid % W;
+
+  // largest cn[c], c >= from (lowest index among equals) -> sPivot; every thread gets the value
+  auto argmax = [&](uint32_t from) -> double {
+    double bv = -1.0; uint32_t bi = 0xffffffffu;
+    for (uint32_t c = from + tid; c < me; c += nthreads) { double const v = cn[c]; if (v > bv) { bv = v; bi = c; } }
+#pragma unroll
+    for (int m = 1; m < W; m <<= 1) {
+      double const ov = __shfl_xor(bv, m, W); uint32_t const oi = __shfl_xor(bi, m, W);
+      if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    }
+    if (l == 0) { redVal[g] = bv; redIdx[g] = bi; }
+    __syncthreads();
+    if (tid == 0) {
+      for (uint32_t k = 1; k < groups; ++k)
+        if (redVal[k] > bv || (redVal[k] == bv && redIdx[k] < bi)) { bv = redVal[k]; bi = redIdx[k]; }
+      redVal[0] = bv; sPivot = bi;
+    }
+    __syncthreads();
+    return redVal[0];
+  };
+
+  for (uint32_t c = g; c < me; c += groups) {
+    double2 const *ac = A + (uint64_t)c * mt;
+    double s2 = 0;
+    for (uint32_t r = l; r < mt; r += W) { double2 const a = ac[r]; s2 = fma(a.x, a.x, fma(a.y, a.y, s2)); }
+    s2 = bfGroupSum<W>(s2);
+    if (l == 0) { cn[c] = s2; perm[c] = c; }
+  }
+  __syncthreads();
+  {
+    double const mx = argmax(0);
+    double const deadRel = (double)P.dim * 2.220446049250313e-16;
+    if (tid == 0) sDead2 = deadRel * deadRel * mx;
+    __syncthreads();
+  }
+  uint32_t const steps = mt < me ? mt : me;
+  uint32_t j = 0;
+  for (; j < steps; ++j) {
+    double const best = argmax(j);
+    if (!(best >= sDead2) || best <= 0.0) break;       // everything left is below the threshold (or not a number)
+    uint32_t const p = sPivot;
+    if (p != j) {
+      double2 *aj = A + (uint64_t)j * mt, *ap = A + (uint64_t)p * mt;
+      for (uint32_t r = tid; r < mt; r += nthreads) { double2 const t = aj[r]; aj[r] = ap[r]; ap[r] = t; }
+      if (tid == 0) { double const t = cn[j]; cn[j] = cn[p]; cn[p] = t; uint32_t const q = perm[j]; perm[j] = perm[p]; perm[p] = q; }
+    }
+    __syncthreads();
+    // reflector H = I - coef u u^H with u = x + e^{i arg x0} |x| e_1:  H x = -e^{i arg x0} |x| e_1
+    uint32_t const L = mt - j;
+    double2 *aj = A + (uint64_t)j * mt + j;
+    for (uint32_t i = tid; i < L; i += nthreads) u[i] = aj[i];
+    __syncthreads();
+    if (tid == 0) {
+      double2 const x0 = u[0];
+      double const nx = sqrt(best), a0 = hypot(x0.x, x0.y);
+      double const pr = a0 > 0.0 ? x0.x / a0 : 1.0, pi = a0 > 0.0 ? x0.y / a0 : 0.0;
+      u[0] = make_double2(x0.x + pr * nx, x0.y + pi * nx);
+      sCoef = 1.0 / (nx * (nx + a0));                  // 2 / (u^H u)
+      aj[0] = make_double2(-pr * nx, -pi * nx);          // R[j][j]
+    }
+    __syncthreads();
+    double const coef = sCoef;
+    uint32_t const trailing = me - j - 1, cols = trailing + n;
+    for (uint32_t c = g; c < cols; c += groups) {
+      double2 *col = c < trailing ? A + (uint64_t)(j + 1 + c) * mt + j : B + (uint64_t)(c - trailing) * mt + j;
+      double sr = 0, si = 0, nn = 0;
+      if (L <= 16 * W) {
+        double2 v[16];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+          uint32_t const i = l + W * t;
+          v[t] = i < L ? col[i] : make_double2(0.0, 0.0);
+          double2 const ui = i < L ? u[i] : make_double2(0.0, 0.0);
+          sr = fma(ui.x, v[t].x, fma(ui.y, v[t].y, sr));     // conj(u) * v
+          si = fma(ui.x, v[t].y, fma(-ui.y, v[t].x, si));
+        }
+        sr = bfGroupSum<W>(sr) * coef; si = bfGroupSum<W>(si) * coef;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+          uint32_t const i = l + W * t;
+          if (i < L) {
+            double2 const ui = u[i];
+            double2 const w = make_double2(v[t].x - (sr * ui.x - si * ui.y), v[t].y - (sr * ui.y + si * ui.x));
+            col[i] = w;
+            if (i) nn = fma(w.x, w.x, fma(w.y, w.y, nn));
+          }
+        }
+      } else {
+        for (uint32_t i = l; i < L; i += W) {
+          double2 const ui = u[i], x = col[i];
+          sr = fma(ui.x, x.x, fma(ui.y, x.y, sr));
+          si = fma(ui.x, x.y, fma(-ui.y, x.x, si));
+        }
+        sr = bfGroupSum<W>(sr) * coef; si = bfGroupSum<W>(si) * coef;
+        for (uint32_t i = l; i < L; i += W) {
+          double2 const ui = u[i], x = col[i];
+          double2 const w = make_double2(x.x - (sr * ui.x - si * ui.y), x.y - (sr * ui.y + si * ui.x));
+          col[i] = w;
+          if (i) nn = fma(w.x, w.x, fma(w.y, w.y, nn));
+        }
+      }
+      nn = bfGroupSum<W>(nn);
+      if (l == 0 && c < trailing) cn[j + 1 + c] = nn;
+    }
+    __syncthreads();
+  }
+  uint32_t const r = j;
+  if (tid == 0) ranks[blockIdx.x] = r;
+  // X[perm[c] + i me] = conj(R[i][c]), i <= c; zero below the diagonal of R
+  for (uint32_t c = g; c < me; c += groups) {
+    double2 const *rc = A + (uint64_t)c * mt;
+    uint32_t const row = perm[c];
+    for (uint32_t i = l; i < r; i += W) {
+      double2 v = make_double2(0.0, 0.0);
+      if (i <= c) { v = rc[i]; v.y = -v.y; }
+      X[(uint64_t)i * me + row] = v;
+    }
+  }
+}
+
+// LDS a problem of the QR kernel needs; 0: does not fit (the caller keeps such a problem on the plain path)
+static uint32_t qrcpLds(uint32_t mt, uint32_t me) {
+  uint64_t const need = (uint64_t)mt * 16 + (uint64_t)me * 12 + 64;
+  return need <= (150u << 10) ? (uint32_t)need : 0;
+}
+
+int bfdevQrcpFits(uint32_t mt, uint32_t me) { return qrcpLds(mt, me) != 0; }
+
+// problems sorted by LDS need would pack better; one launch per power-of-two LDS class keeps it simple
+int bfdevBuildQrcp(BfQrProb const *hostProbs, uint64_t numProbs, uint32_t *hostRanks) {
+  if (!numProbs) return 0;
+  enum { NC = 6 };                                       /* <= 8, 16, 32, 64, 128, 150 KiB */
+  static uint32_t const cap[NC] = {8u << 10, 16u << 10, 32u << 10, 64u << 10, 128u << 10, 150u << 10};
+  uint32_t *order = (uint32_t *)malloc(numProbs * sizeof(uint32_t));
+  BfQrProb *sorted = (BfQrProb *)malloc(numProbs * sizeof(BfQrProb));
+  uint32_t *ranks = (uint32_t *)malloc(numProbs * sizeof(uint32_t));
+  uint64_t count[NC + 1] = {0};
+  int rc = order && sorted && ranks ? 0 : bfhipFail(BFABI_ERROR_MEMORY_ERROR, "host OOM");
+  for (uint64_t i = 0; i < numProbs && !rc; ++i) {
+    uint32_t const need = qrcpLds(hostProbs[i].mt, hostProbs[i].me);
+    if (!need) { rc = bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "QR preconditioner: problem %llu does not fit LDS", (unsigned long long)i); break; }
+    int c = 0;
+    while (cap[c] < need) ++c;
+    order[i] = (uint32_t)c;
+    count[c + 1] += 1;
+  }
+  for (int c = 0; c < NC; ++c) count[c + 1] += count[c];
+  if (!rc) {
+    uint64_t cursor[NC];
+    for (int c = 0; c < NC; ++c) cursor[c] = count[c];
+    for (uint64_t i = 0; i < numProbs; ++i) { uint64_t const at = cursor[order[i]]++; sorted[at] = hostProbs[i]; order[i] = (uint32_t)at; }
+  }
+  BfQrProb *dP = NULL;
+  uint32_t *dR = NULL;
+  if (!rc) rc = uploadArrayB(&dP, sorted, numProbs, "qr problems");
+  if (!rc) rc = hipFailB(hipMalloc((void **)&dR, numProbs * sizeof(uint32_t)), "qr ranks");
+  if (!rc) rc = hipFailB(hipFuncSetAttribute((void const *)bfQrcpKernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cap[NC - 1]), "hipFuncSetAttribute(QR LDS)");
+  for (int c = NC - 1; c >= 0 && !rc; --c) {              /* the big ones first */
+    uint64_t const nc = count[c + 1] - count[c];
+    if (!nc) continue;
+    uint32_t const threads = c >= 2 ? 512 : 256;          /* LDS class ~ rows: short columns need few lane groups */
+    hipLaunchKernelGGL(bfQrcpKernel, dim3((uint32_t)nc), dim3(threads), cap[c], 0, dP + count[c], dR + count[c]);
+    rc = hipFailB(hipGetLastError(), "QR preconditioner launch");
+  }
+  if (!rc) rc = hipFailB(hipDeviceSynchronize(), "QR preconditioner");
+  if (!rc) rc = hipFailB(hipMemcpy(ranks, dR, numProbs * sizeof(uint32_t), hipMemcpyDeviceToHost), "qr ranks");
+  for (uint64_t i = 0; i < numProbs && !rc; ++i) hostRanks[i] = ranks[order[i]];
+  (void)hipFree(dP); (void)hipFree(dR);
+  free(order); free(sorted); free(ranks);
+  return rc;
 }
 
 // Launch classes.  Workgroup: 256 threads for <= 64 columns, 1024 above.  LDS: the smallest of
@@ -560,6 +762,9 @@ int bfdevBuildJacobi(BfSvdProb const *hostProbs, uint64_t numProbs, BfSvdStats *
   BfSvdStats zero = {0, 0, 0, 0};
   if (!rc) rc = uploadArrayB(&dS, &zero, 1, "svd stats");
   uint32_t *dL[NCLS] = {0};
+  // BFHIP_JACOBI_PROFILE=1: time every class launch on its own (a synchronisation per class) and print it
+  char const *penv = getenv("BFHIP_JACOBI_PROFILE");
+  int const profile = penv && penv[0] == '1';
   // classes are launched back to back (largest tiles first: they run longest) and synchronised once
   for (int lc = NL - 1; lc >= 0 && !rc; --lc)
     for (int wb = 0; wb < 2 * NW && !rc; ++wb) {
@@ -568,12 +773,35 @@ int bfdevBuildJacobi(BfSvdProb const *hostProbs, uint64_t numProbs, BfSvdStats *
       rc = uploadArrayB(&dL[c], lists[c], counts[c], "svd class list");
       if (rc) break;
       uint32_t const threads = wb & 1 ? 1024 : 256, lds = kJacobiLds[lc], n = (uint32_t)counts[c];
+      struct timespec t0, t1;
+      BfSvdStats before = {0, 0, 0, 0};
+      if (profile) {
+        (void)hipDeviceSynchronize();
+        (void)hipMemcpy(&before, dS, sizeof before, hipMemcpyDeviceToHost);
+        clock_gettime(CLOCK_MONOTONIC, &t0);
+      }
       switch (wb >> 1) {
         case 0: rc = jacobiLaunch<4>(n, threads, lds, dP, dL[c], dS); break;
         case 1: rc = jacobiLaunch<8>(n, threads, lds, dP, dL[c], dS); break;
         case 2: rc = jacobiLaunch<16>(n, threads, lds, dP, dL[c], dS); break;
         case 3: rc = jacobiLaunch<32>(n, threads, lds, dP, dL[c], dS); break;
         default: rc = jacobiLaunch<64>(n, threads, lds, dP, dL[c], dS); break;
+      }
+      if (profile && !rc) {
+        (void)hipDeviceSynchronize();
+        clock_gettime(CLOCK_MONOTONIC, &t1);
+        BfSvdStats after;
+        (void)hipMemcpy(&after, dS, sizeof after, hipMemcpyDeviceToHost);
+        uint32_t lo = 0xffffffffu, hi = 0;
+        double cube = 0;
+        for (uint64_t i = 0; i < counts[c]; ++i) {
+          BfSvdProb const *q = &hostProbs[lists[c][i]];
+          lo = q->me < lo ? q->me : lo; hi = q->me > hi ? q->me : hi;
+          cube += (double)q->me * q->me * (q->mt + q->me);
+        }
+        fprintf(stderr, "[jacobi] W=%d threads=%u lds=%uK problems=%u me=%u..%u sum(me^2 (mt+me))=%.3g sweeps=%.1f  %.3f s\n", 4 << (wb >> 1), threads,
+                lds >> 10, n, lo, hi, cube, (double)(after.sumSweeps - before.sumSweeps) / n,
+                (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec));
       }
     }
   uint32_t *dG = NULL;

@@ -344,9 +344,22 @@ typedef struct BfSvdProb {
   void *a, *v;
   double *scale;         /* [me] */
   uint32_t mt, me;
+  uint32_t dim, pad;     /* the max(rows, cols) of the truncation rule (src/mat_dense_complex.c:1800-1812): that of the ORIGINAL
+                            matrix when (a) is the QR-preconditioned one */
 } BfSvdProb;
 typedef struct BfSvdStats { unsigned long long maxSweeps, notConverged, truncated, sumSweeps; } BfSvdStats;
 int bfdevBuildJacobi(BfSvdProb const *hostProbs, uint64_t numProbs, BfSvdStats *stats);
+
+/* QR with column pivoting ahead of the Jacobi SVD (bfQrcpKernel): a (mt x me, ld mt) is overwritten (R in its upper
+ * triangle), b (mt x n, ld mt) becomes Q^H b, x (me x me workspace) receives the me x rank matrix the Jacobi kernel
+ * then works on (ld me); hostRanks[i] = the number of steps taken before the largest remaining column fell below
+ * dim * eps * (largest column of a). */
+typedef struct BfQrProb {
+  void *a, *b, *x;
+  uint32_t mt, me, n, dim;
+} BfQrProb;
+int bfdevQrcpFits(uint32_t mt, uint32_t me);
+int bfdevBuildQrcp(BfQrProb const *hostProbs, uint64_t numProbs, uint32_t *hostRanks);
 
 /* C (M x N) = op(A) * B with optional row scaling C[i,:] *= scale[i];
  * transA: op(A)[i,k] = conj(A[k + i*lda]) (A stored K x M), else A[i + k*lda] */

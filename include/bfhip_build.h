@@ -118,6 +118,9 @@ typedef struct BfhipBuildStats {
   uint64_t truncated;        /* singular values dropped, total */
   uint64_t sumSweeps;        /* Jacobi sweeps summed over all problems */
   double seconds;            /* wall time of the value build (device work + orchestration) */
+  uint64_t qrProblems;       /* least-squares problems that went through the QR preconditioner (>= 65 equivalent sources) */
+  uint64_t qrColumns;        /* their columns, total ... */
+  uint64_t qrRank;           /* ... and how many of those the Jacobi kernel still had to orthogonalise */
 } BfhipBuildStats;
 
 /* Compile `desc` (all dense leaves must have leafData == NULL and a recipe)

@@ -420,6 +420,42 @@ def test_global_memory_jacobi_fallback(monkeypatch, helm2_cases):
     assert rel(z_eq @ X, z_eq @ hb.lstsq_truncated(z_eq, z_or)) <= 1e-10
 
 
+def test_qr_preconditioned_jacobi(monkeypatch, helm2_cases):
+    """Least-squares problems of >= 65 equivalent sources (the ones that do not stay in LDS) are QR-factored with
+    column pivoting first and the Jacobi kernel orthogonalises (R[0:r] P^T)^H; BFHIP_JACOBI_QR_MIN moves that limit.
+    Every problem through the preconditioner, and none, give the same operator to rounding; tall and square
+    problems reproduce the truncated-SVD least-squares field."""
+    from butterfly_amd.operator import HipOperator, helm2_build_leaf
+    from oracle import helm2_build as hb
+    n, k = 4096, 256.0
+    desc, tp, _ = helm2_cases(n, k)
+    x = hb.complex_randn(n, 0)
+    monkeypatch.setenv("BFHIP_JACOBI_QR_MIN", "1000000")
+    op, st = HipOperator.build_helm2(desc, tp, k)
+    assert st["qrProblems"] == 0 and st["notConverged"] == 0
+    y = op.apply_host(x)
+    op.close()
+    monkeypatch.setenv("BFHIP_JACOBI_QR_MIN", "0")
+    op, st2 = HipOperator.build_helm2(desc, tp, k)
+    assert st2["qrProblems"] == st2["reexpLeaves"] == st["reexpLeaves"] and st2["notConverged"] == 0
+    assert 0 < st2["qrRank"] <= st2["qrColumns"]
+    assert st2["sumSweeps"] < st["sumSweeps"]                      # what the preconditioner is for
+    assert rel(op.apply_host(x), y) <= 1e-11
+    y_dense = hb.kernel_matrix(k, tp, tp) @ x
+    assert rel(op.apply_host(x), y_dense) <= 1e-9
+    op.close()
+    pts = tp[:16]
+    for (nsrc, me, mt, kk) in [(70, 45, 51, 400.0), (90, 100, 100, 900.0), (170, 150, 190, 1500.0), (64, 300, 300, 3000.0)]:
+        rc = ("reexp", ("circle", 0.55, 0.05, 0.08, nsrc), ("circle", 0.5, 0.0, 0.16, me), ("circle", -0.6, 0.1, 0.2, mt))
+        X = helm2_build_leaf(pts, kk, rc)
+        src, eq, tgt = (hb.resolve_points(s, pts) for s in rc[1:])
+        z_or, z_eq = hb.kernel_matrix(kk, src, tgt), hb.kernel_matrix(kk, eq, tgt)
+        want = hb.lstsq_truncated(z_eq, z_or)
+        assert X.shape == want.shape
+        assert rel(z_eq @ X, z_eq @ want) <= 1e-10, (nsrc, me, mt)
+        assert np.linalg.norm(X) <= 1.5 * np.linalg.norm(want), (nsrc, me, mt)
+
+
 def test_single_pair_butterfly_built_on_the_device_matches_the_golden_vectors():
     """examples/simple/bf_one_block.c: bfFacHelm2MakeSingleLevel for one node pair -- native layout,
     device values -- against the committed golden (numpy/LAPACK-built operand, its x and y)."""
