@@ -9,6 +9,7 @@
  * the packed arena the apply kernels read.  Nothing but the recipes and the
  * point coordinates crosses PCIe.
  */
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
@@ -179,10 +180,31 @@ static uint64_t recipeCost(BfhipHelm2Recipe const *r) {
   return c;
 }
 
+/* Device buffers of the batches, kept from one batch to the next (allocating and freeing ~100 GB per batch costs seconds). */
+typedef struct BatchBufs { void *store, *ws; uint64_t storeElems, wsElems; } BatchBufs;
+static void batchBufsFree(BatchBufs *b) { bfdevFree(b->store); bfdevFree(b->ws); memset(b, 0, sizeof *b); }
+static int batchBufsReserve(BatchBufs *b, uint64_t storeElems, uint64_t wsElems) {
+  int rc = 0;
+  if (storeElems > b->storeElems || !b->store) {
+    bfdevFree(b->store); b->store = NULL; b->storeElems = 0;
+    if ((rc = bfdevMalloc(&b->store, (size_t)(storeElems ? storeElems : 1) * 16))) return rc;
+    b->storeElems = storeElems;
+  }
+  if (wsElems > b->wsElems) {
+    bfdevFree(b->ws); b->ws = NULL; b->wsElems = 0;
+    if ((rc = bfdevMalloc(&b->ws, (size_t)wsElems * 16))) return rc;
+    b->wsElems = wsElems;
+  }
+  return 0;
+}
+
+/* leaf-store and workspace elements of a batch */
+static void batchSizes(BfhipHelm2Problem const *prob, uint64_t const *idx, uint64_t count, uint32_t qrMin, uint64_t *storeElems, uint64_t *wsElems);
+
 /* Compute recipes idx[0..count) on the current device.  *dStore receives a
  * device buffer holding the leaves column-major at storeOff[i] (elements). */
 static int buildBatch(BfhipHelm2Problem const *prob, uint64_t const *idx, uint64_t count, BfEvalEnv const *env,
-                      void **dStore, uint64_t *storeOff, BfhipBuildStats *st) {
+                      BatchBufs *bufs, void **dStore, uint64_t *storeOff, BfhipBuildStats *st) {
   int rc = 0;
   *dStore = NULL;
   void *dWs = NULL;
@@ -208,8 +230,9 @@ static int buildBatch(BfhipHelm2Problem const *prob, uint64_t const *idx, uint64
     wsOff[i] = wsElems;
     if (r->kind == BFHIP_LEAF_REEXP) { wsElems += reexpWs(r, qrMin).total; ++numReexp; }
   }
-  if ((rc = bfdevMalloc(dStore, (size_t)(storeElems ? storeElems : 1) * 16))) goto done;
-  if (wsElems && (rc = bfdevMalloc(&dWs, (size_t)wsElems * 16))) goto done;
+  double const tAlloc = nowSeconds();
+  if ((rc = batchBufsReserve(bufs, storeElems, wsElems))) goto done;
+  *dStore = bufs->store; dWs = bufs->ws;
   char *store = (char *)*dStore, *ws = (char *)dWs;
   uint64_t nm = 0, np = 0;
   prefix[0] = 0;
@@ -256,10 +279,17 @@ static int buildBatch(BfhipHelm2Problem const *prob, uint64_t const *idx, uint64
     st->reexpLeaves += 1;
     st->kernelEvals += (uint64_t)mt * me + (uint64_t)mt * n;
   }
+  char const *penv = getenv("BFHIP_JACOBI_PROFILE");
+  int const profile = penv && penv[0] == '1';
+  double tp = tAlloc;
+#define BF_PHASE(name) do { if (profile) { double const t = nowSeconds(); fprintf(stderr, "[build] %-12s %.3f s\n", name, t - tp); tp = t; } } while (0)
+  BF_PHASE("alloc + lists");
   if ((rc = bfdevBuildEval(mats, prefix, nm, env))) goto done;
+  BF_PHASE("kernel eval");
   /* QR-preconditioned problems: A P = Q R in place, Z_orig <- Q^H Z_orig, and the Jacobi kernel gets X = (R[0:r] P^T)^H
    * (me x r) instead of A:  X V1 = W  =>  pinv(A) Z_orig = W diag(1/sigma^2) V1^H (Q^H Z_orig)[0:r]  (bfhip_build.hip) */
   if ((rc = bfdevBuildQrcp(qr, nq, qrRank))) goto done;
+  BF_PHASE("qr");
   for (uint64_t k = 0; k < nq; ++k) {
     uint64_t const q = qrOf[k];
     uint32_t const me = qr[k].me, rk = qrRank[k];
@@ -271,14 +301,26 @@ static int buildBatch(BfhipHelm2Problem const *prob, uint64_t const *idx, uint64
   BfSvdStats ss = {st->maxSweeps, 0, 0, 0};
   if ((rc = bfdevBuildJacobi(probs, np, &ss))) goto done;
   st->maxSweeps = ss.maxSweeps; st->notConverged += ss.notConverged; st->truncated += ss.truncated; st->sumSweeps += ss.sumSweeps;
+  BF_PHASE("jacobi");
   if ((rc = bfdevBuildGemm(g1, np))) goto done;
   if ((rc = bfdevBuildGemm(g2, np))) goto done;
+  BF_PHASE("gemm");
+#undef BF_PHASE
   st->numBatches += 1;
 done:
-  bfdevFree(dWs);
-  if (rc) { bfdevFree(*dStore); *dStore = NULL; }
+  if (rc) *dStore = NULL;
   free(wsOff); free(mats); free(prefix); free(probs); free(g1); free(g2); free(qr); free(qrOf); free(qrRank);
   return rc;
+}
+
+static void batchSizes(BfhipHelm2Problem const *prob, uint64_t const *idx, uint64_t count, uint32_t qrMin, uint64_t *storeElems, uint64_t *wsElems) {
+  uint64_t se = 0, we = 0;
+  for (uint64_t i = 0; i < count; ++i) {
+    BfhipHelm2Recipe const *r = &prob->recipes[idx[i]];
+    se += (uint64_t)leafRows(r) * r->src.count;
+    if (r->kind == BFHIP_LEAF_REEXP) we += reexpWs(r, qrMin).total;
+  }
+  *storeElems = se; *wsElems = we;
 }
 
 /* ---- arena fill: called by the compile step instead of packing host values ---- */
@@ -303,6 +345,8 @@ static int fillArena(BfPlan const *pl, BfIr const *ir, void *dArena, void *vctx)
   BfPackPiece *pack = NULL;
   DevEnv dev;
   memset(&dev, 0, sizeof dev);
+  BatchBufs bufs;
+  memset(&bufs, 0, sizeof bufs);
   if (!recOf || !pieceBegin) { rc = bfhipFail(BFABI_ERROR_MEMORY_ERROR, "host OOM (builder)"); goto done; }
   for (uint64_t i = 0; i < ir->numNodes; ++i) recOf[i] = -1;
   for (uint64_t i = 0; i < R && !rc; ++i) {
@@ -357,6 +401,9 @@ static int fillArena(BfPlan const *pl, BfIr const *ir, void *dArena, void *vctx)
     free(cursor);
   }
 
+  char const *penv = getenv("BFHIP_JACOBI_PROFILE");
+  int const profile = penv && penv[0] == '1';
+  double tph = nowSeconds();
   if ((rc = envUpload(prob, &dev))) goto done;
 
   /* default workspace: half of what is free once the arena is allocated, at least 8 GiB asked for --
@@ -371,6 +418,24 @@ static int fillArena(BfPlan const *pl, BfIr const *ir, void *dArena, void *vctx)
   batch = malloc((R + 1) * sizeof *batch);
   storeOff = malloc((R + 1) * sizeof *storeOff);
   if (!batch || !storeOff) { rc = bfhipFail(BFABI_ERROR_MEMORY_ERROR, "host OOM (builder)"); goto done; }
+  /* the largest batch sizes the buffers once */
+  {
+    uint64_t maxStore = 0, maxWs = 0;
+    for (uint64_t j = 0; j < R;) {
+      uint64_t nb = 0, cost = 0;
+      for (; j < R; ++j) {
+        if (pieceBegin[j + 1] == pieceBegin[j]) continue;
+        uint64_t const c = recipeCost(&prob->recipes[j]);
+        if (nb && cost + c > budget) break;
+        batch[nb++] = j; cost += c;
+      }
+      if (!nb) break;
+      uint64_t se, we;
+      batchSizes(prob, batch, nb, qrMinCols(), &se, &we);
+      maxStore = se > maxStore ? se : maxStore; maxWs = we > maxWs ? we : maxWs;
+    }
+    if ((rc = batchBufsReserve(&bufs, maxStore, maxWs))) goto done;
+  }
   uint64_t i = 0;
   while (i < R && !rc) {
     /* next batch: recipes whose leaves survive in this plan, until the workspace is full */
@@ -383,7 +448,9 @@ static int fillArena(BfPlan const *pl, BfIr const *ir, void *dArena, void *vctx)
     }
     if (!nb) break;
     void *dStore = NULL;
-    if ((rc = buildBatch(prob, batch, nb, &dev.env, &dStore, storeOff, st))) break;
+    if (profile) { double const t = nowSeconds(); fprintf(stderr, "[build] host before batch %.3f s\n", t - tph); tph = t; }
+    if ((rc = buildBatch(prob, batch, nb, &dev.env, &bufs, &dStore, storeOff, st))) break;
+    if (profile) { double const t = nowSeconds(); fprintf(stderr, "[build] batch total %.3f s (%llu recipes)\n", t - tph, (unsigned long long)nb); tph = t; }
     pack = malloc((packCount + 1) * sizeof *pack);
     if (!pack) rc = bfhipFail(BFABI_ERROR_MEMORY_ERROR, "host OOM (builder pack list)");
     uint64_t q = 0;
@@ -400,7 +467,7 @@ static int fillArena(BfPlan const *pl, BfIr const *ir, void *dArena, void *vctx)
     }
     if (!rc) rc = bfdevBuildPack(dArena, dStore, pack, q);
     free(pack); pack = NULL;
-    bfdevFree(dStore);
+    if (profile) { double const t = nowSeconds(); fprintf(stderr, "[build] pack + free  %.3f s\n", t - tph); tph = t; }
   }
   /* every KR pair must have been met exactly once by a dense near-field leaf; a pair inside a
    * butterflied block cannot be corrected through the values */
@@ -412,6 +479,7 @@ static int fillArena(BfPlan const *pl, BfIr const *ir, void *dArena, void *vctx)
                      hits, 2ull * prob->krOrder * prob->numPoints);
   }
 done:
+  batchBufsFree(&bufs);
   envFree(&dev);
   free(recOf); free(pieceBegin); free(pieces); free(sorted); free(batch); free(storeOff);
   return rc;
@@ -465,14 +533,16 @@ int bfhipHelm2BuildLeaf(BfhipHelm2Problem const *prob, uint64_t recipeIndex, int
   uint64_t off = 0;
   if (!tmp) rc = bfhipFail(BFABI_ERROR_MEMORY_ERROR, "host OOM");
   if (!rc) rc = envUpload(prob, &dev);
-  if (!rc) rc = buildBatch(prob, &recipeIndex, 1, &dev.env, &dStore, &off, &st);
+  BatchBufs bufs;
+  memset(&bufs, 0, sizeof bufs);
+  if (!rc) rc = buildBatch(prob, &recipeIndex, 1, &dev.env, &bufs, &dStore, &off, &st);
   if (!rc) rc = bfdevMemcpyD2H(tmp, dStore, (size_t)m * n * 16);
   if (!rc) {
     double *o = out;                                   /* column-major store -> row-major result */
     for (uint64_t i = 0; i < m; ++i)
       for (uint64_t j = 0; j < n; ++j) { o[2 * (i * n + j)] = tmp[2 * (j * m + i)]; o[2 * (i * n + j) + 1] = tmp[2 * (j * m + i) + 1]; }
   }
-  bfdevFree(dStore); envFree(&dev); free(tmp);
+  batchBufsFree(&bufs); envFree(&dev); free(tmp);
   if (prev >= 0) bfdevSetDevice(prev);
   return rc;
 }

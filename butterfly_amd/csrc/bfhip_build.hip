@@ -319,6 +319,8 @@ __device__ __forceinline__ bool bfJacobiAngle(double alpha, double beta, double 
   return true;
 }
 
+#define BF_JACOBI_MAX_COLS 2304          /* 2 (rows + cols) 16 B <= the LDS tile  =>  cols <= 2300 */
+
 template <int W>
 __global__ __launch_bounds__(1024) void bfJacobiKernel(BfSvdProb const *probs, uint32_t const *list, BfSvdStats *stats, uint32_t ldsBytes) {
   extern __shared__ __attribute__((aligned(16))) unsigned char bfJacobiLds[];
@@ -326,8 +328,11 @@ __global__ __launch_bounds__(1024) void bfJacobiKernel(BfSvdProb const *probs, u
   __shared__ int rotated;
   __shared__ double sigMax;
   __shared__ unsigned long long maxNormBits;
+  __shared__ uint32_t numLive;
+  __shared__ uint16_t live[BF_JACOBI_MAX_COLS];     // the columns still above the threshold, in column order
   BfSvdProb const P = probs[list[blockIdx.x]];
   uint32_t const mt = P.mt, me = P.me;
+  if (me == 0) return;                              // rank 0 after the QR preconditioner: nothing to orthogonalise
   double2 *A = (double2 *)P.a, *V = (double2 *)P.v;
   uint32_t const nthreads = blockDim.x, tid = threadIdx.x;
   uint32_t const groups = nthreads / W, g = tid / W, l = tid % W;
@@ -335,27 +340,31 @@ __global__ __launch_bounds__(1024) void bfJacobiKernel(BfSvdProb const *probs, u
   uint32_t C = (ldsBytes / 16u) / Rp;               // stacked columns the tile holds
   C = C < 2 ? 2 : C & ~1u;
   uint32_t const b = C / 2 < (me + 1) / 2 ? C / 2 : (me + 1) / 2;
-  uint32_t const nb = (me + b - 1) / b;             // >= 2
-  uint32_t const NB = nb + (nb & 1u);
-  bool const resident = nb == 2;
+  bool const resident = (me + b - 1) / b <= 2;      // everything fits: loaded once, slot = column
   double const tol2 = (double)mt * 2.220446049250313e-16 * 2.220446049250313e-16;   // xGESVJ: sqrt(mt) eps
 
-  // slot -> global column of the block pair (I, J); >= me: empty slot
+  // Columns below the truncation threshold (relative to the largest column norm, a lower bound of
+  // sigma_max) are never rotated: they will be dropped, and what they carry is below the rounding
+  // error of the matrix.  Left alone they would keep the sweeps busy orthogonalising noise.  A column
+  // that is never rotated never changes, so it stays below: every sweep starts by listing the columns
+  // still above the threshold and visits the pairs of THAT list only (with half of the columns
+  // frozen, a quarter of the pairs).
+  double const deadRel = (double)P.dim * 2.220446049250313e-16;
+  double const dead2 = deadRel * deadRel * bfJacobiMaxNorm2<W>(P, &maxNormBits);
+
+  // slot of the staged block pair (I, J) of the live list -> global column; none: 0xffffffff
+  uint32_t nLive = me;
   auto slotCol = [&](uint32_t I, uint32_t J, uint32_t slot) -> uint32_t {
     uint32_t const blk = slot < b ? I : J, off = slot < b ? slot : slot - b;
-    uint32_t const c = blk * b + off;
-    return (blk * b + off < (blk + 1) * b && c < me) ? c : 0xffffffffu;
+    uint32_t const a = blk * b + off;
+    return a < nLive ? (uint32_t)live[a] : 0xffffffffu;
   };
-  auto loadPair = [&](uint32_t I, uint32_t J, bool first) {
+  auto loadPair = [&](uint32_t I, uint32_t J) {
     for (uint32_t e = tid; e < 2 * b * R; e += nthreads) {
       uint32_t const slot = e / R, r = e - slot * R;
       uint32_t const c = slotCol(I, J, slot);
       if (c == 0xffffffffu) continue;
-      double2 v;
-      if (r < mt) v = A[(uint64_t)c * mt + r];
-      else if (first) v = make_double2(r - mt == c ? 1.0 : 0.0, 0.0);       // V starts as the identity
-      else v = V[(uint64_t)c * me + (r - mt)];
-      tile[slot * Rp + r] = v;
+      tile[slot * Rp + r] = r < mt ? A[(uint64_t)c * mt + r] : V[(uint64_t)c * me + (r - mt)];
     }
   };
   auto storePair = [&](uint32_t I, uint32_t J) {
@@ -367,65 +376,110 @@ __global__ __launch_bounds__(1024) void bfJacobiKernel(BfSvdProb const *probs, u
       if (r < mt) A[(uint64_t)c * mt + r] = v; else V[(uint64_t)c * me + (r - mt)] = v;
     }
   };
+  // one column pair held in the tile at slots (p, q): inner products over the A rows, rotation of all R rows
+  auto rotatePair = [&](uint32_t p, uint32_t q) {
+    double2 *sp = tile + p * Rp, *sq = tile + q * Rp;
+    double alpha = 0, beta = 0, gr = 0, gi = 0;
+    for (uint32_t r = l; r < mt; r += W) {
+      double2 const x = sp[r], y = sq[r];
+      alpha = fma(x.x, x.x, fma(x.y, x.y, alpha));
+      beta = fma(y.x, y.x, fma(y.y, y.y, beta));
+      gr = fma(x.x, y.x, fma(x.y, y.y, gr));     // conj(x) * y
+      gi = fma(x.x, y.y, fma(-x.y, y.x, gi));
+    }
+    alpha = bfGroupSum<W>(alpha); beta = bfGroupSum<W>(beta);
+    gr = bfGroupSum<W>(gr); gi = bfGroupSum<W>(gi);
+    double c, sn, er, ei;
+    if (!bfJacobiAngle(alpha, beta, gr, gi, tol2, dead2, c, sn, er, ei)) return;
+    for (uint32_t r = l; r < R; r += W) {
+      double2 const x = sp[r], y = sq[r];
+      double2 const yt = make_double2(er * y.x - ei * y.y, er * y.y + ei * y.x);
+      sp[r] = make_double2(c * x.x - sn * yt.x, c * x.y - sn * yt.y);
+      sq[r] = make_double2(sn * x.x + c * yt.x, sn * x.y + c * yt.y);
+    }
+    if (l == 0) rotated = 1;
+  };
 
-  // Columns below the truncation threshold (relative to the largest column norm, a lower bound of
-  // sigma_max) are never rotated: they will be dropped, and what they carry is below the rounding
-  // error of the matrix.  Left alone they would keep the sweeps busy orthogonalising noise.
-  double const deadRel = (double)P.dim * 2.220446049250313e-16;
-  double const dead2 = deadRel * deadRel * bfJacobiMaxNorm2<W>(P, &maxNormBits);
-  if (resident) loadPair(0, 1, true);
-  else {
+  // V starts as the identity
+  if (resident) {
+    for (uint32_t e = tid; e < me * R; e += nthreads) {
+      uint32_t const c = e / R, r = e - c * R;
+      tile[c * Rp + r] = r < mt ? A[(uint64_t)c * mt + r] : make_double2(r - mt == c ? 1.0 : 0.0, 0.0);
+    }
+  } else {
     for (uint64_t e = tid; e < (uint64_t)me * me; e += nthreads) V[e] = make_double2((e % me == e / me) ? 1.0 : 0.0, 0.0);
   }
   int sweep = 0;
   bool converged = false;
   __syncthreads();
   for (; sweep < BF_JACOBI_MAX_SWEEPS; ++sweep) {
-    if (tid == 0) rotated = 0;
+    // the live list of this sweep (P.scale is free until the end: scratch for the squared norms)
+    for (uint32_t j = g; j < me; j += groups) {
+      double2 const *aj = resident ? tile + j * Rp : A + (uint64_t)j * mt;
+      double s2 = 0;
+      for (uint32_t r = l; r < mt; r += W) { double2 const a = aj[r]; s2 = fma(a.x, a.x, fma(a.y, a.y, s2)); }
+      s2 = bfGroupSum<W>(s2);
+      if (l == 0) P.scale[j] = s2;
+    }
     __syncthreads();
-    for (uint32_t S = 0; S + 1 < NB; ++S) {
-      for (uint32_t KK = 0; KK < NB / 2; ++KK) {
-        uint32_t I, J;
-        bfRoundRobin(NB, S, KK, I, J);
-        if (J >= nb) continue;                       // the dummy block of an odd block count
-        if (!resident) { loadPair(I, J, false); __syncthreads(); }
-        // one complete sweep over the 2b staged columns
-        for (uint32_t s = 0; s + 1 < 2 * b; ++s) {
-          for (uint32_t kk = g; kk < b; kk += groups) {
-            uint32_t p, q;
-            bfRoundRobin(2 * b, s, kk, p, q);
-            if (slotCol(I, J, p) == 0xffffffffu || slotCol(I, J, q) == 0xffffffffu) continue;
-            double2 *sp = tile + p * Rp, *sq = tile + q * Rp;
-            double alpha = 0, beta = 0, gr = 0, gi = 0;
-            for (uint32_t r = l; r < mt; r += W) {
-              double2 const x = sp[r], y = sq[r];
-              alpha = fma(x.x, x.x, fma(x.y, x.y, alpha));
-              beta = fma(y.x, y.x, fma(y.y, y.y, beta));
-              gr = fma(x.x, y.x, fma(x.y, y.y, gr));     // conj(x) * y
-              gi = fma(x.x, y.y, fma(-x.y, y.x, gi));
+    if (tid == 0) {
+      uint32_t n = 0;
+      for (uint32_t j = 0; j < me; ++j)
+        if (P.scale[j] >= dead2) live[n++] = (uint16_t)j;
+      numLive = n;
+      rotated = 0;
+    }
+    __syncthreads();
+    nLive = numLive;
+    if (nLive < 2) { converged = true; break; }
+    if (resident) {
+      uint32_t const M = nLive + (nLive & 1u);
+      for (uint32_t s = 0; s + 1 < M; ++s) {
+        for (uint32_t kk = g; kk < M / 2; kk += groups) {
+          uint32_t p, q;
+          bfRoundRobin(M, s, kk, p, q);
+          if (q >= nLive) continue;                  // the dummy player of an odd count
+          rotatePair(live[p], live[q]);
+        }
+        __syncthreads();
+      }
+    } else {
+      uint32_t nb = (nLive + b - 1) / b;
+      nb = nb < 2 ? 2 : nb;
+      uint32_t const NB = nb + (nb & 1u);
+      for (uint32_t S = 0; S + 1 < NB; ++S) {
+        for (uint32_t KK = 0; KK < NB / 2; ++KK) {
+          uint32_t I, J;
+          bfRoundRobin(NB, S, KK, I, J);
+          if (J >= nb) continue;                       // the dummy block of an odd block count
+          loadPair(I, J);
+          __syncthreads();
+          // one complete sweep over the 2b staged columns
+          for (uint32_t s = 0; s + 1 < 2 * b; ++s) {
+            for (uint32_t kk = g; kk < b; kk += groups) {
+              uint32_t p, q;
+              bfRoundRobin(2 * b, s, kk, p, q);
+              if (slotCol(I, J, p) == 0xffffffffu || slotCol(I, J, q) == 0xffffffffu) continue;
+              rotatePair(p, q);
             }
-            alpha = bfGroupSum<W>(alpha); beta = bfGroupSum<W>(beta);
-            gr = bfGroupSum<W>(gr); gi = bfGroupSum<W>(gi);
-            double c, sn, er, ei;
-            if (!bfJacobiAngle(alpha, beta, gr, gi, tol2, dead2, c, sn, er, ei)) continue;
-            for (uint32_t r = l; r < R; r += W) {
-              double2 const x = sp[r], y = sq[r];
-              double2 const yt = make_double2(er * y.x - ei * y.y, er * y.y + ei * y.x);
-              sp[r] = make_double2(c * x.x - sn * yt.x, c * x.y - sn * yt.y);
-              sq[r] = make_double2(sn * x.x + c * yt.x, sn * x.y + c * yt.y);
-            }
-            if (l == 0) rotated = 1;
+            __syncthreads();
           }
+          storePair(I, J);
           __syncthreads();
         }
-        if (!resident) { storePair(I, J); __syncthreads(); }
       }
     }
     converged = rotated == 0;
     __syncthreads();
     if (converged) break;
   }
-  if (resident) storePair(0, 1);
+  if (resident) {
+    for (uint32_t e = tid; e < me * R; e += nthreads) {
+      uint32_t const c = e / R, r = e - c * R;
+      double2 const v = tile[c * Rp + r];
+      if (r < mt) A[(uint64_t)c * mt + r] = v; else V[(uint64_t)c * me + (r - mt)] = v;
+    }
+  }
   __syncthreads();
   bfJacobiFinish<W>(P, stats, sweep, converged, &sigMax);
 }
@@ -648,7 +702,15 @@ static uint32_t qrcpLds(uint32_t mt, uint32_t me) {
 
 int bfdevQrcpFits(uint32_t mt, uint32_t me) { return qrcpLds(mt, me) != 0; }
 
-// problems sorted by LDS need would pack better; one launch per power-of-two LDS class keeps it simple
+typedef struct QrOrder { double cost; uint32_t idx; int cls; } QrOrder;
+static int qrOrderCmp(void const *pa, void const *pb) {
+  QrOrder const *a = (QrOrder const *)pa, *b = (QrOrder const *)pb;
+  if (a->cls != b->cls) return a->cls < b->cls ? -1 : 1;
+  if (a->cost != b->cost) return a->cost > b->cost ? -1 : 1;
+  return a->idx < b->idx ? -1 : 1;
+}
+
+// one launch per LDS class (several small problems then share a CU)
 int bfdevBuildQrcp(BfQrProb const *hostProbs, uint64_t numProbs, uint32_t *hostRanks) {
   if (!numProbs) return 0;
   enum { NC = 6 };                                       /* <= 8, 16, 32, 64, 128, 150 KiB */
@@ -658,20 +720,24 @@ int bfdevBuildQrcp(BfQrProb const *hostProbs, uint64_t numProbs, uint32_t *hostR
   uint32_t *ranks = (uint32_t *)malloc(numProbs * sizeof(uint32_t));
   uint64_t count[NC + 1] = {0};
   int rc = order && sorted && ranks ? 0 : bfhipFail(BFABI_ERROR_MEMORY_ERROR, "host OOM");
+  QrOrder *ord = (QrOrder *)malloc(numProbs * sizeof(QrOrder));
+  if (!rc && !ord) rc = bfhipFail(BFABI_ERROR_MEMORY_ERROR, "host OOM");
   for (uint64_t i = 0; i < numProbs && !rc; ++i) {
     uint32_t const need = qrcpLds(hostProbs[i].mt, hostProbs[i].me);
     if (!need) { rc = bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "QR preconditioner: problem %llu does not fit LDS", (unsigned long long)i); break; }
     int c = 0;
     while (cap[c] < need) ++c;
-    order[i] = (uint32_t)c;
+    ord[i].cls = c; ord[i].idx = (uint32_t)i;
+    ord[i].cost = (double)hostProbs[i].mt * hostProbs[i].me * (hostProbs[i].me + hostProbs[i].n);
     count[c + 1] += 1;
   }
   for (int c = 0; c < NC; ++c) count[c + 1] += count[c];
   if (!rc) {
-    uint64_t cursor[NC];
-    for (int c = 0; c < NC; ++c) cursor[c] = count[c];
-    for (uint64_t i = 0; i < numProbs; ++i) { uint64_t const at = cursor[order[i]]++; sorted[at] = hostProbs[i]; order[i] = (uint32_t)at; }
+    // by LDS class, the longest first within a class (dispatch order: the tail of a launch is made of cheap problems)
+    qsort(ord, numProbs, sizeof(QrOrder), qrOrderCmp);
+    for (uint64_t at = 0; at < numProbs; ++at) { sorted[at] = hostProbs[ord[at].idx]; order[ord[at].idx] = (uint32_t)at; }
   }
+  free(ord);
   BfQrProb *dP = NULL;
   uint32_t *dR = NULL;
   if (!rc) rc = uploadArrayB(&dP, sorted, numProbs, "qr problems");
@@ -700,7 +766,7 @@ static uint32_t const kJacobiLds[4] = {16u << 10, 32u << 10, 64u << 10, BF_JACOB
 
 static int jacobiClass(BfSvdProb const *p, int forceGlobal, int *wlog, int *big, int *ldsClass) {
   uint64_t const R = (uint64_t)p->mt + p->me, Rp = R | 1u;
-  if (2 * Rp * 16 > BF_JACOBI_LDS_MAX || forceGlobal) { *ldsClass = -1; *big = 1; *wlog = 4; return 0; }   /* global-memory fallback */
+  if (2 * Rp * 16 > BF_JACOBI_LDS_MAX || p->me > BF_JACOBI_MAX_COLS || forceGlobal) { *ldsClass = -1; *big = 1; *wlog = 4; return 0; }   /* global-memory fallback */
   uint64_t const meEven = p->me + (p->me & 1u);
   int lc = 3;
   for (int c = 0; c < 3; ++c)
@@ -725,6 +791,13 @@ template <int W> static int jacobiLaunch(uint32_t count, uint32_t threads, uint3
   if (rc) return rc;
   hipLaunchKernelGGL(bfJacobiKernel<W>, dim3(count), dim3(threads), lds, 0, dP, dL, dS, lds);
   return hipFailB(hipGetLastError(), "Jacobi SVD launch");
+}
+
+typedef struct JacobiOrder { double cost; uint32_t idx; } JacobiOrder;
+static int jacobiCostDescending(void const *pa, void const *pb) {
+  JacobiOrder const *a = (JacobiOrder const *)pa, *b = (JacobiOrder const *)pb;
+  if (a->cost != b->cost) return a->cost > b->cost ? -1 : 1;
+  return a->idx < b->idx ? -1 : 1;
 }
 
 int bfdevBuildJacobi(BfSvdProb const *hostProbs, uint64_t numProbs, BfSvdStats *stats) {
@@ -756,6 +829,20 @@ int bfdevBuildJacobi(BfSvdProb const *hostProbs, uint64_t numProbs, BfSvdStats *
   }
   for (uint64_t i = 0; i < numProbs && !rc; ++i)
     if (cls[i] != 0xff) lists[cls[i]][counts[cls[i]]++] = (uint32_t)i;
+  // longest first within a class (workgroups are dispatched in list order): the tail of a launch is then made of
+  // the cheap problems, not of one 890-column problem started last
+  for (int c = 0; c < NCLS && !rc; ++c) {
+    if (counts[c] < 2) continue;
+    JacobiOrder *ord = (JacobiOrder *)malloc(counts[c] * sizeof(JacobiOrder));
+    if (!ord) { rc = bfhipFail(BFABI_ERROR_MEMORY_ERROR, "host OOM"); break; }
+    for (uint64_t i = 0; i < counts[c]; ++i) {
+      BfSvdProb const *q = &hostProbs[lists[c][i]];
+      ord[i].cost = (double)q->me * q->me * (q->mt + q->me); ord[i].idx = lists[c][i];
+    }
+    qsort(ord, counts[c], sizeof(JacobiOrder), jacobiCostDescending);
+    for (uint64_t i = 0; i < counts[c]; ++i) lists[c][i] = ord[i].idx;
+    free(ord);
+  }
   BfSvdProb *dP = NULL;
   BfSvdStats *dS = NULL;
   if (!rc) rc = uploadArrayB(&dP, hostProbs, numProbs, "svd problems");
