@@ -10,6 +10,8 @@
 //       (LAPACK zgesvd + truncation + two zgemm)
 //       -> bfJacobiKernel: one-sided (Hestenes) Jacobi SVD, one workgroup per
 //          problem, column pairs of a round-robin step spread over lane groups;
+//          bfQrcpKernel ahead of it for the problems that do not stay in LDS
+//          (Householder QR with column pivoting; Jacobi then works on R^H);
 //          bfGemmKernel: T = diag(1/sigma^2) (U Sigma)^H Z_orig, X = V T;
 //   * the leaf -> packed-arena copy that bfhip_api.c does on the host for
 //     host-valued operands -> bfPackKernel.

@@ -20,7 +20,8 @@
  * of a reference-built operand).  Numerics: the kernel is (i/4) H0^(1)(k r), 0
  * at r == 0; a re-expansion leaf is X = pinv_trunc(Z_equiv) Z_orig with the
  * reference's truncation rule (singular values below max(m,n) eps s_max + eps
- * dropped), computed by a one-sided Jacobi SVD instead of LAPACK zgesvd.
+ * dropped), computed by a one-sided Jacobi SVD (QR-preconditioned with column pivoting from 65 equivalent sources up)
+ * instead of LAPACK zgesvd.
  * Element-wise agreement with the CPU path is therefore at the level of the
  * truncation (the dropped directions), while Z_equiv X, and hence every
  * apply result, agrees to ~1e-12; see tests/test_gpu_build.py.

@@ -237,6 +237,8 @@ STUB(bfdevBuildEval)
 STUB(bfdevBuildGemm)
 STUB(bfdevBuildJacobi)
 STUB(bfdevBuildPack)
+STUB(bfdevBuildQrcp)
+STUB(bfdevQrcpFits)
 STUB(bfdevEventCreate)
 STUB(bfdevEventElapsed)
 STUB(bfdevEventRecord)

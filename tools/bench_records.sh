@@ -40,6 +40,7 @@ run ${TAG}_bench_streamer_n1048576_f32   $S --adjoint --steps 10
 run ${TAG}_bench_streamer_n1048576_f64   $S --dtype f64 --adjoint --steps 10 --no-cpu-baseline
 run ${TAG}_bench_streamer_n262144_f32    $S --npoints 262144 --lmax 127 --adjoint --steps 10
 run ${TAG}_build_n65536                  timeout -k 10 400 python tools/build_fullsize.py --npoints 65536
+run ${TAG}_build_n262144                 timeout -k 10 400 python tools/build_fullsize.py --npoints 262144
 run ${TAG}_bie_device_n65536_k100        timeout -k 10 400 python tools/helm2_bie_device.py --npoints 65536 --wavenumber 100 --max-iter 300
 hipcc -O3 --offload-arch=gfx950 tools/hbm_peak.hip -o /tmp/hbm_peak 2>/dev/null && run ${TAG}_hbm_peak timeout -k 5 120 /tmp/hbm_peak
 hipcc -O3 --offload-arch=gfx950 tools/mfma_peak.hip -o /tmp/mfma_peak 2>/dev/null && run ${TAG}_mfma_peak timeout -k 5 120 /tmp/mfma_peak
@@ -47,6 +48,4 @@ hipcc -O3 --offload-arch=gfx950 tools/launch_floor.hip -o /tmp/launch_floor 2>/d
 run ${TAG}_timeline_n65536               timeout -k 10 300 python tools/timeline.py --npoints 65536
 run ${TAG}_timeline_shard3of8            timeout -k 10 300 python tools/timeline.py --npoints 262144 --world 8 --rank 3
 fi
-# the 195 s build of the headline operand is not part of the default set:
-#   python tools/build_fullsize.py --npoints 262144 > $O/${TAG}_build_n262144.json
 ls $O
