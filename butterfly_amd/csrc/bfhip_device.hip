@@ -355,30 +355,30 @@ __device__ __forceinline__ void bfStageBodyReal(StageParams const &p, uint32_t c
     return;
   }
 
-  bool const merged = (it.mrFlags & BF_ITEM_MERGED) != 0;
+  // The pieces of an item are packed back to back, so a run of consecutive narrow pieces is ONE contiguous mrPad x n
+  // block (n <= BF_MERGE_COLS): lane l gathers x for columns l, l + 64, ... of the block from whichever piece holds
+  // them -- all pieces' loads in flight together -- and the block is contracted in one go.  A narrow item (what a
+  // streamed butterfly's inner factors are made of) costs three dependent memory round trips instead of three per
+  // piece; an item of hundreds of 5-column pieces (the transposes of few-row leaves in a packed adjoint plan) is a few
+  // such runs instead of hundreds of two-step contractions.  Items the planner flags BF_ITEM_MERGED are a single run.
+  // A piece wider than BF_MERGE_COLS is contracted on its own, its x handed over through LDS in one loop.
   for (uint32_t q = 0; q < nrhs; ++q) {
     S acc[EPL];
 #pragma unroll
     for (int e = 0; e < EPL; ++e) acc[e] = 0;
-    uint32_t const npass = merged ? 1u : it.numPieces;
-    for (uint32_t pi = 0; pi < npass; ++pi) {
-      uint32_t n;
-      V const *ap;
-      if (merged) {
-        // <= 64 pieces whose dense parts are one contiguous mrPad x n block, n <= BF_MERGE_COLS (the planner packs an
-        // item's pieces back to back): lane l gathers x for columns l, l + 64, ... of the block from whichever piece
-        // holds them -- all pieces' loads in flight together -- and the block is contracted in one go.  A narrow
-        // item (what a streamed butterfly's inner factors are made of) costs three dependent memory round trips
-        // instead of three per piece.
+    for (uint32_t p0 = 0; p0 < it.numPieces; p0 += 64) {
+      uint32_t const np = it.numPieces - p0 < 64u ? it.numPieces - p0 : 64u;
+      BfPieceWin const win = bfPieceWinLoad(p.pieces + it.pieceBegin + p0, np, lane);
+      uint32_t k = 0;
+      while (k < np) {
         constexpr int XS = BF_MERGE_COLS / 64;
         uint32_t src[XS];                 // input element index of the lane's column t, ~0 = none
         uint32_t srcX = 0;                // bit t: that index is into x (else the vector arena)
 #pragma unroll
         for (int t = 0; t < XS; ++t) src[t] = ~0u;
-        uint32_t base = 0;
-        uint64_t data0 = 0;
-        BfPieceWin const win = bfPieceWinLoad(p.pieces + it.pieceBegin, it.numPieces, lane);
-        for (uint32_t k = 0; k < it.numPieces; ++k) {
+        uint32_t base = 0, wideCols = 0, wideIn = 0, wideFlags = 0;
+        uint64_t data0 = 0, nextOff = 0;
+        for (; k < np; ++k) {
           BfDevPiece const pc = bfPieceWinGet(win, k);
           if (pc.flags & BF_PIECE_IDENTITY) {
             S const *xin = (pc.flags & BF_PIECE_IN_X) ? (S const *)p.x : (S const *)p.temp;
@@ -392,7 +392,15 @@ __device__ __forceinline__ void bfStageBodyReal(StageParams const &p, uint32_t c
             }
             continue;
           }
+          if (pc.ncols > BF_MERGE_COLS) {                   // a wide piece: on its own, after the run before it
+            if (base) break;
+            wideCols = pc.ncols; wideIn = pc.inOff; wideFlags = pc.flags; data0 = pc.dataOff;
+            ++k;
+            break;
+          }
+          if (base && (pc.dataOff != nextOff || base + pc.ncols > BF_MERGE_COLS)) break;
           if (base == 0) data0 = pc.dataOff;
+          nextOff = pc.dataOff + (uint64_t)mrPad * pc.ncols;
 #pragma unroll
           for (int t = 0; t < XS; ++t) {
             uint32_t const J = (uint32_t)lane + 64u * t - base;        // wraps below base
@@ -400,74 +408,66 @@ __device__ __forceinline__ void bfStageBodyReal(StageParams const &p, uint32_t c
           }
           base += pc.ncols;
         }
-        n = base;
-        ap = arena + data0 / EPL + lc;
-        // a block of at most 2 wave loads is fetched before x is handed over, so both trips overlap
-        bool const tiny = n <= 2 * g;
-        V a2[2];
-        if (tiny) {
+        uint32_t n;
+        V const *ap = arena + data0 / EPL + lc;               // dataOff is in elements; a lane load is EPL elements
+        if (wideCols) {
+          S const *xin = (wideFlags & BF_PIECE_IN_X) ? (S const *)p.x : (S const *)p.temp;
+          xin += (uint64_t)wideIn * nrhs + q;
+          n = wideCols;
+          waveSync();
+          for (uint32_t j = lane; j < n; j += 64) xs[j] = xin[(uint64_t)j * nrhs];
+          waveSync();
+        } else if (base) {
+          n = base;
+          // a block of at most 2 wave loads is fetched before x is handed over, so both trips overlap
+          bool const tiny = n <= 2 * g;
+          V a2[2];
+          if (tiny) {
 #pragma unroll
-          for (int k = 0; k < 2; ++k) {
+            for (int kk = 0; kk < 2; ++kk) {
 #pragma unroll
-            for (int e = 0; e < EPL; ++e) a2[k].v[e] = 0;
-            if (active && c + k * g < n) a2[k] = bfLoadStreamV(ap + (uint64_t)k * G);
-          }
-        }
-        S xg[XS];
-#pragma unroll
-        for (int t = 0; t < XS; ++t)
-          xg[t] = src[t] != ~0u ? (((srcX >> t) & 1u) ? (S const *)p.x : (S const *)p.temp)[(uint64_t)src[t] * nrhs + q] : (S)0;
-        waveSync();
-#pragma unroll
-        for (int t = 0; t < XS; ++t) if ((uint32_t)lane + 64u * t < n) xs[lane + 64 * t] = xg[t];
-        waveSync();
-        if (tiny) {
-#pragma unroll
-          for (int k = 0; k < 2; ++k) {
-            S xv = (active && c + k * g < n) ? xs[c + k * g] : (S)0;
-#pragma unroll
-            for (int e = 0; e < EPL; ++e) acc[e] = fma(a2[k].v[e], xv, acc[e]);
-          }
-          continue;
-        }
-      } else {
-        BfDevPiece const pc = p.pieces[it.pieceBegin + pi];
-        S const *xin = (pc.flags & BF_PIECE_IN_X) ? (S const *)p.x : (S const *)p.temp;
-        xin += (uint64_t)pc.inOff * nrhs + q;
-        n = pc.ncols;
-        if (pc.flags & BF_PIECE_IDENTITY) {
-          if (c == 0 && active) {
-#pragma unroll
-            for (int e = 0; e < EPL; ++e) {
-              uint32_t row = rs * EPL + e;
-              if (row < mr) acc[e] += xin[(uint64_t)row * nrhs];
+              for (int e = 0; e < EPL; ++e) a2[kk].v[e] = 0;
+              if (active && c + kk * g < n) a2[kk] = bfLoadStreamV(ap + (uint64_t)kk * G);
             }
           }
-          continue;
+          S xg[XS];
+#pragma unroll
+          for (int t = 0; t < XS; ++t)
+            xg[t] = src[t] != ~0u ? (((srcX >> t) & 1u) ? (S const *)p.x : (S const *)p.temp)[(uint64_t)src[t] * nrhs + q] : (S)0;
+          waveSync();
+#pragma unroll
+          for (int t = 0; t < XS; ++t) if ((uint32_t)lane + 64u * t < n) xs[lane + 64 * t] = xg[t];
+          waveSync();
+          if (tiny) {
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+              S xv = (active && c + kk * g < n) ? xs[c + kk * g] : (S)0;
+#pragma unroll
+              for (int e = 0; e < EPL; ++e) acc[e] = fma(a2[kk].v[e], xv, acc[e]);
+            }
+            continue;
+          }
+        } else {
+          continue;                                          // identity pieces only
         }
-        waveSync();
-        for (uint32_t j = lane; j < n; j += 64) xs[j] = xin[(uint64_t)j * nrhs];
-        waveSync();
-        // dataOff is in elements; a lane load is EPL elements
-        ap = arena + pc.dataOff / EPL + lc;
-      }
-      uint32_t const nfull = n / g;
-      uint32_t j = c;
-      uint32_t s = 0;
+        uint32_t const nfull = n / g;
+        uint32_t j = c;
+        uint32_t s = 0;
 #pragma unroll 8
-      for (; s < nfull; ++s) {
-        V a = bfLoadStreamV(ap + (uint64_t)s * G);
-        S xv = xs[j];
+        for (; s < nfull; ++s) {
+          V a = bfLoadStreamV(ap + (uint64_t)s * G);
+          S xv = xs[j];
 #pragma unroll
-        for (int e = 0; e < EPL; ++e) acc[e] = fma(a.v[e], xv, acc[e]);
-        j += g;
-      }
-      uint32_t const rem = n - nfull * g;
-      if (active && c < rem) {
-        V a = bfLoadStreamV(ap + (uint64_t)nfull * G);
-        S xv = xs[j];
+          for (int e = 0; e < EPL; ++e) acc[e] = fma(a.v[e], xv, acc[e]);
+          j += g;
+        }
+        uint32_t const rem = n - nfull * g;
+        if (active && c < rem) {
+          V a = bfLoadStreamV(ap + (uint64_t)nfull * G);
+          S xv = xs[j];
 #pragma unroll
-        for (int e = 0; e < EPL; ++e) acc[e] = fma(a.v[e], xv, acc[e]);
+          for (int e = 0; e < EPL; ++e) acc[e] = fma(a.v[e], xv, acc[e]);
+        }
       }
     }
     waveSync();

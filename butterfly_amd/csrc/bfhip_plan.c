@@ -930,7 +930,11 @@ int bfPlanBuild(BfIr const *ir, BfPlanOptions const *po, BfPlan *plan) {
        * granule (+60 % bytes) and give the transposed kernel 2 of its 16 row lanes; row-major every lane owns
        * 16 bytes of consecutive columns, forward and transposed, and nothing is padded but the row ends. */
       /* (the small items of a stage are row-major too, whatever their width: their kernel reads nothing else) */
-      int const rowMajor = !T && plan->dtype != BFHIP_C128 && mr <= 2 * plan->epl && (g->colsSum >= 128 || tmp[i].small);
+      /* (not a chunk made of hundreds of pieces a few columns wide -- the transposes of few-row leaves in a packed adjoint plan:
+       * row-major each piece is a dependent step that keeps two lanes busy; column-major the kernel contracts runs of them as
+       * one block) */
+      int const rowMajor = !T && plan->dtype != BFHIP_C128 && mr <= 2 * plan->epl &&
+                           (tmp[i].small || (g->colsSum >= 128 && g->colsSum >= 16 * g->piecesPerChunk));
       if (rowMajor) flags |= BF_ITEM_ROWMAJOR;
       if (g->reduced) outOff = g->slotOff + r0;
       else if (g->outBuf == by) { outOff = g->outOff + r0; flags |= BF_ITEM_OUT_Y; }
