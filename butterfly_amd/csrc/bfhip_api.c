@@ -167,7 +167,7 @@ static void packPiece(BfPlan const *pl, BfIr const *ir, BfDevPiece const *pc, Bf
       if (r < mr) {
         uint64_t i = src->row0 + r, j = src->col0 + c;
         if (data) {
-          if (cplx && !ir->leafReal[node]) { double const *e = A + 2 * (i * ldr + j * ldc); re = e[0]; im = e[1]; }
+          if (cplx && !(ir->leafReal[node] & BF_LEAF_REAL)) { double const *e = A + 2 * (i * ldr + j * ldc); re = e[0]; im = (ir->leafReal[node] & BF_LEAF_CONJ) ? -e[1] : e[1]; }
           else re = A[i * ldr + j * ldc];
         } else {
           re = bfhip_synth_value(seed, vbase + i * sR + j * sC, 0) * scale;
@@ -1406,16 +1406,24 @@ static void *shimMulImpl(void const *rhsV, BfhipOperator *op, int transpose) {
    * bfMatDenseComplexGetColRange leaves colStride as it is, src/mat_dense_complex.c:648-672) is gathered into a packed
    * copy first -- cblas_zgemm in the reference cannot take it either (it passes ldb = rowStride and assumes unit column
    * stride, :1754), so this is more than the reference does, not less */
+  /* A transposed COMPLEX object multiplies as its conjugate transpose, as in the reference: bfMatTranspose ends in
+   * bfMatDenseComplexTranspose = bfMatConjTrans on every dense leaf (src/mat_dense_complex.c:1475-1478, src/mat.c:359-362) and
+   * getCblasTranspose maps the flags to CblasConjTrans (:27-35).  A^H X = conj(A^T conj(X)): the right-hand side is
+   * conjugated into the packed copy, the result in place. */
   void *packed = NULL;
   void const *xdata = x->data;
   size_t xld = x->rowStride;
-  if (x->colStride != 1) {
+  if (x->colStride != 1 || transpose) {
     if (x->colStride == 0) SHIM_FAIL(BFABI_ERROR_INVALID_ARGUMENTS, "right-hand side with colStride 0");
     size_t const nr = rhs->numRows, nc = rhs->numCols;
     packed = malloc((nr && nc ? nr * nc : 1) * 16);
     if (!packed) SHIM_FAIL(BFABI_ERROR_MEMORY_ERROR, "host OOM");
     for (size_t i = 0; i < nr; ++i)
-      for (size_t q = 0; q < nc; ++q) memcpy((char *)packed + (i * nc + q) * 16, (char const *)x->data + (i * x->rowStride + q * x->colStride) * 16, 16);
+      for (size_t q = 0; q < nc; ++q) {
+        double const *e = (double const *)((char const *)x->data + (i * x->rowStride + q * x->colStride) * 16);
+        double *d = (double *)((char *)packed + (i * nc + q) * 16);
+        d[0] = e[0]; d[1] = transpose ? -e[1] : e[1];
+      }
     xdata = packed; xld = nc;
   }
   BfAbiMat *res = emptyLike(rhs, outLen, rhs->numCols);
@@ -1424,6 +1432,9 @@ static void *shimMulImpl(void const *rhsV, BfhipOperator *op, int transpose) {
   int rc;
   if (y->colStride != 1) rc = bfhipFail(BFABI_ERROR_NOT_IMPLEMENTED, "EmptyLike returned a result with colStride != 1");
   else rc = applyHost(op, transpose, xdata, xld, rhs->numCols, y->data, y->rowStride);
+  if (!rc && transpose)
+    for (size_t i = 0; i < outLen; ++i)
+      for (size_t q = 0; q < rhs->numCols; ++q) ((double *)y->data)[2 * (i * y->rowStride + q) + 1] *= -1.0;
   free(packed);
   if (rc) {
     BfAbiDeleteFn del = (BfAbiDeleteFn)res->vtbl->slot[BFABI_SLOT_Delete];
@@ -1443,7 +1454,8 @@ static BfAbiMat *shimMul(BfAbiMat const *lhs, BfAbiMat const *rhs) {
 /* bfMatTranspose (slot 63, src/mat.c:271-273): in place, as bfMatProductTranspose reverses and transposes its factors
  * (src/mat_product.c:409-420).  The adjoint plan over the same packed leaves exists already (BFHIP_FLAG_ADJOINT), so the
  * object only changes which of its two plans Mul / MulVec / RmulVec run and what GetNumRows / GetNumCols answer; twice
- * is the identity.  A plain transpose (no conjugation), like the reference's.  The slot returns nothing: without an
+ * is the identity.  For a REAL operator that is the transpose; a COMPLEX one multiplies as its conjugate transpose
+ * afterwards, as the reference's does (its dense complex leaves transpose by bfMatConjTrans: shimMulImpl).  The slot returns nothing: without an
  * adjoint plan the reference's error state is raised (NOT_IMPLEMENTED) and the object is left as it was. */
 static void shimTranspose(BfAbiMat *m) {
   BfhipMat *s = (BfhipMat *)m;

@@ -21,6 +21,8 @@ int bfhipFail(int code, char const *fmt, ...);   /* records message, returns cod
 /* ------------------------------------------------------------------------
  * IR: owned copy of a BfhipDesc (or of a walked BfMat graph)
  * ---------------------------------------------------------------------- */
+#define BF_LEAF_REAL 1u
+#define BF_LEAF_CONJ 2u
 typedef struct BfIr {
   uint32_t dtype;
   uint64_t numNodes, numChildren, root;
@@ -31,7 +33,9 @@ typedef struct BfIr {
   void const **leafData;       /* borrowed host pointers (valid during compile only) */
   uint64_t *leafRowStride;
   uint64_t *leafColStride;     /* element stride between columns (BfMat graphs may have colStride != 1) */
-  uint8_t *leafReal;           /* host values of this leaf are real doubles even in a complex operand (BfMatDiagReal terms) */
+  uint8_t *leafReal;           /* bit 0 (BF_LEAF_REAL): host values of this leaf are real doubles even in a complex operand (BfMatDiagReal
+                                * terms); bit 1 (BF_LEAF_CONJ): the leaf is the CONJUGATE of the host values it points at (a dense complex
+                                * leaf the reference flagged TRANS | CONJ: its strides are swapped as well) */
   uint64_t *synthBase;         /* per node: base index in the synthetic stream */
   int transposedView;          /* this IR is the transpose of the one the operator was compiled from (bfIrTransposed): synthetic leaf
                                 * values are stream(base + col * rows + row), i.e. the ORIGINAL leaf's row-major index */

@@ -241,7 +241,7 @@ static int tryFold(Walk *w, uint64_t node, uint64_t i, uint64_t j, double re, do
   BfIr *ir = w->ir;
   if (level > 64) return 0;
   if (ir->kind[node] == BFHIP_NODE_DENSE) {
-    if (!ir->leafData[node] || ir->leafReal[node] || ir->rows[node] * ir->cols[node] == 1) return 0;
+    if (!ir->leafData[node] || (ir->leafReal[node] & BF_LEAF_REAL) || ir->rows[node] * ir->cols[node] == 1) return 0;
     if (ir->numPatches == ir->capPatches) {
       uint64_t cap = ir->capPatches ? ir->capPatches * 2 : 4096;
       BfIrPatch *p = realloc(ir->patches, cap * sizeof *p);
@@ -274,26 +274,35 @@ static int walkMat(Walk *w, BfAbiMat const *mat, uint64_t *outId, int level) {
   switch (type) {
   case BFABI_TYPE_MAT_DENSE_COMPLEX: {
     BfAbiMatDenseComplex const *d = (BfAbiMatDenseComplex const *)mat;
-    if (mat->props & (BFABI_MAT_PROPS_TRANS | BFABI_MAT_PROPS_CONJ))
-      return bfhipFail(BFABI_ERROR_NOT_IMPLEMENTED, "transposed/conjugated dense leaf (reference maps both to CblasConjTrans, mat_dense_complex.c:27-35); refusing to guess");
+    /* A leaf bfMatDenseComplexTranspose has flagged (= bfMatConjTrans: TRANS | CONJ, src/mat_dense_complex.c:1475-1478): the
+     * reference multiplies by it through CblasConjTrans -- getCblasTranspose maps TRANS *or* CONJ to it (:27-35) -- with the
+     * extents GetNumRows / GetNumCols report, swapped under TRANS (:503-511).  Here: the conjugate of the stored values read
+     * with the strides swapped.  CONJ without TRANS would be ConjTrans with UNswapped extents; nothing in the reference
+     * produces that state and it is refused. */
+    int const flagged = (mat->props & (BFABI_MAT_PROPS_TRANS | BFABI_MAT_PROPS_CONJ)) != 0;
+    if (flagged && !(mat->props & BFABI_MAT_PROPS_TRANS))
+      return bfhipFail(BFABI_ERROR_NOT_IMPLEMENTED, "dense complex leaf flagged CONJ without TRANS (mat_dense_complex.c:27-35 would pass zgemm ConjTrans with untransposed extents)");
     if (!d->data && mat->numRows && mat->numCols) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "dense complex leaf has NULL data");
     w->sawComplex = 1;
-    if ((rc = walkNewNode(w, BFHIP_NODE_DENSE, mat->numRows, mat->numCols, outId))) return rc;
+    if ((rc = walkNewNode(w, BFHIP_NODE_DENSE, flagged ? mat->numCols : mat->numRows, flagged ? mat->numRows : mat->numCols, outId))) return rc;
     w->ir->leafData[*outId] = d->data;
-    w->ir->leafRowStride[*outId] = d->rowStride;
-    w->ir->leafColStride[*outId] = d->colStride;
+    w->ir->leafRowStride[*outId] = flagged ? d->colStride : d->rowStride;
+    w->ir->leafColStride[*outId] = flagged ? d->rowStride : d->colStride;
+    if (flagged) w->ir->leafReal[*outId] |= BF_LEAF_CONJ;
     return 0;
   }
   case BFABI_TYPE_MAT_DENSE_REAL: {
     BfAbiMatDenseReal const *d = (BfAbiMatDenseReal const *)mat;
-    if (mat->props & (BFABI_MAT_PROPS_TRANS | BFABI_MAT_PROPS_CONJ))
-      return bfhipFail(BFABI_ERROR_NOT_IMPLEMENTED, "transposed dense real leaf");
+    /* a real leaf flagged TRANS (src/mat_dense_real.c:20-28, :291-298): the transpose, read with the strides swapped */
+    int const flagged = (mat->props & (BFABI_MAT_PROPS_TRANS | BFABI_MAT_PROPS_CONJ)) != 0;
+    if (flagged && !(mat->props & BFABI_MAT_PROPS_TRANS))
+      return bfhipFail(BFABI_ERROR_NOT_IMPLEMENTED, "dense real leaf flagged CONJ without TRANS");
     if (!d->data && mat->numRows && mat->numCols) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "dense real leaf has NULL data");
     w->sawReal = 1;
-    if ((rc = walkNewNode(w, BFHIP_NODE_DENSE, mat->numRows, mat->numCols, outId))) return rc;
+    if ((rc = walkNewNode(w, BFHIP_NODE_DENSE, flagged ? mat->numCols : mat->numRows, flagged ? mat->numRows : mat->numCols, outId))) return rc;
     w->ir->leafData[*outId] = d->data;
-    w->ir->leafRowStride[*outId] = d->super.rowStride;
-    w->ir->leafColStride[*outId] = d->super.colStride;
+    w->ir->leafRowStride[*outId] = flagged ? d->super.colStride : d->super.rowStride;
+    w->ir->leafColStride[*outId] = flagged ? d->super.rowStride : d->super.colStride;
     return 0;
   }
   case BFABI_TYPE_MAT_IDENTITY:

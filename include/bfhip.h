@@ -156,7 +156,8 @@ typedef struct BfhipStats {
  * (layouts: bfhip_abi.h).  Replaces the recursive dispatch the reference does
  * on every bfMatMul call (src/mat.c:183 and callees listed above).
  * Errors: TYPE_ERROR (unknown node type / mixed real+complex),
- * NOT_IMPLEMENTED (transposed or conjugated leaf, mat_dense_complex.c:27-35),
+ * NOT_IMPLEMENTED (a dense leaf flagged CONJ without TRANS; a leaf flagged TRANS is read as the reference multiplies by
+ * it: a complex one as its conjugate transpose, mat_dense_complex.c:27-35, 503-511, a real one as its transpose),
  * INVALID_ARGUMENTS (NULL vtable, non-monotone offsets, shape mismatch),
  * MEMORY_ERROR (host or device OOM), RUNTIME_ERROR (HIP failure). */
 int bfhipCompile(const void *bfMat, const BfhipOptions *opts, BfhipOperator **out);
@@ -416,8 +417,10 @@ void bfhipFree(BfhipOperator **op);
  * (src/mat_product.c:409-420): the object switches between the forward and the
  * adjoint plan of `op` (BFHIP_FLAG_ADJOINT; without it the slot raises
  * BF_ERROR_NOT_IMPLEMENTED and changes nothing), GetNumRows / GetNumCols answer
- * for A^T, Mul / MulVec multiply by A^T and RmulVec by A; twice is the
- * identity; the transpose is plain (no conjugation), as in the reference.
+ * for A^T, MulVec multiplies by A^T and RmulVec by A (real operators); Mul on a
+ * complex operator multiplies by A^H afterwards, as in the reference, whose dense
+ * complex leaves transpose by bfMatConjTrans and multiply through CblasConjTrans
+ * (src/mat_dense_complex.c:1475-1478, 27-35); twice is the identity.
  * Delete releases the shim and, if `ownsOperator`, the operator; a GetView copy
  * never owns it (and is transposed if its source was). */
 void *bfhipMatNew(BfhipOperator *op, int ownsOperator);

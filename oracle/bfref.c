@@ -92,7 +92,12 @@ void bfMatDelete(BfMat **mat) {
 }
 /* src/mat.c:271-273: in-place transposition is one more virtual call (the types restated here do not fill the slot;
  * the dispatcher is what a foreign operator behind the vtable is driven through) */
-void bfMatTranspose(BfMat *mat) { SLOT(mat, BFABI_SLOT_Transpose, BfAbiTransposeFn)(mat); }
+/* src/mat.c:271-273.  (A type without the slot -- BlockCoo, DenseReal -- is a NULL call in the reference; an error here.) */
+void bfMatTranspose(BfMat *mat) {
+  BfAbiTransposeFn f = SLOT(mat, BFABI_SLOT_Transpose, BfAbiTransposeFn);
+  if (!f) { setError(BFABI_ERROR_NOT_IMPLEMENTED); return; }
+  f(mat);
+}
 size_t bfMatGetNumRows(BfMat const *mat) { return SLOT(mat, BFABI_SLOT_GetNumRows, BfAbiGetSizeFn)(mat); }
 size_t bfMatGetNumCols(BfMat const *mat) { return SLOT(mat, BFABI_SLOT_GetNumCols, BfAbiGetSizeFn)(mat); }
 int bfMatGetType(BfMat const *mat) { return SLOT(mat, BFABI_SLOT_GetType, BfAbiGetTypeFn)(mat); }
@@ -321,30 +326,57 @@ static void zgemm_builtin(size_t m, size_t n, size_t k, cplx const *A, size_t ld
   }
 }
 
-/* :1024-1051 -> :1704-1765: result = new m x n; zgemm(alpha=1, beta=0) */
+/* built-in row-major C[m x n] = A^H B with A stored k x m (what cblas_zgemm computes at :1754 for CblasConjTrans) */
+static void zgemm_builtin_conjtrans(size_t m, size_t n, size_t k, cplx const *A, size_t lda,
+                                    cplx const *B, size_t ldb, cplx *C, size_t ldc) {
+  for (size_t i = 0; i < m; ++i) {
+    double *c = (double *)(C + i * ldc);
+    for (size_t j = 0; j < 2 * n; ++j) c[j] = 0;
+    for (size_t p = 0; p < k; ++p) {
+      double ar = creal(A[p * lda + i]), ai = -cimag(A[p * lda + i]);
+      double const *b = (double const *)(B + p * ldb);
+      for (size_t j = 0; j < n; ++j) {
+        c[2 * j] += ar * b[2 * j] - ai * b[2 * j + 1];
+        c[2 * j + 1] += ar * b[2 * j + 1] + ai * b[2 * j];
+      }
+    }
+  }
+}
+
+/* :1024-1051 -> :1704-1765: result = new m x n; zgemm(alpha=1, beta=0).
+ * getCblasTranspose (:27-35) maps TRANS *or* CONJ to CblasConjTrans (its `else if` for a plain CblasTrans can never be
+ * reached): a left operand that bfMatDenseComplexTranspose (:1475-1478, = bfMatConjTrans, src/mat.c:359-362) has flagged
+ * multiplies as its conjugate transpose, with the extents bfMatGetNumRows / GetNumCols report (:503-511, swapped under
+ * TRANS).  CONJ without TRANS would hand zgemm ConjTrans with UNswapped extents -- nothing in the reference produces
+ * that state; refused here.  A flagged right operand is not on the apply path; refused. */
 static BfMat *denseComplexMul(BfMat const *op1, BfMat const *op2) {
   if (bfMatGetNumCols(op1) != bfMatGetNumRows(op2)) { setError(BFABI_ERROR_INVALID_ARGUMENTS); return NULL; }
   if (bfMatGetType(op2) != BFABI_TYPE_MAT_DENSE_COMPLEX) { setError(BFABI_ERROR_NOT_IMPLEMENTED); return NULL; }
-  /* untransposed operands only: the reference maps TRANS *or* CONJ to
-   * CblasConjTrans (:27-35), which no factorization leaf relies on */
-  if ((op1->props | op2->props) & (BFABI_MAT_PROPS_TRANS | BFABI_MAT_PROPS_CONJ)) { setError(BFABI_ERROR_NOT_IMPLEMENTED); return NULL; }
+  if (op2->props & (BFABI_MAT_PROPS_TRANS | BFABI_MAT_PROPS_CONJ)) { setError(BFABI_ERROR_NOT_IMPLEMENTED); return NULL; }
+  int const flagged = (op1->props & (BFABI_MAT_PROPS_TRANS | BFABI_MAT_PROPS_CONJ)) != 0;
+  if (flagged && !(op1->props & BFABI_MAT_PROPS_TRANS)) { setError(BFABI_ERROR_NOT_IMPLEMENTED); return NULL; }
   BfAbiMatDenseComplex const *a = (BfAbiMatDenseComplex const *)op1;
   BfAbiMatDenseComplex const *b = (BfAbiMatDenseComplex const *)op2;
-  size_t m = op1->numRows, k = op1->numCols, n = op2->numCols;
+  size_t m = bfMatGetNumRows(op1), k = bfMatGetNumCols(op1), n = op2->numCols;
   if (!(m > 0 && n > 0 && k > 0)) { setError(BFABI_ERROR_INVALID_ARGUMENTS); return NULL; }
   BfAbiMatDenseComplex *c = denseComplexNewInit(m, n, 0);
   ++counters.gemmCalls;
   counters.macs += (uint64_t)m * n * k;
   if (blas_zgemm) {
     double alpha[2] = {1, 0}, beta[2] = {0, 0};
-    blas_zgemm(101 /*RowMajor*/, 111, 111, (int)m, (int)n, (int)k, alpha, a->data, (int)a->rowStride,
+    blas_zgemm(101 /*RowMajor*/, flagged ? 113 /*ConjTrans*/ : 111, 111, (int)m, (int)n, (int)k, alpha, a->data, (int)a->rowStride,
                b->data, (int)b->rowStride, beta, c->data, (int)c->rowStride);
+  } else if (flagged) {
+    zgemm_builtin_conjtrans(m, n, k, (cplx const *)a->data, a->rowStride, (cplx const *)b->data, b->rowStride,
+                            (cplx *)c->data, c->rowStride);
   } else {
     zgemm_builtin(m, n, k, (cplx const *)a->data, a->rowStride, (cplx const *)b->data, b->rowStride,
                   (cplx *)c->data, c->rowStride);
   }
   return &c->super;
 }
+/* :1475-1478 */
+static void denseComplexTranspose(BfMat *mat) { mat->props ^= (BFABI_MAT_PROPS_TRANS | BFABI_MAT_PROPS_CONJ); }
 
 static BfAbiMatVtable MatDenseComplexVtable = {.slot = {
   [BFABI_SLOT_GetView] = (void *)denseComplexGetView,
@@ -359,6 +391,7 @@ static BfAbiMatVtable MatDenseComplexVtable = {.slot = {
   [BFABI_SLOT_SetRowRange] = (void *)denseComplexSetRowRange,
   [BFABI_SLOT_AddInplace] = (void *)denseComplexAddInplace,
   [BFABI_SLOT_Mul] = (void *)denseComplexMul,
+  [BFABI_SLOT_Transpose] = (void *)denseComplexTranspose,
 }};
 
 BfMat *bfMatDenseComplexNewFromPtr(size_t m, size_t n, double *data, int policy) {
@@ -497,7 +530,10 @@ static BfVec *identityMulVec(BfMat const *mat, BfVec const *vec) {
 }
 /* src/mat_identity.c:183-198 RmulVec: square only, result = copy(vec) */
 static BfVec *identityRmulVec(BfMat const *mat, BfVec const *vec) { return identityMulVec(mat, vec); }
+/* src/mat_identity.c:210-212 */
+static void identityTranspose(BfMat *mat) { size_t const t = mat->numRows; mat->numRows = mat->numCols; mat->numCols = t; }
 static BfAbiMatVtable MatIdentityVtable = {.slot = {
+  [BFABI_SLOT_Transpose] = (void *)identityTranspose,
   [BFABI_SLOT_RmulVec] = (void *)identityRmulVec,
   [BFABI_SLOT_Delete] = (void *)identityDelete,
   [BFABI_SLOT_GetType] = (void *)identityGetType,
@@ -631,7 +667,19 @@ static BfVec *blockDiagRmulVec(BfMat const *mat, BfVec const *vec) {
   }
   return result;
 }
+/* src/mat_block_diag.c:603-624: extents and offsets swapped, every diagonal block transposed in place */
+static void blockDiagTranspose(BfMat *mat) {
+  BfAbiMatBlock *b = (BfAbiMatBlock *)mat;
+  if (mat->props & BFABI_MAT_PROPS_VIEW) { setError(BFABI_ERROR_INVALID_ARGUMENTS); return; }
+  size_t const t = mat->numRows; mat->numRows = mat->numCols; mat->numCols = t;
+  size_t *o = b->rowOffset; b->rowOffset = b->colOffset; b->colOffset = o;
+  for (size_t k = 0; k < blockDiagNumBlocks(mat); ++k) {
+    bfMatTranspose(b->block[k]);
+    if (currentError) return;
+  }
+}
 static BfAbiMatVtable MatBlockDiagVtable = {.slot = {
+  [BFABI_SLOT_Transpose] = (void *)blockDiagTranspose,
   [BFABI_SLOT_RmulVec] = (void *)blockDiagRmulVec,
   [BFABI_SLOT_Delete] = (void *)blockDiagDelete,
   [BFABI_SLOT_GetType] = (void *)blockDiagGetType,
@@ -887,7 +935,26 @@ static BfVec *blockDenseRmulVec(BfMat const *mat, BfVec const *vec) {
   }
   return result;
 }
+/* src/mat_block_dense.c:950-986: the matrix of block pointers transposed, extents and offsets swapped, every block
+ * transposed in place.  (BfMatBlockCoo has no Transpose: its slot is NULL in the reference too.) */
+static void blockDenseTranspose(BfMat *mat) {
+  BfAbiMatBlock *b = (BfAbiMatBlock *)mat;
+  size_t const nbr = mat->numRows, nbc = mat->numCols;
+  BfMat **bt = xmalloc((nbr * nbc + 1) * sizeof(BfMat *));
+  size_t k = 0;
+  for (size_t j = 0; j < nbc; ++j)
+    for (size_t i = 0; i < nbr; ++i) bt[k++] = b->block[i * nbc + j];
+  mat->numRows = nbc; mat->numCols = nbr;
+  size_t *o = b->rowOffset; b->rowOffset = b->colOffset; b->colOffset = o;
+  free(b->block);
+  b->block = bt;
+  for (k = 0; k < nbr * nbc; ++k) {
+    bfMatTranspose(b->block[k]);
+    if (currentError) return;
+  }
+}
 static BfAbiMatVtable MatBlockDenseVtable = {.slot = {
+  [BFABI_SLOT_Transpose] = (void *)blockDenseTranspose,
   [BFABI_SLOT_RmulVec] = (void *)blockDenseRmulVec,
   [BFABI_SLOT_Delete] = (void *)blockDenseDelete,
   [BFABI_SLOT_GetType] = (void *)blockDenseGetType,
@@ -970,7 +1037,18 @@ static BfVec *productRmulVec(BfMat const *matProduct, BfVec const *vec) {
   }
   return result;
 }
+/* :409-420: the factors reversed, each transposed in place */
+static void productTranspose(BfMat *mat) {
+  BfAbiMatProduct *p = (BfAbiMatProduct *)mat;
+  size_t const nf = p->factorArr.num_elts;
+  for (size_t i = 0; i < nf / 2; ++i) { void *t = p->factorArr.data[i]; p->factorArr.data[i] = p->factorArr.data[nf - 1 - i]; p->factorArr.data[nf - 1 - i] = t; }
+  for (size_t i = 0; i < nf; ++i) {
+    bfMatTranspose(p->factorArr.data[i]);
+    if (currentError) return;
+  }
+}
 static BfAbiMatVtable MatProductVtable = {.slot = {
+  [BFABI_SLOT_Transpose] = (void *)productTranspose,
   [BFABI_SLOT_RmulVec] = (void *)productRmulVec,
   [BFABI_SLOT_Delete] = (void *)productDelete,
   [BFABI_SLOT_GetType] = (void *)productGetType,
@@ -1152,6 +1230,8 @@ static size_t findIndex(size_t const *a, size_t n, size_t v) {
   return lo;
 }
 
+static int fromDescTyped = 0;        /* set by bfrefMatFromDescTyped for the duration of one build */
+BfMat *bfrefMatFromDesc(BfhipDesc const *d, uint64_t seed, uint64_t rootOverride);
 static BfMat *fromDescRec(BfhipDesc const *d, uint64_t const *bases, uint64_t seed, uint64_t node) {
   uint64_t m = d->rows[node], n = d->cols[node];
   switch (d->kind[node]) {
@@ -1213,13 +1293,39 @@ static BfMat *fromDescRec(BfhipDesc const *d, uint64_t const *bases, uint64_t se
       ri[c - b] = i; ci[c - b] = j;
       blocks[c - b] = fromDescRec(d, bases, seed, ch);
     }
-    BfMat *r = bfMatBlockCooNewFromArrays(nr - 1, ncb - 1, nc, rb, cb, ri, ci, blocks);
+    BfMat *r = NULL;
+    /* bfrefMatFromDescTyped: a BLOCK node the descriptor calls BlockDiag / BlockDense becomes that container when its
+     * children are exactly the diagonal / the full grid (else, and by default, the general BlockCoo) */
+    uint8_t const want = (fromDescTyped && d->blockKind) ? d->blockKind[node] : 0;
+    if (want == BFABI_TYPE_MAT_BLOCK_DIAG && nc && nr - 1 == nc && ncb - 1 == nc) {
+      BfMat **ordered = xmalloc(nc * sizeof(BfMat *));
+      int ok = 1;
+      for (size_t k = 0; k < nc; ++k) ordered[k] = NULL;
+      for (size_t k = 0; k < nc; ++k) { if (ri[k] != ci[k] || ordered[ri[k]]) ok = 0; else ordered[ri[k]] = blocks[k]; }
+      if (ok) r = bfMatBlockDiagNewFromBlocks(nc, ordered);
+      free(ordered);
+    } else if (want == BFABI_TYPE_MAT_BLOCK_DENSE && nc && (nr - 1) * (ncb - 1) == nc) {
+      BfMat **grid = xmalloc(nc * sizeof(BfMat *));
+      int ok = 1;
+      for (size_t k = 0; k < nc; ++k) grid[k] = NULL;
+      for (size_t k = 0; k < nc; ++k) { size_t const at = ri[k] * (ncb - 1) + ci[k]; if (grid[at]) ok = 0; else grid[at] = blocks[k]; }
+      if (ok) r = bfMatBlockDenseNewFromBlocks(nr - 1, ncb - 1, rb, cb, grid);
+      free(grid);
+    }
+    if (!r) r = bfMatBlockCooNewFromArrays(nr - 1, ncb - 1, nc, rb, cb, ri, ci, blocks);
     free(rb); free(cb); free(blocks); free(ri); free(ci);
     return r;
   }
   }
   setError(BFABI_ERROR_TYPE_ERROR);
   return NULL;
+}
+
+BfMat *bfrefMatFromDescTyped(BfhipDesc const *d, uint64_t seed, uint64_t rootOverride) {
+  fromDescTyped = 1;
+  BfMat *r = bfrefMatFromDesc(d, seed, rootOverride);
+  fromDescTyped = 0;
+  return r;
 }
 
 BfMat *bfrefMatFromDesc(BfhipDesc const *d, uint64_t seed, uint64_t rootOverride) {

@@ -102,6 +102,9 @@ struct BfhipDesc;
  * with the engine's synthetic value stream for `seed` (same values the
  * device generates).  `rootOverride` == UINT64_MAX uses desc->root. */
 BfMat *bfrefMatFromDesc(struct BfhipDesc const *desc, uint64_t seed, uint64_t rootOverride);
+/* the same, but BLOCK nodes the descriptor calls BlockDiag / BlockDense (blockKind) become those containers when their
+ * children are exactly the diagonal / the full grid: the graphs bfMatTranspose can walk (BlockCoo has no Transpose slot) */
+BfMat *bfrefMatFromDescTyped(struct BfhipDesc const *desc, uint64_t seed, uint64_t rootOverride);
 
 #ifdef __cplusplus
 }

@@ -42,6 +42,7 @@ def load():
     lib.bfMatRmulVec.argtypes = [vp, vp]; lib.bfMatRmulVec.restype = vp
     lib.bfMatDelete.argtypes = [C.POINTER(vp)]; lib.bfMatDelete.restype = None
     lib.bfMatTranspose.argtypes = [vp]; lib.bfMatTranspose.restype = None
+    lib.bfrefMatFromDescTyped.argtypes = [vp, C.c_uint64, C.c_uint64]; lib.bfrefMatFromDescTyped.restype = vp
     lib.bfVecDelete.argtypes = [C.POINTER(vp)]; lib.bfVecDelete.restype = None
     for f in ("bfMatGetNumRows", "bfMatGetNumCols", "bfMatNumBytes"):
         getattr(lib, f).argtypes = [vp]; getattr(lib, f).restype = sz
@@ -229,6 +230,19 @@ def mat_mul_vec(a: Mat, x: np.ndarray) -> np.ndarray:
     return out
 
 
+def mat_transpose(a: Mat) -> None:
+    """bfMatTranspose(A): in place (src/mat.c:271-273).  Dense complex leaves are flagged TRANS | CONJ
+    (bfMatDenseComplexTranspose = bfMatConjTrans, src/mat_dense_complex.c:1475-1478), so a transposed complex operator
+    multiplies as its CONJUGATE transpose; BlockCoo and DenseReal have no Transpose slot (RuntimeError here)."""
+    lib = load()
+    lib.bfClearError()
+    lib.bfMatTranspose(a.ptr)
+    err = lib.bfGetError()
+    if err:
+        lib.bfClearError()
+        raise RuntimeError(f"oracle bfMatTranspose failed (BfError {err})")
+
+
 def mat_rmul_vec(a: Mat, x: np.ndarray) -> np.ndarray:
     """y = bfMatRmulVec(A, x) = A^T x with x a real vector of length numRows."""
     lib = load()
@@ -247,13 +261,15 @@ def mat_rmul_vec(a: Mat, x: np.ndarray) -> np.ndarray:
     return out
 
 
-def from_desc(desc, leaf_values=None, seed=0, root=None) -> Mat:
+def from_desc(desc, leaf_values=None, seed=0, root=None, typed=False) -> Mat:
     """Build the oracle graph for a butterfly_amd.helm2_structure.Desc (or any
     object with .arrays()); leaves without values get the engine's synthetic
-    value stream for `seed`."""
+    value stream for `seed`.  typed=True: BLOCK nodes the descriptor calls BlockDiag /
+    BlockDense become those containers (bfrefMatFromDescTyped) instead of the general BlockCoo."""
     from butterfly_amd._capi import DescArrays
     da = DescArrays(desc, root=root, leaf_values=leaf_values)
-    r = load().bfrefMatFromDesc(C.addressof(da.struct), seed, 0xFFFFFFFFFFFFFFFF)
+    lib = load()
+    r = (lib.bfrefMatFromDescTyped if typed else lib.bfrefMatFromDesc)(C.addressof(da.struct), seed, 0xFFFFFFFFFFFFFFFF)
     return Mat(r)
 
 

@@ -17,7 +17,7 @@ def _split(rng, total, parts):
     return [int(b - a) for a, b in zip(edges[:-1], edges[1:])]
 
 
-def _gen(rng, d, vals, m, n, depth, cplx):
+def _gen(rng, d, vals, m, n, depth, cplx, coo=True):
     """A node computing an m x n operator."""
     choice = rng.random()
     if depth == 0 or m < 4 or n < 4 or choice < 0.25:
@@ -32,33 +32,34 @@ def _gen(rng, d, vals, m, n, depth, cplx):
     if choice < 0.5:   # product through random inner dims
         nf = int(rng.integers(2, 4))
         dims = [m] + [int(rng.integers(2, max(3, min(m, n) + 8))) for _ in range(nf - 1)] + [n]
-        fs = [_gen(rng, d, vals, dims[i], dims[i + 1], depth - 1, cplx) for i in range(nf)]
+        fs = [_gen(rng, d, vals, dims[i], dims[i + 1], depth - 1, cplx, coo) for i in range(nf)]
         return d.add(NODE_PRODUCT, m, n, [(f, 0, 0) for f in fs])
     rs = _split(rng, m, int(rng.integers(1, 4)))
     cs = _split(rng, n, int(rng.integers(1, 4)))
     ro = np.concatenate([[0], np.cumsum(rs)])
     co = np.concatenate([[0], np.cumsum(cs)])
     if choice < 0.65 and len(rs) == len(cs):   # block diagonal
-        ch = [(_gen(rng, d, vals, rs[i], cs[i], depth - 1, cplx), int(ro[i]), int(co[i])) for i in range(len(rs))]
+        ch = [(_gen(rng, d, vals, rs[i], cs[i], depth - 1, cplx, coo), int(ro[i]), int(co[i])) for i in range(len(rs))]
         return d.add(NODE_BLOCK, m, n, ch, BF_TYPE_BLOCK_DIAG)
-    if choice < 0.85:                          # sparse of blocks, possibly with empty block rows
+    if choice < 0.85 and coo:                  # sparse of blocks, possibly with empty block rows
         ch = []
         for i in range(len(rs)):
             for j in range(len(cs)):
                 if rng.random() < 0.6:
-                    ch.append((_gen(rng, d, vals, rs[i], cs[j], depth - 1, cplx), int(ro[i]), int(co[j])))
+                    ch.append((_gen(rng, d, vals, rs[i], cs[j], depth - 1, cplx, coo), int(ro[i]), int(co[j])))
         return d.add(NODE_BLOCK, m, n, ch, BF_TYPE_BLOCK_COO)
-    ch = [(_gen(rng, d, vals, rs[i], cs[j], depth - 1, cplx), int(ro[i]), int(co[j]))
+    ch = [(_gen(rng, d, vals, rs[i], cs[j], depth - 1, cplx, coo), int(ro[i]), int(co[j]))
           for i in range(len(rs)) for j in range(len(cs))]
     return d.add(NODE_BLOCK, m, n, ch, BF_TYPE_BLOCK_DENSE)
 
 
-def random_operand(rng, depth=3, size_hint=80, cplx=False, m=None, n=None):
+def random_operand(rng, depth=3, size_hint=80, cplx=False, m=None, n=None, coo=True):
+    """coo=False: no BfMatBlockCoo nodes (the one container the reference cannot transpose: its Transpose slot is NULL)."""
     d = Desc(dtype=0 if cplx else 1)
     vals = {}
     m = m or int(rng.integers(size_hint // 2, size_hint * 2))
     n = n or int(rng.integers(size_hint // 2, size_hint * 2))
-    d.root = _gen(rng, d, vals, m, n, depth, cplx)
+    d.root = _gen(rng, d, vals, m, n, depth, cplx, coo)
     return d, vals
 
 

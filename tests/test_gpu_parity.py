@@ -706,9 +706,11 @@ def test_transpose_slot_flips_the_shim_between_its_two_plans(m, n):
     op.close()
 
 
-def test_transposed_complex_shim_multiplies_by_the_plain_transpose(helm2_cases):
-    """bfMatTranspose on a complex operator: bfMatMul(A_hip, X) is then A^T X (no conjugation, as in the reference),
-    checked against the dense A^T obtained column by column from the oracle."""
+def test_transposed_complex_shim_multiplies_by_the_conjugate_transpose(helm2_cases):
+    """bfMatTranspose on a complex operator: bfMatMul(A_hip, X) is then A^H X, as in the reference -- its dense complex
+    leaves transpose by bfMatConjTrans (src/mat_dense_complex.c:1475-1478) and multiply through CblasConjTrans (:27-35).
+    Checked against the dense matrix obtained column by column from the oracle; the library's own transposed apply
+    (bfhipApplyTranspose) stays the plain transpose."""
     from butterfly_amd import _capi
     from butterfly_amd.operator import HipOperator
     from oracle import bfref, helm2_build as hb
@@ -722,9 +724,49 @@ def test_transposed_complex_shim_multiplies_by_the_plain_transpose(helm2_cases):
     a_hip = C.c_void_p(op.as_bfmat())
     h = _handle(a_hip, (n, n))
     lib.bfMatTranspose(a_hip)
-    assert rel(bfref.mat_mul(h, x), dense.T @ x) <= 1e-11
+    assert rel(bfref.mat_mul(h, x), dense.conj().T @ x) <= 1e-11
+    assert rel(bfref.mat_mul(h, x[:, ::2]), dense.conj().T @ x[:, ::2]) <= 1e-11      # a column-strided right-hand side
     lib.bfMatTranspose(a_hip)
     assert rel(bfref.mat_mul(h, x), dense @ x) <= 1e-11
+    assert rel(op.apply_transpose_host(x), dense.T @ x) <= 1e-11
+    lib.bfMatDelete(C.byref(a_hip))
+    op.close()
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_transpose_of_complex_graphs_equals_the_oracles_transpose(seed):
+    """Graphs the reference can transpose (Product / BlockDiag / BlockDense / Identity / DenseComplex; BlockCoo has no slot),
+    complex: (a) the oracle transposes its graph in place (leaves flagged TRANS | CONJ) and the shim, wrapped around the
+    UNtransposed graph and transposed through its own slot, multiplies to the same result; (b) an operator compiled from
+    the ALREADY transposed graph -- the walker reads flagged dense leaves as conjugates with their strides swapped
+    (src/mat_dense_complex.c:27-35, 503-511) -- is A^H, and its own transposed apply gives conj(A) back."""
+    import randgraph
+    from butterfly_amd import _capi
+    from butterfly_amd.operator import HipOperator
+    from oracle import bfref
+    rng = np.random.default_rng(9100 + seed)
+    desc, vals = randgraph.random_operand(rng, depth=int(rng.integers(1, 4)), size_hint=60, cplx=True, coo=False)
+    m, n = desc.rows[desc.root], desc.cols[desc.root]
+    dense = randgraph.densify(desc, vals, desc.root)
+    A = bfref.from_desc(desc, vals, typed=True)
+    x = rng.standard_normal((m, 3)) + 1j * rng.standard_normal((m, 3))
+    xf = rng.standard_normal((n, 2)) + 1j * rng.standard_normal((n, 2))
+    lib = bfref.load()
+    op = HipOperator.from_bfmat(A.ptr.value, flags=_capi.FLAG_ADJOINT, max_rhs=3)
+    a_hip = C.c_void_p(op.as_bfmat())
+    h = _handle(a_hip, (m, n))
+    assert rel(bfref.mat_mul(h, xf) + 1, bfref.mat_mul(A, xf) + 1) <= TOL
+    lib.bfMatTranspose(a_hip)
+    bfref.mat_transpose(A)
+    want = bfref.mat_mul(A, x)
+    assert rel(want + 1, dense.conj().T @ x + 1) <= TOL
+    assert rel(bfref.mat_mul(h, x) + 1, want + 1) <= TOL
+    # (b) compiled from the transposed graph
+    op2 = HipOperator.from_bfmat(A.ptr.value, flags=_capi.FLAG_ADJOINT, max_rhs=3)
+    assert op2.shape == (n, m)
+    assert rel(op2.apply_host(x) + 1, want + 1) <= TOL
+    assert rel(op2.apply_transpose_host(xf) + 1, dense.conj() @ xf + 1) <= TOL
+    op2.close()
     lib.bfMatDelete(C.byref(a_hip))
     op.close()
 

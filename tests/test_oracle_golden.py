@@ -135,6 +135,30 @@ def test_oracle_block_types_against_numpy():
     assert prod.num_bytes() == 16 * (sum(v.size for v in g) + e.size + f.size)
 
 
+@pytest.mark.parametrize("seed", range(6))
+def test_oracle_transpose_is_the_conjugate_transpose_for_complex_leaves(seed):
+    """bfMatTranspose through the restated slots (Product :409-420, BlockDiag mat_block_diag.c:603-624, BlockDense
+    mat_block_dense.c:950-986, Identity, DenseComplex :1475-1478 = bfMatConjTrans): dense complex leaves end up flagged
+    TRANS | CONJ and getCblasTranspose (:27-35) turns that into CblasConjTrans, so the transposed operator multiplies as
+    A^H; extents swap; twice is the identity.  BlockCoo has no Transpose slot (a NULL call in the reference)."""
+    rng = np.random.default_rng(7300 + seed)
+    desc, vals = randgraph.random_operand(rng, depth=int(rng.integers(1, 4)), size_hint=40, cplx=True, coo=False)
+    m, n = desc.rows[desc.root], desc.cols[desc.root]
+    A = bfref.from_desc(desc, vals, typed=True)
+    dense = randgraph.densify(desc, vals, desc.root)
+    x = rng.standard_normal((m, 3)) + 1j * rng.standard_normal((m, 3))
+    xf = rng.standard_normal((n, 2)) + 1j * rng.standard_normal((n, 2))
+    bfref.mat_transpose(A)
+    assert A.shape == (n, m)
+    assert rel(bfref.mat_mul(A, x) + 1, dense.conj().T @ x + 1) < 1e-13
+    bfref.mat_transpose(A)
+    assert A.shape == (m, n)
+    assert rel(bfref.mat_mul(A, xf) + 1, dense @ xf + 1) < 1e-13
+    coo = bfref.block_coo([0, 4], [0, 6], [0], [0], [bfref.dense_complex(np.ones((4, 6), dtype=complex))])
+    with pytest.raises(RuntimeError, match="BfError 3"):
+        bfref.mat_transpose(coo)
+
+
 def test_oracle_error_behaviour():
     """Shape mismatch -> NULL + error code, as the reference (mat_block_coo.c:391-392)."""
     a = bfref.dense_complex(np.ones((3, 4), dtype=complex))

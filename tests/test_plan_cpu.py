@@ -320,14 +320,36 @@ def _compile_bfmat(ptr):
     return rc, lib.bfhipLastErrorMessage().decode()
 
 
-def test_transposed_leaf_is_refused():
+def test_flagged_leaves_follow_the_reference_and_conj_alone_is_refused():
+    """props of a dense leaf (the int at offset 8 of BfMat): TRANS (with or without CONJ) makes a complex leaf multiply as
+    its conjugate transpose -- getCblasTranspose maps TRANS *or* CONJ to CblasConjTrans (src/mat_dense_complex.c:27-35), the
+    extents follow TRANS (:503-511) -- and a real leaf as its transpose (src/mat_dense_real.c:20-28, 291-298); CONJ without
+    TRANS would be ConjTrans with untransposed extents, which nothing in the reference produces: refused."""
     from butterfly_amd._capi import ERROR_NAMES
-    a = bfref.dense_complex(np.ones((4, 4), dtype=complex))
-    # set BF_MAT_PROPS_TRANS on the leaf (props is the int at offset 8 of BfMat)
-    C.c_int.from_address(a.ptr.value + 8).value |= 2
+    rng = np.random.default_rng(77)
+    TRANS, CONJ = 2, 4
+    v = rng.standard_normal((5, 9)) + 1j * rng.standard_normal((5, 9))
+    a = bfref.dense_complex(v)
+    x = rng.standard_normal(5) + 1j * rng.standard_normal(5)
+    for flags in (TRANS, TRANS | CONJ):
+        C.c_int.from_address(a.ptr.value + 8).value |= flags
+        op = HipOperator.from_bfmat(a.ptr.value, flags=_capi.FLAG_PLAN_ONLY)
+        assert op.shape == (9, 5)
+        assert rel(plan_emulator.run_plan(op, x), v.conj().T @ x) < 1e-14
+        assert rel(bfref.mat_mul(a, x), v.conj().T @ x) < 1e-14
+        C.c_int.from_address(a.ptr.value + 8).value &= ~(TRANS | CONJ)
+    C.c_int.from_address(a.ptr.value + 8).value |= CONJ
     rc, msg = _compile_bfmat(a.ptr.value)
-    assert ERROR_NAMES[rc] == "BF_ERROR_NOT_IMPLEMENTED" and "transposed" in msg
-    C.c_int.from_address(a.ptr.value + 8).value &= ~2
+    assert ERROR_NAMES[rc] == "BF_ERROR_NOT_IMPLEMENTED" and "CONJ without TRANS" in msg
+    C.c_int.from_address(a.ptr.value + 8).value &= ~CONJ
+    w = rng.standard_normal((4, 7))
+    r = bfref.dense_real(w)
+    C.c_int.from_address(r.ptr.value + 8).value |= TRANS
+    op = HipOperator.from_bfmat(r.ptr.value, flags=_capi.FLAG_PLAN_ONLY)
+    assert op.shape == (7, 4)
+    xr = rng.standard_normal(4)
+    assert rel(plan_emulator.run_plan(op, xr), w.T @ xr) < 1e-14
+    C.c_int.from_address(r.ptr.value + 8).value &= ~TRANS
 
 
 def test_mixed_real_and_complex_is_a_type_error():
@@ -424,6 +446,26 @@ def test_packed_adjoint_plan_random_graphs(seed):
         xf = rng.standard_normal(n) + (1j * rng.standard_normal(n) if cplx else 0)
         fwd = bfref.mat_mul(A, xf) if cplx else bfref.mat_mul_vec(A, xf)
         assert rel(plan_emulator.run_plan(op, xf) + 1, fwd + 1) < (2e-5 if demote else 1e-12)
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_walker_reads_flagged_dense_leaves_as_conjugate_transposes(seed):
+    """A graph the oracle has transposed in place (bfMatTranspose: dense complex leaves flagged TRANS | CONJ, containers
+    restructured) compiles to A^H: the walker takes a flagged leaf as the conjugate of its stored values with the strides
+    swapped (reference src/mat_dense_complex.c:27-35, 503-511, 1475-1478).  Plan interpreter on the CPU."""
+    rng = np.random.default_rng(9300 + seed)
+    desc, vals = randgraph.random_operand(rng, depth=int(rng.integers(1, 4)), size_hint=50, cplx=True, coo=False)
+    m, n = desc.rows[desc.root], desc.cols[desc.root]
+    dense = randgraph.densify(desc, vals, desc.root)
+    A = bfref.from_desc(desc, vals, typed=True)
+    bfref.mat_transpose(A)
+    op = HipOperator.from_bfmat(A.ptr.value, flags=_capi.FLAG_PLAN_ONLY | _capi.FLAG_ADJOINT)
+    assert op.shape == (n, m)
+    x = rng.standard_normal(m) + 1j * rng.standard_normal(m)
+    xf = rng.standard_normal(n) + 1j * rng.standard_normal(n)
+    assert rel(plan_emulator.run_plan(op, x) + 1, dense.conj().T @ x + 1) < 1e-12
+    assert rel(plan_emulator.run_plan(op, xf, transpose=True) + 1, dense.conj() @ xf + 1) < 1e-12
+    assert rel(bfref.mat_mul(A, x) + 1, dense.conj().T @ x + 1) < 1e-12
 
 
 def test_transposed_plan_helm2(helm2_cases):
