@@ -373,9 +373,9 @@ def main():
     real = dtype != "c128"
     esz = {"c128": 16, "f64": 8, "f32": 4}[dtype]
     tdtype = {"c128": torch.complex128, "f64": torch.float64, "f32": torch.float32}[dtype]
-    if streamer and os.environ.get("BENCH_STREAMER_PACKED") != "1":
-        args.adjoint_shared = True      # the transposed expression of a streamed butterfly (tall-narrow transposed leaves) suits the forward kernels
-                                        # badly: 2x slower than the transposed kernels on the shared leaves
+    # (round 4: the packed copy is the default for the streamed operand too -- with runs of narrow pieces contracted as one block
+    #  and >= 32768 items per stage its transposed expression runs at 0.765 of the HBM peak on the forward kernels, the transposed
+    #  kernels on the shared leaves at 0.737: DESIGN.md section 10; --adjoint-shared measures the latter)
     flags = _capi.FLAG_PROFILE | ((_capi.FLAG_ADJOINT if args.adjoint_shared else _capi.FLAG_ADJOINT_PACKED) if args.adjoint else 0)
 
     # ---- the operand's block layout -------------------------------------------------------------------

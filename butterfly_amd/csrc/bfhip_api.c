@@ -456,6 +456,12 @@ int bfhipCompileIrFill(BfIr *ir, BfhipOptions const *opts, BfFillFn fill, void *
     if (po.rowEnd > 0 || po.rowBlockEnd > 0) { rc = bfhipFail(BFABI_ERROR_NOT_IMPLEMENTED, "BFHIP_FLAG_ADJOINT_PACKED on a row-sharded operator"); goto done; }
     if ((rc = bfIrTransposed(ir, &irT))) goto done;
     BfPlanOptions pt = po;
+    /* The block columns of a real (streamed) butterfly are long -- hundreds of leaves -- and the 1 MiB item cap leaves a stage of
+     * the transposed expression with ~8000 items for 4096 wavefront slots: two uneven rounds.  Cutting them for >= 32768 items
+     * per stage (N = 1M fp32: 8.66 -> 8.08 ms; 16384: 8.25, 65536: 8.15) costs nothing but a few more partial sums.  Complex
+     * (fac_helm2) plans keep 4096: their stages are 10 GB, the cap binds either way and more items measured 1-2 % slower, as did
+     * more items in the FORWARD plan of either operand. */
+    if (op->plan.dtype != BFHIP_C128) pt.itemsWanted = 32768;
     if ((rc = bfPlanBuild(&irT, &pt, &op->tplan))) { bfIrFree(&irT); goto done; }
     op->hasTplan = 1;
     op->packedT = 1;

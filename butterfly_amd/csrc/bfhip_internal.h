@@ -178,6 +178,7 @@ typedef struct BfPlanOptions {
   uint32_t itemRows;         /* rows per item cap (<= 64*epl); 0 -> default */
   uint32_t xcap;
   uint32_t groupByInput;     /* forward plans: order a stage's items by cost bucket, then by the input rows they read (RHS-block kernel: neighbours share an L2) */
+  uint32_t itemsWanted;      /* a stage's groups are cut so that it has about this many items at least (0 -> 4096); never above 1 MiB per item */
   uint32_t minChunkRows;     /* lower bound of the adaptive item height, in 16-byte row units (0 -> 16): 32 keeps the RHS-block kernel's two-slab passes full */
   uint64_t rowBlockBegin, rowBlockEnd;
   uint64_t rowBegin, rowEnd;   /* row-range shard: keep what output rows [rowBegin, rowEnd) depend on; rowEnd == 0 -> all */

@@ -702,7 +702,8 @@ int bfPlanBuild(BfIr const *ir, BfPlanOptions const *po, BfPlan *plan) {
     uint64_t const stageElems = fullStageElems[s];
     uint64_t const itemBytes = BF_ITEM_BYTES;
     uint64_t capBytes = 1u << 20;
-    if (stageElems * plan->elemSize / 4096 < capBytes) capBytes = stageElems * plan->elemSize / 4096;
+    uint64_t const itemsWanted = po->itemsWanted ? po->itemsWanted : 4096;
+    if (stageElems * plan->elemSize / itemsWanted < capBytes) capBytes = stageElems * plan->elemSize / itemsWanted;
     if (capBytes < itemBytes) capBytes = itemBytes;
     uint64_t const floorRowsCap = T ? itemRows : (uint64_t)(po->minChunkRows ? po->minChunkRows : 16) * plan->epl;
     uint64_t capColsCls[2];

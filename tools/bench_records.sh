@@ -37,6 +37,7 @@ BFHIP_LIB_PATH=$EXPLIB BFHIP_PERSISTENT=1 run ${TAG}_bench_n262144_persistent $B
 # BASELINE configs[4]: the streamed real butterfly (fac_streamer structure, rank model), fp32 and fp64
 S="timeout -k 10 900 python bench.py --workload streamer"
 run ${TAG}_bench_streamer_n1048576_f32   $S --adjoint --steps 10
+run ${TAG}_bench_streamer_n1048576_f32_adjoint_shared $S --adjoint --adjoint-shared --steps 10 --no-cpu-baseline
 run ${TAG}_bench_streamer_n1048576_f64   $S --dtype f64 --adjoint --steps 10 --no-cpu-baseline
 run ${TAG}_bench_streamer_n262144_f32    $S --npoints 262144 --lmax 127 --adjoint --steps 10
 run ${TAG}_build_n65536                  timeout -k 10 400 python tools/build_fullsize.py --npoints 65536

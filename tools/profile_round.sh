@@ -45,11 +45,12 @@ run write_st   --kernel-trace --pmc WRITE_SIZE -- --workload streamer --steps 2 
 run sq_st      --kernel-trace --pmc $SQSET -- --workload streamer --steps 2 --warmup 1
 fi
 if [ "$PART" != "helm2" ]; then
-# its transposed apply (bfStageKernelT<f32>: the 16- and the 64-column tiling of a stage in one launch, shared items)
-run stats_stT  --kernel-trace --stats -- --workload streamer --adjoint --steps 5 --warmup 1
-run fetch_stT  --kernel-trace --pmc FETCH_SIZE -- --workload streamer --adjoint --steps 2 --warmup 1
-run write_stT  --kernel-trace --pmc WRITE_SIZE -- --workload streamer --adjoint --steps 2 --warmup 1
+# its transposed apply on the shared leaves (bfStageKernelT<f32>: the 16- and the 64-column tiling of a stage in one launch; bench.py's
+# default, a packed copy for A^T, runs the forward kernels)
+run stats_stT  --kernel-trace --stats -- --workload streamer --adjoint --adjoint-shared --steps 5 --warmup 1
+run fetch_stT  --kernel-trace --pmc FETCH_SIZE -- --workload streamer --adjoint --adjoint-shared --steps 2 --warmup 1
+run write_stT  --kernel-trace --pmc WRITE_SIZE -- --workload streamer --adjoint --adjoint-shared --steps 2 --warmup 1
 # where the wavefronts' cycles go (parked on memory / issuing): the transposed kernels next to the forward ones in the same pass
-run sq_stT     --kernel-trace --pmc $SQSET -- --workload streamer --adjoint --steps 2 --warmup 1
+run sq_stT     --kernel-trace --pmc $SQSET -- --workload streamer --adjoint --adjoint-shared --steps 2 --warmup 1
 fi
 ls $OUT

@@ -130,11 +130,11 @@ packed()     { step pytest_p 600 python -m pytest tests -m gpu -x -q -k "adjoint
                done; }
 stpacked()   { step pytest_st 900 python -m pytest tests -m gpu -x -q -k "real or nested or streamer or adjoint or transpose or rmul or cov or packed"; tail -3 $O/pytest_st.out
                for v in shared packed; do
-                 if [ $v = packed ]; then export BENCH_STREAMER_PACKED=1; else unset BENCH_STREAMER_PACKED; fi
-                 step stadj_$v 400 $B --workload streamer --adjoint --steps 10 --warmup 2 --no-cpu-baseline --no-extra
+                 if [ $v = shared ]; then X=--adjoint-shared; else X=; fi
+                 step stadj_$v 400 $B --workload streamer --adjoint $X --steps 10 --warmup 2 --no-cpu-baseline --no-extra
                  python -c "import json; d = json.load(open('$O/stadj_$v.out')); print('$v streamer fwd', d['ms_per_step'], d['roofline']['frac'], 'adjoint', d['adjoint']['ms_per_apply'], d['adjoint']['frac_of_hbm_peak'], d['adjoint']['transpose_identity_rel'], 'cov', d['cov_matvec']['ms_per_product'], d['cov_matvec']['rel_vs_separate_applies'])"
-               done; unset BENCH_STREAMER_PACKED; }
-tracePk()    { ( cd /tmp && export TMPDIR=/tmp && export BENCH_STREAMER_PACKED=1 && timeout -k 10 600 rocprofv3 --kernel-trace --output-format csv -d $O/tracePk -- python3 $R/bench.py --workload streamer --adjoint --steps 2 --warmup 1 --no-cpu-baseline --no-extra > $O/tracePk.json 2> $O/tracePk.log ); echo "tracePk exit=$?";
+               done; }
+tracePk()    { ( cd /tmp && export TMPDIR=/tmp && timeout -k 10 600 rocprofv3 --kernel-trace --output-format csv -d $O/tracePk -- python3 $R/bench.py --workload streamer --adjoint --steps 2 --warmup 1 --no-cpu-baseline --no-extra > $O/tracePk.json 2> $O/tracePk.log ); echo "tracePk exit=$?";
                python tools/trace_apply.py $O/tracePk 70 > $O/tracePk.txt; find $O/tracePk -name "*.csv" -size +2M -delete; grep -v "at::native\|rocclr" $O/tracePk.txt | tail -45; }
 rehearse()   { step rh_rccl 300 $B --force-collective --steps 10 --warmup 2 --no-cpu-baseline --no-extra
                python -c "import json; d = json.load(open('$O/rh_rccl.out')); m = d['multi_gpu']; print('rccl', d['ms_per_step'], m['collective_impl'], m['ranks_agree'], m['max_local_ms'], m['max_collective_ms'])"
