@@ -88,7 +88,8 @@ uint64_t bfPlanCountCoop(BfDevItem const *items, BfDevPiece const *pieces, uint6
 #define BF_ITEM_TNARROW (1u << 20)    /* transposed plans: an item of <= 16 columns of a tall leaf (16-row-lane kernel); such items are the START of the list */
 #define BF_ITEM_SMALL (1u << 19)      /* real, forward: <= 2 lane granules of rows, <= 16 pieces, <= BF_SMALL_COLS dense columns (one block);
                                         * small items are the END of a stage's item list and run four to a wavefront */
-#define BF_SMALL_COLS 128u
+#define BF_SMALL_COLS 384u            /* (128 until round 4: the 8 KB row-major items of 130 - 380 columns of a streamed butterfly's stage 5 ran one per
+                                        * wavefront at 5.56 TB/s; four to a wavefront 6.38) */
 #define BF_SMALL_PIECES 16u
 #define BF_ITEM_MERGED (1u << 18)     /* real, column-major: <= 64 pieces whose dense parts are ONE contiguous mrPad x n block, n <= BF_MERGE_COLS */
 #define BF_MERGE_COLS 256u

@@ -89,7 +89,7 @@ def run_plan(op, x, transpose=False):
                 mine = pieces[int(it["pieceBegin"]):int(it["pieceBegin"]) + int(it["numPieces"])]
                 dense = [pc for pc in mine if not int(pc["flags"]) & BF_PIECE_IDENTITY]
                 assert not transpose and info.dtype != 0 and len(mine) <= 64 and dense
-                assert sum(int(pc["ncols"]) for pc in dense) <= (128 if int(it["mrFlags"]) & BF_ITEM_SMALL else 256)
+                assert sum(int(pc["ncols"]) for pc in dense) <= (384 if int(it["mrFlags"]) & BF_ITEM_SMALL else 256)
                 nxt = int(dense[0]["dataOff"])
                 for pc in dense:
                     assert int(pc["dataOff"]) == nxt and not int(pc["flags"]) & BF_PIECE_ROWMAJOR

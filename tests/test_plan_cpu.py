@@ -166,7 +166,7 @@ def test_few_row_leaves_are_stored_row_major(demote):
 def test_narrow_items_are_merged_and_small_ones_close_the_list(demote):
     """What the inner factors of a streamed butterfly are made of: row nodes of 1 - 8 rows whose terms are an Identity
     and a leaf of a few dozen columns, next to ordinary leaves.  Items whose dense pieces span <= 256 columns are flagged
-    MERGED (one contiguous block), those of <= 2 lane granules of rows and < 128 columns SMALL -- and the small ones are
+    MERGED (one contiguous block), those of <= 2 lane granules of rows and < 384 columns SMALL -- and the small ones are
     the END of the stage's item list, behind the zero fills (they get their own launch, four to a wavefront)."""
     rng = np.random.default_rng(5)
     d, vals, dense = randgraph.narrow_items_operand(rng)

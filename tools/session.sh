@@ -134,6 +134,12 @@ stpacked()   { step pytest_st 900 python -m pytest tests -m gpu -x -q -k "real o
                  step stadj_$v 400 $B --workload streamer --adjoint $X --steps 10 --warmup 2 --no-cpu-baseline --no-extra
                  python -c "import json; d = json.load(open('$O/stadj_$v.out')); print('$v streamer fwd', d['ms_per_step'], d['roofline']['frac'], 'adjoint', d['adjoint']['ms_per_apply'], d['adjoint']['frac_of_hbm_peak'], d['adjoint']['transpose_identity_rel'], 'cov', d['cov_matvec']['ms_per_product'], d['cov_matvec']['rel_vs_separate_applies'])"
                done; }
+libab()      { for v in ${LIB_VARIANTS:-base}; do
+                 if [ $v = base ]; then unset BFHIP_LIB_PATH; else export BFHIP_LIB_PATH=$R/butterfly_amd/csrc/exp/libbfhip_$v.so; fi
+                 step st_$v 400 $B --workload streamer --adjoint --steps 10 --warmup 2 --no-cpu-baseline --no-extra
+                 python -c "import json; d = json.load(open('$O/st_$v.out')); print('$v streamer fwd', d['ms_per_step'], d['roofline']['frac'], 'adjoint', d['adjoint']['ms_per_apply'], d['adjoint']['frac_of_hbm_peak'], d['adjoint']['transpose_identity_rel'])"
+                 grep "stage " $O/st_$v.err | head -9
+               done; unset BFHIP_LIB_PATH; }
 tracePk()    { ( cd /tmp && export TMPDIR=/tmp && timeout -k 10 600 rocprofv3 --kernel-trace --output-format csv -d $O/tracePk -- python3 $R/bench.py --workload streamer --adjoint --steps 2 --warmup 1 --no-cpu-baseline --no-extra > $O/tracePk.json 2> $O/tracePk.log ); echo "tracePk exit=$?";
                python tools/trace_apply.py $O/tracePk 70 > $O/tracePk.txt; find $O/tracePk -name "*.csv" -size +2M -delete; grep -v "at::native\|rocclr" $O/tracePk.txt | tail -45; }
 rehearse()   { step rh_rccl 300 $B --force-collective --steps 10 --warmup 2 --no-cpu-baseline --no-extra
