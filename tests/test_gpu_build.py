@@ -454,6 +454,12 @@ def test_qr_preconditioned_jacobi(monkeypatch, helm2_cases):
         assert X.shape == want.shape
         assert rel(z_eq @ X, z_eq @ want) <= 1e-10, (nsrc, me, mt)
         assert np.linalg.norm(X) <= 1.5 * np.linalg.norm(want), (nsrc, me, mt)
+    # the preconditioner ahead of the global-memory fallback kernel (what a problem of > 2300 columns gets)
+    monkeypatch.setenv("BFHIP_JACOBI_GLOBAL", "1")
+    op, st3 = HipOperator.build_helm2(desc, tp, k)
+    assert st3["qrProblems"] == st3["reexpLeaves"] and st3["notConverged"] == 0
+    assert rel(op.apply_host(x), y) <= 1e-11
+    op.close()
 
 
 def test_single_pair_butterfly_built_on_the_device_matches_the_golden_vectors():
