@@ -486,6 +486,232 @@ __global__ __launch_bounds__(1024) void bfJacobiKernel(BfSvdProb const *probs, u
   bfJacobiFinish<W>(P, stats, sweep, converged, &sigMax);
 }
 
+// ---------------------------------------------------------------------------
+// Block form for the problems whose stacked columns are too long for the LDS tile (rows + columns >~ 770: only 2 - 5
+// stacked columns of a block fit, an inner step keeps 2 - 5 of 16 wavefronts busy and every block pair is a round trip
+// of its columns for a handful of rotations).  Here a block is 16 columns whatever their length.  For a pair of blocks
+// (32 columns Xp):
+//   A. G = Xp^H Xp, 32 x 32, one pass over the rows (32-row chunks staged in LDS, 4 x 4 register blocks, 8 row slices);
+//   B. two-sided Jacobi on G in LDS by ONE wavefront (no barriers; 16 disjoint rotations per round-robin step, 4 lanes
+//      each; the same rotation formula and the same thresholds as the scalar kernel -- the inner products it would
+//      compute are the entries of G), two sweeps, the rotations accumulated in Q (32 x 32);
+//   C. [Xp; Vp] <- [Xp; Vp] Q, one thread per row, the row's 32 values in registers, Q broadcast from LDS.
+// The next outer sweep forms every G afresh from the columns, so what an inner solve leaves undone (its later rotations
+// use updated, not recomputed, inner products) is met again; a sweep in which no fresh G holds a pair above the
+// threshold ends the iteration, exactly the scalar kernel's criterion.  (CPU prototype on re-expansion matrices of
+// 160 - 300 columns: 6 - 9 outer sweeps against 9 scalar ones, V orthogonal to 1e-13.)  Traffic per sweep falls by
+// the block size over the tile's 2 - 5 columns, and the arithmetic is two GEMM-shaped passes all wavefronts share.
+// ---------------------------------------------------------------------------
+#define BF_GRAM_NB 16
+#define BF_GRAM_P 32
+#define BF_GRAM_THREADS 512
+#define BF_GRAM_RC 32
+#define BF_GRAM_LD 33
+#define BF_GRAM_MAX_COLS 4096
+#define BF_GRAM_NONE 0xffffu
+
+__device__ __forceinline__ void bfWaveSync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__global__ __launch_bounds__(BF_GRAM_THREADS) void bfJacobiGramKernel(BfSvdProb const *probs, uint32_t const *list, BfSvdStats *stats) {
+  constexpr int W = 64;
+  __shared__ __attribute__((aligned(16))) double2 G[BF_GRAM_P * BF_GRAM_LD];
+  __shared__ __attribute__((aligned(16))) double2 Q[BF_GRAM_P * BF_GRAM_LD];
+  __shared__ __attribute__((aligned(16))) double2 tile[BF_GRAM_P * BF_GRAM_LD];      // [column][row of the chunk]
+  __shared__ uint16_t live[BF_GRAM_MAX_COLS];
+  __shared__ uint16_t pcol[BF_GRAM_P];
+  __shared__ int rotated, pairRot;
+  __shared__ double sigMax;
+  __shared__ unsigned long long maxNormBits;
+  __shared__ uint32_t numLive;
+  BfSvdProb const P = probs[list[blockIdx.x]];
+  uint32_t const mt = P.mt, me = P.me;
+  if (me == 0) return;
+  double2 *A = (double2 *)P.a, *V = (double2 *)P.v;
+  uint32_t const nthreads = blockDim.x, tid = threadIdx.x;
+  uint32_t const groups = nthreads / W, g = tid / W, l = tid % W;
+  double const tol2 = (double)mt * 2.220446049250313e-16 * 2.220446049250313e-16;
+  double const deadRel = (double)P.dim * 2.220446049250313e-16;
+  double const dead2 = deadRel * deadRel * bfJacobiMaxNorm2<W>(P, &maxNormBits);
+  for (uint64_t e = tid; e < (uint64_t)me * me; e += nthreads) V[e] = make_double2((e % me == e / me) ? 1.0 : 0.0, 0.0);
+  int sweep = 0;
+  bool converged = false;
+  __syncthreads();
+  for (; sweep < BF_JACOBI_MAX_SWEEPS; ++sweep) {
+    for (uint32_t j = g; j < me; j += groups) {
+      double2 const *aj = A + (uint64_t)j * mt;
+      double s2 = 0;
+      for (uint32_t r = l; r < mt; r += W) { double2 const a = aj[r]; s2 = fma(a.x, a.x, fma(a.y, a.y, s2)); }
+      s2 = bfGroupSum<W>(s2);
+      if (l == 0) P.scale[j] = s2;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      uint32_t n = 0;
+      for (uint32_t j = 0; j < me; ++j)
+        if (P.scale[j] >= dead2) live[n++] = (uint16_t)j;
+      numLive = n;
+      rotated = 0;
+    }
+    __syncthreads();
+    uint32_t const nLive = numLive;
+    if (nLive < 2) { converged = true; break; }
+    uint32_t nb = (nLive + BF_GRAM_NB - 1) / BF_GRAM_NB;
+    nb = nb < 2 ? 2 : nb;
+    uint32_t const NBk = nb + (nb & 1u);
+    for (uint32_t S = 0; S + 1 < NBk; ++S) {
+      for (uint32_t KK = 0; KK < NBk / 2; ++KK) {
+        uint32_t I, J;
+        bfRoundRobin(NBk, S, KK, I, J);
+        if (J >= nb) continue;
+        if (tid < BF_GRAM_P) {
+          uint32_t const a = (tid < BF_GRAM_NB ? I : J) * BF_GRAM_NB + (tid % BF_GRAM_NB);
+          pcol[tid] = a < nLive ? live[a] : (uint16_t)BF_GRAM_NONE;
+        }
+        for (uint32_t e = tid; e < BF_GRAM_P * BF_GRAM_LD; e += nthreads) {
+          G[e] = make_double2(0.0, 0.0);
+          uint32_t const i = e / BF_GRAM_LD, j = e - i * BF_GRAM_LD;
+          Q[e] = make_double2(i == j ? 1.0 : 0.0, 0.0);
+        }
+        if (tid == 0) pairRot = 0;
+        __syncthreads();
+        // ---- A: the Gram matrix of the pair's columns
+        {
+          uint32_t const slice = tid / 64, w = tid % 64, bp = w / 8, bq = w % 8;
+          double ar[4][4], ai[4][4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { ar[i][j] = 0; ai[i][j] = 0; }
+          for (uint32_t r0 = 0; r0 < mt; r0 += BF_GRAM_RC) {
+#pragma unroll
+            for (int k = 0; k < (BF_GRAM_P * BF_GRAM_RC) / BF_GRAM_THREADS; ++k) {
+              uint32_t const e = tid + BF_GRAM_THREADS * k, c = e / BF_GRAM_RC, r = e % BF_GRAM_RC;
+              uint32_t const col = pcol[c];
+              double2 v = make_double2(0.0, 0.0);
+              if (col != BF_GRAM_NONE && r0 + r < mt) v = A[(uint64_t)col * mt + r0 + r];
+              tile[c * BF_GRAM_LD + r] = v;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+              uint32_t const r = slice * 4 + rr;
+              double2 a[4], b[4];
+#pragma unroll
+              for (int i = 0; i < 4; ++i) { a[i] = tile[(4 * bp + i) * BF_GRAM_LD + r]; b[i] = tile[(4 * bq + i) * BF_GRAM_LD + r]; }
+#pragma unroll
+              for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {            // conj(a) * b
+                  ar[i][j] = fma(a[i].x, b[j].x, fma(a[i].y, b[j].y, ar[i][j]));
+                  ai[i][j] = fma(a[i].x, b[j].y, fma(-a[i].y, b[j].x, ai[i][j]));
+                }
+            }
+            __syncthreads();
+          }
+          for (uint32_t sl = 0; sl < BF_GRAM_THREADS / 64; ++sl) {      // the row slices added in a fixed order
+            if (slice == sl) {
+#pragma unroll
+              for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                  double2 &gg = G[(4 * bp + i) * BF_GRAM_LD + 4 * bq + j];
+                  gg = make_double2(gg.x + ar[i][j], gg.y + ai[i][j]);
+                }
+            }
+            __syncthreads();
+          }
+        }
+        // ---- B: two-sided Jacobi on G by one wavefront; Q accumulates the rotations
+        if (g == 0) {
+          uint32_t const kk = l / 4, sub = l % 4;
+          int any = 0;
+          for (int inner = 0; inner < 2; ++inner) {
+            for (uint32_t s = 0; s + 1 < BF_GRAM_P; ++s) {
+              uint32_t p, q;
+              bfRoundRobin(BF_GRAM_P, s, kk, p, q);
+              double2 const gpq = G[p * BF_GRAM_LD + q];
+              double const alpha = G[p * BF_GRAM_LD + p].x, beta = G[q * BF_GRAM_LD + q].x;
+              double c, sn, er, ei;
+              bool const rot = bfJacobiAngle(alpha, beta, gpq.x, gpq.y, tol2, dead2, c, sn, er, ei);
+              bfWaveSync();
+              if (rot) {
+                if (inner == 0) any = 1;
+#pragma unroll
+                for (int t = 0; t < BF_GRAM_P / 4; ++t) {                 // columns p, q of G and of Q
+                  uint32_t const i = sub + 4 * t;
+                  double2 x = G[i * BF_GRAM_LD + p], y = G[i * BF_GRAM_LD + q];
+                  double2 yt = make_double2(er * y.x - ei * y.y, er * y.y + ei * y.x);
+                  G[i * BF_GRAM_LD + p] = make_double2(c * x.x - sn * yt.x, c * x.y - sn * yt.y);
+                  G[i * BF_GRAM_LD + q] = make_double2(sn * x.x + c * yt.x, sn * x.y + c * yt.y);
+                  x = Q[i * BF_GRAM_LD + p]; y = Q[i * BF_GRAM_LD + q];
+                  yt = make_double2(er * y.x - ei * y.y, er * y.y + ei * y.x);
+                  Q[i * BF_GRAM_LD + p] = make_double2(c * x.x - sn * yt.x, c * x.y - sn * yt.y);
+                  Q[i * BF_GRAM_LD + q] = make_double2(sn * x.x + c * yt.x, sn * x.y + c * yt.y);
+                }
+              }
+              bfWaveSync();
+              if (rot) {
+#pragma unroll
+                for (int t = 0; t < BF_GRAM_P / 4; ++t) {                 // rows p, q of G: J^H G, conj(e) on row q
+                  uint32_t const j = sub + 4 * t;
+                  double2 const x = G[p * BF_GRAM_LD + j], y = G[q * BF_GRAM_LD + j];
+                  double2 const yt = make_double2(er * y.x + ei * y.y, er * y.y - ei * y.x);
+                  G[p * BF_GRAM_LD + j] = make_double2(c * x.x - sn * yt.x, c * x.y - sn * yt.y);
+                  G[q * BF_GRAM_LD + j] = make_double2(sn * x.x + c * yt.x, sn * x.y + c * yt.y);
+                }
+              }
+              bfWaveSync();
+            }
+          }
+          any = __any(any);
+          if (l == 0 && any) { pairRot = 1; rotated = 1; }
+        }
+        __syncthreads();
+        // ---- C: the pair's columns of [X; V] times Q
+        if (pairRot) {
+          uint32_t const R = mt + me;
+          for (uint32_t row0 = 0; row0 < R; row0 += nthreads) {
+            uint32_t const row = row0 + tid;
+            if (row < R) {
+              double2 *base = row < mt ? A + row : V + (row - mt);
+              uint64_t const ld = row < mt ? mt : me;
+              double2 x[BF_GRAM_P];
+#pragma unroll
+              for (int k = 0; k < BF_GRAM_P; ++k) {
+                uint32_t const col = pcol[k];
+                x[k] = col != BF_GRAM_NONE ? base[(uint64_t)col * ld] : make_double2(0.0, 0.0);
+              }
+#pragma unroll 4
+              for (int c = 0; c < BF_GRAM_P; ++c) {
+                uint32_t const col = pcol[c];
+                if (col == BF_GRAM_NONE) continue;
+                double yr = 0, yi = 0;
+#pragma unroll
+                for (int k = 0; k < BF_GRAM_P; ++k) {
+                  double2 const qk = Q[k * BF_GRAM_LD + c];
+                  yr = fma(x[k].x, qk.x, fma(-x[k].y, qk.y, yr));
+                  yi = fma(x[k].x, qk.y, fma(x[k].y, qk.x, yi));
+                }
+                base[(uint64_t)col * ld] = make_double2(yr, yi);
+              }
+            }
+          }
+        }
+        __syncthreads();
+      }
+    }
+    converged = rotated == 0;
+    __syncthreads();
+    if (converged) break;
+  }
+  __syncthreads();
+  bfJacobiFinish<W>(P, stats, sweep, converged, &sigMax);
+}
+
 // Fallback for problems whose stacked column pair does not fit the LDS tile (check points +
 // equivalent sources > ~4600): the same sweeps straight out of global memory, one column pair per
 // 64-lane group of a 1024-thread workgroup.  Slow (every rotation streams its columns), but total.
@@ -816,9 +1042,23 @@ int bfdevBuildJacobi(BfSvdProb const *hostProbs, uint64_t numProbs, BfSvdStats *
   uint32_t *globalList = (uint32_t *)malloc(numProbs * sizeof(uint32_t));
   uint64_t numGlobal = 0;
   if (!globalList) rc = bfhipFail(BFABI_ERROR_MEMORY_ERROR, "host OOM");
+  // Problems of rows + columns >= 768 (fewer than six stacked columns of a block would fit the LDS tile) run the block form
+  // on Gram matrices (bfJacobiGramKernel), as do those too long for the tile at all when they have <= 4096 columns.
+  // BFHIP_JACOBI_GRAM_MIN moves the limit (0: every problem -- a test hook; a huge value: none).
+  char const *genv = getenv("BFHIP_JACOBI_GRAM_MIN");
+  uint64_t const gramMin = genv && genv[0] ? strtoull(genv, NULL, 10) : 768;
+  JacobiOrder *gramList = (JacobiOrder *)malloc((numProbs ? numProbs : 1) * sizeof(JacobiOrder));
+  uint64_t numGram = 0;
+  if (!gramList) rc = bfhipFail(BFABI_ERROR_MEMORY_ERROR, "host OOM");
   for (uint64_t i = 0; i < numProbs && !rc; ++i) {
     int wlog, big, lc;
     rc = jacobiClass(&hostProbs[i], forceGlobal, &wlog, &big, &lc);
+    if (!forceGlobal && hostProbs[i].me <= BF_GRAM_MAX_COLS && (lc < 0 || (uint64_t)hostProbs[i].mt + hostProbs[i].me >= gramMin)) {
+      cls[i] = 0xff;
+      gramList[numGram].idx = (uint32_t)i;
+      gramList[numGram++].cost = (double)hostProbs[i].me * hostProbs[i].me * (hostProbs[i].mt + hostProbs[i].me);
+      continue;
+    }
     if (lc < 0) { cls[i] = 0xff; globalList[numGlobal++] = (uint32_t)i; continue; }
     cls[i] = (uint8_t)((wlog * 2 + big) * NL + lc);
     counts[cls[i]] += 1;
@@ -893,6 +1133,30 @@ int bfdevBuildJacobi(BfSvdProb const *hostProbs, uint64_t numProbs, BfSvdStats *
                 (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec));
       }
     }
+  uint32_t *dGram = NULL;
+  if (!rc && numGram) {
+    qsort(gramList, numGram, sizeof(JacobiOrder), jacobiCostDescending);
+    uint32_t *ids = (uint32_t *)malloc(numGram * sizeof(uint32_t));
+    if (!ids) rc = bfhipFail(BFABI_ERROR_MEMORY_ERROR, "host OOM");
+    for (uint64_t i = 0; i < numGram && !rc; ++i) ids[i] = gramList[i].idx;
+    if (!rc) rc = uploadArrayB(&dGram, ids, numGram, "svd block-form list");
+    free(ids);
+    struct timespec t0, t1;
+    BfSvdStats before = {0, 0, 0, 0};
+    if (profile && !rc) { (void)hipDeviceSynchronize(); (void)hipMemcpy(&before, dS, sizeof before, hipMemcpyDeviceToHost); clock_gettime(CLOCK_MONOTONIC, &t0); }
+    if (!rc) {
+      hipLaunchKernelGGL(bfJacobiGramKernel, dim3((uint32_t)numGram), dim3(BF_GRAM_THREADS), 0, 0, dP, dGram, dS);
+      rc = hipFailB(hipGetLastError(), "Jacobi SVD (block form) launch");
+    }
+    if (profile && !rc) {
+      (void)hipDeviceSynchronize();
+      clock_gettime(CLOCK_MONOTONIC, &t1);
+      BfSvdStats after;
+      (void)hipMemcpy(&after, dS, sizeof after, hipMemcpyDeviceToHost);
+      fprintf(stderr, "[jacobi] block form (Gram) problems=%llu sweeps=%.1f  %.3f s\n", (unsigned long long)numGram,
+              (double)(after.sumSweeps - before.sumSweeps) / (double)numGram, (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec));
+    }
+  }
   uint32_t *dG = NULL;
   if (!rc && numGlobal) {
     rc = uploadArrayB(&dG, globalList, numGlobal, "svd fallback list");
@@ -902,8 +1166,8 @@ int bfdevBuildJacobi(BfSvdProb const *hostProbs, uint64_t numProbs, BfSvdStats *
     }
   }
   if (!rc) rc = hipFailB(hipDeviceSynchronize(), "Jacobi SVD");
-  (void)hipFree(dG);
-  free(globalList);
+  (void)hipFree(dG); (void)hipFree(dGram);
+  free(globalList); free(gramList);
   for (int c = 0; c < NCLS; ++c) (void)hipFree(dL[c]);
   if (!rc && stats) {
     BfSvdStats got;

@@ -462,6 +462,40 @@ def test_qr_preconditioned_jacobi(monkeypatch, helm2_cases):
     op.close()
 
 
+def test_block_form_jacobi_on_gram_matrices(monkeypatch, helm2_cases):
+    """Problems of rows + columns >= 768 run the block form of the Jacobi SVD (bfJacobiGramKernel: 16-column blocks, the Gram
+    matrix of a block pair diagonalised in LDS, the pair's columns updated by a 32 x 32 unitary); BFHIP_JACOBI_GRAM_MIN moves
+    the limit.  Every problem through it, with and without the QR preconditioner, gives the operator of the scalar kernel to
+    rounding; single leaves (square, tall, with more columns than one block pair and with fewer than one block) reproduce the
+    truncated-SVD least-squares field."""
+    from butterfly_amd.operator import HipOperator, helm2_build_leaf
+    from oracle import helm2_build as hb
+    n, k = 4096, 256.0
+    desc, tp, _ = helm2_cases(n, k)
+    x = hb.complex_randn(n, 0)
+    monkeypatch.setenv("BFHIP_JACOBI_GRAM_MIN", "1000000000")
+    op, st = HipOperator.build_helm2(desc, tp, k)
+    y = op.apply_host(x)
+    op.close()
+    for qr_min in ("1000000", "0"):
+        monkeypatch.setenv("BFHIP_JACOBI_GRAM_MIN", "0")
+        monkeypatch.setenv("BFHIP_JACOBI_QR_MIN", qr_min)
+        op, st2 = HipOperator.build_helm2(desc, tp, k)
+        assert st2["notConverged"] == 0 and st2["reexpLeaves"] == st["reexpLeaves"]
+        assert rel(op.apply_host(x), y) <= 1e-11, qr_min
+        op.close()
+    monkeypatch.delenv("BFHIP_JACOBI_QR_MIN")
+    pts = tp[:16]
+    for (nsrc, me, mt, kk) in [(20, 12, 14, 100.0), (70, 45, 51, 400.0), (90, 100, 100, 900.0), (170, 150, 190, 1500.0), (64, 300, 300, 3000.0), (96, 420, 420, 4200.0)]:
+        rc = ("reexp", ("circle", 0.55, 0.05, 0.08, nsrc), ("circle", 0.5, 0.0, 0.16, me), ("circle", -0.6, 0.1, 0.2, mt))
+        X = helm2_build_leaf(pts, kk, rc)
+        src, eq, tgt = (hb.resolve_points(s, pts) for s in rc[1:])
+        z_or, z_eq = hb.kernel_matrix(kk, src, tgt), hb.kernel_matrix(kk, eq, tgt)
+        want = hb.lstsq_truncated(z_eq, z_or)
+        assert rel(z_eq @ X, z_eq @ want) <= 1e-10, (nsrc, me, mt)
+        assert np.linalg.norm(X) <= 1.5 * np.linalg.norm(want), (nsrc, me, mt)
+
+
 def test_single_pair_butterfly_built_on_the_device_matches_the_golden_vectors():
     """examples/simple/bf_one_block.c: bfFacHelm2MakeSingleLevel for one node pair -- native layout,
     device values -- against the committed golden (numpy/LAPACK-built operand, its x and y)."""
