@@ -487,7 +487,7 @@ __global__ __launch_bounds__(1024) void bfJacobiKernel(BfSvdProb const *probs, u
 }
 
 // ---------------------------------------------------------------------------
-// Block form for the problems whose stacked columns are too long for the LDS tile (rows + columns >~ 770: only 2 - 5
+// Block form for the problems whose stacked columns are long for the LDS tile (rows + columns >= 512: only 2 - 8
 // stacked columns of a block fit, an inner step keeps 2 - 5 of 16 wavefronts busy and every block pair is a round trip
 // of its columns for a handful of rotations).  Here a block is 16 columns whatever their length.  For a pair of blocks
 // (32 columns Xp):
@@ -1042,11 +1042,12 @@ int bfdevBuildJacobi(BfSvdProb const *hostProbs, uint64_t numProbs, BfSvdStats *
   uint32_t *globalList = (uint32_t *)malloc(numProbs * sizeof(uint32_t));
   uint64_t numGlobal = 0;
   if (!globalList) rc = bfhipFail(BFABI_ERROR_MEMORY_ERROR, "host OOM");
-  // Problems of rows + columns >= 768 (fewer than six stacked columns of a block would fit the LDS tile) run the block form
+  // Problems of rows + columns >= 512 (fewer than nine stacked columns of a block would fit the LDS tile) run the block form
   // on Gram matrices (bfJacobiGramKernel), as do those too long for the tile at all when they have <= 4096 columns.
+  // (N = 262144 build with the limit at 384 / 512 / 768 / 1024: 21.5 / 22.0 / 22.0 - 23.6 / 27.5 s.)
   // BFHIP_JACOBI_GRAM_MIN moves the limit (0: every problem -- a test hook; a huge value: none).
   char const *genv = getenv("BFHIP_JACOBI_GRAM_MIN");
-  uint64_t const gramMin = genv && genv[0] ? strtoull(genv, NULL, 10) : 768;
+  uint64_t const gramMin = genv && genv[0] ? strtoull(genv, NULL, 10) : 512;
   JacobiOrder *gramList = (JacobiOrder *)malloc((numProbs ? numProbs : 1) * sizeof(JacobiOrder));
   uint64_t numGram = 0;
   if (!gramList) rc = bfhipFail(BFABI_ERROR_MEMORY_ERROR, "host OOM");
@@ -1094,6 +1095,34 @@ int bfdevBuildJacobi(BfSvdProb const *hostProbs, uint64_t numProbs, BfSvdStats *
   // BFHIP_JACOBI_PROFILE=1: time every class launch on its own (a synchronisation per class) and print it
   char const *penv = getenv("BFHIP_JACOBI_PROFILE");
   int const profile = penv && penv[0] == '1';
+  // the block-form problems go first, on a stream of their own: they are the longest, and the class launches below (null
+  // stream; a non-blocking stream does not order with it) fill the CUs their tail leaves idle
+  uint32_t *dGram = NULL;
+  hipStream_t sGram = NULL;
+  if (!rc && numGram) rc = hipFailB(hipStreamCreateWithFlags(&sGram, hipStreamNonBlocking), "hipStreamCreate");
+  if (!rc && numGram) {
+    qsort(gramList, numGram, sizeof(JacobiOrder), jacobiCostDescending);
+    uint32_t *ids = (uint32_t *)malloc(numGram * sizeof(uint32_t));
+    if (!ids) rc = bfhipFail(BFABI_ERROR_MEMORY_ERROR, "host OOM");
+    for (uint64_t i = 0; i < numGram && !rc; ++i) ids[i] = gramList[i].idx;
+    if (!rc) rc = uploadArrayB(&dGram, ids, numGram, "svd block-form list");
+    free(ids);
+    struct timespec t0, t1;
+    BfSvdStats before = {0, 0, 0, 0};
+    if (profile && !rc) { (void)hipDeviceSynchronize(); (void)hipMemcpy(&before, dS, sizeof before, hipMemcpyDeviceToHost); clock_gettime(CLOCK_MONOTONIC, &t0); }
+    if (!rc) {
+      hipLaunchKernelGGL(bfJacobiGramKernel, dim3((uint32_t)numGram), dim3(BF_GRAM_THREADS), 0, sGram, dP, dGram, dS);
+      rc = hipFailB(hipGetLastError(), "Jacobi SVD (block form) launch");
+    }
+    if (profile && !rc) {
+      (void)hipDeviceSynchronize();
+      clock_gettime(CLOCK_MONOTONIC, &t1);
+      BfSvdStats after;
+      (void)hipMemcpy(&after, dS, sizeof after, hipMemcpyDeviceToHost);
+      fprintf(stderr, "[jacobi] block form (Gram) problems=%llu sweeps=%.1f  %.3f s\n", (unsigned long long)numGram,
+              (double)(after.sumSweeps - before.sumSweeps) / (double)numGram, (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec));
+    }
+  }
   // classes are launched back to back (largest tiles first: they run longest) and synchronised once
   for (int lc = NL - 1; lc >= 0 && !rc; --lc)
     for (int wb = 0; wb < 2 * NW && !rc; ++wb) {
@@ -1133,30 +1162,6 @@ int bfdevBuildJacobi(BfSvdProb const *hostProbs, uint64_t numProbs, BfSvdStats *
                 (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec));
       }
     }
-  uint32_t *dGram = NULL;
-  if (!rc && numGram) {
-    qsort(gramList, numGram, sizeof(JacobiOrder), jacobiCostDescending);
-    uint32_t *ids = (uint32_t *)malloc(numGram * sizeof(uint32_t));
-    if (!ids) rc = bfhipFail(BFABI_ERROR_MEMORY_ERROR, "host OOM");
-    for (uint64_t i = 0; i < numGram && !rc; ++i) ids[i] = gramList[i].idx;
-    if (!rc) rc = uploadArrayB(&dGram, ids, numGram, "svd block-form list");
-    free(ids);
-    struct timespec t0, t1;
-    BfSvdStats before = {0, 0, 0, 0};
-    if (profile && !rc) { (void)hipDeviceSynchronize(); (void)hipMemcpy(&before, dS, sizeof before, hipMemcpyDeviceToHost); clock_gettime(CLOCK_MONOTONIC, &t0); }
-    if (!rc) {
-      hipLaunchKernelGGL(bfJacobiGramKernel, dim3((uint32_t)numGram), dim3(BF_GRAM_THREADS), 0, 0, dP, dGram, dS);
-      rc = hipFailB(hipGetLastError(), "Jacobi SVD (block form) launch");
-    }
-    if (profile && !rc) {
-      (void)hipDeviceSynchronize();
-      clock_gettime(CLOCK_MONOTONIC, &t1);
-      BfSvdStats after;
-      (void)hipMemcpy(&after, dS, sizeof after, hipMemcpyDeviceToHost);
-      fprintf(stderr, "[jacobi] block form (Gram) problems=%llu sweeps=%.1f  %.3f s\n", (unsigned long long)numGram,
-              (double)(after.sumSweeps - before.sumSweeps) / (double)numGram, (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec));
-    }
-  }
   uint32_t *dG = NULL;
   if (!rc && numGlobal) {
     rc = uploadArrayB(&dG, globalList, numGlobal, "svd fallback list");
@@ -1167,6 +1172,7 @@ int bfdevBuildJacobi(BfSvdProb const *hostProbs, uint64_t numProbs, BfSvdStats *
   }
   if (!rc) rc = hipFailB(hipDeviceSynchronize(), "Jacobi SVD");
   (void)hipFree(dG); (void)hipFree(dGram);
+  if (sGram) (void)hipStreamDestroy(sGram);
   free(globalList); free(gramList);
   for (int c = 0; c < NCLS; ++c) (void)hipFree(dL[c]);
   if (!rc && stats) {

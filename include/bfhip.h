@@ -71,10 +71,12 @@ enum {
                                     (DESIGN.md section 15).  The product library (libbfhip.so) does not contain that executor
                                     and refuses the flag with BF_ERROR_NOT_IMPLEMENTED */
 };
-/* Environment variables.  The product library reads five, all test / diagnosis hooks:
+/* Environment variables.  The product library reads six, all test / diagnosis hooks:
  *   BFHIP_JACOBI_GLOBAL=1   builder: every SVD problem through the global-memory fallback kernel (test hook)
  *   BFHIP_JACOBI_QR_MIN=n   builder: least-squares problems of >= n equivalent sources are QR-factored with column pivoting
  *                           before the Jacobi SVD (default 65; 0: every problem, a test hook; a huge value: none)
+ *   BFHIP_JACOBI_GRAM_MIN=n builder: least-squares problems of rows + columns >= n run the block form of the Jacobi SVD on Gram matrices
+ *                           (default 512; 0: every problem, a test hook; a huge value: none)
  *   BFHIP_JACOBI_PROFILE=1  builder: prints the time of every phase and of every SVD size class to stderr (synchronises per class)
  *   BFHIP_ALLOW_UNCONVERGED_SVD=1   builder: keep an operator whose Jacobi SVDs hit the sweep limit (diagnosis)
  *   BFHIP_GMRES_MGS=1       GMRES: the reference's modified Gram-Schmidt order instead of batched CGS2 (as the per-call option)
