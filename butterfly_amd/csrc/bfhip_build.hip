@@ -494,7 +494,7 @@ __global__ __launch_bounds__(1024) void bfJacobiKernel(BfSvdProb const *probs, u
 //   A. G = Xp^H Xp, 32 x 32, one pass over the rows (32-row chunks staged in LDS, 4 x 4 register blocks, 8 row slices);
 //   B. two-sided Jacobi on G in LDS by ONE wavefront (no barriers; 16 disjoint rotations per round-robin step, 4 lanes
 //      each; the same rotation formula and the same thresholds as the scalar kernel -- the inner products it would
-//      compute are the entries of G), two sweeps, the rotations accumulated in Q (32 x 32);
+//      compute are the entries of G), one sweep, the rotations accumulated in Q (32 x 32);
 //   C. [Xp; Vp] <- [Xp; Vp] Q, one thread per row, the row's 32 values in registers, Q broadcast from LDS.
 // The next outer sweep forms every G afresh from the columns, so what an inner solve leaves undone (its later rotations
 // use updated, not recomputed, inner products) is met again; a sweep in which no fresh G holds a pair above the
@@ -509,6 +509,8 @@ __global__ __launch_bounds__(1024) void bfJacobiKernel(BfSvdProb const *probs, u
 #define BF_GRAM_LD 33
 #define BF_GRAM_MAX_COLS 4096
 #define BF_GRAM_NONE 0xffffu
+#define BF_GRAM_INNER 1                  /* sweeps of the inner solve per visit of a block pair (2: 10.2 instead of 10.5 outer sweeps on
+                                          * average, but the one-wavefront solve is half of a visit's time: 4.66 against 3.76 s per batch) */
 
 __device__ __forceinline__ void bfWaveSync() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -629,7 +631,7 @@ __global__ __launch_bounds__(BF_GRAM_THREADS) void bfJacobiGramKernel(BfSvdProb 
         if (g == 0) {
           uint32_t const kk = l / 4, sub = l % 4;
           int any = 0;
-          for (int inner = 0; inner < 2; ++inner) {
+          for (int inner = 0; inner < BF_GRAM_INNER; ++inner) {
             for (uint32_t s = 0; s + 1 < BF_GRAM_P; ++s) {
               uint32_t p, q;
               bfRoundRobin(BF_GRAM_P, s, kk, p, q);
