@@ -129,6 +129,15 @@ def test_full_operator_fp32_fp64_linearity_adjoint_and_factor_chain(operand):
         opf.close()
     assert rel(cur.cpu().numpy(), y32.cpu().numpy()) <= 1e-5
     operand["op32"], operand["x32"], operand["y32"], operand["t32"], operand["v32"] = op32, x32, y32, t32, v32
+    # the packed copy for A^T (what bench.py --adjoint runs: the transposed expression on the forward kernels, runs of narrow
+    # pieces contracted as one block, >= 32768 items per stage) against the transposed kernels on the shared leaves
+    opp = HipOperator.from_desc(desc, None, seed=3, flags=_capi.FLAG_ADJOINT_PACKED, demote_to_f32=True)
+    tp = opp.apply_transpose_device(v32).clone()
+    assert rel(tp.cpu().numpy(), t32.cpu().numpy()) <= 2e-5
+    assert rel(tp.cpu().numpy(), t64.cpu().numpy()) <= 2e-5
+    assert torch.equal(opp.apply_device(x32), y32)                                  # its forward plan is the same plan
+    assert torch.equal(opp.apply_transpose_device(v32), tp)                         # reproducible
+    opp.close()
 
 
 def test_save_load_round_trip(operand, tmp_path):
