@@ -491,9 +491,10 @@ __global__ __launch_bounds__(1024) void bfJacobiKernel(BfSvdProb const *probs, u
 // stacked columns of a block fit, an inner step keeps 2 - 5 of 16 wavefronts busy and every block pair is a round trip
 // of its columns for a handful of rotations).  Here a block is 16 columns whatever their length.  For a pair of blocks
 // (32 columns Xp):
-//   A. G = Xp^H Xp, 32 x 32, one pass over the rows (32-row chunks staged in LDS, 4 x 4 register blocks, 8 row slices);
-//   B. two-sided Jacobi on G in LDS by ONE wavefront (no barriers; 16 disjoint rotations per round-robin step, 4 lanes
-//      each; the same rotation formula and the same thresholds as the scalar kernel -- the inner products it would
+//   A. G = Xp^H Xp, 32 x 32, one pass over the rows (32-row chunks staged in LDS, 4 x 4 register blocks, 8 row slices;
+//      accumulating only the upper triangle -- 36 blocks x 14 slices -- measured no faster);
+//   B. two-sided Jacobi on G in LDS (16 disjoint rotations per round-robin step, four to a wavefront on each of the four
+//      SIMDs, 16 lanes each; the same rotation formula and the same thresholds as the scalar kernel -- the inner products it would
 //      compute are the entries of G), one sweep, the rotations accumulated in Q (32 x 32);
 //   C. [Xp; Vp] <- [Xp; Vp] Q, one thread per row, the row's 32 values in registers, Q broadcast from LDS.
 // The next outer sweep forms every G afresh from the columns, so what an inner solve leaves undone (its later rotations
@@ -627,24 +628,27 @@ __global__ __launch_bounds__(BF_GRAM_THREADS) void bfJacobiGramKernel(BfSvdProb 
             __syncthreads();
           }
         }
-        // ---- B: two-sided Jacobi on G by one wavefront; Q accumulates the rotations
-        if (g == 0) {
-          uint32_t const kk = l / 4, sub = l % 4;
-          int any = 0;
+        // ---- B: two-sided Jacobi on G; Q accumulates the rotations.  Wavefronts 0 - 3 (one per SIMD) take four of the 16
+        // disjoint rotations of a round-robin step each, 16 lanes per rotation; the others only keep the barriers.
+        {
+          bool const worker = tid < 256;
+          uint32_t const kk = tid / 16, sub = tid % 16;
           for (int inner = 0; inner < BF_GRAM_INNER; ++inner) {
             for (uint32_t s = 0; s + 1 < BF_GRAM_P; ++s) {
-              uint32_t p, q;
-              bfRoundRobin(BF_GRAM_P, s, kk, p, q);
-              double2 const gpq = G[p * BF_GRAM_LD + q];
-              double const alpha = G[p * BF_GRAM_LD + p].x, beta = G[q * BF_GRAM_LD + q].x;
-              double c, sn, er, ei;
-              bool const rot = bfJacobiAngle(alpha, beta, gpq.x, gpq.y, tol2, dead2, c, sn, er, ei);
-              bfWaveSync();
+              uint32_t p = 0, q = 1;
+              double c = 1, sn = 0, er = 1, ei = 0;
+              bool rot = false;
+              if (worker) {
+                bfRoundRobin(BF_GRAM_P, s, kk, p, q);
+                double2 const gpq = G[p * BF_GRAM_LD + q];
+                rot = bfJacobiAngle(G[p * BF_GRAM_LD + p].x, G[q * BF_GRAM_LD + q].x, gpq.x, gpq.y, tol2, dead2, c, sn, er, ei);
+              }
+              __syncthreads();                                       // every rotation of the step has read its inputs
               if (rot) {
-                if (inner == 0) any = 1;
+                if (inner == 0 && sub == 0) { pairRot = 1; rotated = 1; }
 #pragma unroll
-                for (int t = 0; t < BF_GRAM_P / 4; ++t) {                 // columns p, q of G and of Q
-                  uint32_t const i = sub + 4 * t;
+                for (int t = 0; t < BF_GRAM_P / 16; ++t) {                // columns p, q of G and of Q
+                  uint32_t const i = sub + 16 * t;
                   double2 x = G[i * BF_GRAM_LD + p], y = G[i * BF_GRAM_LD + q];
                   double2 yt = make_double2(er * y.x - ei * y.y, er * y.y + ei * y.x);
                   G[i * BF_GRAM_LD + p] = make_double2(c * x.x - sn * yt.x, c * x.y - sn * yt.y);
@@ -655,22 +659,20 @@ __global__ __launch_bounds__(BF_GRAM_THREADS) void bfJacobiGramKernel(BfSvdProb 
                   Q[i * BF_GRAM_LD + q] = make_double2(sn * x.x + c * yt.x, sn * x.y + c * yt.y);
                 }
               }
-              bfWaveSync();
+              __syncthreads();
               if (rot) {
 #pragma unroll
-                for (int t = 0; t < BF_GRAM_P / 4; ++t) {                 // rows p, q of G: J^H G, conj(e) on row q
-                  uint32_t const j = sub + 4 * t;
+                for (int t = 0; t < BF_GRAM_P / 16; ++t) {                // rows p, q of G: J^H G, conj(e) on row q
+                  uint32_t const j = sub + 16 * t;
                   double2 const x = G[p * BF_GRAM_LD + j], y = G[q * BF_GRAM_LD + j];
                   double2 const yt = make_double2(er * y.x + ei * y.y, er * y.y - ei * y.x);
                   G[p * BF_GRAM_LD + j] = make_double2(c * x.x - sn * yt.x, c * x.y - sn * yt.y);
                   G[q * BF_GRAM_LD + j] = make_double2(sn * x.x + c * yt.x, sn * x.y + c * yt.y);
                 }
               }
-              bfWaveSync();
+              __syncthreads();
             }
           }
-          any = __any(any);
-          if (l == 0 && any) { pairRot = 1; rotated = 1; }
         }
         __syncthreads();
         // ---- C: the pair's columns of [X; V] times Q
