@@ -453,13 +453,34 @@ __device__ __forceinline__ void bfStageBodyReal(StageParams const &p, uint32_t c
         uint32_t const nfull = n / g;
         uint32_t j = c;
         uint32_t s = 0;
-#pragma unroll 8
-        for (; s < nfull; ++s) {
-          V a = bfLoadStreamV(ap + (uint64_t)s * G);
-          S xv = xs[j];
+        // whole groups of 8 steps, then the ragged end with ITS loads issued together as well (the compiler's remainder
+        // loop waits for every load on its own: up to 7 memory round trips per run; bfhip_stage_c128.h)
+        V a8[8];
+#pragma unroll 1
+        for (; s + 8 <= nfull; s += 8) {
 #pragma unroll
-          for (int e = 0; e < EPL; ++e) acc[e] = fma(a.v[e], xv, acc[e]);
-          j += g;
+          for (int k = 0; k < 8; ++k) a8[k] = bfLoadStreamV(ap + (uint64_t)(s + k) * G);
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            S const xv = xs[j];
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) acc[e] = fma(a8[k].v[e], xv, acc[e]);
+            j += g;
+          }
+        }
+        if (s < nfull) {                                         // wave-uniform
+          uint32_t const left = nfull - s;
+#pragma unroll
+          for (int k = 0; k < 7; ++k)
+            if ((uint32_t)k < left) a8[k] = bfLoadStreamV(ap + (uint64_t)(s + k) * G);
+#pragma unroll
+          for (int k = 0; k < 7; ++k)
+            if ((uint32_t)k < left) {
+              S const xv = xs[j];
+#pragma unroll
+              for (int e = 0; e < EPL; ++e) acc[e] = fma(a8[k].v[e], xv, acc[e]);
+              j += g;
+            }
         }
         uint32_t const rem = n - nfull * g;
         if (active && c < rem) {

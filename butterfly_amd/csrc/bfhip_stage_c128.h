@@ -123,13 +123,35 @@ __device__ __forceinline__ void bfItemC128(StageParams const &p, BfDevItem const
       uint32_t const nfull = n / g;
       uint32_t j = c;
       uint32_t s = 0;
-#pragma unroll BF_C128_UNROLL
-      for (; s < nfull; ++s) {
-        double2 a = bfLoadStream(ap + (uint64_t)s * G);
-        double2 xv = xs[j];
-        accr = fma(a.x, xv.x, accr); accr = fma(-a.y, xv.y, accr);
-        acci = fma(a.x, xv.y, acci); acci = fma(a.y, xv.x, acci);
-        j += g;
+      // whole groups of BF_C128_UNROLL steps: their loads are issued together ...
+      double2 a[BF_C128_UNROLL];
+#pragma unroll 1
+      for (; s + BF_C128_UNROLL <= nfull; s += BF_C128_UNROLL) {
+#pragma unroll
+        for (int k = 0; k < BF_C128_UNROLL; ++k) a[k] = bfLoadStream(ap + (uint64_t)(s + k) * G);
+#pragma unroll
+        for (int k = 0; k < BF_C128_UNROLL; ++k) {
+          double2 const xv = xs[j];
+          accr = fma(a[k].x, xv.x, accr); accr = fma(-a[k].y, xv.y, accr);
+          acci = fma(a[k].x, xv.y, acci); acci = fma(a[k].y, xv.x, acci);
+          j += g;
+        }
+      }
+      // ... and so are those of the ragged end (left to the compiler's remainder loop every one of its up to 7 steps waited
+      // for its own load: a memory round trip each, on pieces of 60 - 250 columns -- N = 65536, row shards -- a tenth of an item)
+      if (s < nfull) {                                           // wave-uniform
+        uint32_t const left = nfull - s;                         // 1 .. BF_C128_UNROLL - 1
+#pragma unroll
+        for (int k = 0; k < BF_C128_UNROLL - 1; ++k)
+          if ((uint32_t)k < left) a[k] = bfLoadStream(ap + (uint64_t)(s + k) * G);
+#pragma unroll
+        for (int k = 0; k < BF_C128_UNROLL - 1; ++k)
+          if ((uint32_t)k < left) {
+            double2 const xv = xs[j];
+            accr = fma(a[k].x, xv.x, accr); accr = fma(-a[k].y, xv.y, accr);
+            acci = fma(a[k].x, xv.y, acci); acci = fma(a[k].y, xv.x, acci);
+            j += g;
+          }
       }
       uint32_t const rem = n - nfull * g;
       if (active && c < rem) {
