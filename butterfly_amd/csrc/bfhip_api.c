@@ -738,6 +738,7 @@ static int runPlan(BfhipOperator *op, BfPlan *plan, void const *dX, size_t nrhs,
           BfReduce *rd = &st->reduce[r0 + r];
           ra[r].rowInterval = rd->dRowInterval; ra[r].ivBegin = rd->dIvBegin; ra[r].srcBias = rd->dSrcBias;
           ra[r].numRows = rd->numRows; ra[r].temp = op->dTemp; ra[r].nrhs = (uint32_t)nrhs; ra[r].dtype = plan->dtype;
+          ra[r].longLists = rd->maxSrc >= 64; ra[r].pad = 0;
           ra[r].dest = dY;          /* flowOk: every reduce sums into y */
         }
         if ((rc = bfdevLaunchReduce(ra, cnt, stream))) goto out;
@@ -765,6 +766,7 @@ static int runPlan(BfhipOperator *op, BfPlan *plan, void const *dX, size_t nrhs,
         BfReduce *rd = &st->reduce[r0 + r];
         ra[r].rowInterval = rd->dRowInterval; ra[r].ivBegin = rd->dIvBegin; ra[r].srcBias = rd->dSrcBias;
         ra[r].numRows = rd->numRows; ra[r].temp = op->dTemp; ra[r].nrhs = (uint32_t)nrhs; ra[r].dtype = plan->dtype;
+        ra[r].longLists = rd->maxSrc >= 64; ra[r].pad = 0;
         ra[r].dest = rd->destSpace == BF_SPACE_Y ? dY : (void *)((char *)op->dTemp + rd->destOff * nrhs * plan->elemSize);
       }
       if ((rc = bfdevLaunchReduce(ra, cnt, stream))) goto out;
@@ -1182,6 +1184,7 @@ static int validateReduce(BfPlan const *pl, BfReduce const *rd, uint32_t const *
     if (ivBegin[i + 1] < ivBegin[i]) return bfhipFail(BFABI_ERROR_FILE_ERROR, "corrupt operator file: reduce interval table not monotone");
   for (uint64_t r = 0; r < rd->numRows; ++r) {
     uint32_t const iv = rowInterval[r];
+    if (iv == BF_REDUCE_SKIP) continue;
     if (iv >= rd->numIntervals) return bfhipFail(BFABI_ERROR_FILE_ERROR, "corrupt operator file: reduce row %llu", (unsigned long long)r);
     for (uint32_t k = ivBegin[iv]; k < ivBegin[iv + 1]; ++k) {
       int64_t src;
@@ -1248,6 +1251,11 @@ static int loadPlan(FILE *fp, BfhipOperator *op, BfPlan *pl, FileHeader const *f
       if (!rc) rc = readMetaArray(fp, &rd->dIvBegin, &hIv, (rd->numIntervals + 1) * 4, &op->metaBytes);
       if (!rc) rc = readMetaArray(fp, &rd->dSrcBias, &hBias, rd->numSrc * 8, &op->metaBytes);
       if (!rc) rc = validateReduce(pl, rd, hRow, hIv, hBias);
+      if (!rc) {
+        uint32_t const *iv = hIv;
+        rd->maxSrc = 0;
+        for (uint64_t i = 0; i < rd->numIntervals; ++i) if (iv[i + 1] - iv[i] > rd->maxSrc) rd->maxSrc = iv[i + 1] - iv[i];
+      }
       free(hRow); free(hIv); free(hBias);
     }
   }

@@ -819,7 +819,7 @@ struct ReduceBatch {
   } e[BF_REDUCE_BATCH];
 };
 
-template <typename T, int NC>   // NC = scalar components per element
+template <typename T, int NC, bool LONG = false>   // NC = scalar components per element; LONG: some row has >= 64 partial sums
 __global__ __launch_bounds__(256) void bfReduceKernel(ReduceBatch const B) {
   uint32_t k = 0;
   while (k + 1 < B.count && B.e[k + 1].blockBegin <= blockIdx.x) ++k;
@@ -831,14 +831,34 @@ __global__ __launch_bounds__(256) void bfReduceKernel(ReduceBatch const B) {
   uint64_t row = idx / nrhs;
   uint32_t q = (uint32_t)(idx - row * nrhs);
   uint32_t iv = E.rowInterval[row];
+  if (iv == 0xffffffffu) return;              // BF_REDUCE_SKIP: the one group that owns this row wrote it where it belongs
   uint32_t b = E.ivBegin[iv], e = E.ivBegin[iv + 1];
   T const *temp = (T const *)B.temp;
   T *dest = (T *)E.dest;
   T acc[NC];
 #pragma unroll
   for (int c = 0; c < NC; ++c) acc[c] = 0;
+  uint32_t s = b;
+  if (LONG) {
+    // a long list (a block column cut into hundreds of groups: a finely cut stage of a packed adjoint plan has rows with ~1000
+    // partial sums) 32 loads at a time: with 8 in flight its few wavefronts were the whole launch (86 us; 59 so).  Its own
+    // instantiation: in the common one the 32 registers cost occupancy (12 -> 20 us on a 1.3 M-row reduce).
+    for (; s + 32 <= e; s += 32) {
+      T v[32][NC];
+#pragma unroll
+      for (int k = 0; k < 32; ++k) {
+        T const *src = temp + ((uint64_t)(E.srcBias[s + k] + (int64_t)row) * nrhs + q) * NC;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) v[k][c] = src[c];
+      }
+#pragma unroll
+      for (int k = 0; k < 32; ++k)
+#pragma unroll
+        for (int c = 0; c < NC; ++c) acc[c] += v[k][c];
+    }
+  }
 #pragma unroll 8
-  for (uint32_t s = b; s < e; ++s) {          // same order as before; the unrolled loads are issued together
+  for (; s < e; ++s) {          // same order as before; the unrolled loads are issued together
     T const *src = temp + ((uint64_t)(E.srcBias[s] + (int64_t)row) * nrhs + q) * NC;
 #pragma unroll
     for (int c = 0; c < NC; ++c) acc[c] += src[c];
@@ -1287,8 +1307,12 @@ int bfdevLaunchReduce(BfReduceArgs const *a, uint32_t count, void *stream) {
     }
     if (!blocks) continue;
     uint32_t const dtype = a[base].dtype;
+    bool longLists = false;
+    for (uint32_t k = 0; k < B.count; ++k) longLists = longLists || a[base + k].longLists;
     if (dtype == BFHIP_C128) hipLaunchKernelGGL((bfReduceKernel<double, 2>), dim3(blocks), dim3(256), 0, s, B);
+    else if (dtype == BFHIP_F64 && longLists) hipLaunchKernelGGL((bfReduceKernel<double, 1, true>), dim3(blocks), dim3(256), 0, s, B);
     else if (dtype == BFHIP_F64) hipLaunchKernelGGL((bfReduceKernel<double, 1>), dim3(blocks), dim3(256), 0, s, B);
+    else if (longLists) hipLaunchKernelGGL((bfReduceKernel<float, 1, true>), dim3(blocks), dim3(256), 0, s, B);
     else hipLaunchKernelGGL((bfReduceKernel<float, 1>), dim3(blocks), dim3(256), 0, s, B);
     int rc = hipFail(hipGetLastError(), "reduce launch");
     if (rc) return rc;

@@ -21,6 +21,7 @@ int bfhipFail(int code, char const *fmt, ...);   /* records message, returns cod
 /* ------------------------------------------------------------------------
  * IR: owned copy of a BfhipDesc (or of a walked BfMat graph)
  * ---------------------------------------------------------------------- */
+#define BF_REDUCE_SKIP 0xffffffffu
 #define BF_LEAF_REAL 1u
 #define BF_LEAF_CONJ 2u
 typedef struct BfIr {
@@ -111,10 +112,11 @@ typedef struct BfReduce {
   uint64_t destOff;         /* element offset in dest space */
   uint64_t numRows;
   uint64_t numIntervals;
-  uint32_t *rowInterval;    /* [numRows] interval id of each row */
+  uint32_t *rowInterval;    /* [numRows] interval id of each row; BF_REDUCE_SKIP: the row is written directly by the one group that owns it */
   uint32_t *ivBegin;        /* [numIntervals+1] CSR into srcBias */
   int64_t *srcBias;         /* per source: (slot offset in arena) - (first row of the group) */
   uint64_t numSrc;
+  uint32_t maxSrc;          /* longest source list of an interval (not stored in files: recomputed on load) */
   /* device copies */
   void *dRowInterval, *dIvBegin, *dSrcBias;
 } BfReduce;
@@ -284,6 +286,8 @@ typedef struct BfReduceArgs {
   void *dest;            /* already offset to destOff*nrhs */
   uint32_t nrhs;
   uint32_t dtype;
+  uint32_t longLists;    /* some row has >= 64 partial sums: the launch uses the kernel that loads them 32 at a time */
+  uint32_t pad;
 } BfReduceArgs;
 /* all `count` reduces (one stage; same temp / nrhs / dtype) in as few launches as possible */
 int bfdevLaunchReduce(BfReduceArgs const *a, uint32_t count, void *stream);

@@ -789,8 +789,6 @@ int bfPlanBuild(BfIr const *ir, BfPlanOptions const *po, BfPlan *plan) {
           uint64_t nbp = 0;
           bp[nbp++] = 0; bp[nbp++] = blen;
           for (uint64_t g = gi; g < gj; ++g) {
-            groups[g].reduced = 1;
-            groups[g].slotOff = arenaAlloc(&top, groups[g].rows);
             bp[nbp++] = groups[g].outOff; bp[nbp++] = groups[g].outOff + groups[g].rows;
           }
           qsort(bp, nbp, 8, cmpU64);
@@ -803,8 +801,6 @@ int bfPlanBuild(BfIr const *ir, BfPlanOptions const *po, BfPlan *plan) {
           rd->rowInterval = malloc((blen ? blen : 1) * 4);
           rd->ivBegin = calloc(niv + 2, 4);
           if (!rd->rowInterval || !rd->ivBegin) { free(bp); free(seen); rc = bfhipFail(BFABI_ERROR_MEMORY_ERROR, "host OOM"); goto stage_fail; }
-          for (uint64_t i = 0; i < niv; ++i)
-            for (uint64_t r = bp[i]; r < bp[i + 1]; ++r) rd->rowInterval[r] = (uint32_t)i;
           /* count sources per interval */
           uint64_t nsrc = 0;
           for (uint64_t g = gi; g < gj; ++g) {
@@ -813,6 +809,32 @@ int bfPlanBuild(BfIr const *ir, BfPlanOptions const *po, BfPlan *plan) {
             uint64_t endRow = groups[g].outOff + groups[g].rows;
             for (uint64_t i = lo; i < niv && bp[i] < endRow; ++i) { ++rd->ivBegin[i + 1]; ++nsrc; }
           }
+          /* A group that meets no other group writes where it would without the overlap of its neighbours, and the reduce
+           * leaves its rows alone (row interval BF_REDUCE_SKIP): the block columns of a packed adjoint plan of a streamed
+           * butterfly are cut into several groups only where they are long, and 80 - 96 % of the rows of its stages have
+           * exactly one source -- as slots they were written, read and copied once more for nothing.  (Real operands: the
+           * overlaps of a complex fac_helm2 plan are whole block rows, every row has several sources.) */
+          uint8_t *skip = calloc(niv + 1, 1);
+          if (!skip) { free(bp); free(seen); rc = bfhipFail(BFABI_ERROR_MEMORY_ERROR, "host OOM"); goto stage_fail; }
+          for (uint64_t g = gi; g < gj; ++g) {
+            uint64_t lo = 0, hi = nbp;
+            while (lo < hi) { uint64_t mid = (lo + hi) / 2; if (bp[mid] < groups[g].outOff) lo = mid + 1; else hi = mid; }
+            uint64_t endRow = groups[g].outOff + groups[g].rows;
+            int alone = plan->dtype != BFHIP_C128;
+            for (uint64_t i = lo; alone && i < niv && bp[i] < endRow; ++i) alone = rd->ivBegin[i + 1] == 1;
+            if (alone) {
+              for (uint64_t i = lo; i < niv && bp[i] < endRow; ++i) { skip[i] = 1; rd->ivBegin[i + 1] = 0; --nsrc; }
+              groups[g].reduced = 0;
+            } else {
+              groups[g].reduced = 1;
+              groups[g].slotOff = arenaAlloc(&top, groups[g].rows);
+            }
+          }
+          for (uint64_t i = 0; i < niv; ++i)
+            for (uint64_t r = bp[i]; r < bp[i + 1]; ++r) rd->rowInterval[r] = skip[i] ? BF_REDUCE_SKIP : (uint32_t)i;
+          free(skip);
+          rd->maxSrc = 0;
+          for (uint64_t i = 0; i < niv; ++i) { if (rd->ivBegin[i + 1] > rd->maxSrc) rd->maxSrc = rd->ivBegin[i + 1]; }
           for (uint64_t i = 0; i < niv; ++i) rd->ivBegin[i + 1] += rd->ivBegin[i];
           rd->numSrc = nsrc;
           rd->srcBias = malloc((nsrc ? nsrc : 1) * 8);
@@ -820,6 +842,7 @@ int bfPlanBuild(BfIr const *ir, BfPlanOptions const *po, BfPlan *plan) {
           if (!rd->srcBias || !fill) { free(fill); free(bp); free(seen); rc = bfhipFail(BFABI_ERROR_MEMORY_ERROR, "host OOM"); goto stage_fail; }
           /* deterministic order: groups in (outOff, rows, emission) order */
           for (uint64_t g = gi; g < gj; ++g) {
+            if (!groups[g].reduced) continue;
             uint64_t lo = 0, hi = nbp;
             while (lo < hi) { uint64_t mid = (lo + hi) / 2; if (bp[mid] < groups[g].outOff) lo = mid + 1; else hi = mid; }
             uint64_t endRow = groups[g].outOff + groups[g].rows;

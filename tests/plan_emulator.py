@@ -141,10 +141,13 @@ def run_plan(op, x, transpose=False):
             dest = y if rv.destIsY else temp[int(rv.destOff):]
             rows = np.arange(int(rv.numRows))
             out = np.zeros((int(rv.numRows), nrhs), dtype=dt)
-            cnt = iv_begin[row_iv + 1] - iv_begin[row_iv]
+            keep = row_iv != 0xFFFFFFFF           # BF_REDUCE_SKIP: written directly by the one group that owns the row
+            assert keep.all() or info.dtype != 0
+            riv = np.where(keep, row_iv, 0)
+            cnt = np.where(keep, iv_begin[riv + 1] - iv_begin[riv], 0)
             for k in range(int(cnt.max()) if len(cnt) else 0):
                 sel = cnt > k
-                src_rows = bias[iv_begin[row_iv[sel]] + k] + rows[sel]
+                src_rows = bias[iv_begin[riv[sel]] + k] + rows[sel]
                 out[sel] += temp[src_rows]
-            dest[:int(rv.numRows)] = out
+            dest[:int(rv.numRows)][keep] = out[keep]
     return y[:, 0] if one_d else y
