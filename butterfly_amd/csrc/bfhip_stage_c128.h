@@ -48,7 +48,9 @@ __device__ __forceinline__ void waveSync() {
 
 
 #ifndef BF_C128_UNROLL
-#define BF_C128_UNROLL 8
+#define BF_C128_UNROLL 12       /* loads of a contraction issued together.  8 until late in round 4 (78 VGPRs, 6 wavefronts per SIMD once the
+                                 * ragged end was batched); 10 / 12 / 14 / 16 (87 - 120 VGPRs, 5 or 4 wavefronts) alternated with it on two
+                                 * boxes: headline -0.2 %, N = 65536 -1.2 ... -2.4 %, slowest 1/8 shard -0.7 ... -1.5 %, no clear order among them */
 #endif
 // Wavefronts per workgroup of this kernel.  A wavefront slot is refilled only when a whole workgroup's worth of slots is
 // free on its CU: with 4-wavefront workgroups of unequal items, per-item timelines (tools/timeline.py) show 10 - 15 % of
