@@ -281,6 +281,9 @@ __global__ __launch_bounds__(BF_WAVES_PER_WG * 64) __attribute__((amdgpu_waves_p
 // ---------------------------------------------------------------------------
 // real stage kernel (f64: 2 rows per lane, f32: 4 rows per lane)
 // ---------------------------------------------------------------------------
+#ifndef BF_REAL_UNROLL
+#define BF_REAL_UNROLL 8
+#endif
 template <int DT>
 __device__ __forceinline__ void bfStageBodyReal(StageParams const &p, uint32_t const bid, unsigned char (*ldsRaw)[BF_WAVE_LDS_BYTES]) {
   using S = typename Traits<DT>::S;
@@ -455,13 +458,13 @@ __device__ __forceinline__ void bfStageBodyReal(StageParams const &p, uint32_t c
         uint32_t s = 0;
         // whole groups of 8 steps, then the ragged end with ITS loads issued together as well (the compiler's remainder
         // loop waits for every load on its own: up to 7 memory round trips per run; bfhip_stage_c128.h)
-        V a8[8];
+        V a8[BF_REAL_UNROLL];
 #pragma unroll 1
-        for (; s + 8 <= nfull; s += 8) {
+        for (; s + BF_REAL_UNROLL <= nfull; s += BF_REAL_UNROLL) {
 #pragma unroll
-          for (int k = 0; k < 8; ++k) a8[k] = bfLoadStreamV(ap + (uint64_t)(s + k) * G);
+          for (int k = 0; k < BF_REAL_UNROLL; ++k) a8[k] = bfLoadStreamV(ap + (uint64_t)(s + k) * G);
 #pragma unroll
-          for (int k = 0; k < 8; ++k) {
+          for (int k = 0; k < BF_REAL_UNROLL; ++k) {
             S const xv = xs[j];
 #pragma unroll
             for (int e = 0; e < EPL; ++e) acc[e] = fma(a8[k].v[e], xv, acc[e]);
@@ -471,10 +474,10 @@ __device__ __forceinline__ void bfStageBodyReal(StageParams const &p, uint32_t c
         if (s < nfull) {                                         // wave-uniform
           uint32_t const left = nfull - s;
 #pragma unroll
-          for (int k = 0; k < 7; ++k)
+          for (int k = 0; k < BF_REAL_UNROLL - 1; ++k)
             if ((uint32_t)k < left) a8[k] = bfLoadStreamV(ap + (uint64_t)(s + k) * G);
 #pragma unroll
-          for (int k = 0; k < 7; ++k)
+          for (int k = 0; k < BF_REAL_UNROLL - 1; ++k)
             if ((uint32_t)k < left) {
               S const xv = xs[j];
 #pragma unroll
