@@ -513,11 +513,6 @@ __global__ __launch_bounds__(1024) void bfJacobiKernel(BfSvdProb const *probs, u
 #define BF_GRAM_INNER 1                  /* sweeps of the inner solve per visit of a block pair (2: 10.2 instead of 10.5 outer sweeps on
                                           * average, but the one-wavefront solve is half of a visit's time: 4.66 against 3.76 s per batch) */
 
-__device__ __forceinline__ void bfWaveSync() {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
 
 __global__ __launch_bounds__(BF_GRAM_THREADS) void bfJacobiGramKernel(BfSvdProb const *probs, uint32_t const *list, BfSvdStats *stats) {
   constexpr int W = 64;
