@@ -511,7 +511,7 @@ __global__ __launch_bounds__(1024) void bfJacobiKernel(BfSvdProb const *probs, u
 #define BF_GRAM_MAX_COLS 4096
 #define BF_GRAM_NONE 0xffffu
 #define BF_GRAM_INNER 1                  /* sweeps of the inner solve per visit of a block pair (2: 10.2 instead of 10.5 outer sweeps on
-                                          * average, but the one-wavefront solve is half of a visit's time: 4.66 against 3.76 s per batch) */
+                                          * average, but the solve -- then by one wavefront -- was half of a visit's time: 4.66 against 3.76 s per batch) */
 
 
 __global__ __launch_bounds__(BF_GRAM_THREADS) void bfJacobiGramKernel(BfSvdProb const *probs, uint32_t const *list, BfSvdStats *stats) {
