@@ -403,6 +403,24 @@ static int ensureTemp(BfhipOperator *op, uint32_t nrhs) {
   return 0;
 }
 
+/* The adjoint plan over the forward plan's packed leaves (BFHIP_FLAG_ADJOINT): index metadata only.  Needs the forward plan's
+ * host mirrors.  Row-range / row-block shards: the transposed plan of the shard's own tasks (bfPlanBuild prunes the same way). */
+static int buildSharedTplan(BfhipOperator *op, BfIr const *ir, BfPlanOptions const *po) {
+  BfFwdPiece *fwd = NULL;
+  uint64_t nf = 0;
+  int rc = bfPlanFwdPieces(&op->plan, &fwd, &nf);
+  if (rc) return rc;
+  BfPlanOptions pt = *po;
+  pt.itemsWanted = 0;
+  pt.fwdPieces = fwd;
+  pt.numFwdPieces = nf;
+  pt.tCols = 0;      /* item width (16 or 64 columns of A) chosen stage by stage */
+  rc = bfPlanBuild(ir, &pt, &op->tplan);
+  free(fwd);
+  if (!rc) { op->hasTplan = 1; op->packedT = 0; }
+  return rc;
+}
+
 int bfhipCompileIrFill(BfIr *ir, BfhipOptions const *opts, BfFillFn fill, void *fillCtx, BfhipOperator **out) {
   BfhipOptions o;
   memset(&o, 0, sizeof o);
@@ -416,6 +434,8 @@ int bfhipCompileIrFill(BfIr *ir, BfhipOptions const *opts, BfFillFn fill, void *
   int rc = 0;
   int prevDev = -1;
   int const planOnly = (o.flags & BFHIP_FLAG_PLAN_ONLY) != 0;
+  BfIr irT;                      /* the transposed expression of a packed adjoint plan: released under `done` on every path */
+  memset(&irT, 0, sizeof irT);
   op->flags = o.flags;
   op->seed = o.seed;
 #ifndef BFHIP_EXPERIMENTAL
@@ -449,11 +469,10 @@ int bfhipCompileIrFill(BfIr *ir, BfhipOptions const *opts, BfFillFn fill, void *
   /* The adjoint plan.  BFHIP_FLAG_ADJOINT_PACKED: a FORWARD plan of the transposed expression over its own packed copy of the
    * leaves (twice the leaf memory; A^T x then runs on the forward kernels at the forward rate).  Not with a caller-side
    * value builder (its values exist in the forward arena only) and not plan-only: those get the shared-leaf plan below. */
-  BfIr irT;
-  memset(&irT, 0, sizeof irT);
-  int const packedT = (o.flags & BFHIP_FLAG_ADJOINT_PACKED) && !fill;      /* (plan-only: the plan can be inspected, bfhipPlanPackArena packs the forward arena only) */
+  /* (a row shard's adjoint is the shared-leaf plan as well: its input is the shard's rows of v, its transposed expression would have
+   *  to be pruned by COLUMNS -- bfPlanBuild prunes the transposed task list instead, pruneToRowRangeT) */
+  int packedT = (o.flags & BFHIP_FLAG_ADJOINT_PACKED) && !fill && !(po.rowEnd > 0 || po.rowBlockEnd > 0);
   if (packedT) {
-    if (po.rowEnd > 0 || po.rowBlockEnd > 0) { rc = bfhipFail(BFABI_ERROR_NOT_IMPLEMENTED, "BFHIP_FLAG_ADJOINT_PACKED on a row-sharded operator"); goto done; }
     if ((rc = bfIrTransposed(ir, &irT))) goto done;
     BfPlanOptions pt = po;
     /* The block columns of a real (streamed) butterfly are long -- hundreds of leaves -- and the 1 MiB item cap leaves a stage of
@@ -462,28 +481,17 @@ int bfhipCompileIrFill(BfIr *ir, BfhipOptions const *opts, BfFillFn fill, void *
      * (fac_helm2) plans keep 4096: their stages are 10 GB, the cap binds either way and more items measured 1-2 % slower, as did
      * more items in the FORWARD plan of either operand. */
     if (op->plan.dtype != BFHIP_C128) pt.itemsWanted = 32768;
-    if ((rc = bfPlanBuild(&irT, &pt, &op->tplan))) { bfIrFree(&irT); goto done; }
+    if ((rc = bfPlanBuild(&irT, &pt, &op->tplan))) goto done;
     op->hasTplan = 1;
     op->packedT = 1;
     if (planOnly) {          /* kept for bfhipPlanPackArenaT */
       op->irT = malloc(sizeof *op->irT);
-      if (!op->irT) { bfIrFree(&irT); rc = bfhipFail(BFABI_ERROR_MEMORY_ERROR, "host OOM"); goto done; }
+      if (!op->irT) { rc = bfhipFail(BFABI_ERROR_MEMORY_ERROR, "host OOM"); goto done; }
       *op->irT = irT;
       memset(&irT, 0, sizeof irT);
     }
   } else if (o.flags & (BFHIP_FLAG_ADJOINT | BFHIP_FLAG_ADJOINT_PACKED)) {
-    BfFwdPiece *fwd = NULL;
-    uint64_t nf = 0;
-    if ((rc = bfPlanFwdPieces(&op->plan, &fwd, &nf))) goto done;
-    BfPlanOptions pt = po;
-    if (po.rowEnd > 0 || po.rowBlockEnd > 0) { free(fwd); rc = bfhipFail(BFABI_ERROR_NOT_IMPLEMENTED, "BFHIP_FLAG_ADJOINT on a row-sharded operator"); goto done; }
-    pt.fwdPieces = fwd;
-    pt.numFwdPieces = nf;
-    pt.tCols = 0;      /* item width (16 or 64 columns of A) chosen stage by stage */
-    rc = bfPlanBuild(ir, &pt, &op->tplan);
-    free(fwd);
-    if (rc) goto done;
-    op->hasTplan = 1;
+    if ((rc = buildSharedTplan(op, ir, &po))) goto done;
   }
   if (planOnly) {
 #ifdef BFHIP_EXPERIMENTAL
@@ -504,12 +512,22 @@ int bfhipCompileIrFill(BfIr *ir, BfhipOptions const *opts, BfFillFn fill, void *
   if ((rc = uploadPlanMeta(op, &op->plan))) goto done;
   if (op->hasTplan && (rc = uploadPlanMeta(op, &op->tplan))) goto done;
   /* leaf values: computed on the device by the caller's builder, or packed / synthesized from the IR */
-  if ((rc = fill ? fill(&op->plan, ir, op->dArena, fillCtx) : packLeaves(op, ir, o.seed, NULL))) { bfIrFree(&irT); goto done; }
+  if ((rc = fill ? fill(&op->plan, ir, op->dArena, fillCtx) : packLeaves(op, ir, o.seed, NULL))) goto done;
   if (packedT) {
     rc = bfdevMalloc(&op->dArenaT, (size_t)op->tplan.arenaElems * op->tplan.elemSize + BF_ARENA_SLACK);
-    if (!rc) rc = packLeavesPlan(&op->tplan, op->dArenaT, &irT, o.seed, NULL);
-    bfIrFree(&irT);
-    if (rc) goto done;
+    if (rc == BFABI_ERROR_MEMORY_ERROR) {
+      /* no room for a second copy of the leaves (the flag doubles the leaf memory): the adjoint degrades to the shared-leaf plan
+       * on the transposed kernels instead of failing the compile */
+      op->dArenaT = NULL;
+      freeDevicePlanOf(&op->tplan);
+      bfPlanFree(&op->tplan);
+      op->hasTplan = 0; op->packedT = 0; packedT = 0;
+      if ((rc = buildSharedTplan(op, ir, &po))) goto done;
+      if ((rc = uploadPlanMeta(op, &op->tplan))) goto done;
+    } else {
+      if (!rc) rc = packLeavesPlan(&op->tplan, op->dArenaT, &irT, o.seed, NULL);
+      if (rc) goto done;
+    }
   }
 #ifdef BFHIP_EXPERIMENTAL
   {
@@ -547,6 +565,7 @@ int bfhipCompileIrFill(BfIr *ir, BfhipOptions const *opts, BfFillFn fill, void *
   }
 done:
   bfIrFree(ir);
+  bfIrFree(&irT);
   if (rc) { bfhipFree(&op); if (prevDev >= 0) bfdevSetDevice(prevDev); return rc; }
   if (prevDev >= 0 && o.device >= 0) bfdevSetDevice(prevDev);
   *out = op;

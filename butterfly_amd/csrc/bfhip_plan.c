@@ -288,6 +288,53 @@ static int pruneToRowRange(Builder *b, uint32_t bx, uint32_t by, int32_t S, uint
 }
 
 
+/* The same shard, transposed: z = A_r^T v_r, where A_r = rows [rowBegin, rowEnd) of A (what pruneToRowRange keeps) and v_r the
+ * matching entries of v -- a rank's contribution to A^T v, full length; the ranks' contributions add up (ONE all-reduce,
+ * bfhipShardedApplyTransposeDevice).  In the transposed task list data flows from v to z, so the forward plan's backward
+ * liveness becomes forward reachability: walking the stages upwards, a task is kept if any element it reads has been written by
+ * a kept task (or is an entry of v inside the range), and what it writes becomes reachable.  Tasks reading v are trimmed to the
+ * range (the shard's input is compact: rows [rowBegin, rowEnd) only).  Every kept task's leaf is one the forward shard holds
+ * (reachability from the range through a leaf <=> the forward liveness of that leaf), so the pieces are found in its arena.
+ * On return `lm` marks what must hold a defined value: every element a kept task reads, and all of z -- the gap fill writes
+ * zeros there where no kept task does. */
+static int pruneToRowRangeT(Builder *b, uint32_t bx, uint32_t by, uint64_t rowBegin, uint64_t rowEnd, LiveMap *lm) {
+  LiveMap reach;
+  int rc = liveInit(&reach, b->bufs, b->numBufs);
+  if (rc) return rc;
+  if ((rc = liveInit(lm, b->bufs, b->numBufs))) { liveFree(&reach); return rc; }
+  uint8_t *keep = calloc(b->numTasks ? b->numTasks : 1, 1);
+  uint8_t *written = calloc(b->numBufs, 1);
+  if (!keep || !written) { free(keep); free(written); liveFree(&reach); return bfhipFail(BFABI_ERROR_MEMORY_ERROR, "host OOM (liveness)"); }
+  for (uint64_t t = 0; t < b->numTasks; ++t) {       /* stages ascending: every writer of a buffer comes before its readers */
+    Task *tk = &b->tasks[t];
+    if (tk->inBuf == bx) {
+      uint64_t const lo = tk->inOff > rowBegin ? tk->inOff : rowBegin;
+      uint64_t const hi = tk->inOff + tk->cols < rowEnd ? tk->inOff + tk->cols : rowEnd;
+      if (lo >= hi) continue;
+      tk->sub0 += lo - tk->inOff;
+      if (b->ir->kind[tk->leaf] == BFHIP_NODE_IDENTITY) { tk->outOff += lo - tk->inOff; tk->rows = hi - lo; }   /* an identity copies entry i to entry i */
+      tk->inOff = lo - rowBegin;
+      tk->cols = hi - lo;
+    } else {
+      if (!liveAny(&reach, tk->inBuf, tk->inOff, tk->cols)) continue;
+      liveMark(lm, tk->inBuf, tk->inOff, tk->cols);
+    }
+    keep[t] = 1;
+    written[tk->outBuf] = 1;
+    liveMark(&reach, tk->outBuf, tk->outOff, tk->rows);
+  }
+  uint64_t w = 0;
+  for (uint64_t t = 0; t < b->numTasks; ++t) if (keep[t]) b->tasks[w++] = b->tasks[t];
+  b->numTasks = w;
+  for (uint64_t i = 2; i < b->numBufs; ++i) if (!written[i]) b->bufs[i].len = 0;
+  liveMark(lm, by, 0, b->bufs[by].len);
+  b->bufs[bx].len = rowEnd - rowBegin;
+  free(keep); free(written);
+  liveFree(&reach);
+  return 0;
+}
+
+
 /* ---- balanced row ranges for W ranks ---------------------------------------------------------------
  * cuts[0] = 0 < cuts[1] < ... < cuts[W] = rows: rank r owns rows [cuts[r], cuts[r + 1]).  A cut is only placed where
  * no leaf that writes y straddles it (a "clean" position: quadtree node boundaries in a fac_helm2 operand), so no leaf
@@ -562,7 +609,6 @@ int bfPlanBuild(BfIr const *ir, BfPlanOptions const *po, BfPlan *plan) {
      * the element size: the transposed kernel tiles a forward piece as 4 columns x 16 row units per load */
     itemRows = po->tCols > 16 ? po->tCols : 16;
     plan->maxItemRows = po->tCols ? itemRows : 64;      /* tCols == 0: chosen stage by stage below */
-    if (po->rowBlockEnd > 0 || po->rowEnd > 0) return bfhipFail(BFABI_ERROR_NOT_IMPLEMENTED, "transposed plan of a row-sharded operator");
   }
   if (po->rowEnd > 0 && po->rowBlockEnd > 0) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "row range and row-block range are exclusive");
   LiveMap lm;
@@ -596,7 +642,8 @@ int bfPlanBuild(BfIr const *ir, BfPlanOptions const *po, BfPlan *plan) {
       base[i] = acc;
       if (i >= po->rowBlockBegin && i < po->rowBlockEnd && lo[i] != UINT64_MAX) acc += hi[i] - lo[i];
     }
-    numRows = acc;
+    if (T) { numColsOp = acc; b.bufs[bx].len = acc; }      /* the shard's A^T takes the kept block rows' entries of v, compacted, and yields all of z */
+    else numRows = acc;
     /* depth of the kept part */
     uint32_t dep = 1;
     for (uint64_t c = cb; c < ce; ++c) {
@@ -608,7 +655,8 @@ int bfPlanBuild(BfIr const *ir, BfPlanOptions const *po, BfPlan *plan) {
     for (uint64_t c = cb; c < ce && !rc; ++c) {
       uint64_t rb = ir->topRowBlock[c - cb];
       if (rb < po->rowBlockBegin || rb >= po->rowBlockEnd) continue;
-      rc = emit(&b, ir->childNode[c], bx, ir->childCol0[c], by, ir->childRow0[c] - lo[rb] + base[rb], S - 1);
+      if (T) rc = emitT(&b, ir->childNode[c], bx, ir->childRow0[c] - lo[rb] + base[rb], by, ir->childCol0[c], S - 1);
+      else rc = emit(&b, ir->childNode[c], bx, ir->childCol0[c], by, ir->childRow0[c] - lo[rb] + base[rb], S - 1);
     }
     free(lo); free(hi); free(base);
     if (rc) goto fail;
@@ -648,11 +696,19 @@ int bfPlanBuild(BfIr const *ir, BfPlanOptions const *po, BfPlan *plan) {
 
   if (po->rowEnd > 0) {
     /* row-range shard: keep what rows [rowBegin, rowEnd) of y depend on (see pruneToRowRange) */
-    if (po->rowBegin >= po->rowEnd || po->rowEnd > numRows) { rc = bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "row range [%llu, %llu) outside the operator's %llu rows", (unsigned long long)po->rowBegin, (unsigned long long)po->rowEnd, (unsigned long long)numRows); goto fail; }
-    if ((rc = pruneToRowRange(&b, bx, by, S, po->rowBegin, po->rowEnd, &lm))) goto fail;
-    qsort(b.tasks, b.numTasks, sizeof(Task), cmpTask);      /* trimmed tasks may have moved */
-    numRows = po->rowEnd - po->rowBegin;
-    plan->numRows = numRows;
+    uint64_t const opRows = T ? numColsOp : numRows;       /* rows of A */
+    if (po->rowBegin >= po->rowEnd || po->rowEnd > opRows) { rc = bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "row range [%llu, %llu) outside the operator's %llu rows", (unsigned long long)po->rowBegin, (unsigned long long)po->rowEnd, (unsigned long long)opRows); goto fail; }
+    if (T) {
+      if ((rc = pruneToRowRangeT(&b, bx, by, po->rowBegin, po->rowEnd, &lm))) goto fail;
+      qsort(b.tasks, b.numTasks, sizeof(Task), cmpTask);
+      numColsOp = po->rowEnd - po->rowBegin;
+      plan->numCols = numColsOp;
+    } else {
+      if ((rc = pruneToRowRange(&b, bx, by, S, po->rowBegin, po->rowEnd, &lm))) goto fail;
+      qsort(b.tasks, b.numTasks, sizeof(Task), cmpTask);      /* trimmed tasks may have moved */
+      numRows = po->rowEnd - po->rowBegin;
+      plan->numRows = numRows;
+    }
   }
 
   /* vector arena: intermediates first */

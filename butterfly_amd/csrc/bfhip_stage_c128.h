@@ -77,6 +77,30 @@ __device__ __forceinline__ T bfConstLoad(T const *q) {
   return r.v;
 }
 
+typedef unsigned int bf_u4 __attribute__((ext_vector_type(4)));
+
+// a window of 64 piece descriptors held one per lane: a single vector load replaces one
+// dependent scalar load (an L2/HBM round trip) per piece; fields are broadcast by readlane
+struct BfPieceWin { uint32_t w[6]; };
+static_assert(sizeof(BfDevPiece) == 24, "BfDevPiece is 6 dwords");
+__device__ __forceinline__ BfPieceWin bfPieceWinLoad(BfDevPiece const *pieces, uint32_t n, int lane) {
+  BfPieceWin win;
+  uint2 const *src = (uint2 const *)(pieces + (lane < (int)n ? lane : 0));
+  uint2 a = src[0], b = src[1], c = src[2];
+  win.w[0] = a.x; win.w[1] = a.y; win.w[2] = b.x; win.w[3] = b.y; win.w[4] = c.x; win.w[5] = c.y;
+  return win;
+}
+__device__ __forceinline__ BfDevPiece bfPieceWinGet(BfPieceWin const &win, uint32_t i) {
+  BfDevPiece pc;
+  pc.dataOff = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)win.w[0], (int)i) |
+               ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)win.w[1], (int)i) << 32);
+  pc.inOff = (uint32_t)__builtin_amdgcn_readlane((int)win.w[2], (int)i);
+  pc.ncols = (uint32_t)__builtin_amdgcn_readlane((int)win.w[3], (int)i);
+  pc.flags = (uint32_t)__builtin_amdgcn_readlane((int)win.w[4], (int)i);
+  pc.ld = (uint32_t)__builtin_amdgcn_readlane((int)win.w[5], (int)i);
+  return pc;
+}
+
 struct BfNoHook { __device__ __forceinline__ void operator()() const {} };
 
 // One item: `it` is its record (index `item`: only for the timeline).  `midHook` runs once, after the first dense piece has

@@ -285,15 +285,59 @@ def test_row_ranges_of_random_nested_graphs(seed):
                 assert np.array_equal(plan_emulator.run_plan(op, x), y[int(cuts[r]):int(cuts[r + 1])])
 
 
+@pytest.mark.parametrize("seed", range(8))
+def test_transposed_plans_of_row_range_shards_add_up(seed):
+    """The adjoint of a row-range shard (BFHIP_FLAG_ADJOINT + rowBegin / rowEnd): rank r holds A_r = rows [a_r, b_r) of A and
+    applies A_r^T to ITS entries of v; the ranks' full-length results add up to A^T v (what the closing all-reduce of
+    bfhipShardedApplyTransposeDevice computes).  Arbitrary nested graphs, real (f64, f32) and complex; arbitrary range ends
+    (leaves that straddle them are entered part-way) and the clean cuts of bfhipRowPartition; BFHIP_FLAG_ADJOINT_PACKED on a
+    shard falls back to the shared-leaf plan."""
+    rng = np.random.default_rng(9100 + seed)
+    cplx = seed % 2 == 1
+    desc, vals = randgraph.random_operand(rng, depth=int(rng.integers(2, 5)), size_hint=int(rng.integers(60, 220)), cplx=cplx)
+    m, n = desc.rows[desc.root], desc.cols[desc.root]
+    v = rng.standard_normal(m) + (1j * rng.standard_normal(m) if cplx else 0)
+    want = randgraph.densify(desc, vals, desc.root).T @ v
+    for demote in ((False,) if cplx else (False, True)):
+        tol = 2e-5 if demote else 1e-12
+        for packed in (False, True):
+            flags = _capi.FLAG_PLAN_ONLY | (_capi.FLAG_ADJOINT_PACKED if packed else _capi.FLAG_ADJOINT)
+            # arbitrary ends
+            ends = sorted({0, m} | {int(e) for e in rng.integers(1, m, size=3)} if m > 1 else {0, m})
+            z = np.zeros(n, dtype=want.dtype)
+            for a, b in zip(ends[:-1], ends[1:]):
+                op = HipOperator.from_desc(desc, vals, demote_to_f32=demote, row_range=(a, b), flags=flags)
+                info = _capi.BfhipPlanInfo()
+                info.structSize = C.sizeof(info)
+                _capi.check(_capi.load().bfhipPlanGetInfo(op.handle, C.byref(info)))
+                assert int(info.reserved) == 0 and int(info.numStagesT) > 0          # the shared-leaf plan, packed flag or not
+                zr = plan_emulator.run_plan(op, v[a:b], transpose=True)
+                assert zr.shape == (n,) and not np.isnan(zr).any()
+                # the forward plan of the same operator still yields rows [a, b)
+                z += zr
+            assert rel(z + 1, want + 1) < tol
+        # the library's own cuts
+        for world in (2, 3):
+            cuts = np.zeros(world + 1, dtype=np.uint64)
+            da = _capi.DescArrays(desc)
+            if _capi.load().bfhipRowPartition(da.byref(), world, cuts.ctypes.data, None):
+                continue
+            z = np.zeros(n, dtype=want.dtype)
+            for r in range(world):
+                a, b = int(cuts[r]), int(cuts[r + 1])
+                op = HipOperator.from_desc(desc, vals, demote_to_f32=demote, row_range=(a, b), flags=_capi.FLAG_PLAN_ONLY | _capi.FLAG_ADJOINT)
+                z += plan_emulator.run_plan(op, v[a:b], transpose=True)
+            assert rel(z + 1, want + 1) < tol
+
+
 def test_row_range_arguments_are_checked(helm2_cases):
     desc, tp, vals = helm2_cases(1024, 100)
     for bad in ((5, 5), (9, 3), (0, 1025)):
         with pytest.raises(_capi.BfhipError) as e:
             HipOperator.from_desc(desc, vals, row_range=bad, **PLAN)
         assert e.value.code == 1
-    with pytest.raises(_capi.BfhipError) as e:          # the transposed plan of a shard is not defined (its input would be the shard's rows)
-        HipOperator.from_desc(desc, vals, row_range=(0, 512), flags=_capi.FLAG_PLAN_ONLY | _capi.FLAG_ADJOINT)
-    assert e.value.code == 3
+    # (round 5: the transposed plan of a shard exists -- its input is the shard's rows of v: test_transposed_plans_of_row_range_shards_add_up)
+    HipOperator.from_desc(desc, vals, row_range=(0, 512), flags=_capi.FLAG_PLAN_ONLY | _capi.FLAG_ADJOINT).close()
     with pytest.raises(_capi.BfhipError) as e:
         HipOperator.from_desc(desc, vals, row_range=(0, 512), row_blocks=(0, 1), **PLAN)
     assert e.value.code == 1
@@ -478,6 +522,24 @@ def test_transposed_plan_helm2(helm2_cases):
     assert rel(y, dense_t) < 1e-9
     # single-layer kernel on a symmetric point set: S^T = S, so A^T x must agree with A x to truncation accuracy
     assert rel(y, plan_emulator.run_plan(op, x)) < 1e-9
+
+
+def test_transposed_plans_of_helm2_row_shards_add_up(helm2_cases):
+    """A fac_helm2 operator dealt to 2, 3 and 5 ranks by bfhipRowPartition: the shards' transposed plans applied to their
+    own rows of v add up to the one-operator A^T v (to rounding: the order of additions differs)."""
+    from butterfly_amd.dist import row_partition
+    desc, tp, vals = helm2_cases(2048, 128)
+    v = hb.complex_randn(2048, 5)
+    full = HipOperator.from_desc(desc, vals, **ADJ)
+    want = plan_emulator.run_plan(full, v, transpose=True)
+    for world in (2, 3, 5):
+        cuts, loads = row_partition(desc, world)
+        z = np.zeros_like(want)
+        for r in range(world):
+            op = HipOperator.from_desc(desc, vals, row_range=(cuts[r], cuts[r + 1]), **ADJ)
+            assert op.stats()["leafElems"] == loads[r]
+            z += plan_emulator.run_plan(op, v[cuts[r]:cuts[r + 1]], transpose=True)
+        assert rel(z, want) < 1e-13
 
 
 def test_transpose_needs_the_adjoint_flag():

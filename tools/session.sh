@@ -167,4 +167,7 @@ rhssweep()   { for q in 1 2 3 4 8 16 32 48 64; do
                  step rhs_$q 200 $B --nrhs $q --steps 5 --warmup 2 --no-cpu-baseline --no-extra
                  python -c "import json; d = json.load(open('$O/rhs_$q.out')); print('nrhs $q', round(d['ms_per_step'], 3), 'ms', d['roofline']['kernel'], round(d['roofline']['frac'], 3))"
                done; }
+loopprobe()  { step loop_probe 200 tools/mfma_loop_probe.bin; cat $O/loop_probe.out
+               ( cd /tmp && export TMPDIR=/tmp && timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_loop -- $R/tools/mfma_loop_probe.bin 300 > $O/pmc_loop.out 2> $O/pmc_loop.log; echo "pmc_loop exit=$?"
+                 PMC_QUICK_PER_DISPATCH=1 PMC_QUICK_FILTER=probeLoop python3 $R/tools/pmc_quick.py $O/pmc_loop ) }
 for s in "$@"; do $s; done
