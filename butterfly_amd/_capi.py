@@ -420,6 +420,19 @@ def load():
     lib.bfhipShardedCreate.restype = C.c_int
     lib.bfhipShardedApplyDevice.argtypes = [vp, vp, C.c_size_t, vp, vp]
     lib.bfhipShardedApplyDevice.restype = C.c_int
+    lib.bfhipShardedApplyTransposeDevice.argtypes = [vp, vp, C.c_size_t, vp, vp]
+    lib.bfhipShardedApplyTransposeDevice.restype = C.c_int
+    lib.bfhipShardedCovMatvecDevice.argtypes = [vp, vp, vp, vp, vp, vp, vp]
+    lib.bfhipShardedCovMatvecDevice.restype = C.c_int
+    lib.bfhipShardedSolveGMRESDevice.argtypes = [vp, C.POINTER(BfhipGmresOptions), vp, C.c_size_t, vp, C.POINTER(C.c_size_t),
+                                                 C.POINTER(C.c_double), vp, vp]
+    lib.bfhipShardedSolveGMRESDevice.restype = C.c_int
+    lib.bfhipShardedGetNumRows.argtypes = [vp]
+    lib.bfhipShardedGetNumRows.restype = C.c_size_t
+    lib.bfhipShardedGetNumCols.argtypes = [vp]
+    lib.bfhipShardedGetNumCols.restype = C.c_size_t
+    lib.bfhipShardedMatNew.argtypes = [vp, C.c_int]
+    lib.bfhipShardedMatNew.restype = vp
     lib.bfhipShardedLastTimes.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     lib.bfhipShardedLastTimes.restype = C.c_int
     lib.bfhipShardedSetTiming.argtypes = [vp, C.c_int]

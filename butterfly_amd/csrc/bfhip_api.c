@@ -952,6 +952,8 @@ int bfhipApplyTranspose(BfhipOperator *op, void const *X, size_t ldx, size_t nrh
 }
 
 /* ---- introspection ---------------------------------------------------------- */
+int bfhipOperatorHasAdjoint(BfhipOperator const *op) { return op ? op->hasTplan : 0; }
+uint32_t bfhipOperatorSrcDtype(BfhipOperator const *op) { return op ? op->srcDtype : BFHIP_C128; }
 int bfhipOperatorDevice(BfhipOperator const *op) { return (!op || (op->flags & BFHIP_FLAG_PLAN_ONLY)) ? -1 : op->device; }
 size_t bfhipGetNumRows(BfhipOperator const *op) { return op ? op->plan.numRows : 0; }
 size_t bfhipGetNumCols(BfhipOperator const *op) { return op ? op->plan.numCols : 0; }
@@ -1366,10 +1368,20 @@ done:
  * ============================================================================= */
 typedef struct BfhipMat {
   BfAbiMat super;             /* must be first: this IS a BfMat */
-  BfhipOperator *op;
+  BfhipOperator *op;          /* the operator; with `sh`: this rank's share of it (shape queries go to `sh`) */
   int ownsOperator;
   int transposed;             /* bfMatTranspose has been applied an odd number of times: Mul / MulVec run the adjoint plan */
+  struct BfhipSharded *sh;    /* bfhipShardedMatNew: applies are the sharded step (every rank's host calls with the same vectors) */
+  int ownsSharded;
 } BfhipMat;
+
+/* rows / columns of the operator the object stands for (untransposed), and the host-vector apply behind every slot */
+static uint64_t shimOpRows(BfhipMat const *s) { return s->sh ? bfhipShardedGetNumRows(s->sh) : bfhipGetNumRows(s->op); }
+static uint64_t shimOpCols(BfhipMat const *s) { return s->sh ? bfhipShardedGetNumCols(s->sh) : bfhipGetNumCols(s->op); }
+static int applyHost(BfhipOperator *op, int transpose, void const *X, size_t ldx, size_t nrhs, void *Y, size_t ldy);
+static int shimApplyHost(BfhipMat const *s, int transpose, void const *X, size_t ldx, size_t nrhs, void *Y, size_t ldy) {
+  return s->sh ? bfhipShardedApplyHost(s->sh, transpose, X, ldx, nrhs, Y, ldy) : applyHost(s->op, transpose, X, ldx, nrhs, Y, ldy);
+}
 
 /* Failures surface the way the reference's own Mul failures do: the global error code is set
  * (bfSetError, src/error.c:20-24) and NULL is returned (the RAISE_ERROR / BF_ERROR_END idiom, e.g.
@@ -1392,8 +1404,8 @@ static void shimRaise(int code) {
 
 /* shape of what the object currently stands for: A, or A^T after bfMatTranspose (the reference's transposed product
  * answers with its reversed, transposed factors' shapes: src/mat_product.c:146-192, 409-420) */
-static size_t shimGetNumRows(BfAbiMat const *m) { BfhipMat const *s = (BfhipMat const *)m; return s->transposed ? bfhipGetNumCols(s->op) : bfhipGetNumRows(s->op); }
-static size_t shimGetNumCols(BfAbiMat const *m) { BfhipMat const *s = (BfhipMat const *)m; return s->transposed ? bfhipGetNumRows(s->op) : bfhipGetNumCols(s->op); }
+static size_t shimGetNumRows(BfAbiMat const *m) { BfhipMat const *s = (BfhipMat const *)m; return s->transposed ? shimOpCols(s) : shimOpRows(s); }
+static size_t shimGetNumCols(BfAbiMat const *m) { BfhipMat const *s = (BfhipMat const *)m; return s->transposed ? shimOpRows(s) : shimOpCols(s); }
 static int shimGetType(BfAbiMat const *m) { (void)m; return BFABI_TYPE_MAT_FUNC; }
 static size_t shimNumBytes(BfAbiMat const *m) { return bfhipNumBytes(((BfhipMat const *)m)->op); }
 static void shimDelete(BfAbiMat **m) {
@@ -1401,6 +1413,7 @@ static void shimDelete(BfAbiMat **m) {
   BfhipMat *s = (BfhipMat *)*m;
   /* a view never owns the operator (bfMatDenseRealDeinit skips the payload of a view the same way,
    * src/mat_dense_real.c:1667-1672) */
+  if (s->ownsSharded && s->sh && !(s->super.props & BFABI_MAT_PROPS_VIEW)) bfhipShardedFree(&s->sh);
   if (s->ownsOperator && !(s->super.props & BFABI_MAT_PROPS_VIEW)) bfhipFree(&s->op);
   free(s);
   *m = NULL;
@@ -1420,11 +1433,12 @@ static BfAbiMat *shimGetView(BfAbiMat *m) {
 /* Y = A X for a reference dense RHS; the result is allocated through the
  * RHS's own EmptyLike slot so the reference owns and frees it
  * (bfMatBlockCooMul does the same with ZerosLike, mat_block_coo.c:401). */
-static void *shimMulImpl(void const *rhsV, BfhipOperator *op, int transpose) {
+static void *shimMulImpl(void const *rhsV, BfhipMat const *self, int transpose) {
   BfAbiMat const *rhs = rhsV;
+  BfhipOperator *op = self ? self->op : NULL;
   if (!op || !rhs || !rhs->vtbl) SHIM_FAIL(BFABI_ERROR_INVALID_ARGUMENTS, "NULL operand");
   if (transpose && !op->hasTplan) SHIM_FAIL(BFABI_ERROR_NOT_IMPLEMENTED, "Mul on a transposed operator needs BFHIP_FLAG_ADJOINT");
-  uint64_t const inLen = transpose ? op->plan.numRows : op->plan.numCols, outLen = transpose ? op->plan.numCols : op->plan.numRows;
+  uint64_t const inLen = transpose ? shimOpRows(self) : shimOpCols(self), outLen = transpose ? shimOpCols(self) : shimOpRows(self);
   BfAbiGetTypeFn getType = (BfAbiGetTypeFn)rhs->vtbl->slot[BFABI_SLOT_GetType];
   if (!getType || getType(rhs) != BFABI_TYPE_MAT_DENSE_COMPLEX || op->srcDtype != BFHIP_C128)
     /* same restriction as bfMatDenseComplexMul's switch (mat_dense_complex.c:1036-1047) */
@@ -1464,7 +1478,7 @@ static void *shimMulImpl(void const *rhsV, BfhipOperator *op, int transpose) {
   BfAbiMatDenseComplex *y = (BfAbiMatDenseComplex *)res;
   int rc;
   if (y->colStride != 1) rc = bfhipFail(BFABI_ERROR_NOT_IMPLEMENTED, "EmptyLike returned a result with colStride != 1");
-  else rc = applyHost(op, transpose, xdata, xld, rhs->numCols, y->data, y->rowStride);
+  else rc = shimApplyHost(self, transpose, xdata, xld, rhs->numCols, y->data, y->rowStride);
   if (!rc && transpose)
     for (size_t i = 0; i < outLen; ++i)
       for (size_t q = 0; q < rhs->numCols; ++q) ((double *)y->data)[2 * (i * y->rowStride + q) + 1] *= -1.0;
@@ -1478,10 +1492,15 @@ static void *shimMulImpl(void const *rhsV, BfhipOperator *op, int transpose) {
   return res;
 }
 
-void *bfhipMatMulFunc(void const *rhsV, void *opV) { return shimMulImpl(rhsV, opV, 0); }
+void *bfhipMatMulFunc(void const *rhsV, void *opV) {
+  BfhipMat tmp;
+  memset(&tmp, 0, sizeof tmp);
+  tmp.op = opV;
+  return shimMulImpl(rhsV, &tmp, 0);
+}
 
 static BfAbiMat *shimMul(BfAbiMat const *lhs, BfAbiMat const *rhs) {
-  return shimMulImpl(rhs, ((BfhipMat const *)lhs)->op, ((BfhipMat const *)lhs)->transposed);
+  return shimMulImpl(rhs, (BfhipMat const *)lhs, ((BfhipMat const *)lhs)->transposed);
 }
 
 /* bfMatTranspose (slot 63, src/mat.c:271-273): in place, as bfMatProductTranspose reverses and transposes its factors
@@ -1516,8 +1535,9 @@ static BfAbiVec *shimApplyVec(BfAbiMat const *lhs, BfAbiVec const *vec, int rmul
   if (!getType || getType(vec) != BFABI_TYPE_VEC_REAL || op->srcDtype != BFHIP_F64)
     SHIM_FAIL(BFABI_ERROR_NOT_IMPLEMENTED, "%s needs a real operator and a BfVecReal", what);
   if (transpose && !op->hasTplan) SHIM_FAIL(BFABI_ERROR_NOT_IMPLEMENTED, "%s needs an operator compiled with BFHIP_FLAG_ADJOINT", what);
-  uint64_t const inLen = transpose ? op->plan.numRows : op->plan.numCols;
-  uint64_t const outLen = transpose ? op->plan.numCols : op->plan.numRows;
+  BfhipMat const *self = (BfhipMat const *)lhs;
+  uint64_t const inLen = transpose ? shimOpRows(self) : shimOpCols(self);
+  uint64_t const outLen = transpose ? shimOpCols(self) : shimOpRows(self);
   if (vec->size != inLen)
     SHIM_FAIL(BFABI_ERROR_INCOMPATIBLE_SHAPES, "%s: operator expects %llu entries, vector has %llu", what, (unsigned long long)inLen, (unsigned long long)vec->size);
   BfAbiVecReal const *x = (BfAbiVecReal const *)vec;
@@ -1529,7 +1549,7 @@ static BfAbiVec *shimApplyVec(BfAbiMat const *lhs, BfAbiVec const *vec, int rmul
   y->super.size = outLen;
   y->stride = 1;
   y->data = data;
-  int rc = applyHost(op, transpose, x->data, x->stride, 1, y->data, 1);
+  int rc = shimApplyHost(self, transpose, x->data, x->stride, 1, y->data, 1);
   if (rc) { free(data); free(y); shimRaise(rc); return NULL; }
   return &y->super;
 }
@@ -1559,5 +1579,20 @@ void *bfhipMatNew(BfhipOperator *op, int ownsOperator) {
   m->super.numCols = op->plan.numCols;
   m->op = op;
   m->ownsOperator = ownsOperator;
+  return m;
+}
+
+/* the same object over a sharded operator: shapes are the whole operator's, applies are the sharded step */
+void *bfhipShardedMatNew(struct BfhipSharded *sh, int ownsSharded) {
+  if (!sh) { bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "NULL sharded operator"); return NULL; }
+  BfhipMat *m = calloc(1, sizeof *m);
+  if (!m) { bfhipFail(BFABI_ERROR_MEMORY_ERROR, "host OOM"); return NULL; }
+  m->super.vtbl = &ShimVtable;
+  m->super.props = BFABI_MAT_PROPS_NONE;
+  m->super.numRows = bfhipShardedGetNumRows(sh);
+  m->super.numCols = bfhipShardedGetNumCols(sh);
+  m->op = bfhipShardedOperator(sh);
+  m->sh = sh;
+  m->ownsSharded = ownsSharded;
   return m;
 }

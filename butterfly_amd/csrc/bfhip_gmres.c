@@ -45,7 +45,7 @@ static void applyGivens(cplx *z0p, cplx *z1p, cplx c, cplx s) {
   *z1p = s * z0 + c * z1;
 }
 
-static int solveDevice(BfhipOperator *op, BfhipOperator *precond, int orth, void const *dB, size_t nrhs, void const *dX0, double tol,
+static int solveDevice(BfGmresApplyFn apply, void *ctx, uint64_t n, BfhipOperator *precond, int orth, void const *dB, size_t nrhs, void const *dX0, double tol,
                        size_t maxNumIter, size_t *numIter, double *residual, void *dX, void *stream);
 
 /* the Krylov basis and every staging buffer live on the OPERATOR's device, whatever device is
@@ -69,9 +69,27 @@ int bfhipSolveGMRESPrecondDevice(BfhipOperator *op, BfhipOperator *solveM, void 
 
 /* The solver with its choices spelled out per call (BfhipGmresOptions, include/bfhip.h): orthogonalisation order,
  * tolerance, iteration cap, left preconditioner. */
+static int applyOperator(void *ctx, void const *dX, size_t nrhs, void *dY, void *stream) { return bfhipApplyDevice(ctx, dX, nrhs, dY, stream); }
+
 int bfhipSolveGMRESOptsDevice(BfhipOperator *op, BfhipGmresOptions const *opt, void const *dB, size_t nrhs, void const *dX0,
                               size_t *numIter, double *residual, void *dX, void *stream) {
-  if (!op || !opt || opt->structSize < sizeof(BfhipGmresOptions)) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "NULL argument / BfhipGmresOptions.structSize too small");
+  if (!op) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "NULL operator");
+  BfhipStats st;
+  memset(&st, 0, sizeof st);
+  st.structSize = sizeof st;
+  int rc = bfhipGetStats(op, &st);
+  if (rc) return rc;
+  if (st.dtype != BFHIP_C128) return bfhipFail(BFABI_ERROR_NOT_IMPLEMENTED, "GMRES is implemented for complex operators");
+  if (st.numRows != st.numCols) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "GMRES needs a square operator (linalg.c:85-87)");
+  int const dev = bfhipOperatorDevice(op);
+  if (dev < 0) return bfhipFail(BFABI_ERROR_RUNTIME_ERROR, "operator has no device (compiled with BFHIP_FLAG_PLAN_ONLY)");
+  return bfGmresSolve(applyOperator, op, st.numRows, dev, opt, dB, nrhs, dX0, numIter, residual, dX, stream);
+}
+
+/* The solver around any device matvec of order n on device `device` (the sharded step of bfhip_shard.hip is the other caller). */
+int bfGmresSolve(BfGmresApplyFn apply, void *ctx, uint64_t n, int device, BfhipGmresOptions const *opt, void const *dB, size_t nrhs,
+                 void const *dX0, size_t *numIter, double *residual, void *dX, void *stream) {
+  if (!apply || !opt || opt->structSize < sizeof(BfhipGmresOptions)) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "NULL argument / BfhipGmresOptions.structSize too small");
   BfhipOperator *solveM = opt->solveM;
   double const tol = opt->tol;
   size_t const maxNumIter = opt->maxNumIter;
@@ -81,8 +99,7 @@ int bfhipSolveGMRESOptsDevice(BfhipOperator *op, BfhipGmresOptions const *opt, v
     char const *mgsEnv = getenv("BFHIP_GMRES_MGS");
     orth = mgsEnv && mgsEnv[0] == '1' ? BFHIP_GMRES_ORTH_MGS : BFHIP_GMRES_ORTH_CGS2;
   }
-  if (solveM && (bfhipOperatorDevice(solveM) != bfhipOperatorDevice(op) || bfhipGetNumRows(solveM) != bfhipGetNumRows(op) ||
-                 bfhipGetNumCols(solveM) != bfhipGetNumRows(op)))
+  if (solveM && (bfhipOperatorDevice(solveM) != device || bfhipGetNumRows(solveM) != n || bfhipGetNumCols(solveM) != n))
     return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "the preconditioner must be an n x n operator on the operator's device (linalg.c:92-97)");
   if (solveM) {
     /* the Krylov vectors are complex128: a real preconditioner would be applied to them as if they were real n-vectors */
@@ -93,28 +110,21 @@ int bfhipSolveGMRESOptsDevice(BfhipOperator *op, BfhipGmresOptions const *opt, v
     if (rcs) return rcs;
     if (ms.dtype != BFHIP_C128) return bfhipFail(BFABI_ERROR_TYPE_ERROR, "the preconditioner must be a complex128 operator like the system it preconditions");
   }
-  int prev = -1, dev = bfhipOperatorDevice(op);
-  if (dev < 0) return bfhipFail(BFABI_ERROR_RUNTIME_ERROR, "operator has no device (compiled with BFHIP_FLAG_PLAN_ONLY)");
+  int prev = -1, dev = device;
   bfdevGetDevice(&prev);
   int rc = prev != dev ? bfdevSetDevice(dev) : 0;
   if (rc) return rc;
-  rc = solveDevice(op, solveM, orth, dB, nrhs, dX0, tol, maxNumIter, numIter, residual, dX, stream);
+  rc = solveDevice(apply, ctx, n, solveM, orth, dB, nrhs, dX0, tol, maxNumIter, numIter, residual, dX, stream);
   if (prev >= 0 && prev != dev) bfdevSetDevice(prev);
   return rc;
 }
 
-static int solveDevice(BfhipOperator *op, BfhipOperator *precond, int orth, void const *dB, size_t nrhs, void const *dX0, double tol,
+static int solveDevice(BfGmresApplyFn apply, void *ctx, uint64_t n, BfhipOperator *precond, int orth, void const *dB, size_t nrhs, void const *dX0, double tol,
                        size_t maxNumIter, size_t *numIter, double *residual, void *dX, void *stream) {
-  if (!op || !dB || !dX) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "NULL argument");
+  if (!dB || !dX) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "NULL argument");
   if (maxNumIter == 0) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "maxNumIter must be positive (linalg.c:81-82)");
   if (nrhs == 0 || nrhs > 0xffffu) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "nrhs out of range");
-  BfhipStats st;
-  st.structSize = sizeof st;
-  int rc = bfhipGetStats(op, &st);
-  if (rc) return rc;
-  if (st.dtype != BFHIP_C128) return bfhipFail(BFABI_ERROR_NOT_IMPLEMENTED, "GMRES is implemented for complex operators");
-  if (st.numRows != st.numCols) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "GMRES needs a square operator (linalg.c:85-87)");
-  uint64_t const n = st.numRows;
+  int rc = 0;
   size_t const m = maxNumIter;
   size_t const vecBytes = (size_t)n * nrhs * 16;
   uint32_t nb = (uint32_t)((n + 255) / 256);          /* row blocks = partial sums per RHS and dot */
@@ -162,7 +172,7 @@ static int solveDevice(BfhipOperator *op, BfhipOperator *precond, int orth, void
   /* R = B - A X0 (linalg.c:127-131); X0 == NULL means zeros (:120-123) */
   if (dX0) {
     CHECK(bfdevMalloc(&dAX0, vecBytes));
-    CHECK(bfhipApplyDevice(op, dX0, nrhs, dAX0, stream));
+    CHECK(apply(ctx, dX0, nrhs, dAX0, stream));
   }
   if (precond) {
     /* R = M^{-1} (B - A X0) (:127-135): the difference goes to a scratch vector, the preconditioner writes W,
@@ -196,10 +206,10 @@ static int solveDevice(BfhipOperator *op, BfhipOperator *precond, int orth, void
     size_t const j_ = (J); \
     char *Vj = (char *)dV + j_ * vecBytes; \
     if (precond) { \
-      CHECK(bfhipApplyDevice(op, Vj, nrhs, dPre, stream));                   /* W = M^{-1} (A V[j])  (:155-163) */ \
+      CHECK(apply(ctx, Vj, nrhs, dPre, stream));                   /* W = M^{-1} (A V[j])  (:155-163) */ \
       CHECK(bfhipApplyDevice(precond, dPre, nrhs, dW, stream)); \
     } else \
-    CHECK(bfhipApplyDevice(op, Vj, nrhs, dW, stream));                       /* W = A V[j]  (:157) */ \
+    CHECK(apply(ctx, Vj, nrhs, dW, stream));                       /* W = A V[j]  (:157) */ \
     void *pin = dPartA, *pout = dPartB; \
     if (useMgs) { \
       /* modified Gram-Schmidt (:174-184): dot with V_0, then for each i subtract and start the next dot */ \

@@ -212,6 +212,22 @@ int bfhipOperatorDevice(struct BfhipOperator const *op);
 /* vector arena for `nrhs` right-hand sides allocated now, so that applies of up to that many cannot fail on it */
 int bfhipOperatorReserveRhs(struct BfhipOperator *op, uint32_t nrhs);
 
+/* has the operator a plan of A^T (BFHIP_FLAG_ADJOINT / _PACKED); element type of the operand as given (BFHIP_C128 / BFHIP_F64) */
+int bfhipOperatorHasAdjoint(struct BfhipOperator const *op);
+uint32_t bfhipOperatorSrcDtype(struct BfhipOperator const *op);
+
+/* GMRES around any device matvec (bfhip_gmres.c): `apply(ctx, dX, nrhs, dY, stream)` enqueues Y = A X on `stream`; n = order of A;
+ * `device` = the HIP ordinal everything lives on.  bfhipSolveGMRESOptsDevice and bfhipShardedSolveGMRESDevice are this. */
+typedef int (*BfGmresApplyFn)(void *ctx, void const *dX, size_t nrhs, void *dY, void *stream);
+struct BfhipGmresOptions;
+int bfGmresSolve(BfGmresApplyFn apply, void *ctx, uint64_t n, int device, struct BfhipGmresOptions const *opt, void const *dB, size_t nrhs,
+                 void const *dX0, size_t *numIter, double *residual, void *dX, void *stream);
+
+/* the sharded step on host vectors (bfhip_shard.hip): staging buffers of the sharded object; used by the vtable shim */
+struct BfhipSharded;
+int bfhipShardedApplyHost(struct BfhipSharded *sh, int transpose, void const *X, size_t ldx, size_t nrhs, void *Y, size_t ldy);
+struct BfhipOperator *bfhipShardedOperator(struct BfhipSharded const *sh);
+
 /* ------------------------------------------------------------------------
  * Device layer (implemented in bfhip_device.hip)
  * ---------------------------------------------------------------------- */

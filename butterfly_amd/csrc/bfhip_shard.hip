@@ -96,6 +96,19 @@ __global__ __launch_bounds__(256) void bfScatterSegmentsKernel(Seg const *segs, 
   y[u] = gathered[(segs[lo].srcOff + (row - segs[lo].globalOff)) * unitsPerRow + k];
 }
 
+// the inverse of a rank's compaction, for the adjoint step: vr[local row][:] = v[globalOff(seg) + local row - srcOff(seg)][:]
+// over THIS rank's segments (srcOff = first local row of the segment; sorted by it)
+template <typename U>
+__global__ __launch_bounds__(256) void bfGatherSegmentsKernel(Seg const *segs, uint32_t numSegs, uint64_t numLocalRows,
+                                                              U const *v, U *vr, uint64_t unitsPerRow) {
+  uint64_t u = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (u >= numLocalRows * unitsPerRow) return;
+  uint64_t const row = u / unitsPerRow, k = u - row * unitsPerRow;
+  uint32_t lo = 0, hi = numSegs;                       // last segment with srcOff <= row
+  while (hi - lo > 1) { uint32_t mid = (lo + hi) / 2; if (segs[mid].srcOff <= row) lo = mid; else hi = mid; }
+  vr[u] = v[(segs[lo].globalOff + (row - segs[lo].srcOff)) * unitsPerRow + k];
+}
+
 }  // namespace
 
 struct BfhipComm { ncclComm_t comm; int nranks, rank, device; int aborted; };
@@ -115,6 +128,15 @@ struct BfhipSharded {
   hipEvent_t e0, e1, e2;
   int timed;
   int timing;       // record the three events (default on)
+  // the adjoint step (operators compiled with an adjoint plan)
+  uint64_t numCols;              // columns of the operator = length of x and of A^T v
+  int hasAdjoint;
+  Seg *dMySegs;                  // rows mode: this rank's segments, srcOff = first LOCAL row (the order its operator produces them)
+  uint32_t numMySegs;
+  uint64_t myFirstGlobal;        // one segment only: its rows of v are used in place
+  void *dVr;                     // rows mode, several segments: this rank's entries of v, compacted (myRows x maxRhs)
+  void *dCov;                    // covariance products of real operators: two vectors of the longer side
+  void *dHostX, *dHostY;         // staging of the host-vector entry (the vtable shim): the longer side x maxRhs each
 };
 
 extern "C" {
@@ -162,6 +184,7 @@ void bfhipShardedFree(BfhipSharded **ps) {
   (void)hipGetDevice(&prev);
   (void)hipSetDevice(s->device);
   (void)hipFree(s->dGather); (void)hipFree(s->dSegs); (void)hipFree(s->dGroups); (void)hipFree(s->dSrcOff);
+  (void)hipFree(s->dMySegs); (void)hipFree(s->dVr); (void)hipFree(s->dCov); (void)hipFree(s->dHostX); (void)hipFree(s->dHostY);
   if (s->e0) (void)hipEventDestroy(s->e0);
   if (s->e1) (void)hipEventDestroy(s->e1);
   if (s->e2) (void)hipEventDestroy(s->e2);
@@ -267,6 +290,43 @@ int bfhipShardedCreate(BfhipOperator *op, BfhipComm *comm, BfhipShardSpec const 
     }
     free(rowsOf);
   }
+  s->numCols = st.numCols;
+  s->hasAdjoint = bfhipOperatorHasAdjoint(op);
+  if (!rc && s->hasAdjoint && spec->mode == BFHIP_SHARD_ROWS) {
+    // this rank's segments in the order its operator yields them (list order), with their local offsets
+    uint32_t cnt = 0;
+    for (uint32_t i = 0; i < spec->numSegments; ++i) cnt += spec->segOwner[i] == (uint32_t)comm->rank && spec->segRows[i] > 0;
+    Seg *mine = (Seg *)malloc((cnt ? cnt : 1) * sizeof(Seg));
+    if (!mine) rc = bfhipFail(BFABI_ERROR_MEMORY_ERROR, "host OOM");
+    else {
+      uint64_t local = 0, g0 = 0;
+      uint32_t k = 0;
+      for (uint32_t i = 0; i < spec->numSegments; ++i) {
+        uint64_t const goff = segGlobalOff ? segGlobalOff[i] : g0;
+        g0 += spec->segRows[i];
+        if (spec->segOwner[i] != (uint32_t)comm->rank || !spec->segRows[i]) continue;
+        mine[k].globalOff = goff; mine[k].srcOff = local; mine[k].rows = spec->segRows[i];
+        local += spec->segRows[i]; ++k;
+      }
+      s->numMySegs = cnt;
+      // consecutive segments that are consecutive in v as well are one run: a rank that owns ONE run reads v in place
+      int oneRun = cnt > 0;
+      for (uint32_t i = 1; i < cnt; ++i) oneRun = oneRun && mine[i].globalOff == mine[i - 1].globalOff + mine[i - 1].rows;
+      if (oneRun) { s->numMySegs = 1; s->myFirstGlobal = mine[0].globalOff; }
+      else if (cnt) {
+        rc = hipFailS(hipMalloc((void **)&s->dMySegs, cnt * sizeof(Seg)), "hipMalloc(own segments)");
+        if (!rc) rc = hipFailS(hipMemcpy(s->dMySegs, mine, cnt * sizeof(Seg), hipMemcpyHostToDevice), "hipMemcpy(own segments)");
+        if (!rc) rc = hipFailS(hipMalloc(&s->dVr, (size_t)s->myRows * s->maxRhs * s->elemSize + 16), "hipMalloc(compacted v)");
+      }
+      free(mine);
+    }
+  }
+  {
+    uint64_t const big = s->numRowsGlobal > s->numCols ? s->numRowsGlobal : s->numCols;
+    if (!rc && s->hasAdjoint && s->dtype != BFHIP_C128) rc = hipFailS(hipMalloc(&s->dCov, 2 * (size_t)big * s->elemSize + 32), "hipMalloc(covariance scratch)");
+    if (!rc) rc = hipFailS(hipMalloc(&s->dHostX, (size_t)big * s->maxRhs * s->elemSize + 16), "hipMalloc(host staging)");
+    if (!rc) rc = hipFailS(hipMalloc(&s->dHostY, (size_t)big * s->maxRhs * s->elemSize + 16), "hipMalloc(host staging)");
+  }
   s->timing = 1;
   // every allocation a step could need happens here: a step that fails on ONE rank after the others have enqueued
   // their half of the collective would leave them waiting forever
@@ -340,6 +400,112 @@ int bfhipShardedApplyDevice(BfhipSharded *s, void const *dX, size_t nrhs, void *
   }
   if (s->timing) (void)hipEventRecord(s->e2, stream);
   s->timed = !rc && s->timing;
+  if (prev >= 0 && prev != s->device) (void)hipSetDevice(prev);
+  return rc;
+}
+
+// z = A^T v: this rank's partial A_r^T v_r, then ONE all-reduce (see include/bfhip.h)
+int bfhipShardedApplyTransposeDevice(BfhipSharded *s, void const *dV, size_t nrhs, void *dZ, void *streamV) {
+  if (!s || !dV || !dZ) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "NULL argument");
+  if (!s->hasAdjoint) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "the sharded operator was not compiled with BFHIP_FLAG_ADJOINT");
+  if (!nrhs || nrhs > s->maxRhs) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "nrhs %zu exceeds the %u this sharded apply was created for", nrhs, s->maxRhs);
+  if (s->comm->aborted) return bfhipFail(BFABI_ERROR_RUNTIME_ERROR, "the communicator was aborted after a failed step on this rank");
+  hipStream_t stream = (hipStream_t)streamV;
+  int prev = -1;
+  (void)hipGetDevice(&prev);
+  int rc = prev != s->device ? hipFailS(hipSetDevice(s->device), "hipSetDevice") : 0;
+  if (rc) return rc;
+  ncclDataType_t const dt = s->dtype == BFHIP_F32 ? ncclFloat32 : ncclFloat64;
+  size_t const scalarsPerElem = s->dtype == BFHIP_C128 ? 2 : 1;
+  size_t const rowBytes = nrhs * s->elemSize;
+  void const *vr = dV;                                   // blocks mode: the local operator has all rows
+  if (s->mode == BFHIP_SHARD_ROWS) {
+    if (s->numMySegs == 1 && !s->dMySegs) vr = (char const *)dV + (size_t)s->myFirstGlobal * rowBytes;
+    else if (s->numMySegs) {
+      size_t unit = 16;
+      while (rowBytes % unit) unit /= 2;
+      uint64_t const unitsPerRow = rowBytes / unit, total = s->myRows * unitsPerRow;
+      uint32_t const grid = (uint32_t)((total + 255) / 256);
+      if (grid) {
+        if (unit == 16) hipLaunchKernelGGL(bfGatherSegmentsKernel<uint4>, dim3(grid), dim3(256), 0, stream, s->dMySegs, s->numMySegs, s->myRows, (uint4 const *)dV, (uint4 *)s->dVr, unitsPerRow);
+        else if (unit == 8) hipLaunchKernelGGL(bfGatherSegmentsKernel<uint2>, dim3(grid), dim3(256), 0, stream, s->dMySegs, s->numMySegs, s->myRows, (uint2 const *)dV, (uint2 *)s->dVr, unitsPerRow);
+        else hipLaunchKernelGGL(bfGatherSegmentsKernel<uint32_t>, dim3(grid), dim3(256), 0, stream, s->dMySegs, s->numMySegs, s->myRows, (uint32_t const *)dV, (uint32_t *)s->dVr, unitsPerRow);
+        rc = hipFailS(hipGetLastError(), "segment gather launch");
+      }
+      vr = s->dVr;
+    }
+  }
+  if (!rc) {
+    if (s->mode == BFHIP_SHARD_ROWS && !s->numMySegs) rc = hipFailS(hipMemsetAsync(dZ, 0, (size_t)s->numCols * rowBytes, stream), "hipMemsetAsync");      // a rank without rows contributes zeros
+    else rc = bfhipApplyTransposeDevice(s->op, vr, nrhs, dZ, stream);
+  }
+  if (!rc) rc = ncclFail(g.AllReduce(dZ, dZ, (size_t)s->numCols * nrhs * scalarsPerElem, dt, ncclSum, s->comm->comm, stream), "ncclAllReduce");
+  if (rc && !s->comm->aborted && s->comm->nranks > 1) { (void)g.CommAbort(s->comm->comm); s->comm->aborted = 1; }
+  if (prev >= 0 && prev != s->device) (void)hipSetDevice(prev);
+  return rc;
+}
+
+int bfhipShardedCovMatvecDevice(BfhipSharded *s, void const *dGammaLam, uint64_t const *dRowPerm, uint64_t const *dRevRowPerm, void const *dV, void *dZ, void *stream) {
+  if (!s || !dV || !dZ) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "NULL argument");
+  if (s->dtype == BFHIP_C128) return bfhipFail(BFABI_ERROR_TYPE_ERROR, "covariance products are defined for real operators");
+  if (!s->hasAdjoint || !s->dCov) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "the sharded operator was not compiled with BFHIP_FLAG_ADJOINT");
+  int prev = -1;
+  (void)hipGetDevice(&prev);
+  int rc = prev != s->device ? hipFailS(hipSetDevice(s->device), "hipSetDevice") : 0;
+  if (rc) return rc;
+  uint64_t const m = s->numRowsGlobal, n = s->numCols, big = m > n ? m : n;
+  char *t0 = (char *)s->dCov, *t1 = (char *)s->dCov + big * s->elemSize;
+  void const *vin = dV;
+  if (dRevRowPerm) { rc = bfdevScalePermute(t0, dV, NULL, 0, dRevRowPerm, m, s->dtype, stream); vin = t0; }
+  if (!rc) rc = bfhipShardedApplyTransposeDevice(s, vin, 1, t1, stream);                          /* Phi^T v, every rank */
+  if (!rc && dGammaLam) rc = bfdevScalePermute(t1, t1, dGammaLam, 2, NULL, n, s->dtype, stream);   /* GammaLam twice */
+  if (!rc) rc = bfhipShardedApplyDevice(s, t1, 1, dRowPerm ? (void *)t0 : dZ, stream);
+  if (!rc && dRowPerm) rc = bfdevScalePermute(dZ, t0, NULL, 0, dRowPerm, m, s->dtype, stream);
+  if (prev >= 0 && prev != s->device) (void)hipSetDevice(prev);
+  return rc;
+}
+
+static int shardedMatvec(void *ctx, void const *dX, size_t nrhs, void *dY, void *stream) { return bfhipShardedApplyDevice((BfhipSharded *)ctx, dX, nrhs, dY, stream); }
+
+int bfhipShardedSolveGMRESDevice(BfhipSharded *s, BfhipGmresOptions const *opt, void const *dB, size_t nrhs, void const *dX0,
+                                 size_t *numIter, double *residual, void *dX, void *stream) {
+  if (!s) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "NULL sharded operator");
+  if (s->dtype != BFHIP_C128) return bfhipFail(BFABI_ERROR_NOT_IMPLEMENTED, "GMRES is implemented for complex operators");
+  if (s->numRowsGlobal != s->numCols) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "GMRES needs a square operator (linalg.c:85-87)");
+  if (!nrhs || nrhs > s->maxRhs) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "nrhs %zu exceeds the %u this sharded apply was created for", nrhs, s->maxRhs);
+  int const timing = s->timing;
+  s->timing = 0;                 // no event pairs between the iterations' launches
+  int const rc = bfGmresSolve(shardedMatvec, s, s->numRowsGlobal, s->device, opt, dB, nrhs, dX0, numIter, residual, dX, stream);
+  s->timing = timing;
+  return rc;
+}
+
+size_t bfhipShardedGetNumRows(BfhipSharded const *s) { return s ? s->numRowsGlobal : 0; }
+size_t bfhipShardedGetNumCols(BfhipSharded const *s) { return s ? s->numCols : 0; }
+BfhipOperator *bfhipShardedOperator(BfhipSharded const *s) { return s ? s->op : NULL; }
+
+// host vectors through the sharded step (the vtable shim): packed, double precision on the host like bfhipApply
+int bfhipShardedApplyHost(BfhipSharded *s, int transpose, void const *X, size_t ldx, size_t nrhs, void *Y, size_t ldy) {
+  if (!s || !X || !Y) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "NULL argument");
+  if (!nrhs || nrhs > s->maxRhs || ldx < nrhs || ldy < nrhs) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "bad nrhs / leading dimension (the sharded apply was created for %u right-hand sides)", s->maxRhs);
+  int prev = -1;
+  (void)hipGetDevice(&prev);
+  int rc = prev != s->device ? hipFailS(hipSetDevice(s->device), "hipSetDevice") : 0;
+  if (rc) return rc;
+  uint64_t const n = transpose ? s->numRowsGlobal : s->numCols, m = transpose ? s->numCols : s->numRowsGlobal;
+  size_t const es = s->elemSize, hostEs = s->dtype == BFHIP_C128 ? 16 : 8;
+  void *hx = malloc((n * nrhs ? n * nrhs : 1) * es), *hy = malloc((m * nrhs ? m * nrhs : 1) * es);
+  if (!hx || !hy) { free(hx); free(hy); if (prev >= 0 && prev != s->device) (void)hipSetDevice(prev); return bfhipFail(BFABI_ERROR_MEMORY_ERROR, "host OOM"); }
+  if (es == hostEs) for (uint64_t i = 0; i < n; ++i) memcpy((char *)hx + i * nrhs * es, (char const *)X + i * ldx * es, nrhs * es);
+  else for (uint64_t i = 0; i < n; ++i) for (size_t q = 0; q < nrhs; ++q) ((float *)hx)[i * nrhs + q] = (float)((double const *)X)[i * ldx + q];
+  rc = hipFailS(hipMemcpy(s->dHostX, hx, n * nrhs * es, hipMemcpyHostToDevice), "hipMemcpy H2D");
+  if (!rc) rc = transpose ? bfhipShardedApplyTransposeDevice(s, s->dHostX, nrhs, s->dHostY, NULL) : bfhipShardedApplyDevice(s, s->dHostX, nrhs, s->dHostY, NULL);
+  if (!rc) rc = hipFailS(hipMemcpy(hy, s->dHostY, m * nrhs * es, hipMemcpyDeviceToHost), "hipMemcpy D2H");
+  if (!rc) {
+    if (es == hostEs) for (uint64_t i = 0; i < m; ++i) memcpy((char *)Y + i * ldy * es, (char *)hy + i * nrhs * es, nrhs * es);
+    else for (uint64_t i = 0; i < m; ++i) for (size_t q = 0; q < nrhs; ++q) ((double *)Y)[i * ldy + q] = ((float *)hy)[i * nrhs + q];
+  }
+  free(hx); free(hy);
   if (prev >= 0 && prev != s->device) (void)hipSetDevice(prev);
   return rc;
 }

@@ -249,6 +249,48 @@ class ShardedApply:
         self.gathered = torch.empty((layout.world * layout.max_rows,) + tail, dtype=dtype, device=device)
         self.index = torch.from_numpy(layout.gather_index).to(device) if layout.gather_index is not None else None
 
+    def my_rows(self):
+        """Global row indices of this rank's entries of a length-n vector, in the order its local operator yields them."""
+        lay = self.layout
+        if self.mode == "blocks":
+            return np.arange(lay.n, dtype=np.int64)
+        blks = lay.blocks_of[self.rank]
+        if not blks:
+            return np.zeros(0, dtype=np.int64)
+        return np.concatenate([np.arange(lay.row_offsets[rb], lay.row_offsets[rb] + lay.top_rows[rb]) for rb in blks]).astype(np.int64)
+
+    def apply_transpose(self, v, local_apply_transpose, num_cols):
+        """z = A^T v with v replicated: this rank applies A_r^T (local_apply_transpose(v_r, out)) to ITS entries of v and
+        the full-length partials add up -- ONE all-reduce (bfhipShardedApplyTransposeDevice is the C-ABI twin)."""
+        import torch
+        import torch.distributed as dist
+        if getattr(self, "_rows_idx", None) is None:
+            self._rows_idx = torch.from_numpy(self.my_rows()).to(v.device)
+        vr = v.index_select(0, self._rows_idx)
+        z = torch.zeros((num_cols,) + tuple(v.shape[1:]), dtype=v.dtype, device=v.device)
+        if vr.shape[0]:
+            local_apply_transpose(vr, z)
+        if self.layout.world > 1 or self.force_collective:
+            buf = torch.view_as_real(z) if z.is_complex() else z
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
+        return z
+
+    def cov_matvec(self, local_apply_transpose, num_cols, gamma, row_perm, rev_row_perm, v):
+        """cov_matvec of examples/covariance/lbo_cov.c:48-60 over the sharded operator: z = P A G G A^T P' v with the
+        reference's scatter-order permutations (out[perm[i]] = in[i], src/vec_real.c:312-329); every vector replicated."""
+        import torch
+        t = v
+        if rev_row_perm is not None:
+            t = torch.empty_like(v); t[rev_row_perm] = v
+        u = self.apply_transpose(t, local_apply_transpose, num_cols)
+        if gamma is not None:
+            u = u * gamma * gamma
+        z = self(u)
+        if row_perm is not None:
+            zz = torch.empty_like(z); zz[row_perm] = z
+            z = zz
+        return z
+
     def __call__(self, x):
         import torch.distributed as dist
         import torch
@@ -336,6 +378,56 @@ class RcclShardedApply:
         _capi.check(self._lib.bfhipShardedApplyDevice(self._sh, C.c_void_p(x.data_ptr()), nrhs, C.c_void_p(self._y.data_ptr()),
                                                       C.c_void_p(s.cuda_stream)))
         return self._y
+
+    def apply_transpose(self, v):
+        """z = A^T v on every rank (v replicated): bfhipShardedApplyTransposeDevice -- this rank's partial A_r^T v_r, ONE all-reduce."""
+        import ctypes as C
+
+        import torch
+
+        from . import _capi
+        ncols = int(self._lib.bfhipShardedGetNumCols(self._sh))
+        z = torch.empty((ncols,) + tuple(v.shape[1:]), dtype=v.dtype, device=v.device)
+        nrhs = 1 if v.dim() == 1 else v.shape[1]
+        s = torch.cuda.current_stream(v.device)
+        _capi.check(self._lib.bfhipShardedApplyTransposeDevice(self._sh, C.c_void_p(v.data_ptr()), nrhs, C.c_void_p(z.data_ptr()), C.c_void_p(s.cuda_stream)))
+        return z
+
+    def cov_matvec(self, gamma, row_perm, rev_row_perm, v):
+        """bfhipShardedCovMatvecDevice: z = P A G G A^T P' v in one call (real operators; perms int64 / uint64 device tensors or None)."""
+        import ctypes as C
+
+        import torch
+
+        from . import _capi
+        z = torch.empty(self.layout.n, dtype=v.dtype, device=v.device)
+        s = torch.cuda.current_stream(v.device)
+        ptr = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+        _capi.check(self._lib.bfhipShardedCovMatvecDevice(self._sh, ptr(gamma), ptr(row_perm), ptr(rev_row_perm), ptr(v), ptr(z), C.c_void_p(s.cuda_stream)))
+        return z
+
+    def solve_gmres(self, b, x0=None, tol=1e-12, max_num_iter=100, orthogonalization=0, precond=None):
+        """bfhipShardedSolveGMRESDevice: (x, numIter, residual); b / x0 replicated on every rank."""
+        import ctypes as C
+
+        import torch
+
+        from . import _capi
+        opt = _capi.BfhipGmresOptions()
+        opt.structSize, opt.orthogonalization, opt.tol, opt.maxNumIter = C.sizeof(opt), orthogonalization, tol, max_num_iter
+        opt.solveM = precond.handle if precond is not None else None
+        x = torch.empty_like(b)
+        nrhs = 1 if b.dim() == 1 else b.shape[1]
+        it, res = C.c_size_t(), C.c_double()
+        s = torch.cuda.current_stream(b.device)
+        _capi.check(self._lib.bfhipShardedSolveGMRESDevice(self._sh, C.byref(opt), C.c_void_p(b.data_ptr()), nrhs,
+                                                           None if x0 is None else C.c_void_p(x0.data_ptr()), C.byref(it), C.byref(res),
+                                                           C.c_void_p(x.data_ptr()), C.c_void_p(s.cuda_stream)))
+        return x, int(it.value), float(res.value)
+
+    def mat_new(self):
+        """The BfMat vtable shim over the sharded operator (bfhipShardedMatNew); the caller deletes it through its Delete slot."""
+        return self._lib.bfhipShardedMatNew(self._sh, 0)
 
     def set_timing(self, enabled):
         """Record (or not) the three events behind last_times(); they cost ~17 us of stream time per step."""

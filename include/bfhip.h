@@ -269,6 +269,35 @@ int bfhipShardedLastTimes(BfhipSharded *sh, double *localMs, double *collectiveM
 /* The three events behind bfhipShardedLastTimes cost ~17 us of stream time per apply (they are what keeps the stage
  * kernels, the collective and the next apply apart): on by default, turn them off for production loops. */
 int bfhipShardedSetTiming(BfhipSharded *sh, int enabled);
+/* The adjoint of the same step: dZ[numCols x nrhs] = A^T dV[numRowsGlobal x nrhs] on every rank (v replicated in, the FULL z
+ * out), what bfMatRmulVec / cov_matvec need at sizes that only fit sharded (reference src/mat_product.c:312-345,
+ * src/mat_block_dense.c:696-758).  Rank r holds A_r -- a set of rows (ROWS) or of blocks (BLOCKS) of A -- so it applies A_r^T
+ * to ITS entries of v (its segments, gathered into the order its operator produces them) and gets a full-length partial
+ * z_r; the partials add up: ONE in-place ncclAllReduce on dZ.  The local operator needs BFHIP_FLAG_ADJOINT (a row-range
+ * shard's adjoint plan is the transposed task list pruned by reachability from its rows; BFHIP_FLAG_ADJOINT_PACKED falls
+ * back to that shared-leaf plan on a shard).  Sum order is RCCL's: equal to the one-GPU A^T v to rounding. */
+int bfhipShardedApplyTransposeDevice(BfhipSharded *sh, const void *dV, size_t nrhs, void *dZ, void *stream);
+/* cov_matvec (examples/covariance/lbo_cov.c:48-60) over a sharded real operator, one call: z = P A G G A^T P' v with the
+ * sharded adjoint (all-reduce) and the sharded forward step (all-gather) above; arguments as bfhipCovMatvecDevice, every
+ * vector replicated on every rank.  Scratch is allocated in bfhipShardedCreate (real operators with an adjoint plan). */
+int bfhipShardedCovMatvecDevice(BfhipSharded *sh, const void *dGammaLam, const uint64_t *dRowPerm, const uint64_t *dRevRowPerm,
+                                const void *dV, void *dZ, void *stream);
+/* bfSolveGMRES (src/linalg.c:47-317) with the sharded step as the matvec: SURVEY 8(f) row 1, "with multi-GPU the allgathered
+ * iterate is already replicated".  Every rank calls it with the same (replicated) dB / dX0 and receives the same dX: the
+ * Krylov recurrences of bfhipSolveGMRESOptsDevice run redundantly on every GPU, the only communication of an iteration is
+ * the step's one collective, and every rank takes the same decisions (they are computed from identical data).  `opt` as
+ * for bfhipSolveGMRESOptsDevice; a preconditioner, if any, is a whole (unsharded) operator on this rank's GPU.  Complex
+ * square operators. */
+struct BfhipGmresOptions;
+int bfhipShardedSolveGMRESDevice(BfhipSharded *sh, const struct BfhipGmresOptions *opt, const void *dB, size_t nrhs, const void *dX0,
+                                 size_t *numIter, double *residual, void *dX, void *stream);
+size_t bfhipShardedGetNumRows(const BfhipSharded *sh);      /* rows of the whole operator */
+size_t bfhipShardedGetNumCols(const BfhipSharded *sh);
+/* The vtable shim of bfhipMatNew over a SHARDED operator: every rank's host calls bfMatMul / bfMatMulVec / bfMatRmulVec /
+ * bfMatTranspose on its copy with the same (replicated) right-hand side and gets the full result (host vectors are staged
+ * through device buffers allocated in bfhipShardedCreate).  Delete releases the shim and, if `ownsSharded`, the sharded
+ * object (never the operator or the communicator). */
+void *bfhipShardedMatNew(BfhipSharded *sh, int ownsSharded);
 /* Neither the operator nor the communicator is released.  Order: free the sharded objects of a communicator before
  * bfhipCommDestroy (a sharded object keeps a pointer to it for its steps; freeing itself does not touch it). */
 void bfhipShardedFree(BfhipSharded **sh);

@@ -61,7 +61,7 @@ def _worker(rank, world, port, n, k, nrhs, out_dir, mode, native=False):
         bowner, loads = assign_row_blocks(bw, world)
         layout = ShardLayout(desc.meta["top_rows"], [0] * len(desc.meta["top_rows"]), world)
         shard_root = hs.shard_desc_blocks(desc, [i for i in range(len(bw)) if bowner[i] == rank])
-    op = HipOperator.from_desc(desc, None, root=shard_root, seed=11, flags=_capi.FLAG_PLAN_ONLY, row_range=row_range)
+    op = HipOperator.from_desc(desc, None, root=shard_root, seed=11, flags=_capi.FLAG_PLAN_ONLY | _capi.FLAG_ADJOINT, row_range=row_range)
 
     def local_apply(x, out):
         out.copy_(torch.from_numpy(np.ascontiguousarray(plan_emulator.run_plan(op, x.numpy()))))
@@ -73,6 +73,11 @@ def _worker(rank, world, port, n, k, nrhs, out_dir, mode, native=False):
     y = step(x)
     # every rank ends with the full, row-ordered result
     np.save(os.path.join(out_dir, f"y{rank}.npy"), y.numpy().copy())
+    # the adjoint of the same step: this rank's A_r^T on ITS entries of v, ONE all-reduce
+    def local_apply_transpose(vr, out):
+        out.copy_(torch.from_numpy(np.ascontiguousarray(plan_emulator.run_plan(op, vr.numpy(), transpose=True))))
+    z = step.apply_transpose(x, local_apply_transpose, n)
+    np.save(os.path.join(out_dir, f"z{rank}.npy"), z.numpy().copy())
     if rank == 0:
         np.save(os.path.join(out_dir, "x.npy"), x.numpy())
         np.save(os.path.join(out_dir, "loads.npy"), np.asarray(loads))
@@ -96,6 +101,14 @@ def test_two_rank_sharded_apply_matches_full_oracle(tmp_path, nrhs, mode, native
         y = np.load(tmp_path / f"y{r}.npy")
         assert y.shape == y_ref.shape
         assert np.linalg.norm(y - y_ref) / np.linalg.norm(y_ref) < 1e-13
+    # A^T v against the oracle: the reference cannot transpose this graph (BfMatBlockCoo has no Transpose slot, its complex Rmul
+    # chain is not functional: DESIGN.md section 10), so the oracle's bfMatMul densifies A column block by column block
+    A_ref = bfref.from_desc(desc, None, seed=11)
+    A_dense = np.concatenate([bfref.mat_mul(A_ref, np.eye(n, 256, -c0, dtype=complex)) for c0 in range(0, n, 256)], axis=1)
+    z_ref = A_dense.T @ x
+    for r in range(world):
+        z = np.load(tmp_path / f"z{r}.npy")
+        assert z.shape == z_ref.shape and np.linalg.norm(z - z_ref) / np.linalg.norm(z_ref) < 1e-13
     loads = np.load(tmp_path / "loads.npy")
     assert loads.min() > 0.8 * loads.max()       # two (three) ranks are balanced
     if mode == "rows":
@@ -195,3 +208,69 @@ def test_two_rank_gmres_follows_the_restatement(tmp_path, nrhs):
     assert int(z["iters"]) == iters and abs(float(z["res"]) - hist[-1]) <= 1e-6 * hist[-1] + 1e-18
     assert np.linalg.norm(x0 - want) / np.linalg.norm(want) <= 1e-10
     assert np.linalg.norm(A @ x0 - (b if nrhs > 1 else b[:, 0])) / np.linalg.norm(b) <= 1e-9
+
+
+def _real_worker(rank, world, port, seed, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from butterfly_amd import _capi
+    from butterfly_amd.dist import ShardLayout, ShardedApply, row_partition
+    from butterfly_amd.operator import HipOperator
+    import plan_emulator
+    import randgraph
+    rng = np.random.default_rng(seed)
+    desc, vals = randgraph.random_real_operand(rng, depth=3, size_hint=150)
+    m, n = desc.rows[desc.root], desc.cols[desc.root]
+    cuts, loads = row_partition(desc, world)
+    layout = ShardLayout([cuts[r + 1] - cuts[r] for r in range(world)], list(range(world)), world)
+    op = HipOperator.from_desc(desc, vals, flags=_capi.FLAG_PLAN_ONLY | _capi.FLAG_ADJOINT, row_range=(cuts[rank], cuts[rank + 1]))
+
+    def local_apply(x, out):
+        out.copy_(torch.from_numpy(np.ascontiguousarray(plan_emulator.run_plan(op, x.numpy()))))
+
+    def local_apply_transpose(vr, out):
+        out.copy_(torch.from_numpy(np.ascontiguousarray(plan_emulator.run_plan(op, vr.numpy(), transpose=True))))
+
+    step = ShardedApply(layout, rank, local_apply, torch.device("cpu"), torch.float64, nrhs=1, mode="rows")
+    v = torch.from_numpy(rng.standard_normal(m))
+    gam = torch.from_numpy(rng.random(n) + 0.5)
+    perm = torch.from_numpy(rng.permutation(m))
+    rev = torch.empty_like(perm); rev[perm] = torch.arange(m)
+    z = step.apply_transpose(v, local_apply_transpose, n)
+    c = step.cov_matvec(local_apply_transpose, n, gam, perm, rev, v)
+    np.savez(os.path.join(out_dir, f"r{rank}.npz"), z=z.numpy(), c=c.numpy(), v=v.numpy(), gam=gam.numpy(), perm=perm.numpy(), rev=rev.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,seed", [(2, 33), (3, 32), (2, 39), (3, 41)])
+def test_sharded_rmulvec_and_cov_matvec_follow_the_oracle(tmp_path, world, seed):
+    """The adjoint step and cov_matvec (examples/covariance/lbo_cov.c:48-60) over a row-sharded REAL operator on 2 / 3 gloo
+    ranks against the oracle's own bfMatRmulVec / bfMatMulVec / bfVecRealPermute sequence on the whole graph."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import randgraph
+    from oracle import bfref
+    rng = np.random.default_rng(seed)
+    desc, vals = randgraph.random_real_operand(rng, depth=3, size_hint=150)
+    from butterfly_amd.dist import row_partition
+    from butterfly_amd import _capi
+    try:
+        row_partition(desc, world)
+    except _capi.BfhipError:
+        pytest.skip("this random operand offers fewer clean cuts than ranks")
+    mp.spawn(_real_worker, args=(world, _free_port(), seed, str(tmp_path)), nprocs=world, join=True)
+    A = bfref.from_desc(desc, vals)
+    r0 = np.load(tmp_path / "r0.npz")
+    v, gam, perm, rev = r0["v"], r0["gam"], r0["perm"], r0["rev"]
+    z_ref = bfref.mat_rmul_vec(A, v)
+    t = np.empty_like(v); t[rev] = v                      # bfVecRealPermute scatters: out[perm[i]] = in[i]
+    u = bfref.mat_rmul_vec(A, t) * gam * gam
+    c0 = bfref.mat_mul_vec(A, u)
+    c_ref = np.empty_like(c0); c_ref[perm] = c0
+    for r in range(world):
+        d = np.load(tmp_path / f"r{r}.npz")
+        assert np.linalg.norm(d["z"] - z_ref) <= 1e-12 * np.linalg.norm(z_ref)
+        assert np.linalg.norm(d["c"] - c_ref) <= 1e-12 * np.linalg.norm(c_ref)
