@@ -365,6 +365,7 @@ def main():
     if (not streamer and world == 1 and args.n in (None, 262144) and args.k is None and args.nrhs == 1 and args.dtype in (None, "c128")
             and not args.no_extra and args.emulate_world <= 1 and not dry):
         args.adjoint = True
+        args.pcie = True          # ... and the host-vector path an unmodified reference caller takes (pcie_inclusive)
     dtype = args.dtype or ("f32" if streamer else "c128")
     if streamer and dtype == "c128":
         raise SystemExit("the streamed operand is real: --dtype f32 or f64")
@@ -793,12 +794,38 @@ def main():
                     except Exception:
                         pass
         if args.pcie:
-            # host-buffer path (bfhipApply): H2D of x, all stages, D2H of y -- never the headline value
+            # host-buffer path (bfhipApply, what the vtable shim's Mul runs): never the headline value.  Three kinds of caller
+            # memory (include/bfhip.h): pageable (packed through pinned staging), registered (DMA straight from / to it), device
+            pcie = {}
+            hx = np.ascontiguousarray(x_host.astype(np.complex128 if not real else np.float64))
+            hy = np.empty((local_rows,) + shape[1:], dtype=hx.dtype)
+            reps = 10
+
+            def timed(fn):
+                fn(); fn()
+                t1_ = time.perf_counter()
+                for _ in range(reps):
+                    fn()
+                return (time.perf_counter() - t1_) / reps * 1e3
+            pcie["pageable_ms"] = timed(lambda: op.apply_host_into(hx, hy, args.nrhs))
+            try:
+                HipOperator.host_register(hx); HipOperator.host_register(hy)
+                pcie["registered_ms"] = timed(lambda: op.apply_host_into(hx, hy, args.nrhs))
+                HipOperator.host_unregister(hx); HipOperator.host_unregister(hy)
+            except Exception as e:
+                pcie["registered_error"] = repr(e)[:200]
+            if dtype != "f32":
+                yd_ = torch.empty((local_rows,) + shape[1:], dtype=tdtype, device=dev)
+
+                def dev_call():
+                    op.apply_pointers(x.data_ptr(), yd_.data_ptr(), args.nrhs)
+                pcie["device_pointers_ms"] = timed(dev_call)
             t1 = time.perf_counter()
-            reps = 5
             for _ in range(reps):
-                op.apply_host(x_host)
-            pcie_ms = (time.perf_counter() - t1) / reps * 1e3
+                op.apply_device(x, y_buf if sharded is None else None)
+            torch.cuda.synchronize()
+            pcie["resident_ms_same_moment"] = (time.perf_counter() - t1) / reps * 1e3
+            pcie_ms = pcie["pageable_ms"]
         config["stages"] = st["numStages"]
         config["sharding"] = ("none" if sworld == 1 else
                               "contiguous row ranges below the top-level blocks (bfhipRowPartition: balanced, source-side factors replicated) + one all-gather" if mode == "rows"
@@ -882,8 +909,12 @@ def main():
                                      "rel_vs_separate_applies": float(torch.linalg.norm(zc - zr) / torch.linalg.norm(zr)),
                                      "note": "bfhipCovMatvecDevice: z = P A diag(g)^2 A^T P' v, everything resident"}
         if args.pcie:
-            out["pcie_inclusive"] = {"ms_per_apply": pcie_ms, "matvec_per_s": args.nrhs / (pcie_ms / 1e3),
-                                     "note": "bfhipApply: pack into pinned staging + H2D x + apply + D2H y + unpack"}
+            out["pcie_inclusive"] = {"ms_per_apply": pcie_ms, "matvec_per_s": args.nrhs / (pcie_ms / 1e3), **pcie,
+                                     "ratio_pageable": pcie_ms / pcie["resident_ms_same_moment"],
+                                     "ratio_registered": (pcie["registered_ms"] / pcie["resident_ms_same_moment"]) if "registered_ms" in pcie else None,
+                                     "note": "bfhipApply on host vectors, synchronous (what the vtable shim's Mul runs): pageable = pack into pinned staging + H2D + "
+                                             "apply + D2H + unpack; registered = DMA straight from / to the caller's registered buffers (bfhipHostRegister); "
+                                             "device_pointers = the same entry handed device memory (used in place); resident = bfhipApplyDevice, timed at the same moment"}
         if args.emulate_world > 1:
             out["emulated_shard"] = {"world": args.emulate_world, "rank": srank, "mode": mode, "shard_leaf_bytes": st["leafBytes"]}
         # rank 0 times the CPU baseline whatever the world size (the other ranks wait at the closing barrier)
@@ -975,7 +1006,7 @@ def main():
         # BASELINE configs[1] (N = 65536, k = 4096, one right-hand side: launches of ~1 GB) in a child process: its own line
         try:
             torch.cuda.empty_cache()
-            cmd = [sys.executable, os.path.abspath(__file__), "--npoints", "65536", "--steps", "50", "--warmup", "5", "--no-extra",
+            cmd = [sys.executable, os.path.abspath(__file__), "--npoints", "65536", "--steps", "50", "--warmup", "5", "--no-extra", "--pcie",
                    "--seed", str(args.seed), "--cpu-budget-gb", "4.0"]
             env = dict(os.environ)
             for k_ in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
@@ -986,7 +1017,8 @@ def main():
                 raise RuntimeError(f"child exit {pr.returncode}: {pr.stderr[-300:]}")
             c = json.loads(line[-1])
             out["n65536"] = {"config": "BASELINE configs[1]: " + c["config"]["workload"], "value": c["value"], "unit": c["unit"], "dtype": c["dtype"],
-                             "steps": c["steps"], "ms_per_step": c["ms_per_step"], "roofline": c["roofline"], "cpu_baseline": c.get("cpu_baseline")}
+                             "steps": c["steps"], "ms_per_step": c["ms_per_step"], "roofline": c["roofline"], "cpu_baseline": c.get("cpu_baseline"),
+                             "pcie_inclusive": c.get("pcie_inclusive")}
         except Exception as e:
             out["n65536"] = {"error": repr(e)[:400]}
 

@@ -352,6 +352,10 @@ def load():
     lib.bfhipRowPartitionMat.restype = C.c_int
     lib.bfhipApply.argtypes = [vp, vp, C.c_size_t, C.c_size_t, vp, C.c_size_t]
     lib.bfhipApply.restype = C.c_int
+    lib.bfhipHostRegister.argtypes = [vp, C.c_size_t]
+    lib.bfhipHostRegister.restype = C.c_int
+    lib.bfhipHostUnregister.argtypes = [vp]
+    lib.bfhipHostUnregister.restype = C.c_int
     lib.bfhipApplyDevice.argtypes = [vp, vp, C.c_size_t, vp, vp]
     lib.bfhipApplyDevice.restype = C.c_int
     lib.bfhipApplyTranspose.argtypes = [vp, vp, C.c_size_t, C.c_size_t, vp, C.c_size_t]

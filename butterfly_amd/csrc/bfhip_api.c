@@ -897,6 +897,15 @@ out:
   return rc;
 }
 
+/* The host-vector apply behind bfhipApply and every slot of the vtable shim (the path an unmodified reference caller takes:
+ * bfSolveGMRES calls bfMatMul once per iteration, src/linalg.c:125,155).  What each of X and Y is decides what it costs:
+ *   device memory of the operator's GPU, densely packed   used in place: no copy at all (the call is then bfhipApplyDevice + a wait);
+ *   pinned / registered host memory, densely packed       DMA straight from / to the caller's buffer (hipHostMalloc'd, or registered with
+ *                                                         bfhipHostRegister by a caller who knows its lifetime: a Krylov basis, say);
+ *   anything else (pageable memory, ld != nrhs, fp32)     packed through the operator's own pinned staging buffer, then DMA.
+ * The wait is on the apply's own stream, not on the device.  The library never registers a caller's buffer by itself: a cached
+ * registration of memory the caller has since freed (glibc hands 4 MB vectors back to the kernel) would leave the GPU with a stale
+ * mapping. */
 static int applyHost(BfhipOperator *op, int transpose, void const *X, size_t ldx, size_t nrhs, void *Y, size_t ldy) {
   if (!op || !X || !Y) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "NULL argument");
   if (transpose && !op->hasTplan) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "operator was not compiled with BFHIP_FLAG_ADJOINT");
@@ -910,8 +919,10 @@ static int applyHost(BfhipOperator *op, int transpose, void const *X, size_t ldx
   size_t hostEs = op->srcDtype == BFHIP_C128 ? 16 : 8;      /* host side is always double precision */
   uint64_t n = transpose ? op->plan.numRows : op->plan.numCols, m = transpose ? op->plan.numCols : op->plan.numRows;
   uint64_t big = n > m ? n : m;
+  int const same = es == hostEs;
+  int const kx = same && ldx == nrhs ? bfdevPointerKind(X) : 0, ky = same && ldy == nrhs ? bfdevPointerKind(Y) : 0;
   void *hx = NULL, *hy = NULL;
-  if (op->xyRhs < nrhs) {
+  if (op->xyRhs < nrhs && (kx != 1 || ky != 1)) {
     bfdevFree(op->dX); bfdevFree(op->dY); op->dX = op->dY = NULL; op->xyRhs = 0;
     bfdevHostFreePinned(op->hX); bfdevHostFreePinned(op->hY); op->hX = op->hY = NULL;
     if ((rc = bfdevMalloc(&op->dX, big * nrhs * es))) goto out;
@@ -921,27 +932,47 @@ static int applyHost(BfhipOperator *op, int transpose, void const *X, size_t ldx
     if ((rc = bfdevHostAllocPinned(&op->hY, (big * nrhs * es) != 0 ? big * nrhs * es : 16))) goto out;
     op->xyRhs = (uint32_t)nrhs;
   }
-  /* pack to ld == nrhs (and demote if the operator computes in fp32) into the pinned buffer */
   hx = op->hX; hy = op->hY;
-  if (es == hostEs) {
-    if (ldx == nrhs) memcpy(hx, X, n * nrhs * es);
-    else for (uint64_t i = 0; i < n; ++i) memcpy((char *)hx + i * nrhs * es, (char const *)X + i * ldx * es, nrhs * es);
-  } else {
-    for (uint64_t i = 0; i < n; ++i) for (size_t q = 0; q < nrhs; ++q) ((float *)hx)[i * nrhs + q] = (float)((double const *)X)[i * ldx + q];
+  void const *dXuse = op->dX;
+  void *dYuse = ky == 1 ? Y : op->dY;
+  if (kx == 1) dXuse = X;
+  else if (kx == 2 || kx == 3) { if ((rc = bfdevMemcpyAnyAsync(op->dX, X, n * nrhs * es, NULL))) goto out; }
+  else {
+    /* pack to ld == nrhs (and demote if the operator computes in fp32) into the pinned buffer */
+    if (same) {
+      if (ldx == nrhs) memcpy(hx, X, n * nrhs * es);
+      else for (uint64_t i = 0; i < n; ++i) memcpy((char *)hx + i * nrhs * es, (char const *)X + i * ldx * es, nrhs * es);
+    } else {
+      for (uint64_t i = 0; i < n; ++i) for (size_t q = 0; q < nrhs; ++q) ((float *)hx)[i * nrhs + q] = (float)((double const *)X)[i * ldx + q];
+    }
+    if ((rc = bfdevMemcpyH2DAsync(op->dX, hx, n * nrhs * es, NULL))) goto out;
   }
-  if ((rc = bfdevMemcpyH2DAsync(op->dX, hx, n * nrhs * es, NULL))) goto out;
-  if ((rc = runPlan(op, transpose ? &op->tplan : &op->plan, op->dX, nrhs, op->dY, NULL))) goto out;
-  if ((rc = bfdevMemcpyD2HAsync(hy, op->dY, m * nrhs * es, NULL))) goto out;
+  if ((rc = runPlan(op, transpose ? &op->tplan : &op->plan, dXuse, nrhs, dYuse, NULL))) goto out;
+  if (ky == 2 || ky == 3) { if ((rc = bfdevMemcpyAnyAsync(Y, op->dY, m * nrhs * es, NULL))) goto out; }
+  else if (ky != 1 && (rc = bfdevMemcpyD2HAsync(hy, op->dY, m * nrhs * es, NULL))) goto out;
   if ((rc = bfdevSync(NULL))) goto out;
-  if (es == hostEs) {
-    if (ldy == nrhs) memcpy(Y, hy, m * nrhs * es);
-    else for (uint64_t i = 0; i < m; ++i) memcpy((char *)Y + i * ldy * es, (char *)hy + i * nrhs * es, nrhs * es);
-  } else {
-    for (uint64_t i = 0; i < m; ++i) for (size_t q = 0; q < nrhs; ++q) ((double *)Y)[i * ldy + q] = ((float *)hy)[i * nrhs + q];
+  if (ky == 0) {
+    if (same) {
+      if (ldy == nrhs) memcpy(Y, hy, m * nrhs * es);
+      else for (uint64_t i = 0; i < m; ++i) memcpy((char *)Y + i * ldy * es, (char *)hy + i * nrhs * es, nrhs * es);
+    } else {
+      for (uint64_t i = 0; i < m; ++i) for (size_t q = 0; q < nrhs; ++q) ((double *)Y)[i * ldy + q] = ((float *)hy)[i * nrhs + q];
+    }
   }
 out:
   if (prev >= 0 && prev != op->device) bfdevSetDevice(prev);
   return rc;
+}
+
+/* A caller who knows the lifetime of its vectors (the Krylov basis of a solver, a right-hand side applied many times) registers
+ * them once: bfhipApply / the shim's Mul then DMA straight from / to them instead of packing through the staging buffer. */
+int bfhipHostRegister(void *p, size_t bytes) {
+  if (!p || !bytes) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "NULL pointer / zero bytes");
+  return bfdevHostRegister(p, bytes);
+}
+int bfhipHostUnregister(void *p) {
+  if (!p) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "NULL pointer");
+  return bfdevHostUnregister(p);
 }
 
 int bfhipApply(BfhipOperator *op, void const *X, size_t ldx, size_t nrhs, void *Y, size_t ldy) {

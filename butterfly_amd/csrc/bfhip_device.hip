@@ -1119,6 +1119,23 @@ int bfdevMemcpyH2D(void *dst, void const *src, size_t bytes) { return bytes ? hi
 int bfdevMemcpyD2H(void *dst, void const *src, size_t bytes) { return bytes ? hipFail(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost), "hipMemcpy D2H") : 0; }
 int bfdevMemset(void *dst, int value, size_t bytes) { return bytes ? hipFail(hipMemset(dst, value, bytes), "hipMemset") : 0; }
 int bfdevSync(void *stream) { return hipFail(hipStreamSynchronize((hipStream_t)stream), "hipStreamSynchronize"); }
+// What a caller's pointer is: 0 plain (pageable / unknown) host memory, 1 device memory of the CURRENT device, 2 host memory the
+// runtime can DMA from / to directly (hipHostMalloc'd or hipHostRegister'ed), 3 device memory of another device.
+int bfdevPointerKind(void const *p) {
+  hipPointerAttribute_t a;
+  hipError_t const e = hipPointerGetAttributes(&a, p);
+  if (e != hipSuccess) { (void)hipGetLastError(); return 0; }      // older runtimes: an error for unregistered memory
+  if (a.type == hipMemoryTypeDevice) {
+    int cur = -1;
+    (void)hipGetDevice(&cur);
+    return a.device == cur ? 1 : 3;
+  }
+  if (a.type == hipMemoryTypeHost) return 2;
+  return 0;      // unregistered, managed: staged like pageable memory
+}
+int bfdevHostRegister(void *p, size_t bytes) { return hipFail(hipHostRegister(p, bytes, hipHostRegisterDefault), "hipHostRegister"); }
+int bfdevHostUnregister(void *p) { return hipFail(hipHostUnregister(p), "hipHostUnregister"); }
+int bfdevMemcpyAnyAsync(void *dst, void const *src, size_t bytes, void *stream) { return bytes ? hipFail(hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, (hipStream_t)stream), "hipMemcpyAsync") : 0; }
 int bfdevHostAllocPinned(void **p, size_t bytes) { return hipFail(hipHostMalloc(p, bytes, hipHostMallocDefault), "hipHostMalloc"); }
 void bfdevHostFreePinned(void *p) { if (p) (void)hipHostFree(p); }
 

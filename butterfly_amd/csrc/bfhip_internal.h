@@ -239,6 +239,10 @@ int bfdevMemcpyH2D(void *dst, void const *src, size_t bytes);
 int bfdevMemcpyD2H(void *dst, void const *src, size_t bytes);
 int bfdevMemset(void *dst, int value, size_t bytes);
 int bfdevSync(void *stream);
+int bfdevPointerKind(void const *p);            /* 0 pageable host, 1 this device, 2 pinned / registered host, 3 another device */
+int bfdevHostRegister(void *p, size_t bytes);
+int bfdevHostUnregister(void *p);
+int bfdevMemcpyAnyAsync(void *dst, void const *src, size_t bytes, void *stream);
 int bfdevHostAllocPinned(void **p, size_t bytes);
 void bfdevHostFreePinned(void *p);
 

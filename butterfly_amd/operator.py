@@ -178,6 +178,23 @@ class HipOperator:
         check(self._lib.bfhipApply(self._h, x2.ctypes.data, nrhs, nrhs, y.ctypes.data, nrhs))
         return y[:, 0] if one_d else y
 
+    def apply_host_into(self, x: np.ndarray, y: np.ndarray, nrhs=1):
+        """bfhipApply on caller-owned, densely packed host arrays (nothing is allocated: what an unmodified caller's loop costs)."""
+        check(self._lib.bfhipApply(self._h, x.ctypes.data, nrhs, nrhs, y.ctypes.data, nrhs))
+        return y
+
+    def apply_pointers(self, xptr, yptr, nrhs=1):
+        """bfhipApply on raw pointers of any kind (device, pinned / registered host, pageable): include/bfhip.h says what each costs."""
+        check(self._lib.bfhipApply(self._h, C.c_void_p(xptr), nrhs, nrhs, C.c_void_p(yptr), nrhs))
+
+    @staticmethod
+    def host_register(a: np.ndarray):
+        check(_capi.load().bfhipHostRegister(C.c_void_p(a.ctypes.data), a.nbytes))
+
+    @staticmethod
+    def host_unregister(a: np.ndarray):
+        check(_capi.load().bfhipHostUnregister(C.c_void_p(a.ctypes.data)))
+
     def apply_device(self, x, y=None, stream=None):
         """bfhipApplyDevice on torch tensors resident on the operator's GPU.
         x: [numCols] or [numCols, nrhs], contiguous; returns y (async on the

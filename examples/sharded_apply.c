@@ -13,7 +13,10 @@
  * every rank compiles only the block rows it owns (BfhipOptions.rowBlockBegin/End wants a contiguous
  * run, so ownership here is by runs of block rows) and the result is checked against the unsharded
  * operator on rank 0's GPU; a third pass deals the ranks contiguous row RANGES (bfhipRowPartition +
- * BfhipOptions.rowBegin/rowEnd).  Exit code 0 iff all three reproduce it bit for bit. */
+ * BfhipOptions.rowBegin/rowEnd).  Every pass also runs the ADJOINT of the step (bfhipShardedApplyTransposeDevice: the rank's
+ * A_r^T on its entries of v, one all-reduce) against the unsharded A^T v, and a last pass solves a square system with
+ * bfhipShardedSolveGMRESDevice next to bfhipSolveGMRESOptsDevice.  Exit code 0 iff the three forward passes reproduce the
+ * unsharded apply bit for bit, the adjoints agree to rounding and the two solves take the same iterations. */
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -71,6 +74,7 @@ int main(int argc, char **argv) {
   BfhipOptions o;
   memset(&o, 0, sizeof o);
   o.structSize = sizeof o; o.device = device; o.seed = 42; o.maxRhs = 2;
+  o.flags = BFHIP_FLAG_ADJOINT;          /* every operator below also carries the plan of its transpose */
   BfhipOperator *full = NULL, *mine = NULL;
   CHECK(bfhipCompileDesc(&d, &o, &full));
   o.rowBlockBegin = myBegin; o.rowBlockEnd = myEnd;
@@ -100,6 +104,24 @@ int main(int argc, char **argv) {
   CHECK(bfhipApplyDevice(full, dX, nrhs, dY, NULL));
   if (hipDeviceSynchronize() || hipMemcpy(yRef, dY, m * nrhs * 16, 2)) return 4;
 
+  /* the adjoint's reference: z = A^T v on the whole operator */
+  double *v = malloc(m * nrhs * 16), *zRef = malloc(n * nrhs * 16), *z = malloc(n * nrhs * 16);
+  for (uint64_t i = 0; i < 2 * m * nrhs; ++i) v[i] = cos(0.11 * (double)i) - 0.02 * (double)(i % 5);
+  void *dV = NULL, *dZ = NULL;
+  if (hipMalloc(&dV, m * nrhs * 16) || hipMalloc(&dZ, n * nrhs * 16) || hipMemcpy(dV, v, m * nrhs * 16, 1)) return 4;
+  CHECK(bfhipApplyTransposeDevice(full, dV, nrhs, dZ, NULL));
+  if (hipDeviceSynchronize() || hipMemcpy(zRef, dZ, n * nrhs * 16, 2)) return 4;
+  int badT = 0;
+#define CHECK_ADJOINT(what) do { \
+    CHECK(bfhipShardedApplyTransposeDevice(sh, dV, nrhs, dZ, NULL)); \
+    if (hipDeviceSynchronize() || hipMemcpy(z, dZ, n * nrhs * 16, 2)) return 4; \
+    double num_ = 0, den_ = 0; \
+    for (uint64_t i_ = 0; i_ < 2 * n * nrhs; ++i_) { num_ += (z[i_] - zRef[i_]) * (z[i_] - zRef[i_]); den_ += zRef[i_] * zRef[i_]; } \
+    int const ok_ = sqrt(num_ / den_) <= 1e-13; \
+    if (!ok_) badT = 1; \
+    printf("rank %d/%d %s adjoint: rel. diff. to the unsharded A^T v %.1e, %s\n", rank, nranks, what, sqrt(num_ / den_), ok_ ? "adjoint-equal" : "MISMATCH"); \
+  } while (0)
+
   int bad = 0;
   BfhipShardSpec spec;
   memset(&spec, 0, sizeof spec);
@@ -113,6 +135,7 @@ int main(int argc, char **argv) {
   if (hipMemcpy(y, dY, m * nrhs * 16, 2)) return 4;
   if (memcmp(y, yRef, m * nrhs * 16) != 0) { fprintf(stderr, "rank %d: rows mode differs from the unsharded apply\n", rank); bad = 1; }
   printf("rank %d/%d rows mode: local %.3f ms, collective %.3f ms, %s\n", rank, nranks, localMs, collMs, bad ? "MISMATCH" : "bit-identical");
+  CHECK_ADJOINT("rows mode");
   bfhipShardedFree(&sh);
 
   /* blocks mode: a full-length partial y per rank; here simply "my block rows at their original
@@ -134,6 +157,7 @@ int main(int argc, char **argv) {
   int bad2 = memcmp(y, yRef, m * nrhs * 16) != 0;
   if (bad2) fprintf(stderr, "rank %d: blocks mode differs from the unsharded apply\n", rank);
   printf("rank %d/%d blocks mode: local %.3f ms, collective %.3f ms, %s\n", rank, nranks, localMs, collMs, bad2 ? "MISMATCH" : "bit-identical");
+  CHECK_ADJOINT("blocks mode");
   bfhipShardedFree(&sh);
 
   /* row RANGES (round 3): balanced cuts from the library, one contiguous range per rank; the rank's operator keeps
@@ -156,9 +180,65 @@ int main(int argc, char **argv) {
   if (bad3) fprintf(stderr, "rank %d: row-range mode differs from the unsharded apply\n", rank);
   printf("rank %d/%d row ranges [%llu, %llu): local %.3f ms, collective %.3f ms, %s\n", rank, nranks, (unsigned long long)cuts[rank],
          (unsigned long long)cuts[rank + 1], localMs, collMs, bad3 ? "MISMATCH" : "bit-identical");
+  CHECK_ADJOINT("row ranges");
   bfhipShardedFree(&sh);
   bfhipFree(&range);
   bad |= bad3;
+
+  /* GMRES over the sharded step (bfhipShardedSolveGMRESDevice) next to the one-GPU solver on the same square operand:
+   * 4 x 4 blocks of 60 x 60, identities on the diagonal plus seeded dense leaves scaled to a contraction -- built as a
+   * product-free block matrix whose diagonal blocks are BLOCK nodes {Identity, Dense}.  Ranks own runs of block rows. */
+  int badG = 0;
+  {
+    enum { Q = 4, B = 60, NG = Q * Q + Q + 1, NCH = Q * (Q + 1) };
+    uint8_t gk[NG]; uint64_t gr[NG], gc[NG], gcb[NG + 1], gcn[NCH], gr0[NCH], gc0[NCH], gtrb[NCH];
+    uint64_t nc = 0;
+    /* nodes 0 .. Q*Q-1: dense leaves (i, j); Q*Q .. Q*Q+Q-1: the identities of the diagonal; the root last */
+    for (int i = 0; i < NG - 1; ++i) { gk[i] = i < Q * Q ? BFHIP_NODE_DENSE : BFHIP_NODE_IDENTITY; gr[i] = B; gc[i] = B; gcb[i] = 0; }
+    int const rootG = NG - 1;
+    gk[rootG] = BFHIP_NODE_BLOCK; gr[rootG] = Q * B; gc[rootG] = Q * B; gcb[rootG] = 0;
+    for (int i = 0; i < Q; ++i) {
+      for (int j = 0; j < Q; ++j) { gcn[nc] = (uint64_t)(i * Q + j); gr0[nc] = (uint64_t)i * B; gc0[nc] = (uint64_t)j * B; gtrb[nc] = (uint64_t)i; ++nc; }
+      gcn[nc] = (uint64_t)(Q * Q + i); gr0[nc] = (uint64_t)i * B; gc0[nc] = (uint64_t)i * B; gtrb[nc] = (uint64_t)i; ++nc;
+    }
+    gcb[NG] = nc;
+    BfhipDesc dg;
+    memset(&dg, 0, sizeof dg);
+    dg.structSize = sizeof dg; dg.dtype = BFHIP_C128; dg.numNodes = NG; dg.root = (uint64_t)rootG;
+    dg.kind = gk; dg.rows = gr; dg.cols = gc; dg.childBegin = gcb; dg.childNode = gcn; dg.childRow0 = gr0; dg.childCol0 = gc0; dg.topRowBlock = gtrb;
+    uint64_t const ng = (uint64_t)Q * B;
+    uint32_t ownerG[Q];
+    uint64_t rowsG[Q], gb = Q, ge = 0;
+    for (int i = 0; i < Q; ++i) { ownerG[i] = (uint32_t)(i * (nranks < Q ? nranks : Q) / Q); rowsG[i] = B; if ((int)ownerG[i] == rank) { if ((uint64_t)i < gb) gb = (uint64_t)i; ge = (uint64_t)i + 1; } }
+    BfhipOptions og = o;
+    og.flags = 0; og.rowBegin = og.rowEnd = 0; og.rowBlockBegin = og.rowBlockEnd = 0;
+    BfhipOperator *gfull = NULL, *gmine = NULL;
+    CHECK(bfhipCompileDesc(&dg, &og, &gfull));
+    if (gb < ge) { og.rowBlockBegin = gb; og.rowBlockEnd = ge; CHECK(bfhipCompileDesc(&dg, &og, &gmine)); }
+    if (gmine) {
+      memset(&spec, 0, sizeof spec);
+      spec.structSize = sizeof spec; spec.mode = BFHIP_SHARD_ROWS; spec.numRowsGlobal = ng; spec.numSegments = Q; spec.segRows = rowsG; spec.segOwner = ownerG;
+      CHECK(bfhipShardedCreate(gmine, comm, &spec, 1, &sh));
+      double *b = malloc(ng * 16), *xa = malloc(ng * 16), *xb = malloc(ng * 16);
+      for (uint64_t i = 0; i < 2 * ng; ++i) b[i] = sin(0.3 * (double)i + 1.0);
+      void *dB = NULL, *dXa = NULL, *dXb = NULL;
+      if (hipMalloc(&dB, ng * 16) || hipMalloc(&dXa, ng * 16) || hipMalloc(&dXb, ng * 16) || hipMemcpy(dB, b, ng * 16, 1)) return 4;
+      BfhipGmresOptions go;
+      memset(&go, 0, sizeof go);
+      go.structSize = sizeof go; go.orthogonalization = BFHIP_GMRES_ORTH_MGS; go.tol = 1e-10; go.maxNumIter = 60;
+      size_t ita = 0, itb = 0; double ra = 0, rb = 0;
+      CHECK(bfhipSolveGMRESOptsDevice(gfull, &go, dB, 1, NULL, &ita, &ra, dXa, NULL));
+      CHECK(bfhipShardedSolveGMRESDevice(sh, &go, dB, 1, NULL, &itb, &rb, dXb, NULL));
+      if (hipMemcpy(xa, dXa, ng * 16, 2) || hipMemcpy(xb, dXb, ng * 16, 2)) return 4;
+      double num = 0, den = 0;
+      for (uint64_t i = 0; i < 2 * ng; ++i) { num += (xa[i] - xb[i]) * (xa[i] - xb[i]); den += xa[i] * xa[i]; }
+      badG = ita != itb || sqrt(num / den) > 1e-10;
+      printf("rank %d/%d gmres: %zu iterations (one GPU: %zu), residual %.2e, solutions differ by %.1e, %s\n", rank, nranks, itb, ita, rb, sqrt(num / den), badG ? "MISMATCH" : "gmres-equal");
+      hipFree(dB); hipFree(dXa); hipFree(dXb); free(b); free(xa); free(xb);
+      bfhipShardedFree(&sh);
+    }
+    bfhipFree(&gmine); bfhipFree(&gfull);
+  }
 
   /* error behaviour: a spec that does not cover the operator is refused, nothing aborts */
   spec.mode = BFHIP_SHARD_ROWS; spec.numSegments = NBR - 1; spec.segRows = rowsOf; spec.segOwner = owner;
@@ -166,7 +246,7 @@ int main(int argc, char **argv) {
 
   bfhipCommDestroy(&comm);
   bfhipFree(&part); bfhipFree(&mine); bfhipFree(&full);
-  hipFree(dX); hipFree(dY);
-  free(x); free(y); free(yRef);
-  return bad || bad2;
+  hipFree(dX); hipFree(dY); hipFree(dV); hipFree(dZ);
+  free(x); free(y); free(yRef); free(v); free(z); free(zRef);
+  return bad || bad2 || badT || badG;
 }

@@ -187,6 +187,15 @@ int bfhipDescSubtreeLeafElems(const BfhipDesc *desc, uint64_t *leafElems);
  * with colStride == 1, mat_dense_complex.h:69-81).  Synchronous. */
 int bfhipApply(BfhipOperator *op, const void *X, size_t ldx, size_t nrhs, void *Y, size_t ldy);
 
+/* What bfhipApply (and every slot of the vtable shim) does with X and Y depends on what they are (hipPointerGetAttributes):
+ * densely packed (ld == nrhs) double-precision vectors in DEVICE memory of the operator's GPU are used in place, in PINNED or
+ * REGISTERED host memory they are the source / target of the DMA itself, anything else is packed through the operator's pinned
+ * staging buffer (one more pass over the vector on the CPU, each way).  The library never registers a caller's buffer on its own
+ * (it cannot know when the caller frees it); a caller that reuses its vectors -- the Krylov basis of bfSolveGMRES, say --
+ * registers them once (hipHostRegister underneath; undo before freeing the memory). */
+int bfhipHostRegister(void *p, size_t bytes);
+int bfhipHostUnregister(void *p);
+
 /* Same on device-resident, densely packed (ld == nrhs) vectors; enqueued on
  * `stream` (hipStream_t, NULL = default stream) and asynchronous. */
 int bfhipApplyDevice(BfhipOperator *op, const void *dX, size_t nrhs, void *dY, void *stream);

@@ -890,6 +890,7 @@ def test_sharded_apply_from_plain_c(tmp_path):
     p = subprocess.run([exe, "1", "0"], capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stdout + p.stderr
     assert p.stdout.count("bit-identical") == 3, p.stdout          # block rows, (row, col) blocks, row ranges
+    assert p.stdout.count("adjoint-equal") == 3 and p.stdout.count("gmres-equal") == 1, p.stdout      # the adjoint of each, and GMRES over the sharded step
 
 
 @pytest.mark.parametrize("mode", ["rows", "blocks"])
