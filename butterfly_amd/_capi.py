@@ -16,6 +16,7 @@ FLAG_PLAN_ONLY = 2
 FLAG_ADJOINT = 4
 FLAG_FLOW = 8
 FLAG_ADJOINT_PACKED = 16
+FLAG_EXACT_COMPLEX = 32
 
 ERROR_NAMES = {0: "BF_ERROR_NONE", 1: "BF_ERROR_INVALID_ARGUMENTS", 2: "BF_ERROR_RUNTIME_ERROR",
                3: "BF_ERROR_NOT_IMPLEMENTED", 4: "BF_ERROR_MEMORY_ERROR", 5: "BF_ERROR_OUT_OF_RANGE",

@@ -774,6 +774,7 @@ static int runPlan(BfhipOperator *op, BfPlan *plan, void const *dX, size_t nrhs,
     a.x = dX; a.y = dY; a.temp = op->dTemp; a.zero = op->dZero; a.nrhs = (uint32_t)nrhs; a.dtype = plan->dtype; a.maxRows = st->maxRows;
     a.transposed = plan->transposed;
     a.tickets = NULL;
+    a.exactComplex = (op->flags & BFHIP_FLAG_EXACT_COMPLEX) != 0; a.pad2 = 0;
     if (plan->dtype == BFHIP_C128 && !plan->transposed && nrhs < 2) a.tickets = st->dTickets;      /* NULL unless this is an EXPERIMENTAL build run with BFHIP_PERSISTENT=1 (allocated at compile time) */
     if (prof && (rc = bfdevEventRecord(op->evStart[evBase + s], stream))) goto out;
     if ((rc = bfdevLaunchStage(&a, stream))) goto out;
@@ -1246,7 +1247,7 @@ static int validateReduce(BfPlan const *pl, BfReduce const *rd, uint32_t const *
   return 0;
 }
 
-static int loadPlan(FILE *fp, BfhipOperator *op, BfPlan *pl, FileHeader const *fh) {
+static int loadPlan(FILE *fp, BfhipOperator *op, BfPlan *pl, FileHeader const *fh, uint64_t arenaElems) {
   FilePlanHeader ph;
   int rc = readAll(fp, &ph, sizeof ph);
   if (rc) return rc;
@@ -1254,7 +1255,7 @@ static int loadPlan(FILE *fp, BfhipOperator *op, BfPlan *pl, FileHeader const *f
   pl->dtype = fh->dtype; pl->elemSize = fh->elemSize; pl->epl = fh->epl; pl->xcap = fh->xcap;
   pl->maxItemRows = ph.maxItemRows; pl->transposed = (int)ph.transposed;
   pl->numRows = ph.numRows; pl->numCols = ph.numCols; pl->numStages = ph.numStages; pl->tempElems = ph.tempElems;
-  pl->arenaElems = pl->transposed ? 0 : fh->arenaElems;
+  pl->arenaElems = pl->transposed ? 0 : arenaElems;
   pl->leafElems = fh->leafElems; pl->numLeaves = fh->numLeaves;
   if (pl->epl != 16 / pl->elemSize || pl->xcap != 256 || pl->maxItemRows > 64 * pl->epl || (pl->transposed && pl->maxItemRows > 128))
     return bfhipFail(BFABI_ERROR_FILE_ERROR, "corrupt plan header (lane granule / piece width / item height)");
@@ -1275,7 +1276,7 @@ static int loadPlan(FILE *fp, BfhipOperator *op, BfPlan *pl, FileHeader const *f
       while (st->firstSmall && (((BfDevItem const *)hItems)[st->firstSmall - 1].mrFlags & BF_ITEM_SMALL)) --st->firstSmall;
       st->numNarrow = 0;
       while (st->numNarrow < st->numItems && (((BfDevItem const *)hItems)[st->numNarrow].mrFlags & BF_ITEM_TNARROW)) ++st->numNarrow;
-      rc = validateStage(pl, fh->arenaElems, st, hItems, hPieces);
+      rc = validateStage(pl, arenaElems, st, hItems, hPieces);
       if (!rc && pl->transposed) {
         st->maxRowsRest = 0;
         for (uint64_t i = st->numNarrow; i < st->numItems; ++i) {
@@ -1317,7 +1318,6 @@ static int loadPlan(FILE *fp, BfhipOperator *op, BfPlan *pl, FileHeader const *f
 int bfhipSave(BfhipOperator *op, char const *path) {
   if (!op || !path) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "NULL argument");
   if (op->flags & BFHIP_FLAG_PLAN_ONLY) return bfhipFail(BFABI_ERROR_RUNTIME_ERROR, "a plan-only operator has no device data to save");
-  if (op->dArenaT) return bfhipFail(BFABI_ERROR_NOT_IMPLEMENTED, "bfhipSave: operator compiled with BFHIP_FLAG_ADJOINT_PACKED (its second leaf arena is not part of the file format)");
   int prev = -1;
   bfdevGetDevice(&prev);
   int rc = bfdevSetDevice(op->device);
@@ -1330,12 +1330,16 @@ int bfhipSave(BfhipOperator *op, char const *path) {
   memcpy(fh.magic, BFHIP_FILE_MAGIC, 8);
   fh.version = 1; fh.dtype = op->plan.dtype; fh.srcDtype = op->srcDtype; fh.elemSize = op->plan.elemSize; fh.epl = op->plan.epl;
   fh.xcap = op->plan.xcap; fh.hasTplan = (uint32_t)op->hasTplan;
+  fh.reserved = op->dArenaT ? 1u : 0u;        /* bit 0: the adjoint plan is a forward plan of the transposed expression over a second arena (BFHIP_FLAG_ADJOINT_PACKED) */
   fh.numRows = op->plan.numRows; fh.numCols = op->plan.numCols; fh.arenaElems = op->plan.arenaElems;
   fh.leafElems = op->plan.leafElems; fh.numLeaves = op->plan.numLeaves; fh.leafBytesAlgorithmic = op->leafBytesAlgorithmic;
   rc = writeAll(fp, &fh, sizeof fh);
+  uint64_t const arenaElemsT = op->dArenaT ? op->tplan.arenaElems : 0;
+  if (!rc && op->dArenaT) rc = writeAll(fp, &arenaElemsT, sizeof arenaElemsT);
   if (!rc) rc = savePlan(fp, &op->plan);
   if (!rc && op->hasTplan) rc = savePlan(fp, &op->tplan);
   if (!rc) rc = writeDeviceArray(fp, op->dArena, (size_t)op->plan.arenaElems * op->plan.elemSize);
+  if (!rc && op->dArenaT) rc = writeDeviceArray(fp, op->dArenaT, (size_t)arenaElemsT * op->plan.elemSize);
   if (fclose(fp) != 0 && !rc) rc = bfhipFail(BFABI_ERROR_FILE_ERROR, "error closing %s", path);
   if (prev >= 0 && prev != op->device) bfdevSetDevice(prev);
   return rc;
@@ -1364,18 +1368,26 @@ int bfhipLoad(char const *path, BfhipOptions const *opts, BfhipOperator **out) {
   if (!op) { fclose(fp); return bfhipFail(BFABI_ERROR_MEMORY_ERROR, "host OOM"); }
   int prevDev = -1;
   bfdevGetDevice(&prevDev);
-  op->flags = o.flags & ~(uint32_t)BFHIP_FLAG_ADJOINT;
+  op->flags = o.flags & ~(uint32_t)(BFHIP_FLAG_ADJOINT | BFHIP_FLAG_ADJOINT_PACKED);
   op->srcDtype = fh.srcDtype;
   op->leafBytesAlgorithmic = fh.leafBytesAlgorithmic;
   if ((rc = bfdevSetDevice(o.device))) goto done;
   if ((rc = bfdevGetDevice(&op->device))) goto done;
-  if ((rc = loadPlan(fp, op, &op->plan, &fh))) goto done;
+  uint64_t arenaElemsT = 0;
+  int const packedT = (fh.reserved & 1u) != 0;
+  if (fh.reserved & ~1u) { rc = bfhipFail(BFABI_ERROR_FILE_ERROR, "corrupt operator file (header flags)"); goto done; }
+  if (packedT && (!fh.hasTplan || (rc = readAll(fp, &arenaElemsT, sizeof arenaElemsT)))) { if (!rc) rc = bfhipFail(BFABI_ERROR_FILE_ERROR, "corrupt operator file (packed adjoint without a plan)"); goto done; }
+  if ((rc = loadPlan(fp, op, &op->plan, &fh, fh.arenaElems))) goto done;
   if (fh.hasTplan) {
-    if ((rc = loadPlan(fp, op, &op->tplan, &fh))) goto done;
+    if ((rc = loadPlan(fp, op, &op->tplan, &fh, packedT ? arenaElemsT : fh.arenaElems))) goto done;
+    /* a packed adjoint plan is a FORWARD plan over its own arena, a shared one a transposed plan over the forward arena */
+    if ((op->tplan.transposed != 0) == packedT) { rc = bfhipFail(BFABI_ERROR_FILE_ERROR, "corrupt operator file (adjoint plan kind)"); goto done; }
     op->hasTplan = 1;
-    op->flags |= BFHIP_FLAG_ADJOINT;
+    op->packedT = packedT;
+    op->flags |= packedT ? BFHIP_FLAG_ADJOINT_PACKED : BFHIP_FLAG_ADJOINT;
   }
   if ((rc = readDeviceArray(fp, &op->dArena, (size_t)fh.arenaElems * fh.elemSize, NULL))) goto done;
+  if (packedT && (rc = readDeviceArray(fp, &op->dArenaT, (size_t)arenaElemsT * fh.elemSize, NULL))) goto done;
   if ((rc = ensureTemp(op, o.maxRhs ? o.maxRhs : 1))) goto done;
   if ((rc = bfdevMalloc(&op->dZero, 4096))) goto done;
   if ((rc = bfdevMemset(op->dZero, 0, 4096))) goto done;

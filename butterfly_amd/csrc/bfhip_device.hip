@@ -1232,7 +1232,12 @@ int bfdevLaunchStage(BfLaunchArgs const *a, void *stream) {
   }
   if (a->dtype == BFHIP_C128 && a->nrhs >= BF_MFMA_MIN_RHS) {
     dim3 const g((uint32_t)((a->numItems + BF_MF_WG_WAVES - 1) / BF_MF_WG_WAVES)), b(64 * BF_MF_WG_WAVES);
-    if (a->nrhs <= 16) hipLaunchKernelGGL(bfStageKernelC128Mfma1, g, b, 0, s, p);            /* one RHS tile: 5 wavefronts per SIMD */
+    if (a->exactComplex) {                                                                   /* BFHIP_FLAG_EXACT_COMPLEX: four real products per complex one */
+      if (a->nrhs <= 16) hipLaunchKernelGGL(bfStageKernelC128Mfma1Exact, g, b, 0, s, p);
+      else if (a->nrhs <= 32) hipLaunchKernelGGL(bfStageKernelC128Mfma2Exact, g, b, 0, s, p);
+      else hipLaunchKernelGGL(bfStageKernelC128MfmaExact, g, b, 0, s, p);
+    }
+    else if (a->nrhs <= 16) hipLaunchKernelGGL(bfStageKernelC128Mfma1, g, b, 0, s, p);       /* one RHS tile: 5 wavefronts per SIMD */
     else if (a->nrhs <= 32) hipLaunchKernelGGL(bfStageKernelC128Mfma2, g, b, 0, s, p);       /* two: 3 */
     else hipLaunchKernelGGL(bfStageKernelC128Mfma, g, b, 0, s, p);                           /* up to four per pass: 2 */
   }

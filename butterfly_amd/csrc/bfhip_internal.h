@@ -276,6 +276,8 @@ typedef struct BfLaunchArgs {
   uint32_t maxRows;
   int transposed;        /* pieces carry `ld`: lanes own columns of the forward pieces */
   void *tickets;         /* NULL, or BF_TICKET_POOLS x BF_TICKET_STRIDE uint32 owned by this stage, zero between launches (see BfStage.dTickets) */
+  uint32_t exactComplex; /* BFHIP_FLAG_EXACT_COMPLEX: the matrix-core kernels form complex products with four real multiplications */
+  uint32_t pad2;
 } BfLaunchArgs;
 #define BF_TICKET_POOLS 64u
 #define BF_TICKET_STRIDE 64u      /* uint32 between two pools' counters: a 256-byte block each -- counters that share a cache line share its atomic unit (measured: 64 packed counters behaved like one) */

@@ -11,24 +11,30 @@
 // piece is not contiguous, reads another vector (x / intermediates), or the table is full; fac_helm2 items are one
 // segment, two in the last stage.)
 //
-// One pass = MS 16-row slabs x NT 16-RHS tiles: 4 * MS * NT MFMAs per k-step (4 leaf columns).  Fragment maps
-// (cdna_hip_programming.md section 3): A[i = l & 15][k = l >> 4], B[k = l >> 4][j = l & 15], D reg v of lane l =
-// D[i = 4 v + (l >> 4)][j = l & 15]; a complex multiply-accumulate is 4 real MFMAs, the -Ai*Bi term through the NEG
-// bit of the instruction (blgp bit 0 negates A on the f64 MFMA: tools/mfma_probe.hip).
+// One pass = MS 16-row slabs x NT 16-RHS tiles.  Fragment maps (cdna_hip_programming.md section 3): A[i = l & 15][k = l >> 4],
+// B[k = l >> 4][j = l & 15], D reg v of lane l = D[i = 4 v + (l >> 4)][j = l & 15].  A complex multiply-accumulate is
+//   * by default THREE real MFMAs (Gauss: T1 = Ar Xr, T2 = Ai Xi, T3 = (Ar + Ai)(Xr + Xi); Re = T1 - T2, Im = T3 - T1 - T2):
+//     3 MS NT MFMAs per k-step (4 leaf columns), three accumulators per tile.  Normwise as accurate as zgemm's four
+//     multiplications; componentwise the imaginary part carries an error of eps * (|Ar| + |Ai|)(|Xr| + |Xi|) summed over the
+//     contraction, whatever its own size;
+//   * with BFHIP_FLAG_EXACT_COMPLEX the FOUR real MFMAs of the textbook product (GAUSS = false below: Re += Ar Xr - Ai Xi,
+//     Im += Ar Xi + Ai Xr, the -Ai Xi term through the NEG bit of the instruction -- blgp bit 0 negates A on the f64 MFMA:
+//     tools/mfma_probe.hip), two accumulators per tile: componentwise what cblas_zgemm's own recurrence gives
+//     (src/mat_dense_complex.c:1704-1765), a third more matrix-pipe work.
 //
-// What the inner loop is made of, and why (tools/mfma_probe.hip, profiles/r4_mfma_probe.json):
+// What the inner loops are made of, and why (tools/mfma_probe.hip, tools/mfma_loop_probe.hip, profiles/r4_mfma_probe.json):
 //   * ONE wavefront cannot keep the FP64 matrix pipe busy (0.75 of peak with 16 independent accumulators), two or more
 //     can (0.99): every cycle a wavefront spends on anything else costs a quarter of the pipe, so the loop holds no
 //     VALU address arithmetic, no selects and no register copies.  Fragments come through buffer loads -- a loop
 //     invariant VGPR offset, the k-step advance in an SGPR, columns / rows past the end of the segment returned as
 //     zeros by the range check (which includes the SGPR offset) instead of clamps + selects.
-//   * ONE set of fragment registers: a fragment is requested again right after the last MFMA that reads it (A of slab
-//     0 after the first half of the k-step, X tile t inside the second half, A of slab 1 at the end), half a k-step
-//     ahead of its next use; 128 accumulator + 24 fragment registers leave room for THREE wavefronts per SIMD, so a
-//     wavefront between items (table, stores) leaves two on the pipe.
 //   * The loads are asm statements and the waits are placed by hand: hipcc's wait insertion treats every load pending
 //     at a loop header as one lump (s_waitcnt vmcnt(0) at the top: the fragment requested last would be waited for
 //     first).  Loads return in order, so vmcnt(n) = "all but the n youngest have arrived".
+//   * bfMfmaSegment (the kernels of <= 32 right-hand sides, 3 and 5 wavefronts per SIMD): fragments land in registers, two sets
+//     for the leaf stream (requested one k-step ahead), one for the X tiles (requested again right after the MFMAs that read them).
+//   * bfMfmaSegmentDma (the 4-tile kernel, 2 wavefronts per SIMD): fragments land in a two-slot LDS ring per wavefront, two
+//     k-steps ahead of their use (below).
 #ifndef BFHIP_STAGE_MFMA_H
 #define BFHIP_STAGE_MFMA_H
 
@@ -92,6 +98,13 @@ struct BfMfSeg {
 // MFMAs that read it, 3 MS (NT - 1) MFMAs before its next use (tile-outer, slab-inner order).  Requests return in order,
 // so in front of every tile "all but the NT - 1 + MS youngest have arrived" is the wait (s_waitcnt vmcnt).
 // An odd number of k-steps ends with a k-step of zeros (the leaf fragments past the end of the segment).
+// the four real products of a complex multiply-accumulate (BFHIP_FLAG_EXACT_COMPLEX): Re += Ar Xr - Ai Xi, Im += Ar Xi + Ai Xr
+__device__ __forceinline__ void bfMfmaExact(bf_d4 &re, bf_d4 &im, BfFrag const &a, BfFrag const &x) {
+  re = __builtin_amdgcn_mfma_f64_16x16x4f64(a.d[0], x.d[0], re, 0, 0, 0);
+  re = __builtin_amdgcn_mfma_f64_16x16x4f64(a.d[1], x.d[1], re, 0, 0, 1);      // blgp bit 0: -A
+  im = __builtin_amdgcn_mfma_f64_16x16x4f64(a.d[0], x.d[1], im, 0, 0, 0);
+  im = __builtin_amdgcn_mfma_f64_16x16x4f64(a.d[1], x.d[0], im, 0, 0, 0);
+}
 template <int MS, int SET>
 __device__ __forceinline__ void bfMfmaRequestA(BfFrag (&a)[2][2], BfMfSeg const &sg, uint32_t soffA) {
   bfFragLoad<1, 0>(a[SET][0], sg.voffA, sg.ra, soffA);
@@ -101,7 +114,7 @@ template <int T>
 __device__ __forceinline__ void bfMfmaRequestX(BfFrag (&x)[4], BfMfSeg const &sg, uint32_t voffX) {
   bfFragLoad<0, 256 * T>(x[T], voffX, sg.rx, 0);
 }
-template <int NT, int MS, int SET, int T>
+template <int NT, int MS, int SET, int T, bool GAUSS>
 __device__ __forceinline__ void bfMfmaTile(bf_d4 (&acc)[3][2][4], BfFrag (&a)[2][2], BfFrag (&x)[4], double (&as)[2], BfMfSeg const &sg, uint32_t voffXnext) {
   if (T < NT) {
     constexpr int TT = T < NT ? T : 0;
@@ -109,23 +122,28 @@ __device__ __forceinline__ void bfMfmaTile(bf_d4 (&acc)[3][2][4], BfFrag (&a)[2]
     if (T == 0 && MS > 1) asm volatile("s_waitcnt vmcnt(%3)" : "+v"(a[SET][0].u), "+v"(a[SET][1].u), "+v"(x[0].u) : "n"(pending));
     else if (T == 0) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a[SET][0].u), "+v"(x[0].u) : "n"(pending));
     else asm volatile("s_waitcnt vmcnt(%1)" : "+v"(x[TT].u) : "n"(pending));
-    if (T == 0) {
-      as[0] = a[SET][0].d[0] + a[SET][0].d[1];
-      if (MS > 1) as[1] = a[SET][1].d[0] + a[SET][1].d[1];
-    }
-    double const xs = x[TT].d[0] + x[TT].d[1];
+    if (GAUSS) {
+      if (T == 0) {
+        as[0] = a[SET][0].d[0] + a[SET][0].d[1];
+        if (MS > 1) as[1] = a[SET][1].d[0] + a[SET][1].d[1];
+      }
+      double const xs = x[TT].d[0] + x[TT].d[1];
 #pragma unroll
-    for (int m = 0; m < MS; ++m) {
-      acc[0][m][TT] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[SET][m].d[0], x[TT].d[0], acc[0][m][TT], 0, 0, 0);
-      acc[1][m][TT] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[SET][m].d[1], x[TT].d[1], acc[1][m][TT], 0, 0, 0);
-      acc[2][m][TT] = __builtin_amdgcn_mfma_f64_16x16x4f64(as[m], xs, acc[2][m][TT], 0, 0, 0);
+      for (int m = 0; m < MS; ++m) {
+        acc[0][m][TT] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[SET][m].d[0], x[TT].d[0], acc[0][m][TT], 0, 0, 0);
+        acc[1][m][TT] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[SET][m].d[1], x[TT].d[1], acc[1][m][TT], 0, 0, 0);
+        acc[2][m][TT] = __builtin_amdgcn_mfma_f64_16x16x4f64(as[m], xs, acc[2][m][TT], 0, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int m = 0; m < MS; ++m) bfMfmaExact(acc[0][m][TT], acc[1][m][TT], a[SET][m], x[TT]);
     }
     __builtin_amdgcn_sched_barrier(0);
     bfMfmaRequestX<TT>(x, sg, voffXnext);
     __builtin_amdgcn_sched_barrier(0);
   }
 }
-template <int NT, int MS>
+template <int NT, int MS, bool GAUSS = true>
 __device__ __forceinline__ void bfMfmaSegment(bf_d4 (&acc)[3][2][4], BfMfSeg const &sg, uint32_t const *tab, uint32_t lk) {
   BfFrag a[2][2], x[4];
   double as[2];
@@ -150,26 +168,150 @@ __device__ __forceinline__ void bfMfmaSegment(bf_d4 (&acc)[3][2][4], BfMfSeg con
     __builtin_amdgcn_sched_barrier(0);
     bfMfmaRequestA<MS, 1>(a, sg, soffA);
     __builtin_amdgcn_sched_barrier(0);
-    bfMfmaTile<NT, MS, 0, 0>(acc, a, x, as, sg, v1);
-    bfMfmaTile<NT, MS, 0, 1>(acc, a, x, as, sg, v1);
-    bfMfmaTile<NT, MS, 0, 2>(acc, a, x, as, sg, v1);
-    bfMfmaTile<NT, MS, 0, 3>(acc, a, x, as, sg, v1);
+    bfMfmaTile<NT, MS, 0, 0, GAUSS>(acc, a, x, as, sg, v1);
+    bfMfmaTile<NT, MS, 0, 1, GAUSS>(acc, a, x, as, sg, v1);
+    bfMfmaTile<NT, MS, 0, 2, GAUSS>(acc, a, x, as, sg, v1);
+    bfMfmaTile<NT, MS, 0, 3, GAUSS>(acc, a, x, as, sg, v1);
     soffA += sg.stepA;
     bfMfmaRequestA<MS, 0>(a, sg, soffA);
     __builtin_amdgcn_sched_barrier(0);
-    bfMfmaTile<NT, MS, 1, 0>(acc, a, x, as, sg, v2);
-    bfMfmaTile<NT, MS, 1, 1>(acc, a, x, as, sg, v2);
-    bfMfmaTile<NT, MS, 1, 2>(acc, a, x, as, sg, v2);
-    bfMfmaTile<NT, MS, 1, 3>(acc, a, x, as, sg, v2);
+    bfMfmaTile<NT, MS, 1, 0, GAUSS>(acc, a, x, as, sg, v2);
+    bfMfmaTile<NT, MS, 1, 1, GAUSS>(acc, a, x, as, sg, v2);
+    bfMfmaTile<NT, MS, 1, 2, GAUSS>(acc, a, x, as, sg, v2);
+    bfMfmaTile<NT, MS, 1, 3, GAUSS>(acc, a, x, as, sg, v2);
   }
   // the requests of the k-steps past the end (zeros from the range check / a padded table row) must land before the
   // registers are used again
   asm volatile("s_waitcnt vmcnt(0)" : "+v"(a[0][0].u), "+v"(a[0][MS > 1 ? 1 : 0].u), "+v"(x[0].u), "+v"(x[NT > 1 ? 1 : 0].u), "+v"(x[NT > 2 ? 2 : 0].u), "+v"(x[NT > 3 ? 3 : 0].u));
 }
 
+// ---- the same k-loop with its fragments prefetched through LDS (round 5: built, measured, NOT the product's loop: BF_MF_DMA) --------
+// The question it answers (tools/mfma_loop_probe.hip: the loops on the bare machine, no items, no tables rebuilt, no tails): the
+// register loop reaches 0.88 of the FP64 matrix peak with the leaf fragments streamed from HBM, 0.80 when the X rows miss L2 and
+// 0.93 when the leaf fragments come from L2 -- is that the latency of requests made only one k-step (24 MFMAs = 1536 cycles of a
+// SIMD that two wavefronts share, ~1.3 us) ahead?  Requests return in order (one counter), so a deeper prefetch needs a place to
+// land that is not a register: every fragment of k-step ks + 2 is requested, during k-step
+// ks, as an LDS-DMA (buffer_load ... lds: no VGPR destination) into a ring of two 6 KiB slots per wavefront; at the top of a k-step
+// its slot is complete (s_waitcnt vmcnt(F): only the F requests of the next k-step may be pending), the fragments are read with six
+// ds_read_b128 into ONE register set, the slot is handed to the requests of k-step ks + 2 right away, and the MFMAs run from
+// registers.  Same MFMAs in the same order: bit-identical to bfMfmaSegment (the probe compares them on ragged segments).  2 x 6 KiB
+// + the 7.1 KiB table per one-wavefront workgroup: eight of them (two per SIMD) fit a CU's 160 KiB.
+// The answer is NO: with twice the prefetch distance the leaf stream from HBM and the X rows from beyond L2 cost exactly what they
+// cost the register loop (counters: the same clocks, see BF_MF_DMA below), and the ds_read bubble costs 4 % on top.
+//   * LDS-DMA writes M0 + lane * 16 (M0 is written in the statement that uses it: the compiler does not keep it); every instruction
+//     uses offset:0, tile / slab offsets travel in the SGPR offset.
+//   * Columns / rows past the end of the segment: out-of-range lanes of an LDS-DMA deliver zeros like a register load (probed:
+//     tools/mfma_loop_probe.hip `dma_oob`), the padded table rows are rows of the segment.
+#define BF_MF_DMA_SLOT 6144u            /* MS + NT <= 6 fragments of 1 KiB */
+#define BF_MF_DMA_RING (2u * BF_MF_DMA_SLOT)
+template <int STREAM> __device__ __forceinline__ void bfDmaLoad(uint32_t ldsDst, uint32_t voff, bf_i4 rsrc, uint32_t soff) {
+  if (STREAM) asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen nt lds" :: "s"(ldsDst), "v"(voff), "s"(rsrc), "s"(soff));
+  else asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" :: "s"(ldsDst), "v"(voff), "s"(rsrc), "s"(soff));
+}
+// All R = MS + NT fragments of a slot into registers: the wait for the slot's LDS-DMAs, the ds_reads and the wait for THEIR data are
+// ONE asm statement with early-clobber outputs -- hipcc treats an asm output as written when the statement ends, and with the
+// wait in a statement of its own it is free to copy a fragment register before the data has landed (it did: v_mov of the A fragment
+// between the ds_read and the s_waitcnt in the instantiations that needed a copy; cdna_hip_programming.md section 5.7 item 1).
+template <int R, int BASE> __device__ __forceinline__ void bfLdsReadSlot(BfFrag (&f)[6], uint32_t laneLds) {
+  static_assert(R >= 2 && R <= 6, "one to two slabs, one to four tiles");
+  if constexpr (R == 6)
+    asm volatile("s_waitcnt vmcnt(6)\n\tds_read_b128 %0, %6 offset:%7\n\tds_read_b128 %1, %6 offset:%8\n\tds_read_b128 %2, %6 offset:%9\n\tds_read_b128 %3, %6 offset:%10\n\t"
+                 "ds_read_b128 %4, %6 offset:%11\n\tds_read_b128 %5, %6 offset:%12\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(f[0].u), "=&v"(f[1].u), "=&v"(f[2].u), "=&v"(f[3].u), "=&v"(f[4].u), "=&v"(f[5].u)
+                 : "v"(laneLds), "n"(BASE), "n"(BASE + 1024), "n"(BASE + 2048), "n"(BASE + 3072), "n"(BASE + 4096), "n"(BASE + 5120));
+  else if constexpr (R == 5)
+    asm volatile("s_waitcnt vmcnt(5)\n\tds_read_b128 %0, %5 offset:%6\n\tds_read_b128 %1, %5 offset:%7\n\tds_read_b128 %2, %5 offset:%8\n\tds_read_b128 %3, %5 offset:%9\n\t"
+                 "ds_read_b128 %4, %5 offset:%10\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(f[0].u), "=&v"(f[1].u), "=&v"(f[2].u), "=&v"(f[3].u), "=&v"(f[4].u)
+                 : "v"(laneLds), "n"(BASE), "n"(BASE + 1024), "n"(BASE + 2048), "n"(BASE + 3072), "n"(BASE + 4096));
+  else if constexpr (R == 4)
+    asm volatile("s_waitcnt vmcnt(4)\n\tds_read_b128 %0, %4 offset:%5\n\tds_read_b128 %1, %4 offset:%6\n\tds_read_b128 %2, %4 offset:%7\n\tds_read_b128 %3, %4 offset:%8\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(f[0].u), "=&v"(f[1].u), "=&v"(f[2].u), "=&v"(f[3].u)
+                 : "v"(laneLds), "n"(BASE), "n"(BASE + 1024), "n"(BASE + 2048), "n"(BASE + 3072));
+  else if constexpr (R == 3)
+    asm volatile("s_waitcnt vmcnt(3)\n\tds_read_b128 %0, %3 offset:%4\n\tds_read_b128 %1, %3 offset:%5\n\tds_read_b128 %2, %3 offset:%6\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(f[0].u), "=&v"(f[1].u), "=&v"(f[2].u)
+                 : "v"(laneLds), "n"(BASE), "n"(BASE + 1024), "n"(BASE + 2048));
+  else
+    asm volatile("s_waitcnt vmcnt(2)\n\tds_read_b128 %0, %2 offset:%3\n\tds_read_b128 %1, %2 offset:%4\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(f[0].u), "=&v"(f[1].u)
+                 : "v"(laneLds), "n"(BASE), "n"(BASE + 1024));
+}
+// (a buffer instruction's scalar offset is an SGPR or an inline constant, never a literal: the tile offsets are made opaque to hipcc)
+template <uint32_t V> __device__ __forceinline__ uint32_t bfSgprConst() { uint32_t v; asm("s_movk_i32 %0, %1" : "=s"(v) : "n"(V)); return v; }
+template <int NT, int MS, int SLOT>
+__device__ __forceinline__ void bfMfmaDmaRequest(BfMfSeg const &sg, uint32_t ring, uint32_t soffA, uint32_t voffX) {
+  constexpr uint32_t base = SLOT * BF_MF_DMA_SLOT;
+  bfDmaLoad<1>(ring + base, sg.voffA, sg.ra, soffA);
+  if (MS > 1) bfDmaLoad<1>(ring + base + 1024u, sg.voffA, sg.ra, soffA + 256u);
+  bfDmaLoad<0>(ring + base + MS * 1024u, voffX, sg.rx, bfSgprConst<0>());
+  if (NT > 1) bfDmaLoad<0>(ring + base + (MS + 1) * 1024u, voffX, sg.rx, bfSgprConst<256>());
+  if (NT > 2) bfDmaLoad<0>(ring + base + (MS + 2) * 1024u, voffX, sg.rx, bfSgprConst<512>());
+  if (NT > 3) bfDmaLoad<0>(ring + base + (MS + 3) * 1024u, voffX, sg.rx, bfSgprConst<768>());
+}
+// one k-step out of slot SLOT; soffA / voffX: what is requested into the slot once it has been read (k-step + 2)
+template <int NT, int MS, int SLOT, bool GAUSS>
+__device__ __forceinline__ void bfMfmaDmaStep(bf_d4 (&acc)[3][2][4], BfMfSeg const &sg, uint32_t ring, uint32_t laneLds, uint32_t soffA, uint32_t voffX) {
+  constexpr uint32_t base = SLOT * BF_MF_DMA_SLOT;
+  // this slot's MS + NT requests are the oldest (complete once only the other slot's may be pending): wait, read, wait -- one statement
+  BfFrag f[6];
+  bfLdsReadSlot<MS + NT, base>(f, laneLds);
+  BfFrag (&a)[6] = f;
+  BfFrag *const x = f + MS;
+  __builtin_amdgcn_sched_barrier(0);
+  bfMfmaDmaRequest<NT, MS, SLOT>(sg, ring, soffA, voffX);        // the slot is free: everything of it is in registers
+  __builtin_amdgcn_sched_barrier(0);
+  if (GAUSS) {
+    double as[2];
+    as[0] = a[0].d[0] + a[0].d[1];
+    if (MS > 1) as[1] = a[1].d[0] + a[1].d[1];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      double const xs = x[t].d[0] + x[t].d[1];
+#pragma unroll
+      for (int m = 0; m < MS; ++m) {
+        acc[0][m][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m].d[0], x[t].d[0], acc[0][m][t], 0, 0, 0);
+        acc[1][m][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m].d[1], x[t].d[1], acc[1][m][t], 0, 0, 0);
+        acc[2][m][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(as[m], xs, acc[2][m][t], 0, 0, 0);
+      }
+    }
+  } else {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int m = 0; m < MS; ++m) bfMfmaExact(acc[0][m][t], acc[1][m][t], a[m], x[t]);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+}
+template <int NT, int MS, bool GAUSS = true>
+__device__ __forceinline__ void bfMfmaSegmentDma(bf_d4 (&acc)[3][2][4], BfMfSeg const &sg, uint32_t const *tab, uint32_t lk, uint32_t ring, uint32_t laneLds) {
+  uint32_t ti = lk;
+  uint32_t soffA = 0;
+  bfMfmaDmaRequest<NT, MS, 0>(sg, ring, soffA, tab[ti] + sg.cX);
+  soffA += sg.stepA;
+  bfMfmaDmaRequest<NT, MS, 1>(sg, ring, soffA, tab[ti + 4] + sg.cX);
+  soffA += sg.stepA;
+  uint32_t t2 = tab[ti + 8], t3 = tab[ti + 12];      // the rows of k-steps 2 and 3, read an iteration ahead of their use
+  ti += 16;
+  for (uint32_t ks = 0; ks < sg.ksteps; ks += 2) {
+    uint32_t const v2 = t2 + sg.cX, v3 = t3 + sg.cX;
+    t2 = tab[ti];                                     // the table is padded past the last k-step (BF_MF_TABPAD)
+    t3 = tab[ti + 4];
+    ti += 8;
+    bfMfmaDmaStep<NT, MS, 0, GAUSS>(acc, sg, ring, laneLds, soffA, v2);
+    soffA += sg.stepA;
+    bfMfmaDmaStep<NT, MS, 1, GAUSS>(acc, sg, ring, laneLds, soffA, v3);
+    soffA += sg.stepA;
+  }
+  // the requests of the k-steps past the end must land before the ring (and the table) are used again
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 // One pass = rows [s0, s0 + 16 MS) x RHS [q0, q0 + 16 NT) of one item, over all its segments.
-template <int NT, int MS>
-__device__ __forceinline__ void bfMfmaPass(StageParams const &p, BfDevItem const &it, uint32_t mr, uint32_t s0, uint32_t q0, uint32_t *tab, int lane) {
+// (DMA: the k-loop with its fragments prefetched through the wavefront's LDS ring -- the 4-tile kernel; `ring` = its LDS byte address)
+template <int NT, int MS, bool DMA, bool GAUSS>
+__device__ __forceinline__ void bfMfmaPass(StageParams const &p, BfDevItem const &it, uint32_t mr, uint32_t s0, uint32_t q0, uint32_t *tab, int lane, uint32_t ring) {
   uint32_t const nrhs = p.nrhs;
   uint32_t const li = lane & 15, lk = lane >> 4;
   bf_d4 acc[3][2][4];            // T1 = sum Ar Xr, T2 = sum Ai Xi, T3 = sum (Ar + Ai)(Xr + Xi)
@@ -234,7 +376,8 @@ __device__ __forceinline__ void bfMfmaPass(StageParams const &p, BfDevItem const
     sg.rx = bfMakeRsrc(xin + ((uint64_t)minRow * nrhs + q0) * 16u, ((maxRow - minRow) * nrhs + (nrhs - q0)) * 16u);
     sg.voffA = (lk * mr + s0 + li) * 16u;          // rows past the item's end alias the next column: rows of the product that are never stored
     sg.cX = li * 16u;
-    bfMfmaSegment<NT, MS>(acc, sg, tab, lk);
+    if (DMA) bfMfmaSegmentDma<NT, MS, GAUSS>(acc, sg, tab, lk, ring, ring + (uint32_t)lane * 16u);
+    else bfMfmaSegment<NT, MS, GAUSS>(acc, sg, tab, lk);
     waveSync();                                      // the table is rewritten by the next segment
   }
   double2 *out = (it.mrFlags & BF_ITEM_OUT_Y) ? (double2 *)p.y : (double2 *)p.temp;
@@ -252,7 +395,8 @@ __device__ __forceinline__ void bfMfmaPass(StageParams const &p, BfDevItem const
       for (int v = 0; v < 4; ++v) {
         uint32_t const row = s0 + 16u * m + 4 * v + lk2;
         if (row < mr && 16u * t + li2 <= qmax) {
-          double re = acc[0][m][t][v] - acc[1][m][t][v], im = acc[2][m][t][v] - acc[0][m][t][v] - acc[1][m][t][v];
+          double re = GAUSS ? acc[0][m][t][v] - acc[1][m][t][v] : acc[0][m][t][v];
+          double im = GAUSS ? acc[2][m][t][v] - acc[0][m][t][v] - acc[1][m][t][v] : acc[1][m][t][v];
           if (hasIdentity) {      // rare (real-operand zoo; complex operands have none)
             for (uint32_t k = 0; k < np; ++k) {
               BfDevPiece const pc = p.pieces[it.pieceBegin + k];
@@ -269,12 +413,12 @@ __device__ __forceinline__ void bfMfmaPass(StageParams const &p, BfDevItem const
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-template <int MS, int MAXNT>
-__device__ __forceinline__ void bfMfmaDispatch(uint32_t nt, StageParams const &p, BfDevItem const &it, uint32_t mr, uint32_t s0, uint32_t q0, uint32_t *tab, int lane) {
-  if (MAXNT >= 4 && nt == 4) bfMfmaPass<4, MS>(p, it, mr, s0, q0, tab, lane);
-  else if (MAXNT >= 3 && nt == 3) bfMfmaPass<3, MS>(p, it, mr, s0, q0, tab, lane);
-  else if (MAXNT >= 2 && nt == 2) bfMfmaPass<2, MS>(p, it, mr, s0, q0, tab, lane);
-  else bfMfmaPass<1, MS>(p, it, mr, s0, q0, tab, lane);
+template <int MS, int MAXNT, bool DMA, bool GAUSS>
+__device__ __forceinline__ void bfMfmaDispatch(uint32_t nt, StageParams const &p, BfDevItem const &it, uint32_t mr, uint32_t s0, uint32_t q0, uint32_t *tab, int lane, uint32_t ring) {
+  if (MAXNT >= 4 && nt == 4) bfMfmaPass<4, MS, DMA, GAUSS>(p, it, mr, s0, q0, tab, lane, ring);
+  else if (MAXNT >= 3 && nt == 3) bfMfmaPass<3, MS, DMA, GAUSS>(p, it, mr, s0, q0, tab, lane, ring);
+  else if (MAXNT >= 2 && nt == 2) bfMfmaPass<2, MS, DMA, GAUSS>(p, it, mr, s0, q0, tab, lane, ring);
+  else bfMfmaPass<1, MS, DMA, GAUSS>(p, it, mr, s0, q0, tab, lane, ring);
 }
 
 // MAXNT = the widest pass the launch needs (RHS tiles of 16): the accumulators of 4 tiles x 2 slabs x 3 products leave two
@@ -282,11 +426,13 @@ __device__ __forceinline__ void bfMfmaDispatch(uint32_t nt, StageParams const &p
 // stream, not by the pipe, and then it is wavefronts (bytes in flight) that count: the 1- and 2-tile instantiations need
 // a third / half of the registers and run WAVES = 5 / 3 wavefronts per SIMD (N = 262144: 2 - 16 RHS 14.3 - 15.9 -> see
 // DESIGN.md section 4).
-template <int MAXNT, int WAVES>
-__device__ __forceinline__ void bfStageBodyC128Mfma(StageParams const &p, uint32_t (*tabs)[BF_MF_TABCAP + BF_MF_TABPAD]) {
+template <int MAXNT, int WAVES, bool DMA, bool GAUSS = true>
+__device__ __forceinline__ void bfStageBodyC128Mfma(StageParams const &p, uint32_t (*tabs)[BF_MF_TABCAP + BF_MF_TABPAD], char *rings) {
   int const lane = threadIdx.x & 63;
   uint32_t const wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   uint32_t *tab = tabs[wave];
+  // (the low 32 bits of a flat LDS address are the offset inside the workgroup's allocation: what M0 and ds_read take)
+  uint32_t const ring = DMA ? __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(rings + wave * BF_MF_DMA_RING)) : 0u;
   // The wavefronts of a workgroup take neighbours of the item list: row chunks of one row group and of its sibling
   // groups (same cost, same input rows: the planner's order for RHS-block operators).  Workgroups are dealt to the 8 XCDs
   // round robin: runs of BF_MF_XCD_RUN workgroups that are neighbours in the list go to ONE XCD, so that a row of X is
@@ -306,24 +452,56 @@ __device__ __forceinline__ void bfStageBodyC128Mfma(StageParams const &p, uint32
     uint32_t const nt = (nrhs - q0 >= 64) ? 4u : (nrhs - q0 + 15u) / 16u;
     uint32_t s0 = 0;
     while (s0 < mr) {
-      if (mr - s0 > 16) { bfMfmaDispatch<2, MAXNT>(nt, p, it, mr, s0, q0, tab, lane); s0 += 32; }
-      else { bfMfmaDispatch<1, MAXNT>(nt, p, it, mr, s0, q0, tab, lane); s0 += 16; }
+      if (mr - s0 > 16) { bfMfmaDispatch<2, MAXNT, DMA, GAUSS>(nt, p, it, mr, s0, q0, tab, lane, ring); s0 += 32; }
+      else { bfMfmaDispatch<1, MAXNT, DMA, GAUSS>(nt, p, it, mr, s0, q0, tab, lane, ring); s0 += 16; }
     }
   }
 }
 
+// Which k-loop the 4-tile kernel runs.  Measured (tools/mfma_loop_probe.hip with --pmc, profiles/r5_mfma_loop_probe*.json): the register
+// loop keeps the matrix pipe busy 0.93 - 0.94 of the cycles WHEREVER its operands come from -- it is not bound by their latency --
+// and what the traffic beyond L2 costs is CLOCK: 2.37 GHz with the leaf stream and the X rows in L2, 2.23 with the leaf stream from HBM,
+// 2.06 / 2.04 with the X rows from the Infinity Cache / HBM as well.  The LDS-ring loop holds the same clocks and loses 4 % of the
+// pipe to the ds_read bubble at the top of each k-step (busy 0.89): prefetching deeper buys nothing here.  0 = register loop (product),
+// 1 = LDS ring (A/B builds: make variant V=dma DEFS=-DBF_MF_DMA=1).
+#ifndef BF_MF_DMA
+#define BF_MF_DMA 0
+#endif
 __global__ __launch_bounds__(64 * BF_MF_WG_WAVES) __attribute__((amdgpu_waves_per_eu(BF_MFMA_WAVES_PER_SIMD, BF_MFMA_WAVES_PER_SIMD))) void bfStageKernelC128Mfma(StageParams p) {
   __shared__ uint32_t tabs[BF_MF_WG_WAVES][BF_MF_TABCAP + BF_MF_TABPAD];
-  bfStageBodyC128Mfma<4, BF_MFMA_WAVES_PER_SIMD>(p, tabs);
+#if BF_MF_DMA
+  __shared__ __attribute__((aligned(16))) char rings[BF_MF_WG_WAVES * BF_MF_DMA_RING];
+  bfStageBodyC128Mfma<4, BF_MFMA_WAVES_PER_SIMD, true>(p, tabs, rings);
+#else
+  bfStageBodyC128Mfma<4, BF_MFMA_WAVES_PER_SIMD, false>(p, tabs, nullptr);
+#endif
 }
 // <= 32 right-hand sides (2 tiles): 3 wavefronts per SIMD
 __global__ __launch_bounds__(64 * BF_MF_WG_WAVES) __attribute__((amdgpu_waves_per_eu(3, 3))) void bfStageKernelC128Mfma2(StageParams p) {
   __shared__ uint32_t tabs[BF_MF_WG_WAVES][BF_MF_TABCAP + BF_MF_TABPAD];
-  bfStageBodyC128Mfma<2, 3>(p, tabs);
+  bfStageBodyC128Mfma<2, 3, false>(p, tabs, nullptr);
 }
 // <= 16 right-hand sides (1 tile): 5 wavefronts per SIMD
 __global__ __launch_bounds__(64 * BF_MF_WG_WAVES) __attribute__((amdgpu_waves_per_eu(5, 5))) void bfStageKernelC128Mfma1(StageParams p) {
   __shared__ uint32_t tabs[BF_MF_WG_WAVES][BF_MF_TABCAP + BF_MF_TABPAD];
-  bfStageBodyC128Mfma<1, 5>(p, tabs);
+  bfStageBodyC128Mfma<1, 5, false>(p, tabs, nullptr);
+}
+// BFHIP_FLAG_EXACT_COMPLEX: the same three kernels with the four real products of every complex one (componentwise zgemm's recurrence)
+__global__ __launch_bounds__(64 * BF_MF_WG_WAVES) __attribute__((amdgpu_waves_per_eu(BF_MFMA_WAVES_PER_SIMD, BF_MFMA_WAVES_PER_SIMD))) void bfStageKernelC128MfmaExact(StageParams p) {
+  __shared__ uint32_t tabs[BF_MF_WG_WAVES][BF_MF_TABCAP + BF_MF_TABPAD];
+#if BF_MF_DMA
+  __shared__ __attribute__((aligned(16))) char rings[BF_MF_WG_WAVES * BF_MF_DMA_RING];
+  bfStageBodyC128Mfma<4, BF_MFMA_WAVES_PER_SIMD, true, false>(p, tabs, rings);
+#else
+  bfStageBodyC128Mfma<4, BF_MFMA_WAVES_PER_SIMD, false, false>(p, tabs, nullptr);
+#endif
+}
+__global__ __launch_bounds__(64 * BF_MF_WG_WAVES) __attribute__((amdgpu_waves_per_eu(3, 3))) void bfStageKernelC128Mfma2Exact(StageParams p) {
+  __shared__ uint32_t tabs[BF_MF_WG_WAVES][BF_MF_TABCAP + BF_MF_TABPAD];
+  bfStageBodyC128Mfma<2, 3, false, false>(p, tabs, nullptr);
+}
+__global__ __launch_bounds__(64 * BF_MF_WG_WAVES) __attribute__((amdgpu_waves_per_eu(5, 5))) void bfStageKernelC128Mfma1Exact(StageParams p) {
+  __shared__ uint32_t tabs[BF_MF_WG_WAVES][BF_MF_TABCAP + BF_MF_TABPAD];
+  bfStageBodyC128Mfma<1, 5, false, false>(p, tabs, nullptr);
 }
 #endif

@@ -62,8 +62,18 @@ enum {
                                     plan is then a FORWARD plan of the transposed expression (factors reversed, every leaf
                                     transposed -- what bfMatProductTranspose leaves behind, src/mat_product.c:409-420) and
                                     A^T x runs on the forward kernels at the forward rate, for twice the leaf memory.
-                                    Falls back to the shared-leaf plan with a device value builder / BFHIP_FLAG_PLAN_ONLY;
-                                    such operators cannot be saved (bfhipSave: NOT_IMPLEMENTED) */
+                                    Falls back to the shared-leaf plan (BFHIP_FLAG_ADJOINT) with a device value builder (bfhipBuildHelm2: its
+                                    values exist in the forward arena only), on a row shard (rowBegin / rowBlockBegin: the shard's adjoint is the
+                                    pruned transposed task list) and when the second arena does not fit the device's memory; a plan-only operator
+                                    keeps the packed plan (bfhipPlanPackArenaT packs its arena).  bfhipSave / bfhipLoad carry both arenas */
+  BFHIP_FLAG_EXACT_COMPLEX = 1u << 5,  /* complex128 operators applied to blocks of right-hand sides (nrhs >= 2, the matrix-core kernels): form
+                                    every complex product with its FOUR real multiplications, as cblas_zgemm's recurrence does
+                                    (src/mat_dense_complex.c:1704-1765), instead of Gauss's three.  The default is normwise as accurate
+                                    (same 1e-12 tolerance against the oracle) but its imaginary part carries a rounding error of
+                                    eps * sum (|Ar| + |Ai|)(|Xr| + |Xi|) whatever its own size; with this flag each part's error is
+                                    bounded by eps times ITS OWN sum of absolute products (e.g. nearly real data keep a relatively
+                                    accurate small imaginary part).  Costs a third more matrix-pipe work (nrhs = 64: ~25 % slower).
+                                    One right-hand side (the GEMV kernel) always uses the four-product form */
   BFHIP_FLAG_FLOW = 1u << 3      /* EXPERIMENTAL BUILDS ONLY (libbfhip_exp.so, `make -C butterfly_amd/csrc experimental`): complex128
                                     operators applied to ONE right-hand side run the whole plan as ONE dependency-driven
                                     persistent launch (items wait for the intermediate vectors they read, not for the previous

@@ -105,6 +105,44 @@ def test_rhs_block_kernels_have_no_scratch_and_keep_their_occupancy(tmp_path):
         assert "scratch_" not in body and body.count("v_mfma_f64_16x16x4_f64") >= mfmas, sym
 
 
+def test_hand_counted_waits_of_the_rhs_block_kernels_hold_in_the_compiled_code(tmp_path):
+    """The k-loops of the RHS-block kernels issue their fragment loads as asm statements and wait for them by count
+    (bfhip_stage_mfma.h).  hipcc models neither: (a) a vector-memory instruction of its own inside a k-loop would make every
+    vmcnt(n) there one short; (b) it may read, copy or reuse a fragment register before the wait that retires its load (it did, in
+    round 5: a v_mov between a ds_read and its s_waitcnt in some instantiations of the LDS-ring loop).  Audit of the compiled
+    code (tests/asm_audit.py replays the in-order counters over the instruction stream): in every innermost MFMA loop of all six
+    kernels (three tile counts x Gauss / exact) and of the LDS-ring build the only vector-memory instructions are the expected
+    buffer_load_dwordx4, and inside those loops no instruction touches a register a pending load may still write."""
+    import shutil
+    import subprocess
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import asm_audit
+    # the audit itself, on the pattern it exists for: a copy of a fragment between its ds_read and the wait
+    fake = ("k:\n.LBB0_1:\n s_waitcnt vmcnt(0) lgkmcnt(0)\n.LBB0_2:\n ds_read_b128 v[104:107], v1 offset:0\n v_mov_b64_e32 v[126:127], v[106:107]\n"
+            " s_waitcnt lgkmcnt(0)\n v_mfma_f64_16x16x4_f64 v[2:9], v[104:105], v[126:127], v[2:9]\n s_cbranch_scc1 .LBB0_2\n s_endpgm\n")
+    assert [p[1] for p in asm_audit.audit(fake, "k")] == ["v_mov_b64_e32 v[126:127], v[106:107]"] * 3
+    assert not asm_audit.audit(fake.replace(" v_mov_b64_e32 v[126:127], v[106:107]\n s_waitcnt lgkmcnt(0)\n", " s_waitcnt lgkmcnt(0)\n v_mov_b64_e32 v[126:127], v[106:107]\n"), "k")
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        import pytest
+        pytest.skip("no hipcc")
+    for tag, defs in (("product", []), ("ring", ["-DBF_MF_DMA=1"])):
+        out = tmp_path / f"dev_{tag}.s"
+        subprocess.check_call([hipcc, "-O3", "-g", "-fPIC", "--offload-arch=gfx950", "-std=c++17", "-S", "--cuda-device-only", *defs, "-o", str(out),
+                               os.path.join(ROOT, "butterfly_amd", "csrc", "bfhip_device.hip")], stderr=subprocess.DEVNULL)
+        txt = open(out).read()
+        syms = re.findall(r"^(_Z\d+bfStageKernelC128Mfma\w*11StageParams):", txt, flags=re.M)
+        assert len(syms) == 6, syms
+        for sym in syms:
+            loops = asm_audit.loop_vmem(txt, sym)
+            assert loops, sym
+            for mfmas, vm in loops:
+                assert mfmas % 2 == 0 and vm and set(vm) <= {"buffer_load_dwordx4", "buffer_load_dwordx4 lds"}, (sym, mfmas, vm)
+            bad = asm_audit.audit(txt, sym)
+            assert not bad, (tag, sym, bad[:4])
+
+
 def test_builder_structs_match_the_header_and_arguments_are_checked(tmp_path):
     """ctypes / numpy mirrors of include/bfhip_build.h have the C sizes; bad
     arguments are refused before any device is touched."""

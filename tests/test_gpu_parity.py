@@ -370,6 +370,47 @@ def test_rhs_block_kernel_matches_oracle(helm2_cases, nrhs):
 # ---------------------------------------------------------------------------
 # adjoint apply (RmulVec of the reference): the plan of A^T over the same arena
 # ---------------------------------------------------------------------------
+@pytest.mark.parametrize("nrhs", [20, 64])
+def test_exact_complex_flag_keeps_a_small_imaginary_part_accurate(nrhs):
+    """BFHIP_FLAG_EXACT_COMPLEX: the matrix-core kernels form every complex product with its four real multiplications, as
+    cblas_zgemm's recurrence does (reference src/mat_dense_complex.c:1704-1765), instead of Gauss's three.  Nearly real data --
+    A = Ar + i d Ai, X = Xr + i d Xi with d = 1e-9 -- have a result whose imaginary part is of size d next to a real part of
+    size 1.  With the flag each part's rounding error is bounded by eps times ITS OWN sum of absolute products: the imaginary
+    part agrees with the oracle's zgemm to <= 1e-12 of its own size.  Without it (the default) the imaginary part is
+    T3 - T1 - T2, a difference of sums of size |A||X|: its error is bounded by eps * sum (|Ar| + |Ai|)(|Xr| + |Xi|) -- 1e-13 of
+    the REAL part's size here, i.e. ~1e-5 of its own -- while the result stays normwise within the 1e-12 of every other test.
+    Purely real data stored as complex give an exactly zero imaginary part either way (T3 and T1 are then the same sums)."""
+    import torch
+    import randgraph
+    from butterfly_amd import _capi
+    from butterfly_amd.operator import HipOperator
+    from oracle import bfref
+    rng = np.random.default_rng(404)
+    desc, vals = randgraph.random_operand(rng, depth=3, size_hint=300, cplx=True)
+    d = 1e-9
+    vals = {k: np.ascontiguousarray(v.real + 1j * d * v.imag) for k, v in vals.items()}
+    n = desc.cols[desc.root]
+    x = rng.standard_normal((n, nrhs)) + 1j * d * rng.standard_normal((n, nrhs))
+    y_ref = bfref.mat_mul(bfref.from_desc(desc, vals), x)
+    re_scale, im_scale = np.abs(y_ref.real).max(), np.abs(y_ref.imag).max()
+    assert im_scale < 1e-6 * re_scale
+    xd = torch.from_numpy(x).cuda()
+    err = {}
+    for name, flag in (("gauss", 0), ("exact", _capi.FLAG_EXACT_COMPLEX)):
+        op = HipOperator.from_desc(desc, vals, max_rhs=nrhs, flags=flag)
+        y = op.apply_device(xd).cpu().numpy()
+        assert rel(y, y_ref) <= TOL                                     # normwise: both
+        err[name] = np.abs(y.imag - y_ref.imag).max()
+        # purely real data: an exactly zero imaginary part, with or without the flag
+        xr = torch.from_numpy(x.real.astype(np.complex128)).cuda()
+        opr = HipOperator.from_desc(desc, {k: np.ascontiguousarray(v.real.astype(np.complex128)) for k, v in vals.items()}, max_rhs=nrhs, flags=flag)
+        assert not opr.apply_device(xr).cpu().numpy().imag.any()
+        opr.close(); op.close()
+    assert err["exact"] <= 1e-12 * im_scale                              # a few ulps of the imaginary part itself
+    assert err["gauss"] <= 1e-13 * re_scale                              # eps |A||X|: ulps of the REAL part's size
+    assert err["gauss"] > 100 * err["exact"]                             # ... which is what the flag is for
+
+
 @pytest.mark.parametrize("seed", range(6))
 def test_transposed_apply_random_real_graphs_on_gpu(seed):
     import randgraph
@@ -654,9 +695,24 @@ def test_packed_adjoint_runs_the_transposed_expression_on_the_forward_kernels(cp
         # the forward apply is untouched by either
         w = rng.standard_normal((n,) if nrhs == 1 else (n, nrhs)) + (1j * rng.standard_normal((n,) if nrhs == 1 else (n, nrhs)) if cplx else 0)
         assert np.array_equal(packed.apply_host(w), shared.apply_host(w))
+    # round 5: both arenas travel in the file; the loaded operator applies A and A^T bit for bit like the saved one
+    packed.save(tmp_path / "p.bfhip")
+    back = HipOperator.load(tmp_path / "p.bfhip")
+    assert back.stats()["arenaBytes"] == packed.stats()["arenaBytes"]
+    v = rng.standard_normal(m) + (1j * rng.standard_normal(m) if cplx else 0)
+    w = rng.standard_normal(n) + (1j * rng.standard_normal(n) if cplx else 0)
+    assert np.array_equal(back.apply_transpose_host(v), packed.apply_transpose_host(v))
+    assert np.array_equal(back.apply_host(w), packed.apply_host(w))
+    back.close()
+    # a file whose header claims a packed adjoint but whose second plan is a transposed one is refused
+    raw = bytearray(open(tmp_path / "p.bfhip", "rb").read())
+    shared.save(tmp_path / "s.bfhip")
+    raw_s = bytearray(open(tmp_path / "s.bfhip", "rb").read())
+    raw_s[36:40] = (1).to_bytes(4, "little")              # FileHeader.reserved: "packed" on a shared-leaf file
+    open(tmp_path / "bad.bfhip", "wb").write(bytes(raw_s))
     with pytest.raises(_capi.BfhipError) as ei:
-        packed.save(tmp_path / "p.bfhip")
-    assert ei.value.code == 3
+        HipOperator.load(tmp_path / "bad.bfhip")
+    assert ei.value.code == 6
     packed.close(); shared.close()
 
 

@@ -1,5 +1,7 @@
 #!/bin/bash
 # usage: ab.sh tag variants...
+# (a variant is built HERE, before gpurun snapshots the tree: make -C butterfly_amd/csrc variant V=<name> DEFS="-D..." -> exp/libbfhip_<name>.so;
+#  the switches are listed next to that target in butterfly_amd/csrc/Makefile)
 R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out/$1; shift; mkdir -p $O; cd $R
 for v in "$@"; do
   if [ $v = base ]; then unset BFHIP_LIB_PATH; else export BFHIP_LIB_PATH=$R/butterfly_amd/csrc/exp/libbfhip_$v.so; fi

@@ -1,6 +1,8 @@
 #!/bin/bash
 # A/B of library variants (butterfly_amd/csrc/exp/libbfhip_<v>.so; "base" = the product library) on the streamed operand.
 #   usage (GPU box): bash tools/ab_variants_streamer.sh <tag> <variant> [<variant> ...]
+# (a variant is built HERE, before gpurun snapshots the tree: make -C butterfly_amd/csrc variant V=<name> DEFS="-D..." -> exp/libbfhip_<name>.so;
+#  the switches are listed next to that target in butterfly_amd/csrc/Makefile)
 R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out/$1; shift; mkdir -p $O; cd $R
 for v in "$@"; do
   if [ $v = base ]; then unset BFHIP_LIB_PATH; else export BFHIP_LIB_PATH=$R/butterfly_amd/csrc/exp/libbfhip_$v.so; fi

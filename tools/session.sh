@@ -170,4 +170,13 @@ rhssweep()   { for q in 1 2 3 4 8 16 32 48 64; do
 loopprobe()  { step loop_probe 200 tools/mfma_loop_probe.bin; cat $O/loop_probe.out
                ( cd /tmp && export TMPDIR=/tmp && timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_loop -- $R/tools/mfma_loop_probe.bin 300 > $O/pmc_loop.out 2> $O/pmc_loop.log; echo "pmc_loop exit=$?"
                  PMC_QUICK_PER_DISPATCH=1 PMC_QUICK_FILTER=probeLoop python3 $R/tools/pmc_quick.py $O/pmc_loop ) }
+dma1()       { step loop_probe 300 tools/mfma_loop_probe.bin 600; cat $O/loop_probe.out
+               step pytest_dma 900 python -m pytest tests -m gpu -x -q -k "rhs_block or sharded or rccl or plain_c or gmres or dropin or fullsize"; tail -5 $O/pytest_dma.out
+               step r64_head 300 $B --nrhs 64 --steps 10 --warmup 3 --no-extra --no-cpu-baseline
+               python -c "import json; d = json.load(open('$O/r64_head.out')); print('n262144 nrhs64', d['ms_per_step'], d['roofline']['achieved'], d['roofline']['frac'])"; grep "stage " $O/r64_head.err; }
+pmcloop()    { step loop_probe 300 tools/mfma_loop_probe.bin 600; cat $O/loop_probe.out
+               ( cd /tmp && export TMPDIR=/tmp && timeout -k 10 400 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_loop -- $R/tools/mfma_loop_probe.bin 400 > $O/pmc_loop.out 2> $O/pmc_loop.log; echo "pmc_loop exit=$?"
+                 PMC_QUICK_PER_DISPATCH=1 PMC_QUICK_FILTER=probeLoop python3 $R/tools/pmc_quick.py $O/pmc_loop
+                 timeout -k 10 400 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_loop2 -- $R/tools/mfma_loop_probe.bin 400 > $O/pmc_loop2.out 2> $O/pmc_loop2.log; echo "pmc_loop2 exit=$?"
+                 find $O/pmc_loop $O/pmc_loop2 -name "*.csv" -size +4M -delete ) }
 for s in "$@"; do $s; done
