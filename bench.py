@@ -41,11 +41,20 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable copy)
 FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X dense FP64 matrix peak = FP64 vector peak = 1/2 of the 157.3 TFLOP/s FP32 rate
-PROFILE_ROUND = "r4"      # which committed rocprofv3 summaries the `traffic` figure is read from
+PROFILE_ROUND = "r5"      # which committed rocprofv3 summaries the `traffic` figure is read from
 
 
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
+
+
+def load_pmc_summary():
+    """(summary dict, its round tag) of the newest committed rocprofv3 --pmc summary under profiles/."""
+    for rnd in (PROFILE_ROUND, "r4", "r3"):
+        path = os.path.join(ROOT, "profiles", f"{rnd}_pmc_summary.json")
+        if os.path.exists(path):
+            return json.load(open(path)), rnd
+    raise FileNotFoundError("no profiles/*_pmc_summary.json")
 
 
 def parse_args(argv):
@@ -60,7 +69,10 @@ def parse_args(argv):
     ap.add_argument("--freq-depth", type=int, default=None, help="streamer: depth of the frequency tree (default: row-tree depth - 3, lbo_cov.c:97-98)")
     ap.add_argument("--nrhs", type=int, default=1)
     ap.add_argument("--seed", type=int, default=1234)
-    ap.add_argument("--cpu-budget-gb", type=float, default=4.0, help="leaf bytes of the cpu_baseline sample")
+    ap.add_argument("--cpu-budget-gb", type=float, default=None,
+                    help="leaf bytes of the cpu_baseline sample (default: a quarter of the operand's leaf bytes, at least 4 GB and at most 24 GB)")
+    ap.add_argument("--adjoint-both", action="store_true",
+                    help="with --adjoint: after the packed-copy measurement compile the operator again with the shared-leaf adjoint plan and time that too (`adjoint_shared` key)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the 64-RHS and configs[4] measurements appended to the default line")
     ap.add_argument("--no-streamer", action="store_true", help="skip only the configs[4] (streamed butterfly) measurement appended to the default line")
@@ -365,6 +377,7 @@ def main():
     if (not streamer and world == 1 and args.n in (None, 262144) and args.k is None and args.nrhs == 1 and args.dtype in (None, "c128")
             and not args.no_extra and args.emulate_world <= 1 and not dry):
         args.adjoint = True
+        args.adjoint_both = True  # ... both ways: on a packed copy for A^T (twice the leaf memory) and on the shared leaves
         args.pcie = True          # ... and the host-vector path an unmodified reference caller takes (pcie_inclusive)
     dtype = args.dtype or ("f32" if streamer else "c128")
     if streamer and dtype == "c128":
@@ -439,6 +452,15 @@ def main():
         row_offsets = np.concatenate([[0], np.cumsum(top_rows)]).astype(np.int64)
         sworld, srank = (args.emulate_world, max(args.emulate_rank, 0)) if args.emulate_world > 1 else (world, rank)
         mode = choose_mode(desc, sworld, args.shard)
+        if use_pg:
+            # every rank chose on its own copy of the layout: they must have chosen the same way before anything is compiled
+            modes = [None] * world
+            dist.all_gather_object(modes, mode)
+            if any(m_ != modes[0] for m_ in modes):
+                if rank == 0:
+                    log(f"bench.py: the ranks chose different sharding modes {modes}: refusing to run")
+                dist.destroy_process_group()
+                sys.exit(3)
         cuts = [0, n]
         seg_rows = top_rows                     # the row segments of y the closing all-gather carries, in global order
         if mode == "rows":
@@ -462,6 +484,8 @@ def main():
         config = {"workload": workload, "n": n, "k": k, "nrhs": args.nrhs, "leaf_bytes": total_leaf * esz}
         data = "synthetic (structure-exact fac_helm2 layout, seeded values generated in HBM)"
         metric = "butterfly matvecs/sec (2D Helmholtz HODBF apply)"
+    if args.cpu_budget_gb is None:      # >= 25 % of the leaf bytes (the oracle works in the reference's double precision), bounded so that the line stays within minutes
+        args.cpu_budget_gb = min(max(0.26 * total_leaf * (16 if not real else 8) / 1e9, 4.0), 24.0 if not streamer else 40.0)
     t_struct = time.time() - t0
     if rank == 0:
         log(f"structure: {workload}; nodes={desc.num_nodes} leafGB={total_leaf * esz / 1e9:.2f} [{t_struct:.1f}s]; "
@@ -765,7 +789,7 @@ def main():
         # `traffic` = HBM bytes PER LAUNCH (like `achieved`), from the COMMITTED rocprofv3 --pmc profile of this
         # very command (FETCH_SIZE / WRITE_SIZE in separate passes, gfx950 x2 FETCH correction): counters cannot
         # be read from inside the process, so it is not measured in this run and other configurations report null.
-        for rnd in (PROFILE_ROUND, "r3"):
+        for rnd in (PROFILE_ROUND, "r4", "r3"):
             prof = os.path.join(ROOT, "profiles", f"{rnd}_pmc_summary.json")
             helm_cfg = (not streamer and n == 262144 and abs(k - 16384) < 1e-9 and args.nrhs in (1, 64) and not real)
             cfg2 = (not streamer and n == 65536 and abs(k - 4096) < 1e-9 and args.nrhs == 1 and not real)
@@ -787,7 +811,7 @@ def main():
         # non-temporal reads / a bare loop of these MFMAs reaches on an MI355X of this pool
         for key, fn, fld in (("measured_stream_read_gbs", "hbm_peak.json", "read_nt_gbs"), ("measured_mfma_loop_tflops", "mfma_peak.json", "fp64_mfma_16x16x4_tflops")):
             if (roofline["bound"] == "hbm") == (fld == "read_nt_gbs"):
-                for rnd in (PROFILE_ROUND, "r3"):
+                for rnd in (PROFILE_ROUND, "r4", "r3"):
                     try:
                         roofline[key] = json.load(open(os.path.join(ROOT, "profiles", f"{rnd}_{fn}")))[fld]
                         break
@@ -827,6 +851,9 @@ def main():
             pcie["resident_ms_same_moment"] = (time.perf_counter() - t1) / reps * 1e3
             pcie_ms = pcie["pageable_ms"]
         config["stages"] = st["numStages"]
+        # what this configuration keeps in HBM: leaf arena(s) (both packed copies with the packed adjoint), vector arena, index tables
+        config["resident_bytes"] = int(st["arenaBytes"] + st["tempElems"] * args.nrhs * esz + st["metaBytes"])
+        config["arena_bytes"] = int(st["arenaBytes"])
         config["sharding"] = ("none" if sworld == 1 else
                               "contiguous row ranges below the top-level blocks (bfhipRowPartition: balanced, source-side factors replicated) + one all-gather" if mode == "rows"
                               else "top-level row blocks (LPT by leaf bytes) + one all-gather" if mode == "rowblocks"
@@ -871,13 +898,13 @@ def main():
                                          "packed: a second copy of the leaves laid out for A^T, applied by the forward kernels (BFHIP_FLAG_ADJOINT_PACKED; "
                                          f"{2 * st['leafBytes'] / 1e9:.1f} GB of leaves resident)")}
             try:        # HBM bytes per transposed apply from the committed --pmc passes of this command (all bfStageKernelT launches of one apply)
-                pm = json.load(open(os.path.join(ROOT, "profiles", f"{PROFILE_ROUND}_pmc_summary.json")))
+                pm, pm_round = load_pmc_summary()
                 akey = ("bfStageKernelT_f32_streamer_adjoint_per_apply" if (streamer and n == 1048576 and args.lmax == 255 and dtype == "f32") else
                         "bfStageKernelT_c128_adjoint_per_apply" if (not streamer and n == 262144 and not real and abs(k - 16384) < 1e-9) else None)
                 if akey and pm.get(akey) and args.nrhs == 1 and args.adjoint_shared:
                     out["adjoint"]["traffic_per_apply"] = pm[akey]["hbm_bytes"]
                     out["adjoint"]["traffic_ratio"] = pm[akey]["ratio"]
-                    out["adjoint"]["traffic_source"] = f"profiles/{PROFILE_ROUND}_pmc_summary.json [{akey}]: committed rocprofv3 --pmc passes, not measured in this run"
+                    out["adjoint"]["traffic_source"] = f"profiles/{pm_round}_pmc_summary.json [{akey}]: committed rocprofv3 --pmc passes, not measured in this run"
             except Exception:
                 pass
             # <A x, v> = <x, A^T v>: ties the two plans together on the full-size operand
@@ -908,6 +935,30 @@ def main():
                                      "hbm_gbs": 2 * st["leafBytes"] / 1e9 / (cov_ms / 1e3),
                                      "rel_vs_separate_applies": float(torch.linalg.norm(zc - zr) / torch.linalg.norm(zr)),
                                      "note": "bfhipCovMatvecDevice: z = P A diag(g)^2 A^T P' v, everything resident"}
+            if args.adjoint_both and not args.adjoint_shared:
+                # the same adjoint on the SHARED leaves (BFHIP_FLAG_ADJOINT: index tables only, no second copy): what a sharded
+                # operator, or one that fills most of the HBM, has to use.  The operator is compiled again without the packed copy.
+                try:
+                    st_packed = st
+                    op.close()
+                    torch.cuda.empty_cache()
+                    op = HipOperator.from_desc(desc, None, root=desc.root, device=local_rank, flags=_capi.FLAG_PROFILE | _capi.FLAG_ADJOINT, seed=args.seed,
+                                               max_rhs=args.nrhs, demote_to_f32=(dtype == "f32"))
+                    for _ in range(2):
+                        yt2 = op.apply_transpose_device(xt)
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    for _ in range(args.steps):
+                        yt2 = op.apply_transpose_device(xt)
+                    torch.cuda.synchronize()
+                    adj2 = (time.perf_counter() - t1) / args.steps * 1e3
+                    out["adjoint_shared"] = {"ms_per_apply": adj2, "matvec_per_s": args.nrhs / (adj2 / 1e3), "hbm_gbs": st["leafBytes"] / 1e9 / (adj2 / 1e3),
+                                             "frac_of_hbm_peak": st["leafBytes"] / 1e9 / (adj2 / 1e3) / HBM_PEAK_GBS,
+                                             "rel_vs_packed": float(torch.linalg.norm(yt2.to(yt.dtype) - yt) / torch.linalg.norm(yt)),
+                                             "arena_bytes": int(op.stats()["arenaBytes"]), "arena_bytes_packed": int(st_packed["arenaBytes"]),
+                                             "layout": "shared: the forward plan's packed leaves read by the transposed kernels (BFHIP_FLAG_ADJOINT), no extra leaf memory"}
+                except Exception as e:
+                    out["adjoint_shared"] = {"error": repr(e)[:300]}
         if args.pcie:
             out["pcie_inclusive"] = {"ms_per_apply": pcie_ms, "matvec_per_s": args.nrhs / (pcie_ms / 1e3), **pcie,
                                      "ratio_pageable": pcie_ms / pcie["resident_ms_same_moment"],
@@ -963,8 +1014,9 @@ def main():
             op.close()
             op = None
             nr = 64
-            o64, _ = compile_shard(0, nr)
-            x64 = torch.from_numpy((rng.standard_normal((n, nr)) + 1j * rng.standard_normal((n, nr))) / np.sqrt(2)).to(dev)
+            o64 = HipOperator.from_desc(desc, None, root=desc.root, device=local_rank, flags=_capi.FLAG_PROFILE, seed=args.seed, max_rhs=nr)
+            x64_host = (rng.standard_normal((n, nr)) + 1j * rng.standard_normal((n, nr))) / np.sqrt(2)
+            x64 = torch.from_numpy(x64_host).to(dev)
             y64 = torch.empty((n, nr), dtype=tdtype, device=dev)
             for _ in range(8):          # (the clock settles over the first few hundred ms of matrix-core load: early applies measure 1 - 3 % low)
                 o64.apply_device(x64, y64)
@@ -983,6 +1035,9 @@ def main():
             tf = flops * sampled / 1e12 / (float(ms64.sum()) / 1e3)
             out["nrhs64"] = {"config": "BASELINE configs[2]: the same operand, 64 right-hand sides (bfStageKernelC128Mfma)", "steps": reps,
                              "matvec_per_s": nr / dt, "ms_per_apply": dt * 1e3,
+                             # the whole apply (stage kernels + the reduce launches of the last stage + launch gaps) against the same peak
+                             "whole_apply_tflops": flops / 1e12 / dt, "whole_apply_frac": flops / 1e12 / dt / FP64_MFMA_PEAK_TFLOPS,
+                             "resident_bytes": int(o64.stats()["arenaBytes"] + o64.stats()["tempElems"] * nr * 16 + o64.stats()["metaBytes"]),
                              "roofline": {"bound": "mfma", "achieved": tf, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP64_MFMA_PEAK_TFLOPS,
                                           "kernel": "bfStageKernelC128Mfma", "kernel_ms_per_apply": float(ms64.sum()) / sampled,
                                           "algorithmic_flops_per_apply": flops,
@@ -990,15 +1045,25 @@ def main():
                                           "note": "algorithmic flops = 8 nrhs sum(m n) (4 real multiply-adds per complex one, SURVEY 8(d)); the kernel forms each "
                                                   "complex product with Gauss's 3 real multiplications, i.e. issues 6 nrhs sum(m n) MFMA flops (+ tile padding)"}}
             try:        # the matrix pipe's share of the cycles and the clock the chip sustained under this kernel (committed --pmc pass)
-                pm = json.load(open(os.path.join(ROOT, "profiles", f"{PROFILE_ROUND}_pmc_summary.json")))
+                pm, pm_round = load_pmc_summary()
                 clk = pm["mfma_sustained_clock"]
                 out["nrhs64"]["roofline"].update({
                     "sustained_clock_ghz": clk["ghz"], "peak_clock_ghz": clk["peak_ghz"], "mfma_busy_fraction": clk["mfma_busy_fraction"],
                     "traffic": pm["bfStageKernelC128Mfma_per_launch"]["hbm_bytes"],
-                    "clock_source": f"profiles/{PROFILE_ROUND}_pmc_summary.json [mfma_sustained_clock]: GRBM_GUI_ACTIVE / kernel time of the committed --pmc pass of "
+                    "clock_source": f"profiles/{pm_round}_pmc_summary.json [mfma_sustained_clock]: GRBM_GUI_ACTIVE / kernel time of the committed --pmc pass of "
                                     "`bench.py --nrhs 64`, NOT measured in this run; peak 78.6 TFLOP/s assumes 2.4 GHz"})
             except Exception:
                 pass
+            # the CPU baseline of THIS configuration, in the same run: the oracle's bfMatMul on 64 right-hand sides (1 thread = the reference's
+            # behaviour, and OpenBLAS on every host core: SURVEY 8(d)), on a block-row sample, with the parity of the device result on it
+            if not args.no_cpu_baseline:
+                try:
+                    y64_host = y64.cpu().numpy()
+                    out["nrhs64"]["cpu_baseline"] = cpu_baseline_helm2(desc, args.seed, total_leaf, weights, min(args.cpu_budget_gb, 6.0) * 1e9, nr, x64_host,
+                                                                       y64_host, row_offsets)
+                    del y64_host
+                except Exception as e:
+                    out["nrhs64"]["cpu_baseline"] = {"value": None, "unit": "matvec/s", "cores": 1, "kind": "port", "sample": f"failed: {e!r}"}
             o64.close()
         except Exception as e:
             out["nrhs64"] = {"error": repr(e)}
@@ -1007,7 +1072,7 @@ def main():
         try:
             torch.cuda.empty_cache()
             cmd = [sys.executable, os.path.abspath(__file__), "--npoints", "65536", "--steps", "50", "--warmup", "5", "--no-extra", "--pcie",
-                   "--seed", str(args.seed), "--cpu-budget-gb", "4.0"]
+                   "--seed", str(args.seed)]
             env = dict(os.environ)
             for k_ in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
                 env.pop(k_, None)
@@ -1027,19 +1092,20 @@ def main():
         if not args.no_streamer:
             try:
                 torch.cuda.empty_cache()
-                cmd = [sys.executable, os.path.abspath(__file__), "--workload", "streamer", "--steps", "10", "--warmup", "2", "--adjoint",
-                       "--no-extra", "--seed", str(args.seed), "--cpu-budget-gb", "2.0"]
+                cmd = [sys.executable, os.path.abspath(__file__), "--workload", "streamer", "--steps", "10", "--warmup", "2", "--adjoint", "--adjoint-both",
+                       "--no-extra", "--seed", str(args.seed)]
                 env = dict(os.environ)
                 for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
                     env.pop(k, None)
-                pr = subprocess.run(cmd, capture_output=True, text=True, timeout=270, env=env)
+                pr = subprocess.run(cmd, capture_output=True, text=True, timeout=420, env=env)
                 line = [ln for ln in pr.stdout.splitlines() if ln.startswith("{")]
                 if pr.returncode != 0 or not line:
                     raise RuntimeError(f"child exit {pr.returncode}: {pr.stderr[-300:]}")
                 c = json.loads(line[-1])
                 out["configs4_streamer"] = {"config": c["config"]["workload"], "metric": c["metric"], "value": c["value"], "unit": c["unit"],
                                             "dtype": c["dtype"], "steps": c["steps"], "ms_per_step": c["ms_per_step"], "roofline": c["roofline"],
-                                            "adjoint": c.get("adjoint"), "cov_matvec": c.get("cov_matvec"), "cpu_baseline": c.get("cpu_baseline"),
+                                            "adjoint": c.get("adjoint"), "adjoint_shared": c.get("adjoint_shared"), "cov_matvec": c.get("cov_matvec"),
+                                            "cpu_baseline": c.get("cpu_baseline"), "resident_bytes": c["config"].get("resident_bytes"),
                                             "layout": c["config"].get("layout")}
             except Exception as e:
                 out["configs4_streamer"] = {"error": repr(e)[:400]}

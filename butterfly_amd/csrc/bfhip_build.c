@@ -297,6 +297,10 @@ static int buildBatch(BfhipHelm2Problem const *prob, uint64_t const *idx, uint64
     g1[q].a = probs[q].v; g1[q].M = rk; g1[q].K = rk; g1[q].lda = rk;             /* T[0:rk] = diag(1/sigma^2) V1^H (Q^H Z_orig)[0:rk] */
     g2[q].a = qr[k].x; g2[q].K = rk; g2[q].lda = me;                              /* X = W T[0:rk] */
     st->qrProblems += 1; st->qrColumns += me; st->qrRank += rk;
+    /* rank 0: the matrix is zero or not finite (the pivot loop stops on `!(best >= threshold)`) -- nothing for the Jacobi kernel to flag.
+     * Count it like an SVD that did not converge (the build then fails unless BFHIP_ALLOW_UNCONVERGED_SVD=1); with K = 0 the second
+     * GEMM writes an exactly zero leaf instead of leaving what the reused store held from the batch before. */
+    if (!rk) st->notConverged += 1;
   }
   BfSvdStats ss = {st->maxSweeps, 0, 0, 0};
   if ((rc = bfdevBuildJacobi(probs, np, &ss))) goto done;

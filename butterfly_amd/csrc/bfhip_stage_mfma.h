@@ -68,8 +68,12 @@ __device__ __forceinline__ bf_i4 bfMakeRsrc(void const *base, uint32_t bytes) {
   r.w = 0x00020000;
   return r;
 }
+// cache policy of the leaf stream (read once per apply): "nt" = non-temporal; A/B builds try others (-DBF_MF_A_POLICY='"sc0 sc1 nt"')
+#ifndef BF_MF_A_POLICY
+#define BF_MF_A_POLICY "nt"
+#endif
 template <int STREAM, int OFF> __device__ __forceinline__ void bfFragLoad(BfFrag &f, uint32_t voff, bf_i4 rsrc, uint32_t soff) {
-  if (STREAM) asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:%4 nt" : "=v"(f.u) : "v"(voff), "s"(rsrc), "s"(soff), "n"(OFF));
+  if (STREAM) asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:%4 " BF_MF_A_POLICY : "=v"(f.u) : "v"(voff), "s"(rsrc), "s"(soff), "n"(OFF));
   else asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:%4" : "=v"(f.u) : "v"(voff), "s"(rsrc), "s"(soff), "n"(OFF));
 }
 template <int N> __device__ __forceinline__ void bfFragWait(BfFrag &f) { asm volatile("s_waitcnt vmcnt(%1)" : "+v"(f.u) : "n"(N)); }

@@ -179,11 +179,14 @@ def choose_mode(desc, world, requested="auto"):
     # replicated); where a block row has to be shared (8 ranks: +6 % leaves for the replicated first-applied factors)
     # the column split of rowsum is the cheaper way to share it
     has_blocks = getattr(desc, "top_row_block", None) is not None
+    from . import _capi
     try:
         cuts, loads = row_partition(desc, world)
-    except Exception:
-        # fewer clean cut positions than ranks (small or tall-leaf operands): no row ranges -- share block rows instead
-        if not has_blocks:
+    except _capi.BfhipError as e:
+        # fewer clean cut positions than ranks (small or tall-leaf operands: bfhipRowPartition answers INVALID_ARGUMENTS): no row
+        # ranges -- share block rows instead.  Anything else (a malformed descriptor, a bug) propagates: a silent change of the
+        # sharding mode on ONE rank would leave the ranks in different collectives.
+        if e.code != 1 or not has_blocks:
             raise
         return "rowsum"
     total = int(desc.subtree_leaf_elems()[desc.root]) if hasattr(desc, "subtree_leaf_elems") else sum(row_block_weights(desc))

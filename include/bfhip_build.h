@@ -21,7 +21,14 @@
  * at r == 0; a re-expansion leaf is X = pinv_trunc(Z_equiv) Z_orig with the
  * reference's truncation rule (singular values below max(m,n) eps s_max + eps
  * dropped), computed by a one-sided Jacobi SVD (QR-preconditioned with column pivoting from 65 equivalent sources up)
- * instead of LAPACK zgesvd.
+ * instead of LAPACK zgesvd.  Where the two criteria differ: the QR stage stops on COLUMN NORMS (the largest remaining column
+ * of the pivoted factorization below max(m,n) eps x the largest column of Z_equiv -- the threshold under which the Jacobi kernel
+ * freezes a column), the reference truncates on SINGULAR VALUES (sigma < max(m,n) eps sigma_max + eps).  The stop is at the noise
+ * floor, far below the rule's threshold on these matrices, and the rule itself is then applied to the singular values of what the
+ * QR kept; a direction whose singular value lies within a factor ~sqrt(columns) of the threshold can still be dropped by the QR
+ * stage where zgesvd would have kept it -- such directions are rounding noise in either computation (BFHIP_JACOBI_QR_MIN=<huge>
+ * turns the stage off).  A least-squares matrix that is zero or not finite (QR rank 0) is counted in
+ * BfhipBuildStats.notConverged: the build fails unless BFHIP_ALLOW_UNCONVERGED_SVD=1, and the leaf is then exactly zero.
  * Element-wise agreement with the CPU path is therefore at the level of the
  * truncation (the dropped directions), while Z_equiv X, and hence every
  * apply result, agrees to ~1e-12; see tests/test_gpu_build.py.
