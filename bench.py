@@ -390,7 +390,9 @@ def main():
     # (round 4: the packed copy is the default for the streamed operand too -- with runs of narrow pieces contracted as one block
     #  and >= 32768 items per stage its transposed expression runs at 0.765 of the HBM peak on the forward kernels, the transposed
     #  kernels on the shared leaves at 0.737: DESIGN.md section 10; --adjoint-shared measures the latter)
-    flags = _capi.FLAG_PROFILE | ((_capi.FLAG_ADJOINT if args.adjoint_shared else _capi.FLAG_ADJOINT_PACKED) if args.adjoint else 0)
+    # (a sharded operator's adjoint is the shared-leaf plan: a row shard's is the pruned transposed task list, and a packed copy would double every rank's memory)
+    shared_adj = args.adjoint_shared or world > 1 or args.force_collective or args.emulate_world > 1
+    flags = _capi.FLAG_PROFILE | ((_capi.FLAG_ADJOINT if shared_adj else _capi.FLAG_ADJOINT_PACKED) if args.adjoint else 0)
 
     # ---- the operand's block layout -------------------------------------------------------------------
     t0 = time.time()
@@ -573,7 +575,8 @@ def main():
         """The same step with the closing collective issued by torch.distributed (still RCCL over xGMI on GPUs): the
         fallback when libbfhip's own communicator cannot be created on some rank.  Times its two halves with events."""
         def __init__(self, the_op, layout_, mode_):
-            self.inner = ShardedApply(layout_, rank, lambda xin, out: the_op.apply_device(xin, out), dev, tdtype, nrhs=args.nrhs, mode=mode_,
+            self.op = the_op
+            self.inner = ShardedApply(layout_, rank, lambda xin, out: the_op.apply_device(xin, out), dev, tdtype, nrhs=args.nrhs, mode="rows" if mode_ == "rowsum" else mode_,
                                       force_collective=args.force_collective)
             self.timing, self.ev = False, [torch.cuda.Event(enable_timing=True) for _ in range(3)]
             inner_apply = self.inner.local_apply
@@ -595,6 +598,9 @@ def main():
 
         def set_timing(self, on):
             self.timing = bool(on)
+
+        def apply_transpose(self, v):
+            return self.inner.apply_transpose(v, lambda vr, out: self.op.apply_transpose_device(vr, out), ncols)
 
         def last_times(self):
             torch.cuda.synchronize()
@@ -717,6 +723,37 @@ def main():
                  "roofline_rank": prof_rank, "bit_identical_to_one_gpu": mode in ("rows", "rowblocks"),
                  "ranks_max_abs_diff": ydiff, "ranks_agree": ydiff == 0.0,
                  "collective_impl": coll_impl, "collective_fallback_reason": coll_bad}
+        if args.adjoint:
+            # the adjoint of the sharded step (bfhipShardedApplyTransposeDevice): every rank applies A_r^T to its entries of v, ONE all-reduce
+            try:
+                vt = torch.from_numpy(rng.standard_normal((n,) + shape[1:]) if real else x_host).to(dev).to(tdtype) if ncols == n else None
+                if vt is None:
+                    vt = torch.from_numpy(np.random.default_rng(args.seed + 1).standard_normal((n,) + shape[1:])).to(dev).to(tdtype)
+                for _ in range(2):
+                    zt = sharded.apply_transpose(vt)
+                torch.cuda.synchronize()
+                if use_pg:
+                    dist.barrier()
+                t1 = time.perf_counter()
+                for _ in range(args.steps):
+                    zt = sharded.apply_transpose(vt)
+                torch.cuda.synchronize()
+                if use_pg:
+                    dist.barrier()
+                elT = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev)
+                if use_pg:
+                    dist.all_reduce(elT, op=dist.ReduceOp.MAX)
+                dT = ranks_max_abs_diff(dist, zt, use_pg)
+                # <A x, v> = <x, A^T v> ties the sharded adjoint to the sharded forward step on the full-size operand
+                yx = step(x)
+                lhs = torch.sum(yx.to(torch.complex128 if not real else torch.float64) * vt.to(torch.complex128 if not real else torch.float64))
+                rhs = torch.sum(x.to(lhs.dtype) * zt.to(lhs.dtype))
+                multi["adjoint"] = {"ms_per_step": float(elT.item()) / args.steps * 1e3, "value": args.steps * args.nrhs / float(elT.item()), "unit": "matvec/s",
+                                    "collective": "ncclAllReduce (sum) of the full-length partials A_r^T v_r", "ranks_max_abs_diff": dT, "ranks_agree": dT == 0.0,
+                                    "transpose_identity_rel": float(abs(lhs - rhs) / max(abs(lhs), 1e-300)),
+                                    "layout": "shared leaves (BFHIP_FLAG_ADJOINT): a shard's adjoint plan is its transposed task list pruned by reachability from its rows"}
+            except Exception as e:
+                multi["adjoint"] = {"error": repr(e)[:300]}
         # The default at this world size is not the bit-identical row-range shard (8 ranks: rowsum): time that one too
         if ((world > 1 and args.shard == "auto") or os.environ.get("BENCH_ALSO_TIME_ROWS") == "1") and mode != "rows" and not streamer:
             try:
@@ -894,7 +931,7 @@ def main():
             out["adjoint"] = {"ms_per_apply": adj_ms, "matvec_per_s": args.nrhs / (adj_ms / 1e3),
                               "hbm_gbs": st["leafBytes"] / 1e9 / (adj_ms / 1e3), "frac_of_hbm_peak": st["leafBytes"] / 1e9 / (adj_ms / 1e3) / HBM_PEAK_GBS,
                               "traffic_per_apply": None,
-                              "layout": ("shared: the forward plan's packed leaves read by the transposed kernels (BFHIP_FLAG_ADJOINT)" if args.adjoint_shared else
+                              "layout": ("shared: the forward plan's packed leaves read by the transposed kernels (BFHIP_FLAG_ADJOINT)" if shared_adj else
                                          "packed: a second copy of the leaves laid out for A^T, applied by the forward kernels (BFHIP_FLAG_ADJOINT_PACKED; "
                                          f"{2 * st['leafBytes'] / 1e9:.1f} GB of leaves resident)")}
             try:        # HBM bytes per transposed apply from the committed --pmc passes of this command (all bfStageKernelT launches of one apply)
@@ -935,7 +972,7 @@ def main():
                                      "hbm_gbs": 2 * st["leafBytes"] / 1e9 / (cov_ms / 1e3),
                                      "rel_vs_separate_applies": float(torch.linalg.norm(zc - zr) / torch.linalg.norm(zr)),
                                      "note": "bfhipCovMatvecDevice: z = P A diag(g)^2 A^T P' v, everything resident"}
-            if args.adjoint_both and not args.adjoint_shared:
+            if args.adjoint_both and not shared_adj:
                 # the same adjoint on the SHARED leaves (BFHIP_FLAG_ADJOINT: index tables only, no second copy): what a sharded
                 # operator, or one that fills most of the HBM, has to use.  The operator is compiled again without the packed copy.
                 try:

@@ -458,7 +458,10 @@ int bfhipCompileIrFill(BfIr *ir, BfhipOptions const *opts, BfFillFn fill, void *
     po.storeDtype = BFHIP_F32;
   }
   po.groupByInput = o.maxRhs >= 3;
-  po.minChunkRows = o.maxRhs >= 3 ? 32 : 16;   /* operators compiled for RHS blocks run on the matrix-core kernel */
+#ifndef BF_MIN_CHUNK_ROWS
+#define BF_MIN_CHUNK_ROWS 16     /* lower bound of the adaptive item height, in 16-byte row units (A/B builds: 8) */
+#endif
+  po.minChunkRows = o.maxRhs >= 3 ? 32 : BF_MIN_CHUNK_ROWS;   /* operators compiled for RHS blocks run on the matrix-core kernel */
   po.rowBlockBegin = o.rowBlockBegin;
   po.rowAlignBytes = 128;      /* rows of row-major pieces on 128-byte lines: the forward kernel gains 1 - 3 % on them, the transposed one 3 % */
   po.rowBlockEnd = o.rowBlockEnd;

@@ -930,13 +930,13 @@ int bfPlanBuild(BfIr const *ir, BfPlanOptions const *po, BfPlan *plan) {
       for (uint64_t t = gr->taskBegin; t < gr->taskEnd; ++t) {
         Task const *tk = &b.tasks[t];
         if (ir->kind[tk->leaf] == BFHIP_NODE_IDENTITY) { gr->piecesPerChunk += 1; gr->colsSum += 1; }
-        else if (T) { gr->piecesPerChunk += (tk->cols + 15) / 16 + 2; gr->colsSum += tk->cols; }   /* upper bound: forward row chunks have >= 16 rows, one may straddle each end */
+        else if (T) { gr->piecesPerChunk += (tk->cols + 7) / 8 + 2; gr->colsSum += tk->cols; }   /* upper bound: forward row chunks have >= 8 rows, one may straddle each end */
         else { gr->piecesPerChunk += (tk->cols + plan->xcap - 1) / plan->xcap; gr->colsSum += tk->cols; }
       }
       uint64_t chunk = gr->cls ? 16 : itemRows;
       if (!T && gr->colsSum) {
-        uint64_t const gran = 16 * plan->epl;
         uint64_t const floorRows = (po->minChunkRows ? po->minChunkRows : 16) * plan->epl;
+        uint64_t const gran = floorRows < 16 * plan->epl ? floorRows : 16 * plan->epl;
         uint64_t want = (itemBytes / plan->elemSize) / gr->colsSum / gran * gran;
         if (want < floorRows) want = floorRows;
         if (want < chunk) chunk = want;

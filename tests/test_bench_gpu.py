@@ -71,6 +71,33 @@ def test_multi_rank_reporting_with_one_rank(monkeypatch):
     assert m["ranks_agree"] and m["max_local_ms"] > 0 and m["max_collective_ms"] >= 0 and m["also_timed"]["collective_impl"] == "torch.distributed"
 
 
+@pytest.mark.parametrize("shard,torch_coll", [("rows", False), ("rowsum", False), ("blocks", True)])
+def test_multi_rank_adjoint_reporting_with_one_rank(monkeypatch, shard, torch_coll):
+    """`bench.py --gpus N --adjoint`: the adjoint of the sharded step (every rank's A_r^T on its entries of v, ONE all-reduce) is
+    timed next to the forward step with its own rank agreement and <A x, v> = <x, A^T v>; here with ONE rank through the same code,
+    over libbfhip's RCCL communicator and over the torch.distributed fallback."""
+    if torch_coll:
+        monkeypatch.setenv("BENCH_FORCE_TORCH_COLLECTIVE", "1")
+    d = run_bench("--force-collective", "--adjoint", "--shard", shard, "--no-cpu-baseline", "--pcie")
+    a = d["multi_gpu"]["adjoint"]
+    assert "error" not in a, a
+    assert a["ranks_agree"] and a["ms_per_step"] > 0 and a["transpose_identity_rel"] < 1e-12
+    assert d["adjoint"]["layout"].startswith("shared")
+    p = d["pcie_inclusive"]
+    assert p["pageable_ms"] > 0 and p["registered_ms"] > 0 and p["device_pointers_ms"] > 0 and p["resident_ms_same_moment"] > 0
+
+
+def test_default_line_keys_of_round_5():
+    """The keys the default line gained in round 5, on a small operand: adjoint on the packed copy AND on the shared leaves,
+    resident bytes, the host-vector path for three kinds of caller memory."""
+    d = run_bench("--adjoint", "--adjoint-both", "--pcie", "--no-cpu-baseline")
+    assert d["adjoint"]["layout"].startswith("packed") and d["adjoint_shared"]["layout"].startswith("shared")
+    assert d["adjoint_shared"]["rel_vs_packed"] < 1e-12 and d["adjoint_shared"]["arena_bytes"] * 2 == d["adjoint_shared"]["arena_bytes_packed"]
+    assert d["config"]["resident_bytes"] > d["config"]["arena_bytes"] > 0
+    p = d["pcie_inclusive"]
+    assert p["ratio_pageable"] > 0.5 and p["ratio_registered"] > 0.5 and p["device_pointers_ms"] > 0
+
+
 def test_adjoint_layouts_in_the_bench_line():
     """--adjoint: a packed copy of the leaves for A^T on the forward kernels (default for fac_helm2 operands) or the shared
     leaves through the transposed kernels; both tie <A x, v> to <x, A^T v>."""

@@ -34,7 +34,8 @@ def shard():
     assert max(loads) / (sum(loads) / WORLD) < 1.04 and sum(loads) < 1.1 * sum(bw)
     heavy = int(np.argmax(loads))
     a, b = cuts[heavy], cuts[heavy + 1]
-    op = HipOperator.from_desc(desc, None, device=0, seed=7, row_range=(a, b))
+    from butterfly_amd import _capi
+    op = HipOperator.from_desc(desc, None, device=0, seed=7, row_range=(a, b), flags=_capi.FLAG_ADJOINT)      # + the shard's adjoint plan (shared leaves)
     st = op.stats()
     assert st["leafBytes"] == loads[heavy] * 16 and st["leafBytes"] > 110e9 and st["numRows"] == b - a
     # the top-level blocks whose rows this rank holds completely
@@ -75,6 +76,29 @@ def test_linearity_and_reproducibility_of_the_shard(shard):
     torch.cuda.synchronize()
     assert rel(yl.cpu().numpy(), (a * yx + b * yz).cpu().numpy()) <= TOL
     assert torch.equal(op.apply_device(x), yx)
+
+
+def test_adjoint_of_the_heaviest_shard(shard):
+    """The shard's adjoint plan (round 5: the transposed task list pruned by reachability from the rank's rows, over the same
+    125 GB of leaves): <A_r x, v> = <x, A_r^T v> at full size ties it to the forward plan that the tests above hold to the
+    oracle; through the C-ABI's sharded adjoint step (1-rank communicator: this rank's rows are its whole world) the
+    all-reduce leaves the same vector."""
+    import torch
+    from butterfly_amd.dist import RcclShardedApply, ShardLayout
+    op, rng = shard["op"], shard["rng"]
+    rows = shard["b"] - shard["a"]
+    x = torch.from_numpy((rng.standard_normal(N) + 1j * rng.standard_normal(N)) / np.sqrt(2)).cuda()
+    v = torch.from_numpy((rng.standard_normal(rows) + 1j * rng.standard_normal(rows)) / np.sqrt(2)).cuda()
+    y = op.apply_device(x).clone()
+    z = op.apply_transpose_device(v).clone()
+    torch.cuda.synchronize()
+    assert z.shape == (N,)
+    lhs, rhs = torch.sum(y * v), torch.sum(x * z)
+    assert abs(lhs - rhs) / abs(lhs) <= 1e-12
+    assert torch.equal(op.apply_transpose_device(v), z)
+    step = RcclShardedApply(ShardLayout([rows // 3, rows - rows // 3], [0, 0], 1), 0, op, 0, nrhs=1, mode="rows")
+    assert torch.equal(step.apply_transpose(v), z)
+    step.close()
 
 
 def test_closing_collective_on_the_shard(shard):
