@@ -52,9 +52,18 @@ static int drive(double const *pts, uint64_t n, double const *tgt, uint64_t m, d
       /* a row shard through the options (square operators only carry topRowBlock for it) */
       bfhipFree(&op);
       if (!m) {
-        o.rowBlockBegin = 1; o.rowBlockEnd = 3; o.flags = BFHIP_FLAG_PLAN_ONLY;
+        /* (round 5: shards carry the plan of their adjoint too -- the transposed task list pruned by reachability from the shard's
+         *  rows; the packed flag falls back to it on a shard) */
+        o.rowBlockBegin = 1; o.rowBlockEnd = 3; o.flags = BFHIP_FLAG_PLAN_ONLY | (flags & BFHIP_FLAG_ADJOINT ? BFHIP_FLAG_ADJOINT_PACKED : 0);
         CHECK(bfhipCompileDesc(d, &o, &op));
+        if (flags & BFHIP_FLAG_ADJOINT) {
+          memset(&info, 0, sizeof info);
+          info.structSize = sizeof info;
+          CHECK(bfhipPlanGetInfo(op, &info));
+          if (!info.numStagesT || info.reserved) return 6;      /* a shared-leaf adjoint plan, not a packed one */
+        }
         bfhipFree(&op);
+        o.flags = flags;
         /* row ranges: the library's own cuts for 3 ranks, each compiled (liveness pruning), plus an unclean range */
         uint64_t cuts[4], loads[3];
         CHECK(bfhipRowPartition(d, 3, cuts, loads));
@@ -270,5 +279,15 @@ STUB(bfdevMemcpyH2D)
 STUB(bfdevMemcpyH2DAsync)
 STUB(bfdevMemset)
 STUB(bfdevSetDevice)
+STUB(bfdevPointerKind)
+STUB(bfdevMemcpyAnyAsync)
+STUB(bfdevHostRegister)
+STUB(bfdevHostUnregister)
+/* the sharded step lives in bfhip_shard.hip (device layer): the shim's sharded branch is not reached on a plan-only operator */
+size_t bfhipShardedGetNumRows(const BfhipSharded *sh) { (void)sh; fprintf(stderr, "device layer reached: bfhipShardedGetNumRows\n"); abort(); }
+size_t bfhipShardedGetNumCols(const BfhipSharded *sh) { (void)sh; fprintf(stderr, "device layer reached: bfhipShardedGetNumCols\n"); abort(); }
+STUB(bfhipShardedApplyHost)
+STUB(bfhipShardedOperator)
+void bfhipShardedFree(BfhipSharded **p) { if (p && *p) { fprintf(stderr, "device layer reached: bfhipShardedFree(non-NULL)\n"); abort(); } }
 STUB(bfdevSync)
 STUB(bfdevSynthFill)

@@ -179,4 +179,9 @@ pmcloop()    { step loop_probe 300 tools/mfma_loop_probe.bin 600; cat $O/loop_pr
                  PMC_QUICK_PER_DISPATCH=1 PMC_QUICK_FILTER=probeLoop python3 $R/tools/pmc_quick.py $O/pmc_loop
                  timeout -k 10 400 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_loop2 -- $R/tools/mfma_loop_probe.bin 400 > $O/pmc_loop2.out 2> $O/pmc_loop2.log; echo "pmc_loop2 exit=$?"
                  find $O/pmc_loop $O/pmc_loop2 -name "*.csv" -size +4M -delete ) }
+r5tests()    { step pytest_r5 1100 python -m pytest tests/test_gpu_config4.py tests/test_gpu_config4_rowsum.py tests/test_bench_gpu.py tests/test_gpu_sharded_adjoint.py -m gpu -x -q; tail -6 $O/pytest_r5.out; }
+pcie()       { step pcie_head 400 $B --steps 20 --warmup 3 --pcie --no-cpu-baseline --no-extra
+               python -c "import json; d = json.load(open('$O/pcie_head.out')); print('headline', d['ms_per_step'], d['pcie_inclusive'])"
+               step pcie_n65536 300 $B --npoints 65536 --steps 50 --warmup 5 --pcie --no-cpu-baseline --no-extra
+               python -c "import json; d = json.load(open('$O/pcie_n65536.out')); print('n65536', d['ms_per_step'], d['pcie_inclusive'])"; }
 for s in "$@"; do $s; done
