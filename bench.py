@@ -487,7 +487,8 @@ def main():
         data = "synthetic (structure-exact fac_helm2 layout, seeded values generated in HBM)"
         metric = "butterfly matvecs/sec (2D Helmholtz HODBF apply)"
     if args.cpu_budget_gb is None:      # >= 25 % of the leaf bytes (the oracle works in the reference's double precision), bounded so that the line stays within minutes
-        args.cpu_budget_gb = min(max(0.26 * total_leaf * (16 if not real else 8) / 1e9, 4.0), 24.0 if not streamer else 40.0)
+        # (whole top-level block rows are sampled, 1/12 of the operand each on a circle: a third of the bytes as budget is four of them)
+        args.cpu_budget_gb = min(max(0.33 * total_leaf * (16 if not real else 8) / 1e9, 4.0), 24.0 if not streamer else 40.0)
     t_struct = time.time() - t0
     if rank == 0:
         log(f"structure: {workload}; nodes={desc.num_nodes} leafGB={total_leaf * esz / 1e9:.2f} [{t_struct:.1f}s]; "

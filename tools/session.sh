@@ -184,4 +184,17 @@ pcie()       { step pcie_head 400 $B --steps 20 --warmup 3 --pcie --no-cpu-basel
                python -c "import json; d = json.load(open('$O/pcie_head.out')); print('headline', d['ms_per_step'], d['pcie_inclusive'])"
                step pcie_n65536 300 $B --npoints 65536 --steps 50 --warmup 5 --pcie --no-cpu-baseline --no-extra
                python -c "import json; d = json.load(open('$O/pcie_n65536.out')); print('n65536', d['ms_per_step'], d['pcie_inclusive'])"; }
+defline()    { local t0=$(date +%s); step def_line 900 $B; echo "default line wall seconds: $(( $(date +%s) - t0 ))"
+               python - <<PY
+import json
+d = json.load(open("$O/def_line.out"))
+print("headline", d["value"], d["ms_per_step"], d["roofline"]["frac"], "resident", d["config"].get("resident_bytes"))
+print("cpu_baseline", d["cpu_baseline"]["value"], d["cpu_baseline"]["sample"][:160], d["cpu_baseline"].get("parity_rel_l2"))
+print("adjoint", d["adjoint"]["frac_of_hbm_peak"], "shared", d.get("adjoint_shared"))
+print("pcie", {k: v for k, v in d["pcie_inclusive"].items() if k != "note"})
+n = d["nrhs64"]; print("nrhs64", n.get("ms_per_apply"), n.get("roofline", {}).get("frac"), n.get("whole_apply_frac"), n.get("cpu_baseline", {}).get("value"), n.get("cpu_baseline", {}).get("all_cores"), n.get("error"))
+m = d["n65536"]; print("n65536", m.get("ms_per_step"), m.get("roofline", {}).get("frac"), (m.get("cpu_baseline") or {}).get("sample", "")[:100], {k: v for k, v in (m.get("pcie_inclusive") or {}).items() if k != "note"}, m.get("error"))
+c = d["configs4_streamer"]; print("streamer", c.get("ms_per_step"), c.get("roofline", {}).get("frac"), "adj", (c.get("adjoint") or {}).get("frac_of_hbm_peak"), "shared", (c.get("adjoint_shared") or {}).get("frac_of_hbm_peak"), (c.get("cpu_baseline") or {}).get("sample", "")[:120], c.get("error"))
+PY
+             }
 for s in "$@"; do $s; done
