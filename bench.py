@@ -389,7 +389,7 @@ def main():
     tdtype = {"c128": torch.complex128, "f64": torch.float64, "f32": torch.float32}[dtype]
     # (round 4: the packed copy is the default for the streamed operand too -- with runs of narrow pieces contracted as one block
     #  and >= 32768 items per stage its transposed expression runs at 0.765 of the HBM peak on the forward kernels, the transposed
-    #  kernels on the shared leaves at 0.737: DESIGN.md section 10; --adjoint-shared measures the latter)
+    #  kernels on the shared leaves at 0.737: DESIGN_EXPERIMENTS.md section 10; --adjoint-shared measures the latter)
     # (a sharded operator's adjoint is the shared-leaf plan: a row shard's is the pruned transposed task list, and a packed copy would double every rank's memory)
     shared_adj = args.adjoint_shared or world > 1 or args.force_collective or args.emulate_world > 1
     flags = _capi.FLAG_PROFILE | ((_capi.FLAG_ADJOINT if shared_adj else _capi.FLAG_ADJOINT_PACKED) if args.adjoint else 0)
@@ -422,7 +422,7 @@ def main():
         ncols = int(desc.cols[desc.root])
         total_leaf = gstats["leafBytes"] // 8
         workload = (f"fac_streamer butterfly of the N x J Laplace-Beltrami eigenvector matrix of a sphere (examples/covariance): N={n} octree rows, "
-                    f"J={ncols} columns (lmax={args.lmax}), frequency tree depth {fd}, tol=1e-3 rank model (rank-model structure, NOT the reference's SVD-driven structure: DESIGN.md section 12), minNumRows=minNumCols=20, nrhs={args.nrhs}")
+                    f"J={ncols} columns (lmax={args.lmax}), frequency tree depth {fd}, tol=1e-3 rank model (rank-model structure, NOT the reference's SVD-driven structure: DESIGN_EXPERIMENTS.md section 12), minNumRows=minNumCols=20, nrhs={args.nrhs}")
         config = {"workload": workload, "n": n, "num_cols": ncols, "lmax": args.lmax, "freq_depth": fd, "nrhs": args.nrhs,
                   "leaf_bytes": total_leaf * esz, "num_w": num_w,
                   "graph": {k: gstats[k] for k in ("denseReal", "identity", "blockCoo", "blockDense", "blockDiag", "maxNest")},

@@ -485,7 +485,7 @@ int bfhipCompileIrFill(BfIr *ir, BfhipOptions const *opts, BfFillFn fill, void *
      * the transposed expression with ~8000 items for 4096 wavefront slots: two uneven rounds.  Cutting them for >= 32768 items
      * per stage (N = 1M fp32: 8.66 -> 8.08 ms; 16384: 8.25, 65536: 8.15) costs nothing but a few more partial sums.  Complex
      * (fac_helm2) plans keep 4096: their stages are 10 GB, the cap binds either way and more items measured 1-2 % slower, as did
-     * more items in the FORWARD plan of either operand. */
+     * more items in the FORWARD plan of either operand (DESIGN_EXPERIMENTS.md section 10). */
     if (op->plan.dtype != BFHIP_C128) pt.itemsWanted = 32768;
     if ((rc = bfPlanBuild(&irT, &pt, &op->tplan))) goto done;
     op->hasTplan = 1;

@@ -519,11 +519,11 @@ __global__ __launch_bounds__(BF_WAVES_PER_WG * 64) __attribute__((amdgpu_waves_p
 #define BF_T_COLS 16
 // With 4 row lanes a load instruction takes 64 bytes of each column, half a 128-byte line; the other half is asked
 // for by the next block step.  Streamed (non-temporal) lines are not kept for it, so the wide kernel loads its
-// column-major pieces with the default policy (row-major pieces are whole 128-byte lines read once: streamed) (measured on the streamed operand: every transposed stage 10 - 35 % shorter).
+// column-major pieces with the default policy (row-major pieces are whole 128-byte lines read once: streamed) (measured on the streamed operand: every transposed stage 10 - 35 % shorter, DESIGN_EXPERIMENTS.md section 10).
 #ifndef BF_T_WIDE_NT
 #define BF_T_WIDE_NT 0
 #endif
-// Measured on the streamed N = 1M fp32 operand (transposed apply 8.63 ms): two row blocks requested
+// Measured on the streamed N = 1M fp32 operand (transposed apply 8.63 ms, DESIGN_EXPERIMENTS.md section 10): two row blocks requested
 // before the first is used (8 KB per wavefront in flight, 126 VGPRs, still 4 wavefronts per SIMD) -> 8.82 ms; 8 row lanes
 // x 8 loads (BF_T_WIDE_R 8: 155 VGPRs, 3 wavefronts per SIMD) -> 9.65 ms; the same loads at consecutive addresses (wrong
 // results, timing only) -> no change.  Neither bytes in flight nor the 64-byte-per-column pattern bounds this kernel: its

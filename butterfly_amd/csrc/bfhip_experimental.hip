@@ -1,5 +1,5 @@
-// bfhip_experimental.hip -- executors of the complex128 plan that were built, measured and set aside (DESIGN.md section
-// 15).  NOT part of the default library: `make experimental` builds libbfhip_exp.so from the same sources plus this
+// bfhip_experimental.hip -- executors of the complex128 plan that were built, measured and set aside
+// (DESIGN_EXPERIMENTS.md section 15).  NOT part of the default library: `make experimental` builds libbfhip_exp.so from the same sources plus this
 // file and bfhip_persist.hip with -DBFHIP_EXPERIMENTAL; the default libbfhip.so holds no spin-waiting kernel and no
 // environment-switched executor.  Both executors are tested bit-identical to the staged launches
 // (tests/experimental_checks.py, run by the GPU suite against the flagged build).

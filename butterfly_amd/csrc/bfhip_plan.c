@@ -1092,7 +1092,7 @@ int bfPlanBuild(BfIr const *ir, BfPlanOptions const *po, BfPlan *plan) {
           if (rowMajor) {
             /* every row starts on a 128-byte line (rowAlignBytes; +0.3 % arena on the streamed benchmark operand): a
              * 64-column chunk of a row, what a transposed item reads, is then whole lines -- at 16-byte alignment it
-             * touches three lines for two and the transposed stage fetches 1.4x its bytes (PMC) --
+             * touches three lines for two and the transposed stage fetches 1.4x its bytes (PMC, DESIGN_EXPERIMENTS.md section 10) --
              * and the forward kernel's 1 KiB row loads are whole lines too (6.35 -> 6.57 TB/s on the W0 stage) */
             /* (not the narrow pieces of small items: a 47-column row is 188 bytes) */
             uint64_t const al = po->rowAlignBytes > 16 && nc >= 128 ? po->rowAlignBytes / plan->elemSize : plan->epl;

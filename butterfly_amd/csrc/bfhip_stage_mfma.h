@@ -93,8 +93,8 @@ struct BfMfSeg {
 // Complex products by Gauss's three multiplications: with T1 = Ar Xr, T2 = Ai Xi, T3 = (Ar + Ai)(Xr + Xi) summed over
 // the segment, Re = T1 - T2 and Im = T3 - T1 - T2 -- 3 real MFMAs per complex multiply-accumulate instead of 4, paid
 // for with MS + NT v_add_f64 per k-step (the fragment sums) and a third accumulator per tile (24 x 8 = 192 VGPRs: two
-// wavefronts per SIMD still fit).  The kernel is power-bound, not issue-bound (MFMA-busy x clock is
-// constant across every variant of this loop), so a quarter fewer MFMAs is a quarter less time.  Normwise as accurate as
+// wavefronts per SIMD still fit).  The kernel is clock-bound, not issue-bound (the pipe stays 93 % busy and
+// the clock follows the traffic beyond L2 in every variant of this loop), so a quarter fewer MFMAs is a quarter less time.  Normwise as accurate as
 // the four-multiplication form (the imaginary part loses relative accuracy only where it is small next to |A||X|).
 //
 // Registers and requests.  A fragments (streamed from HBM, the long latency) have TWO sets: the A of k-step ks + 1 is
@@ -429,7 +429,7 @@ __device__ __forceinline__ void bfMfmaDispatch(uint32_t nt, StageParams const &p
 // wavefronts per SIMD, which is what the matrix pipe needs at 64 RHS -- but with 2 - 32 RHS the kernel is bound by the leaf
 // stream, not by the pipe, and then it is wavefronts (bytes in flight) that count: the 1- and 2-tile instantiations need
 // a third / half of the registers and run WAVES = 5 / 3 wavefronts per SIMD (N = 262144: 2 - 16 RHS 14.3 - 15.9 -> see
-// DESIGN.md section 4).
+// DESIGN_EXPERIMENTS.md section 4).
 template <int MAXNT, int WAVES, bool DMA, bool GAUSS = true>
 __device__ __forceinline__ void bfStageBodyC128Mfma(StageParams const &p, uint32_t (*tabs)[BF_MF_TABCAP + BF_MF_TABPAD], char *rings) {
   int const lane = threadIdx.x & 63;

@@ -78,7 +78,7 @@ enum {
                                     operators applied to ONE right-hand side run the whole plan as ONE dependency-driven
                                     persistent launch (items wait for the intermediate vectors they read, not for the previous
                                     stage; bit-identical results).  Measured slower than the staged launches on MI355X
-                                    (DESIGN.md section 15).  The product library (libbfhip.so) does not contain that executor
+                                    (DESIGN_EXPERIMENTS.md section 15).  The product library (libbfhip.so) does not contain that executor
                                     and refuses the flag with BF_ERROR_NOT_IMPLEMENTED */
 };
 /* Environment variables.  The product library reads six, all test / diagnosis hooks:

@@ -102,7 +102,7 @@ def test_two_rank_sharded_apply_matches_full_oracle(tmp_path, nrhs, mode, native
         assert y.shape == y_ref.shape
         assert np.linalg.norm(y - y_ref) / np.linalg.norm(y_ref) < 1e-13
     # A^T v against the oracle: the reference cannot transpose this graph (BfMatBlockCoo has no Transpose slot, its complex Rmul
-    # chain is not functional: DESIGN.md section 10), so the oracle's bfMatMul densifies A column block by column block
+    # chain is not functional: DESIGN_EXPERIMENTS.md section 10), so the oracle's bfMatMul densifies A column block by column block
     A_ref = bfref.from_desc(desc, None, seed=11)
     A_dense = np.concatenate([bfref.mat_mul(A_ref, np.eye(n, 256, -c0, dtype=complex)) for c0 in range(0, n, 256)], axis=1)
     z_ref = A_dense.T @ x

@@ -238,7 +238,7 @@ def test_svd_structure_at_65536_x_4096_accepts_the_root_where_the_rank_model_des
     collapses to the root: ONE row node, Psi = a dense 65536 x 10508 block, 7.24 GB -- 3.4x the dense matrix, at the stated
     1e-3 accuracy (3.7e-4).  The rank model's smooth Weyl count never "drops a term" at the root, descends to 12 052 row nodes
     and 0.97 GB.  So the benchmark operand of configs[4] is the structure the streamer's recursion produces when every
-    merge keeps compressing (what the algorithm is designed to do), not what real SVDs give at this ratio (DESIGN.md
+    merge keeps compressing (what the algorithm is designed to do), not what real SVDs give at this ratio (DESIGN_EXPERIMENTS.md
     section 12)."""
     from butterfly_amd import streamer_structure as ss
     from oracle import streamer_values as sv

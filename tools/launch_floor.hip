@@ -1,7 +1,7 @@
 // What a launch costs on top of its bytes: chains of back-to-back launches of a plain streaming kernel (every wavefront reads
 // its own contiguous `itemBytes` with 16-byte non-temporal loads, 8 in flight per lane -- the stage kernels' pattern with
 // nothing else in the way) at the sizes of the short stage kernels.  Fitting t = bytes / BW + c over the sizes gives the cost
-// c of a kernel boundary that no staged executor can avoid.
+// c of a kernel boundary that no staged executor can avoid (DESIGN_EXPERIMENTS.md section 15).
 //   hipcc -O3 --offload-arch=gfx950 tools/launch_floor.hip -o /tmp/launch_floor && /tmp/launch_floor
 #include <hip/hip_runtime.h>
 #include <stdint.h>
