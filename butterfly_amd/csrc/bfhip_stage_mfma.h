@@ -31,10 +31,10 @@
 //   * The loads are asm statements and the waits are placed by hand: hipcc's wait insertion treats every load pending
 //     at a loop header as one lump (s_waitcnt vmcnt(0) at the top: the fragment requested last would be waited for
 //     first).  Loads return in order, so vmcnt(n) = "all but the n youngest have arrived".
-//   * bfMfmaSegment (the kernels of <= 32 right-hand sides, 3 and 5 wavefronts per SIMD): fragments land in registers, two sets
-//     for the leaf stream (requested one k-step ahead), one for the X tiles (requested again right after the MFMAs that read them).
-//   * bfMfmaSegmentDma (the 4-tile kernel, 2 wavefronts per SIMD): fragments land in a two-slot LDS ring per wavefront, two
-//     k-steps ahead of their use (below).
+//   * bfMfmaSegment (all three kernels): fragments land in registers, two sets for the leaf stream (requested one k-step ahead),
+//     one for the X tiles (requested again right after the MFMAs that read them).
+//   * bfMfmaSegmentDma (A/B builds only, BF_MF_DMA = 1): fragments land in a two-slot LDS ring per wavefront, two k-steps ahead of
+//     their use -- built and measured in round 5, bit-identical, 2 - 4 % slower (below).
 #ifndef BFHIP_STAGE_MFMA_H
 #define BFHIP_STAGE_MFMA_H
 
@@ -53,6 +53,9 @@
 #ifndef BF_MFMA_MIN_RHS
 #define BF_MFMA_MIN_RHS 2
 #endif
+// (Round 5, measured and removed: with BF_MF_WG_WAVES = 2 / 4 / 8 an s_barrier every pair of k-steps, so that list neighbours -- which
+// walk the same X rows -- pace each other and their X requests reach the L2 together: 31.38 / 31.67 / 34.07 ms against 30.91 with
+// one-wavefront workgroups; 4 wavefronts without the barrier 31.51.  DESIGN.md section 9.)
 
 typedef double bf_d4 __attribute__((ext_vector_type(4)));
 typedef int bf_i4 __attribute__((ext_vector_type(4)));

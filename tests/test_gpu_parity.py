@@ -1098,10 +1098,10 @@ def test_long_contractions_on_gpu(dtype, demote):
 
 
 @pytest.mark.parametrize("demote", [False, True])
-@pytest.mark.parametrize("nrhs", [1, 3])
+@pytest.mark.parametrize("nrhs", [1, 3, 40])
 def test_few_row_leaves_on_gpu(demote, nrhs):
     """Row-major few-row leaves (the pass-through W blocks of a streamed butterfly) through the real stage kernel and the
-    transposed kernel, mixed with column-major leaves and Identity terms in the same groups; f64 and f32, 1 and 3 RHS."""
+    transposed kernel, mixed with column-major leaves and Identity terms in the same groups; f64 and f32, 1, 3 and 40 RHS."""
     import randgraph
     from butterfly_amd import _capi
     from butterfly_amd.operator import HipOperator

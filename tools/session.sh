@@ -179,6 +179,19 @@ pmcloop()    { step loop_probe 300 tools/mfma_loop_probe.bin 600; cat $O/loop_pr
                  PMC_QUICK_PER_DISPATCH=1 PMC_QUICK_FILTER=probeLoop python3 $R/tools/pmc_quick.py $O/pmc_loop
                  timeout -k 10 400 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_loop2 -- $R/tools/mfma_loop_probe.bin 400 > $O/pmc_loop2.out 2> $O/pmc_loop2.log; echo "pmc_loop2 exit=$?"
                  find $O/pmc_loop $O/pmc_loop2 -name "*.csv" -size +4M -delete ) }
+sharedx()    { step sharedx_probe 300 tools/mfma_sharedx_probe.bin 600; cat $O/sharedx_probe.out
+               ( cd /tmp && export TMPDIR=/tmp && timeout -k 10 400 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_sx -- $R/tools/mfma_sharedx_probe.bin 400 > $O/pmc_sx.out 2> $O/pmc_sx.log; echo "pmc_sx exit=$?"
+                 PMC_QUICK_PER_DISPATCH=1 PMC_QUICK_FILTER=probe python3 $R/tools/pmc_quick.py $O/pmc_sx
+                 timeout -k 10 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_sx_fetch -- $R/tools/mfma_sharedx_probe.bin 400 > $O/pmc_sx_fetch.out 2> $O/pmc_sx_fetch.log; echo "pmc_sx_fetch exit=$?"
+                 python3 - <<PY
+import csv, glob, collections
+cc = sorted(glob.glob("$O/pmc_sx_fetch/*/*_counter_collection.csv"))[-1]
+per = collections.defaultdict(float); nm = {}
+for r in csv.DictReader(open(cc)):
+    if r["Counter_Name"] == "FETCH_SIZE": per[r["Dispatch_Id"]] += float(r["Counter_Value"]); nm[r["Dispatch_Id"]] = r["Kernel_Name"][:30]
+for d in sorted(per, key=int): print("dispatch", d, nm[d], "fetch GB %.2f" % (per[d] * 1024 * 2 / 1e9))
+PY
+                 find $O/pmc_sx $O/pmc_sx_fetch -name "*.csv" -size +4M -delete ) }
 r5tests()    { step pytest_r5 1100 python -m pytest tests/test_gpu_config4.py tests/test_gpu_config4_rowsum.py tests/test_bench_gpu.py tests/test_gpu_sharded_adjoint.py -m gpu -x -q; tail -6 $O/pytest_r5.out; }
 pcie()       { step pcie_head 400 $B --steps 20 --warmup 3 --pcie --no-cpu-baseline --no-extra
                python -c "import json; d = json.load(open('$O/pcie_head.out')); print('headline', d['ms_per_step'], d['pcie_inclusive'])"
