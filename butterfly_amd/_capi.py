@@ -70,7 +70,8 @@ class BfhipPlanInfo(C.Structure):
 
 class BfhipStageView(C.Structure):
     _fields_ = [("structSize", C.c_uint32), ("reserved", C.c_uint32), ("numItems", C.c_uint64),
-                ("numPieces", C.c_uint64), ("numReduce", C.c_uint64), ("items", C.c_void_p), ("pieces", C.c_void_p)]
+                ("numPieces", C.c_uint64), ("numReduce", C.c_uint64), ("items", C.c_void_p), ("pieces", C.c_void_p),
+                ("numBundles", C.c_uint64), ("bundleBegin", C.c_void_p)]
 
 
 class BfhipReduceView(C.Structure):

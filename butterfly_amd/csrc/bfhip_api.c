@@ -12,6 +12,7 @@
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stddef.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -96,6 +97,7 @@ static void freeDevicePlanOf(BfPlan *plan) {
     BfStage *st = &plan->stages[s];
     bfdevFree(st->dItems); st->dItems = NULL;
     bfdevFree(st->dPieces); st->dPieces = NULL;
+    bfdevFree(st->dBundleBegin); st->dBundleBegin = NULL;
     bfdevFree(st->dTickets); st->dTickets = NULL;
     for (uint64_t r = 0; r < st->numReduce; ++r) {
       bfdevFree(st->reduce[r].dRowInterval); bfdevFree(st->reduce[r].dIvBegin); bfdevFree(st->reduce[r].dSrcBias);
@@ -288,6 +290,7 @@ static int uploadPlanMeta(BfhipOperator *op, BfPlan *plan) {
     BfStage *st = &plan->stages[s];
     rc = uploadArray(&st->dItems, st->items, st->numItems * sizeof(BfDevItem), &op->metaBytes);
     if (!rc) rc = uploadArray(&st->dPieces, st->pieces, st->numPieces * sizeof(BfDevPiece), &op->metaBytes);
+    if (!rc && st->bundleBegin) rc = uploadArray(&st->dBundleBegin, st->bundleBegin, (st->numBundles + 1) * 4, &op->metaBytes);      /* forward complex128 */
     for (uint64_t r = 0; r < st->numReduce && !rc; ++r) {
       BfReduce *rd = &st->reduce[r];
       rc = uploadArray(&rd->dRowInterval, rd->rowInterval, rd->numRows * 4, &op->metaBytes);
@@ -304,6 +307,7 @@ static void dropPlanMirrors(BfPlan *plan) {
     free(st->pieceSrc); st->pieceSrc = NULL;
     free(st->pieces); st->pieces = NULL;
     free(st->items); st->items = NULL;
+    free(st->bundleBegin); st->bundleBegin = NULL;
     free(st->pieceBuf); st->pieceBuf = NULL;
     free(st->itemBuf); st->itemBuf = NULL;
     for (uint64_t r = 0; r < st->numReduce; ++r) {
@@ -781,6 +785,7 @@ static int runPlan(BfhipOperator *op, BfPlan *plan, void const *dX, size_t nrhs,
     a.transposed = plan->transposed;
     a.tickets = NULL;
     a.exactComplex = (op->flags & BFHIP_FLAG_EXACT_COMPLEX) != 0; a.pad2 = 0;
+    a.bundles = st->dBundleBegin; a.numBundles = st->numBundles;
     if (plan->dtype == BFHIP_C128 && !plan->transposed && nrhs < 2) a.tickets = st->dTickets;      /* NULL unless this is an EXPERIMENTAL build run with BFHIP_PERSISTENT=1 (allocated at compile time) */
     if (prof && (rc = bfdevEventRecord(op->evStart[evBase + s], stream))) goto out;
     if ((rc = bfdevLaunchStage(&a, stream))) goto out;
@@ -1062,10 +1067,11 @@ int bfhipPlanGetStage(BfhipOperator const *op, uint64_t stage, BfhipStageView *v
   if (rc) return rc;
   BfPlan const *pl = &op->plan;
   if (stage >= pl->numStages && op->hasTplan) { stage -= pl->numStages; pl = &op->tplan; }
-  if (!v || v->structSize < sizeof *v || stage >= pl->numStages) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "bad stage view request");
+  if (!v || v->structSize < offsetof(BfhipStageView, numBundles) || stage >= pl->numStages) return bfhipFail(BFABI_ERROR_INVALID_ARGUMENTS, "bad stage view request");
   BfStage const *st = &pl->stages[stage];
   v->numItems = st->numItems; v->numPieces = st->numPieces; v->numReduce = st->numReduce;
   v->items = st->items; v->pieces = st->pieces;
+  if (v->structSize >= sizeof *v) { v->numBundles = st->numBundles; v->bundleBegin = st->bundleBegin; }
   return 0;
 }
 int bfhipPlanGetReduce(BfhipOperator const *op, uint64_t stage, uint64_t index, BfhipReduceView *v) {
@@ -1310,6 +1316,12 @@ static int loadPlan(FILE *fp, BfhipOperator *op, BfPlan *pl, FileHeader const *f
         }
         st->numCoopNarrow = bfPlanCountCoop(hItems, hPieces, st->numNarrow, pl->elemSize);
         st->numCoop = bfPlanCountCoop((BfDevItem const *)hItems + st->numNarrow, hPieces, st->numItems - st->numNarrow, pl->elemSize);
+      }
+      if (!rc && pl->dtype == BFHIP_C128 && !pl->transposed && st->numItems) {
+        uint32_t *bb = NULL;
+        rc = bfPlanBundles(hItems, hPieces, st->numItems, &bb, &st->numBundles);
+        if (!rc) rc = uploadArray(&st->dBundleBegin, bb, (st->numBundles + 1) * 4, &op->metaBytes);
+        free(bb);
       }
     }
     free(hItems); free(hPieces);

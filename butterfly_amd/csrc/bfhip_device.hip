@@ -1174,7 +1174,8 @@ int bfdevLaunchStage(BfLaunchArgs const *a, void *stream) {
   p.numItems = (uint32_t)a->numItems;
   p.nrhs = a->nrhs;
   p.coopItems = 0;
-  p.pad = 0;
+  p.numBundles = (uint32_t)a->numBundles;
+  p.bundles = (uint32_t const *)a->bundles;
   p.x = a->x;
   p.y = a->y;
   p.temp = a->temp;
@@ -1232,14 +1233,17 @@ int bfdevLaunchStage(BfLaunchArgs const *a, void *stream) {
   }
   if (a->dtype == BFHIP_C128 && a->nrhs >= BF_MFMA_MIN_RHS) {
     dim3 const g((uint32_t)((a->numItems + BF_MF_WG_WAVES - 1) / BF_MF_WG_WAVES)), b(64 * BF_MF_WG_WAVES);
+    /* more than 32 right-hand sides: one workgroup of four wavefronts per BUNDLE of items that read the same X rows */
+    if (a->nrhs > 32 && BF_MF_BUNDLES && (!a->bundles || !a->numBundles)) return bfhipFail(BFABI_ERROR_RUNTIME_ERROR, "internal: a forward complex128 stage without its bundle table");
+    dim3 const gB(BF_MF_BUNDLES ? (uint32_t)a->numBundles : g.x), bB(BF_MF_BUNDLES ? 256u : b.x);
     if (a->exactComplex) {                                                                   /* BFHIP_FLAG_EXACT_COMPLEX: four real products per complex one */
       if (a->nrhs <= 16) hipLaunchKernelGGL(bfStageKernelC128Mfma1Exact, g, b, 0, s, p);
       else if (a->nrhs <= 32) hipLaunchKernelGGL(bfStageKernelC128Mfma2Exact, g, b, 0, s, p);
-      else hipLaunchKernelGGL(bfStageKernelC128MfmaExact, g, b, 0, s, p);
+      else hipLaunchKernelGGL(bfStageKernelC128MfmaExact, gB, bB, 0, s, p);
     }
     else if (a->nrhs <= 16) hipLaunchKernelGGL(bfStageKernelC128Mfma1, g, b, 0, s, p);       /* one RHS tile: 5 wavefronts per SIMD */
     else if (a->nrhs <= 32) hipLaunchKernelGGL(bfStageKernelC128Mfma2, g, b, 0, s, p);       /* two: 3 */
-    else hipLaunchKernelGGL(bfStageKernelC128Mfma, g, b, 0, s, p);                           /* up to four per pass: 2 */
+    else hipLaunchKernelGGL(bfStageKernelC128Mfma, gB, bB, 0, s, p);                         /* up to four per pass: 2 */
   }
   else if (a->dtype == BFHIP_C128) {
     grid = (uint32_t)((a->numItems + BF_C128_WG_WAVES - 1) / BF_C128_WG_WAVES);

@@ -139,8 +139,12 @@ typedef struct BfStage {
    * planner: 0 = x (pieces) or "nothing a later item waits for" (items: y, private slots), >= 2 an intermediate */
   uint32_t *pieceBuf;        /* [numPieces] */
   uint32_t *itemBuf;         /* [numItems] */
+  /* forward complex128 plans: bundles of list neighbours that read the same input rows (bfPlanBundles) -- one workgroup of the
+   * 64-RHS matrix-core kernel each.  bundleBegin[numBundles + 1]; the host copy is dropped with the other mirrors */
+  uint32_t *bundleBegin;
+  uint64_t numBundles;
   /* device copies */
-  void *dItems, *dPieces;
+  void *dItems, *dPieces, *dBundleBegin;
   /* persistent launches of a stage with more items than wavefront slots (bfStageKernelC128P): BF_TICKET_POOLS ticket
    * counters, zero between launches (the wavefront that draws a pool's last ticket of a launch puts it back to zero) */
   void *dTickets;
@@ -193,6 +197,11 @@ typedef struct BfPlanOptions {
 } BfPlanOptions;
 
 int bfPlanBuild(BfIr const *ir, BfPlanOptions const *po, BfPlan *plan);
+#ifndef BF_BUNDLE_ITEMS
+#define BF_BUNDLE_ITEMS 4u      /* wavefronts of the 64-RHS kernel's workgroup (A/B builds: 1 = no bundles) */
+#endif
+#define BF_BUNDLE_MIXED 0x80000000u   /* bundleBegin[] bit: four unrelated items (one-wavefront passes), not one shared X panel */
+int bfPlanBundles(BfDevItem const *items, BfDevPiece const *pieces, uint64_t numItems, uint32_t **out, uint64_t *numBundles);
 /* balanced contiguous row ranges for `world` ranks: cuts[world + 1], loads[world] (leaf elements each range keeps) or NULL */
 int bfPlanRowPartition(BfIr const *ir, uint32_t world, uint64_t *cuts, uint64_t *loads);
 /* table of the forward plan's pieces (needs its host mirrors); caller frees */
@@ -278,6 +287,8 @@ typedef struct BfLaunchArgs {
   void *tickets;         /* NULL, or BF_TICKET_POOLS x BF_TICKET_STRIDE uint32 owned by this stage, zero between launches (see BfStage.dTickets) */
   uint32_t exactComplex; /* BFHIP_FLAG_EXACT_COMPLEX: the matrix-core kernels form complex products with four real multiplications */
   uint32_t pad2;
+  void const *bundles;   /* forward complex128: BfStage.dBundleBegin (NULL: none) */
+  uint64_t numBundles;
 } BfLaunchArgs;
 #define BF_TICKET_POOLS 64u
 #define BF_TICKET_STRIDE 64u      /* uint32 between two pools' counters: a 256-byte block each -- counters that share a cache line share its atomic unit (measured: 64 packed counters behaved like one) */

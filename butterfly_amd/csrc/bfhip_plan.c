@@ -541,6 +541,8 @@ typedef struct ItemTmp {
   uint64_t group;
   uint32_t rowBegin, rows;       /* chunk inside the group */
   uint32_t small, narrow;        /* small: runs four to a wavefront, sorted behind everything else; narrow: 16-column transposed item, sorted first */
+  uint64_t sig;                  /* RHS-block operators: hash of what the item's group reads (bundles, below) */
+  uint64_t bundle;               /* its bundle's place in the list */
 } ItemTmp;
 
 static int cmpItemCost(void const *pa, void const *pb) {
@@ -553,17 +555,99 @@ static int cmpItemCost(void const *pa, void const *pb) {
   if (a->group != b->group) return a->group < b->group ? -1 : 1;
   return a->rowBegin < b->rowBegin ? -1 : (a->rowBegin > b->rowBegin);
 }
+/* RHS-block operators (complex128): items that read exactly the same input rows -- the row chunks of a group and the sibling groups
+ * of a radix-4 stage (src/fac_helm2.c:277-318) -- are brought together (cmpItemSig), cut into runs of up to BF_BUNDLE_ITEMS, and the
+ * list is ordered run by run (cmpItemBundle), big first by cost bucket: list neighbours run side by side on one XCD (the 64-RHS
+ * kernel's workgroup mapping) and walk the same X panel at the same time, so that a row of it is fetched into that L2 once.  Round 4
+ * ordered by the FIRST input only: groups that share their first block but not the others sat in between.  Same box, N = 262144, 64
+ * RHS: 30.3 - 30.6 ms against 30.8 - 31.0.  (The runs are also what the A/B kernel of bfhip_stage_mfma.h, BF_MF_BUNDLES, takes as
+ * workgroups.) */
+static int cmpItemSig(void const *pa, void const *pb) {
+  ItemTmp const *a = pa, *b = pb;
+  if (a->sig != b->sig) return a->sig < b->sig ? -1 : 1;
+  if (a->cost != b->cost) return a->cost > b->cost ? -1 : 1;
+  if (a->group != b->group) return a->group < b->group ? -1 : 1;
+  return a->rowBegin < b->rowBegin ? -1 : (a->rowBegin > b->rowBegin);
+}
+static int cmpItemBundle(void const *pa, void const *pb) {
+  ItemTmp const *a = pa, *b = pb;
+  if (a->bundle != b->bundle) return a->bundle < b->bundle ? -1 : 1;
+  if (a->bundle == UINT64_MAX) return cmpItemCost(pa, pb);      /* the items that found no full bundle: big first, by input inside a cost bucket */
+  if (a->cost != b->cost) return a->cost > b->cost ? -1 : 1;
+  if (a->group != b->group) return a->group < b->group ? -1 : 1;
+  return a->rowBegin < b->rowBegin ? -1 : (a->rowBegin > b->rowBegin);
+}
+typedef struct BundleTmp { uint64_t sortCost, inKey, cost, first; } BundleTmp;
+static int cmpBundle(void const *pa, void const *pb) {
+  BundleTmp const *a = pa, *b = pb;
+  if (a->sortCost != b->sortCost) return a->sortCost > b->sortCost ? -1 : 1;      /* big first, by cost bucket */
+  if (a->inKey != b->inKey) return a->inKey < b->inKey ? -1 : 1;                  /* neighbours read neighbouring input */
+  if (a->cost != b->cost) return a->cost > b->cost ? -1 : 1;
+  return a->first < b->first ? -1 : (a->first > b->first);
+}
+static uint64_t costBucket(uint64_t c) {      /* quarter octaves */
+  if (!c) c = 1;
+  uint32_t const pbit = 63u - (uint32_t)__builtin_clzll(c);
+  return (uint64_t)pbit * 4u + (pbit >= 2 ? (c >> (pbit - 2)) & 3u : 0u);
+}
+static int sameInputs(Task const *tasks, BfIr const *ir, uint64_t aBegin, uint64_t aEnd, uint64_t bBegin, uint64_t bEnd) {
+  if (aEnd - aBegin != bEnd - bBegin) return 0;
+  for (uint64_t i = 0; i < aEnd - aBegin; ++i) {
+    Task const *a = &tasks[aBegin + i], *b = &tasks[bBegin + i];
+    if (a->inBuf != b->inBuf || a->inOff != b->inOff || a->cols != b->cols ||
+        (ir->kind[a->leaf] == BFHIP_NODE_IDENTITY) != (ir->kind[b->leaf] == BFHIP_NODE_IDENTITY)) return 0;
+  }
+  return 1;
+}
+
 static int cmpU64(void const *pa, void const *pb) {
   uint64_t a = *(uint64_t const *)pa, b = *(uint64_t const *)pb;
   return a < b ? -1 : a > b;
 }
 static uint64_t roundUp(uint64_t v, uint64_t m) { return (v + m - 1) / m * m; }
 
+/* Bundles of a forward complex128 stage, from its final item list: the workgroups of the 64-RHS matrix-core kernel, up to
+ * BF_BUNDLE_ITEMS list neighbours each (bundleBegin[numBundles + 1]: first item, bit 31 = BF_BUNDLE_MIXED; the last entry = numItems).
+ *   shared:  exactly BF_BUNDLE_ITEMS items of <= 32 rows and the same number of 16-row slabs whose pieces read the same input rows in
+ *            the same order -- the wavefronts fetch every X tile once for all of them;
+ *   mixed:   any other neighbours (taller items, zero fills, different inputs): four unrelated one-wavefront passes.
+ * Derived from (items, pieces) alone, so that a loaded plan and a row shard get theirs the same way. */
+static int sameBundleInputs(BfDevItem const *a, BfDevItem const *c, BfDevPiece const *pieces) {
+  if (!a->numPieces || c->numPieces != a->numPieces || (a->mrFlags & 0xffffu) > 32u || (c->mrFlags & 0xffffu) > 32u ||
+      ((c->mrFlags & 0xffffu) > 16u) != ((a->mrFlags & 0xffffu) > 16u)) return 0;
+  for (uint32_t k = 0; k < a->numPieces; ++k) {
+    BfDevPiece const *pa = &pieces[a->pieceBegin + k], *pc = &pieces[c->pieceBegin + k];
+    if (pa->inOff != pc->inOff || pa->ncols != pc->ncols || ((pa->flags ^ pc->flags) & (BF_PIECE_IN_X | BF_PIECE_IDENTITY))) return 0;
+  }
+  return 1;
+}
+static int startsSharedBundle(BfDevItem const *items, BfDevPiece const *pieces, uint64_t numItems, uint64_t i) {
+  if (BF_BUNDLE_ITEMS < 2 || i + BF_BUNDLE_ITEMS > numItems) return 0;
+  for (uint64_t j = i + 1; j < i + BF_BUNDLE_ITEMS; ++j) if (!sameBundleInputs(&items[i], &items[j], pieces)) return 0;
+  return 1;
+}
+int bfPlanBundles(BfDevItem const *items, BfDevPiece const *pieces, uint64_t numItems, uint32_t **out, uint64_t *numBundles) {
+  if (numItems >= BF_BUNDLE_MIXED) return bfhipFail(BFABI_ERROR_RUNTIME_ERROR, "stage too large for the bundle table");
+  uint32_t *bb = malloc((numItems + 1) * 4);
+  if (!bb) return bfhipFail(BFABI_ERROR_MEMORY_ERROR, "host OOM (bundles)");
+  uint64_t nb = 0;
+  for (uint64_t i = 0; i < numItems;) {
+    if (startsSharedBundle(items, pieces, numItems, i)) { bb[nb++] = (uint32_t)i; i += BF_BUNDLE_ITEMS; continue; }
+    uint64_t j = i + 1;
+    while (j < numItems && j - i < BF_BUNDLE_ITEMS && !startsSharedBundle(items, pieces, numItems, j)) ++j;      /* never into a shared bundle */
+    bb[nb++] = (uint32_t)i | BF_BUNDLE_MIXED;
+    i = j;
+  }
+  bb[nb] = (uint32_t)numItems;
+  *out = bb; *numBundles = nb;
+  return 0;
+}
+
 void bfPlanFree(BfPlan *plan) {
   if (!plan) return;
   for (uint64_t s = 0; s < plan->numStages && plan->stages; ++s) {
     BfStage *st = &plan->stages[s];
-    free(st->items); free(st->pieces); free(st->pieceSrc); free(st->pieceBuf); free(st->itemBuf);
+    free(st->items); free(st->pieces); free(st->pieceSrc); free(st->pieceBuf); free(st->itemBuf); free(st->bundleBegin);
     for (uint64_t r = 0; r < st->numReduce; ++r) {
       free(st->reduce[r].rowInterval); free(st->reduce[r].ivBegin); free(st->reduce[r].srcBias);
     }
@@ -924,6 +1008,10 @@ int bfPlanBuild(BfIr const *ir, BfPlanOptions const *po, BfPlan *plan) {
      * granularity keeps the MFMA kernel's slabs full; a short remainder still
      * fills the GEMV kernel's lanes through column groups. */
     uint64_t numItems = 0;
+#ifndef BF_PLAN_BUNDLE_ORDER
+#define BF_PLAN_BUNDLE_ORDER 1     /* 1 = runs of equal inputs kept together (product); A/B builds: 0 = items by cost bucket and first input (round 4), 2 = full bundles first, leftovers after (for -DBF_MF_BUNDLES=1 kernels) */
+#endif
+    int const bundled = BF_PLAN_BUNDLE_ORDER && po->groupByInput && !T && plan->dtype == BFHIP_C128;
     for (uint64_t g = 0; g < numGroups; ++g) {
       Group *gr = &groups[g];
       gr->colsSum = 0; gr->piecesPerChunk = 0;
@@ -934,6 +1022,7 @@ int bfPlanBuild(BfIr const *ir, BfPlanOptions const *po, BfPlan *plan) {
         else { gr->piecesPerChunk += (tk->cols + plan->xcap - 1) / plan->xcap; gr->colsSum += tk->cols; }
       }
       uint64_t chunk = gr->cls ? 16 : itemRows;
+      if (bundled && chunk > 32) chunk = 32;        /* one two-slab pass per item: the wavefronts of a bundle run the same number of k-steps */
       if (!T && gr->colsSum) {
         uint64_t const floorRows = (po->minChunkRows ? po->minChunkRows : 16) * plan->epl;
         uint64_t const gran = floorRows < 16 * plan->epl ? floorRows : 16 * plan->epl;
@@ -962,16 +1051,24 @@ int bfPlanBuild(BfIr const *ir, BfPlanOptions const *po, BfPlan *plan) {
         tmp[ni].cost = rows * colsSum;
         tmp[ni].sortCost = tmp[ni].cost;
         tmp[ni].inKey = 0;
+        tmp[ni].sig = 0; tmp[ni].bundle = 0;
         if (po->groupByInput && !T) {
           /* Items that read the same input rows -- the row chunks of a group, and the sibling groups of a radix-4
            * butterfly stage, which read the same column blocks (src/fac_helm2.c:277-318) -- become list neighbours, so
            * that the RHS-block kernel runs them side by side on one XCD and their X panel is fetched into ONE L2 once:
            * the list is big-first by cost BUCKET (quarter octaves), by input inside a bucket. */
-          uint64_t c = tmp[ni].cost ? tmp[ni].cost : 1;
-          uint32_t pbit = 63u - (uint32_t)__builtin_clzll(c);
-          tmp[ni].sortCost = (uint64_t)pbit * 4u + (pbit >= 2 ? (c >> (pbit - 2)) & 3u : 0u);
+          tmp[ni].sortCost = costBucket(tmp[ni].cost);
           Task const *t0 = &b.tasks[groups[g].taskBegin];
           tmp[ni].inKey = ((uint64_t)t0->inBuf << 40) | (t0->inOff & 0xffffffffffull);
+          if (bundled) {
+            uint64_t h = 1469598103934665603ull;
+            for (uint64_t t = groups[g].taskBegin; t < groups[g].taskEnd; ++t) {
+              Task const *tk = &b.tasks[t];
+              uint64_t const w[3] = { ((uint64_t)tk->inBuf << 1) | (ir->kind[tk->leaf] == BFHIP_NODE_IDENTITY), tk->inOff, tk->cols };
+              for (int q = 0; q < 3; ++q) { h ^= w[q]; h *= 1099511628211ull; h ^= h >> 29; }
+            }
+            tmp[ni].sig = h;
+          }
         }
         /* colsSum < 128 also means "not row-major" */
         tmp[ni].small = !T && plan->dtype != BFHIP_C128 && rows <= 2 * plan->epl && colsSum < BF_SMALL_COLS && piecesPerChunk <= BF_SMALL_PIECES;
@@ -981,6 +1078,36 @@ int bfPlanBuild(BfIr const *ir, BfPlanOptions const *po, BfPlan *plan) {
       }
     }
     numItems = ni;
+    if (bundled && numItems) {
+      /* same inputs together, big first inside a run; runs are cut into bundles; bundles are ordered like items were */
+      qsort(tmp, numItems, sizeof(ItemTmp), cmpItemSig);
+      BundleTmp *bt = malloc(numItems * sizeof(BundleTmp));
+      if (!bt) { free(tmp); rc = bfhipFail(BFABI_ERROR_MEMORY_ERROR, "host OOM"); goto stage_fail; }
+      /* a bundle is FULL: BF_BUNDLE_ITEMS items with the same inputs and the same number of 16-row slabs (its wavefronts meet at a
+       * barrier every k-step).  What is left over -- runs shorter than that -- follows the full bundles, ordered as the items of an
+       * unbundled list are: the kernel runs them four unrelated items to a workgroup. */
+      uint64_t nb = 0;
+      for (uint64_t i = 0; i < numItems;) {
+        Group const *g0 = &groups[tmp[i].group];
+        uint64_t j = i + 1;
+        while (j < numItems && j - i < BF_BUNDLE_ITEMS && tmp[j].sig == tmp[i].sig && g0->colsSum && (tmp[j].rows > 16) == (tmp[i].rows > 16) &&
+               (tmp[j].group == tmp[i].group || sameInputs(b.tasks, ir, g0->taskBegin, g0->taskEnd, groups[tmp[j].group].taskBegin, groups[tmp[j].group].taskEnd))) ++j;
+        if ((j - i == BF_BUNDLE_ITEMS && BF_BUNDLE_ITEMS > 1) || BF_PLAN_BUNDLE_ORDER == 1) {
+          bt[nb].cost = tmp[i].cost; bt[nb].sortCost = costBucket(tmp[i].cost); bt[nb].inKey = tmp[i].inKey; bt[nb].first = i;
+          for (uint64_t k = i; k < j; ++k) tmp[k].bundle = nb;
+          ++nb;
+        } else
+          for (uint64_t k = i; k < j; ++k) tmp[k].bundle = UINT64_MAX;
+        i = j;
+      }
+      qsort(bt, nb, sizeof(BundleTmp), cmpBundle);
+      uint64_t *place = malloc((nb ? nb : 1) * 8);
+      if (!place) { free(bt); free(tmp); rc = bfhipFail(BFABI_ERROR_MEMORY_ERROR, "host OOM"); goto stage_fail; }
+      for (uint64_t k = 0; k < nb; ++k) place[tmp[bt[k].first].bundle] = k;
+      for (uint64_t i = 0; i < numItems; ++i) if (tmp[i].bundle != UINT64_MAX) tmp[i].bundle = place[tmp[i].bundle];
+      free(place); free(bt);
+      qsort(tmp, numItems, sizeof(ItemTmp), cmpItemBundle);
+    } else
     qsort(tmp, numItems, sizeof(ItemTmp), cmpItemCost);
     uint64_t totalItems = numItems + numZeroItems;
     if (totalItems >= 0xffffffffu || numPieces >= 0xffffffffu) { free(tmp); rc = bfhipFail(BFABI_ERROR_RUNTIME_ERROR, "stage too large for 32-bit indices"); goto stage_fail; }
@@ -1134,6 +1261,7 @@ int bfPlanBuild(BfIr const *ir, BfPlanOptions const *po, BfPlan *plan) {
     }
     st->numItems = totalItems;
     st->numPieces = np;
+    if (!T && plan->dtype == BFHIP_C128 && totalItems && (rc = bfPlanBundles(st->items, st->pieces, totalItems, &st->bundleBegin, &st->numBundles))) { free(tmp); goto stage_fail; }
     st->numCoopNarrow = T ? bfPlanCountCoop(st->items, st->pieces, st->numNarrow, plan->elemSize) : 0;
     st->numCoop = T ? bfPlanCountCoop(st->items + st->numNarrow, st->pieces, numItems - st->numNarrow, plan->elemSize) : 0;
     /* algorithmic counts */

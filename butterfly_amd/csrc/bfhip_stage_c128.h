@@ -15,11 +15,12 @@ struct StageParams {
   uint32_t numItems;
   uint32_t nrhs;
   uint32_t coopItems;    // transposed: items [0, coopItems) get a workgroup each, its 4 wavefronts share the pieces
-  uint32_t pad;
+  uint32_t numBundles;   // forward complex128, 64-RHS kernel: workgroups (bundles[numBundles + 1] = first item of each, then numItems)
   void const *x;
   void *y;
   void *temp;
   void const *zero;   // >= 1 KiB of zeros (X fragments of out-of-range columns)
+  uint32_t const *bundles;
 };
 
 // Leaf data is read exactly once per apply: stream it with the non-temporal

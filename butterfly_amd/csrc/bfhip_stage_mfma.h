@@ -315,6 +315,43 @@ __device__ __forceinline__ void bfMfmaSegmentDma(bf_d4 (&acc)[3][2][4], BfMfSeg 
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
+// The pass's rows x right-hand sides out of the accumulators (Gauss: Re = T1 - T2, Im = T3 - T1 - T2) into y / the intermediate.
+template <int NT, int MS, bool GAUSS>
+__device__ __forceinline__ void bfMfmaStore(StageParams const &p, BfDevItem const &it, uint32_t mr, uint32_t s0, uint32_t q0, bf_d4 (&acc)[3][2][4], bool hasIdentity, int lane) {
+  uint32_t const nrhs = p.nrhs, np = it.numPieces;
+  double2 *out = (it.mrFlags & BF_ITEM_OUT_Y) ? (double2 *)p.y : (double2 *)p.temp;
+  uint32_t const qmax = nrhs - 1 - q0;
+  // (the lane's coordinates are derived again from an opaque copy: hipcc otherwise computes the store addresses
+  // before the k-loop and carries them through it, which costs the third wavefront per SIMD)
+  uint32_t lane2 = (uint32_t)lane;
+  asm volatile("" : "+v"(lane2));
+  uint32_t const li2 = lane2 & 15u, lk2 = lane2 >> 4;
+#pragma unroll
+  for (int m = 0; m < MS; ++m)
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        uint32_t const row = s0 + 16u * m + 4 * v + lk2;
+        if (row < mr && 16u * t + li2 <= qmax) {
+          double re = GAUSS ? acc[0][m][t][v] - acc[1][m][t][v] : acc[0][m][t][v];
+          double im = GAUSS ? acc[2][m][t][v] - acc[0][m][t][v] - acc[1][m][t][v] : acc[1][m][t][v];
+          if (hasIdentity) {      // rare (real-operand zoo; complex operands have none)
+            for (uint32_t k = 0; k < np; ++k) {
+              BfDevPiece const pc = p.pieces[it.pieceBegin + k];
+              if (!(pc.flags & BF_PIECE_IDENTITY)) continue;
+              double2 const *xin = (pc.flags & BF_PIECE_IN_X) ? (double2 const *)p.x : (double2 const *)p.temp;
+              double2 xv = xin[((uint64_t)pc.inOff + row) * nrhs + q0 + 16 * t + li2];
+              re += xv.x; im += xv.y;
+            }
+          }
+          out[((uint64_t)it.outOff + row) * nrhs + q0 + 16 * t + li2] = make_double2(re, im);
+        }
+      }
+  // stores and fragment requests share vmcnt: nothing of this pass may be pending when the next one counts
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 // One pass = rows [s0, s0 + 16 MS) x RHS [q0, q0 + 16 NT) of one item, over all its segments.
 // (DMA: the k-loop with its fragments prefetched through the wavefront's LDS ring -- the 4-tile kernel; `ring` = its LDS byte address)
 template <int NT, int MS, bool DMA, bool GAUSS>
@@ -387,37 +424,7 @@ __device__ __forceinline__ void bfMfmaPass(StageParams const &p, BfDevItem const
     else bfMfmaSegment<NT, MS, GAUSS>(acc, sg, tab, lk);
     waveSync();                                      // the table is rewritten by the next segment
   }
-  double2 *out = (it.mrFlags & BF_ITEM_OUT_Y) ? (double2 *)p.y : (double2 *)p.temp;
-  uint32_t const qmax = nrhs - 1 - q0;
-  // (the lane's coordinates are derived again from an opaque copy: hipcc otherwise computes the store addresses
-  // before the k-loop and carries them through it, which costs the third wavefront per SIMD)
-  uint32_t lane2 = (uint32_t)lane;
-  asm volatile("" : "+v"(lane2));
-  uint32_t const li2 = lane2 & 15u, lk2 = lane2 >> 4;
-#pragma unroll
-  for (int m = 0; m < MS; ++m)
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-      for (int v = 0; v < 4; ++v) {
-        uint32_t const row = s0 + 16u * m + 4 * v + lk2;
-        if (row < mr && 16u * t + li2 <= qmax) {
-          double re = GAUSS ? acc[0][m][t][v] - acc[1][m][t][v] : acc[0][m][t][v];
-          double im = GAUSS ? acc[2][m][t][v] - acc[0][m][t][v] - acc[1][m][t][v] : acc[1][m][t][v];
-          if (hasIdentity) {      // rare (real-operand zoo; complex operands have none)
-            for (uint32_t k = 0; k < np; ++k) {
-              BfDevPiece const pc = p.pieces[it.pieceBegin + k];
-              if (!(pc.flags & BF_PIECE_IDENTITY)) continue;
-              double2 const *xin = (pc.flags & BF_PIECE_IN_X) ? (double2 const *)p.x : (double2 const *)p.temp;
-              double2 xv = xin[((uint64_t)pc.inOff + row) * nrhs + q0 + 16 * t + li2];
-              re += xv.x; im += xv.y;
-            }
-          }
-          out[((uint64_t)it.outOff + row) * nrhs + q0 + 16 * t + li2] = make_double2(re, im);
-        }
-      }
-  // stores and fragment requests share vmcnt: nothing of this pass may be pending when the next one counts
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  bfMfmaStore<NT, MS, GAUSS>(p, it, mr, s0, q0, acc, hasIdentity, lane);
 }
 
 template <int MS, int MAXNT, bool DMA, bool GAUSS>
@@ -426,6 +433,235 @@ __device__ __forceinline__ void bfMfmaDispatch(uint32_t nt, StageParams const &p
   else if (MAXNT >= 3 && nt == 3) bfMfmaPass<3, MS, DMA, GAUSS>(p, it, mr, s0, q0, tab, lane, ring);
   else if (MAXNT >= 2 && nt == 2) bfMfmaPass<2, MS, DMA, GAUSS>(p, it, mr, s0, q0, tab, lane, ring);
   else bfMfmaPass<1, MS, DMA, GAUSS>(p, it, mr, s0, q0, tab, lane, ring);
+}
+
+// ---- bundles (round 5: built, measured, NOT the product's kernel: BF_MF_BUNDLES) -------------------------------------------------------
+// A workgroup of four wavefronts whose items read the SAME X rows.  The row chunks of a row group and the sibling groups of a radix-4
+// stage (reference src/fac_helm2.c:277-318) multiply different leaf rows by the same rows of the input; the planner keeps them
+// together in the list and bfPlanBundles marks runs of four with equal inputs, <= 32 rows and the same number of slabs (SHARED
+// bundles: ONE pass each, the same number of k-steps); everything else goes four unrelated items to a workgroup (MIXED bundles, the
+// one-wavefront passes above -- a workgroup must keep all four SIMDs busy: workgroups whose other wavefronts had exited ran at a fifth
+// of the rate).  In a shared bundle every wavefront streams its own leaf fragments into registers exactly as bfMfmaSegment does; the
+// four X tiles of a k-step are fetched ONCE per workgroup -- wavefront w brings tile w as an LDS-DMA, two k-steps ahead, into a ring of
+// three 4 KiB slots -- and every wavefront reads them with ds_read_b128 right after the MFMAs that used the previous k-step's copy.
+// One workgroup barrier per k-step: behind it the next k-step's slot is complete and nobody still reads the slot before the current
+// one, which is the one requested into next.  Same MFMAs in the same order per accumulator: bit-identical to the register loop
+// (tools/mfma_sharedx_probe.hip compares them; the GPU suite passes with either kernel).
+// What it does (N = 262144, 64 RHS, counters over the shared bundles alone, 83 - 93 % of a stage's work): HBM traffic 1.08x the
+// algorithmic bytes instead of 1.4x, clock +6 % -- and the matrix pipe busy 0.80 of the cycles instead of 0.87: four wavefronts
+// that wait for each other at every k-step, at every segment's table (written by wavefront 0) and at every segment's first requests.
+// On the bare machine (the probe: no items, no tables) the loop is 9 - 17 % faster than the register loop; in the kernel the shared
+// bundles are 2 - 5 % faster per unit of work, the mixed ones 2 % slower than one-wavefront workgroups, the whole apply 31.2 - 31.7 ms
+// against 30.3 - 30.6 for the one-wavefront kernel on the same plan, same box.  DESIGN.md section 9.
+#define BF_MF_SX_SLOT 4096u
+#define BF_MF_SX_RING (3u * BF_MF_SX_SLOT)
+#ifndef BF_MF_BUNDLES
+#define BF_MF_BUNDLES 0           /* 1: the 64-RHS kernels run bundles (A/B builds: make variant V=bundles DEFS=-DBF_MF_BUNDLES=1) */
+#endif
+#ifndef BF_MF_XCD_RUN_B
+#define BF_MF_XCD_RUN_B 8u           /* bundles (workgroups of four wavefronts) that are list neighbours and go to one XCD */
+#endif
+
+template <int MS, int SET, bool GAUSS>
+__device__ __forceinline__ void bfSxStep(bf_d4 (&acc)[3][2][4], BfFrag (&a)[2][2], BfFrag (&x)[4], BfMfSeg const &sg, uint32_t &soffA, uint32_t voffXnext2,
+                                         uint32_t slotNext, uint32_t slotFree, uint32_t laneLds, uint32_t mine) {
+  // everything this wavefront asked for has arrived: the leaf fragments of this k-step, its tiles of the NEXT k-step's X (LDS-DMA),
+  // the X fragments of this k-step (ds_read) ...
+  if (MS > 1) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(a[SET][0].u), "+v"(a[SET][1].u), "+v"(x[0].u), "+v"(x[1].u), "+v"(x[2].u), "+v"(x[3].u));
+  else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(a[SET][0].u), "+v"(x[0].u), "+v"(x[1].u), "+v"(x[2].u), "+v"(x[3].u));
+  // ... and everybody else's
+  asm volatile("s_barrier" ::: "memory");
+  soffA += sg.stepA;
+  bfMfmaRequestA<MS, SET ^ 1>(a, sg, soffA);
+  if (mine & 1u) bfDmaLoad<0>(slotFree, voffXnext2, sg.rx, bfSgprConst<0>());
+  if (mine & 2u) bfDmaLoad<0>(slotFree + 1024u, voffXnext2, sg.rx, bfSgprConst<256>());
+  if (mine & 4u) bfDmaLoad<0>(slotFree + 2048u, voffXnext2, sg.rx, bfSgprConst<512>());
+  if (mine & 8u) bfDmaLoad<0>(slotFree + 3072u, voffXnext2, sg.rx, bfSgprConst<768>());
+  uint32_t const vaddr = laneLds + slotNext;
+  double as[2];
+  if (GAUSS) {
+    as[0] = a[SET][0].d[0] + a[SET][0].d[1];
+    if (MS > 1) as[1] = a[SET][1].d[0] + a[SET][1].d[1];
+  }
+  __builtin_amdgcn_sched_barrier(0);
+#define BF_SX_TILE(T) do { \
+    if (GAUSS) { \
+      double const xs = x[T].d[0] + x[T].d[1]; \
+      _Pragma("unroll") for (int m = 0; m < MS; ++m) { \
+        acc[0][m][T] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[SET][m].d[0], x[T].d[0], acc[0][m][T], 0, 0, 0); \
+        acc[1][m][T] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[SET][m].d[1], x[T].d[1], acc[1][m][T], 0, 0, 0); \
+        acc[2][m][T] = __builtin_amdgcn_mfma_f64_16x16x4f64(as[m], xs, acc[2][m][T], 0, 0, 0); \
+      } \
+    } else { \
+      _Pragma("unroll") for (int m = 0; m < MS; ++m) bfMfmaExact(acc[0][m][T], acc[1][m][T], a[SET][m], x[T]); \
+    } \
+    __builtin_amdgcn_sched_barrier(0); \
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(x[T].u) : "v"(vaddr), "n"(1024 * T)); \
+    __builtin_amdgcn_sched_barrier(0); \
+  } while (0)
+  BF_SX_TILE(0); BF_SX_TILE(1); BF_SX_TILE(2); BF_SX_TILE(3);
+#undef BF_SX_TILE
+}
+
+// the k-loop of one segment for one wavefront of a bundle (4 tiles, MS slabs); `mine`: bit t = this wavefront fetches tile t
+template <int MS, bool GAUSS>
+__device__ __forceinline__ void bfSxSegment(bf_d4 (&acc)[3][2][4], BfMfSeg const &sg, uint32_t const *tab, uint32_t lk, uint32_t ring, uint32_t lane, uint32_t mine) {
+  BfFrag a[2][2], x[4];
+  uint32_t const laneLds = lane * 16u;
+  uint32_t ti = lk, soffA = 0;
+  uint32_t s0 = ring, s1 = ring + BF_MF_SX_SLOT, s2 = ring + 2u * BF_MF_SX_SLOT;      // slots of k-steps ks, ks + 1, ks + 2 (wave-uniform)
+  {
+    uint32_t const v0 = tab[ti] + sg.cX, v1 = tab[ti + 4] + sg.cX;
+    if (mine & 1u) { bfDmaLoad<0>(s0, v0, sg.rx, bfSgprConst<0>()); bfDmaLoad<0>(s1, v1, sg.rx, bfSgprConst<0>()); }
+    if (mine & 2u) { bfDmaLoad<0>(s0 + 1024u, v0, sg.rx, bfSgprConst<256>()); bfDmaLoad<0>(s1 + 1024u, v1, sg.rx, bfSgprConst<256>()); }
+    if (mine & 4u) { bfDmaLoad<0>(s0 + 2048u, v0, sg.rx, bfSgprConst<512>()); bfDmaLoad<0>(s1 + 2048u, v1, sg.rx, bfSgprConst<512>()); }
+    if (mine & 8u) { bfDmaLoad<0>(s0 + 3072u, v0, sg.rx, bfSgprConst<768>()); bfDmaLoad<0>(s1 + 3072u, v1, sg.rx, bfSgprConst<768>()); }
+  }
+  bfMfmaRequestA<MS, 0>(a, sg, soffA);
+  uint32_t t2 = tab[ti + 8], t3 = tab[ti + 12];      // the rows of k-steps 2 and 3 (the table is padded past the last k-step: BF_MF_TABPAD)
+  ti += 16;
+  // (never the same variable twice in one statement: hipcc then copies it BEFORE the wait and may keep the copy)
+  if (MS > 1) asm volatile("s_waitcnt vmcnt(0)" : "+v"(a[0][0].u), "+v"(a[0][1].u));
+  else asm volatile("s_waitcnt vmcnt(0)" : "+v"(a[0][0].u));
+  asm volatile("s_barrier" ::: "memory");
+  {
+    uint32_t const vaddr = laneLds + s0;
+    asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:1024\n\tds_read_b128 %2, %4 offset:2048\n\tds_read_b128 %3, %4 offset:3072"
+                 : "=&v"(x[0].u), "=&v"(x[1].u), "=&v"(x[2].u), "=&v"(x[3].u) : "v"(vaddr));
+  }
+  for (uint32_t ks = 0; ks < sg.ksteps; ks += 2) {
+    uint32_t const v2 = t2 + sg.cX, v3 = t3 + sg.cX;
+    t2 = tab[ti];
+    t3 = tab[ti + 4];
+    ti += 8;
+    bfSxStep<MS, 0, GAUSS>(acc, a, x, sg, soffA, v2, s1, s2, laneLds, mine);
+    bfSxStep<MS, 1, GAUSS>(acc, a, x, sg, soffA, v3, s2, s0, laneLds, mine);
+    uint32_t const o0 = s0, o1 = s1;
+    s0 = s2; s1 = o0; s2 = o1;                       // two k-steps on
+  }
+  // the requests of the k-steps past the end (zeros from the range check / padded table rows) must land before the registers, the
+  // ring and the table are used again, by anybody
+  if (MS > 1) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(a[0][0].u), "+v"(a[0][1].u), "+v"(a[1][0].u), "+v"(a[1][1].u), "+v"(x[0].u), "+v"(x[1].u), "+v"(x[2].u), "+v"(x[3].u));
+  else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(a[0][0].u), "+v"(a[1][0].u), "+v"(x[0].u), "+v"(x[1].u), "+v"(x[2].u), "+v"(x[3].u));
+  asm volatile("s_barrier" ::: "memory");
+}
+
+// One pass of one wavefront of a bundle: rows [0, mr <= 16 MS) x RHS [q0, q0 + 64) of ITS item; the segment table (the same for every
+// wavefront of the bundle) is written by wavefront 0 into the workgroup's one table.
+template <int MS, bool GAUSS>
+__device__ __forceinline__ void bfMfmaPassBundle(StageParams const &p, BfDevItem const &it, uint32_t mr, uint32_t q0, uint32_t *tab, int lane, uint32_t ring, uint32_t wave, uint32_t mine) {
+  uint32_t const nrhs = p.nrhs;
+  uint32_t const li = lane & 15, lk = lane >> 4;
+  bf_d4 acc[3][2][4];
+#pragma unroll
+  for (int g = 0; g < 3; ++g)
+#pragma unroll
+    for (int m = 0; m < MS; ++m)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[g][m][t] = (bf_d4){0, 0, 0, 0};
+  bool hasIdentity = false;
+  uint32_t const np = it.numPieces;
+  uint32_t const spanRows = BF_MF_SPAN_BYTES / (nrhs * 16u);
+  uint32_t pi = 0;
+  while (pi < np) {
+    // every wavefront walks ITS item's descriptors (same input rows and widths for all of them, its own leaf offsets) and finds the
+    // same segment; wavefront 0 writes the table
+    uint32_t cols = 0, minRow = 0, maxRow = 0, inX = 0;
+    uint64_t aOff = 0, expect = 0;
+    bool started = false;
+    BfPieceWin win;
+    uint32_t wbase = 0xffffff00u;
+    while (pi < np) {
+      if (pi - wbase >= 64u) {
+        wbase = pi;
+        win = bfPieceWinLoad(p.pieces + it.pieceBegin + wbase, np - wbase < 64u ? np - wbase : 64u, lane);
+      }
+      BfDevPiece const pc = bfPieceWinGet(win, pi - wbase);
+      if (pc.flags & BF_PIECE_IDENTITY) { hasIdentity = true; ++pi; continue; }
+      uint32_t const px = pc.flags & BF_PIECE_IN_X, last = pc.inOff + pc.ncols - 1;
+      uint32_t lo = pc.inOff, hi = last;
+      if (started) {
+        if (pc.dataOff != expect || px != inX || cols + pc.ncols > BF_MF_TABCAP) break;
+        lo = minRow < lo ? minRow : lo;
+        hi = maxRow > hi ? maxRow : hi;
+        if (hi - lo >= spanRows) break;
+      } else {
+        started = true;
+        aOff = pc.dataOff;
+        inX = px;
+      }
+      minRow = lo;
+      maxRow = hi;
+      if (wave == 0) for (uint32_t j = (uint32_t)lane; j < pc.ncols; j += 64u) tab[cols + j] = pc.inOff + j;
+      cols += pc.ncols;
+      expect = pc.dataOff + (uint64_t)mr * pc.ncols;
+      ++pi;
+    }
+    if (!cols) break;                      // identity pieces only (the same for every wavefront of the bundle)
+    if (wave == 0) {
+      if ((uint32_t)lane < BF_MF_TABPAD) tab[cols + lane] = minRow;
+      waveSync();
+      for (uint32_t j = (uint32_t)lane; j < cols + BF_MF_TABPAD; j += 64u) tab[j] = (tab[j] - minRow) * (nrhs * 16u);
+      waveSync();
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // the table is there for everybody
+    BfMfSeg sg;
+    sg.stepA = 4u * mr * 16u;
+    sg.ksteps = (cols + 3u) / 4u;
+    sg.ra = bfMakeRsrc((double2 const *)p.arena + aOff, mr * cols * 16u);
+    char const *xin = inX ? (char const *)p.x : (char const *)p.temp;
+    sg.rx = bfMakeRsrc(xin + ((uint64_t)minRow * nrhs + q0) * 16u, ((maxRow - minRow) * nrhs + (nrhs - q0)) * 16u);
+    sg.voffA = (lk * mr + li) * 16u;
+    sg.cX = li * 16u;
+    bfSxSegment<MS, GAUSS>(acc, sg, tab, lk, ring, (uint32_t)lane, mine);      // ends with a barrier: table and ring are free again
+  }
+  bfMfmaStore<4, MS, GAUSS>(p, it, mr, 0u, q0, acc, hasIdentity, lane);
+}
+
+// The 64-RHS kernel's body: workgroup = bundle of four items.  SHARED bundles run the loop above; MIXED ones (items that found nobody
+// to share with, taller ones, zero fills) the one-wavefront passes, four unrelated items side by side -- a workgroup always fills
+// all four SIMDs (measured: workgroups that kept one live wavefront ran at a fifth of the rate, their survivors crowd one SIMD).
+template <bool GAUSS>
+__device__ __forceinline__ void bfStageBodyC128MfmaBundles(StageParams const &p, uint32_t (*tabs)[BF_MF_TABCAP + BF_MF_TABPAD], char *ringMem) {
+  int const lane = threadIdx.x & 63;
+  uint32_t const wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  uint32_t wg = blockIdx.x;
+  uint32_t const numWg = p.numBundles;
+  if (BF_MF_XCD_RUN_B > 1) {      // runs of list neighbours on ONE XCD (workgroups are dealt to the 8 XCDs round robin)
+    uint32_t const blk = 8u * BF_MF_XCD_RUN_B;
+    if (wg < numWg / blk * blk) { uint32_t const r = wg % blk; wg = wg - r + (r % 8u) * BF_MF_XCD_RUN_B + r / 8u; }
+  }
+  if (wg >= numWg) return;
+  uint32_t const entry = __builtin_amdgcn_readfirstlane(p.bundles[wg]), first = entry & 0x7fffffffu;
+  uint32_t const cnt = (__builtin_amdgcn_readfirstlane(p.bundles[wg + 1]) & 0x7fffffffu) - first;
+  bool const mixed = (entry >> 31) != 0;   // four unrelated items: one-wavefront passes, every wavefront its own table
+  if (wave >= cnt) return;                 // (the last bundle of a list; a barrier waits for the surviving wavefronts of a workgroup only)
+#ifdef BF_MF_ONLY_CNT                      /* timing experiments: only the bundles of this many items run (wrong results) */
+  if (cnt != BF_MF_ONLY_CNT) return;
+#endif
+  BfDevItem const it = p.items[first + wave];
+  uint32_t const mr = it.mrFlags & 0xffffu;
+  uint32_t const nrhs = p.nrhs;
+  uint32_t const ring = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)ringMem);
+  uint32_t mine = 0;
+  for (uint32_t t = 0; t < 4u; ++t) if (t % cnt == wave) mine |= 1u << t;
+  mine = __builtin_amdgcn_readfirstlane(mine);
+  uint32_t *tab = tabs[mixed ? wave : 0u];
+  for (uint32_t q0 = 0; q0 < nrhs; q0 += 64) {
+    if (!mixed) {                          // (bfPlanBundles: <= 32 rows each, the same number of slabs)
+      // (the last, partial 64-RHS block of a wider right-hand side runs all four tiles: the columns past nrhs are whatever follows
+      //  them in memory -- zeros past the end of the last row -- and are never stored)
+      if (mr > 16) bfMfmaPassBundle<2, GAUSS>(p, it, mr, q0, tab, lane, ring, wave, mine);
+      else bfMfmaPassBundle<1, GAUSS>(p, it, mr, q0, tab, lane, ring, wave, mine);
+    } else {
+      uint32_t const nt = (nrhs - q0 >= 64) ? 4u : (nrhs - q0 + 15u) / 16u;
+      uint32_t s0 = 0;
+      while (s0 < mr) {
+        if (mr - s0 > 16) { bfMfmaDispatch<2, 4, false, GAUSS>(nt, p, it, mr, s0, q0, tab, lane, 0u); s0 += 32; }
+        else { bfMfmaDispatch<1, 4, false, GAUSS>(nt, p, it, mr, s0, q0, tab, lane, 0u); s0 += 16; }
+      }
+    }
+  }
 }
 
 // MAXNT = the widest pass the launch needs (RHS tiles of 16): the accumulators of 4 tiles x 2 slabs x 3 products leave two
@@ -474,6 +710,13 @@ __device__ __forceinline__ void bfStageBodyC128Mfma(StageParams const &p, uint32
 #ifndef BF_MF_DMA
 #define BF_MF_DMA 0
 #endif
+#if BF_MF_BUNDLES
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BF_MFMA_WAVES_PER_SIMD, BF_MFMA_WAVES_PER_SIMD))) void bfStageKernelC128Mfma(StageParams p) {
+  __shared__ uint32_t tabs[4][BF_MF_TABCAP + BF_MF_TABPAD];
+  __shared__ __attribute__((aligned(16))) char ring[BF_MF_SX_RING];
+  bfStageBodyC128MfmaBundles<true>(p, tabs, ring);
+}
+#else
 __global__ __launch_bounds__(64 * BF_MF_WG_WAVES) __attribute__((amdgpu_waves_per_eu(BF_MFMA_WAVES_PER_SIMD, BF_MFMA_WAVES_PER_SIMD))) void bfStageKernelC128Mfma(StageParams p) {
   __shared__ uint32_t tabs[BF_MF_WG_WAVES][BF_MF_TABCAP + BF_MF_TABPAD];
 #if BF_MF_DMA
@@ -483,6 +726,7 @@ __global__ __launch_bounds__(64 * BF_MF_WG_WAVES) __attribute__((amdgpu_waves_pe
   bfStageBodyC128Mfma<4, BF_MFMA_WAVES_PER_SIMD, false>(p, tabs, nullptr);
 #endif
 }
+#endif
 // <= 32 right-hand sides (2 tiles): 3 wavefronts per SIMD
 __global__ __launch_bounds__(64 * BF_MF_WG_WAVES) __attribute__((amdgpu_waves_per_eu(3, 3))) void bfStageKernelC128Mfma2(StageParams p) {
   __shared__ uint32_t tabs[BF_MF_WG_WAVES][BF_MF_TABCAP + BF_MF_TABPAD];
@@ -494,6 +738,13 @@ __global__ __launch_bounds__(64 * BF_MF_WG_WAVES) __attribute__((amdgpu_waves_pe
   bfStageBodyC128Mfma<1, 5, false>(p, tabs, nullptr);
 }
 // BFHIP_FLAG_EXACT_COMPLEX: the same three kernels with the four real products of every complex one (componentwise zgemm's recurrence)
+#if BF_MF_BUNDLES
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BF_MFMA_WAVES_PER_SIMD, BF_MFMA_WAVES_PER_SIMD))) void bfStageKernelC128MfmaExact(StageParams p) {
+  __shared__ uint32_t tabs[4][BF_MF_TABCAP + BF_MF_TABPAD];
+  __shared__ __attribute__((aligned(16))) char ring[BF_MF_SX_RING];
+  bfStageBodyC128MfmaBundles<false>(p, tabs, ring);
+}
+#else
 __global__ __launch_bounds__(64 * BF_MF_WG_WAVES) __attribute__((amdgpu_waves_per_eu(BF_MFMA_WAVES_PER_SIMD, BF_MFMA_WAVES_PER_SIMD))) void bfStageKernelC128MfmaExact(StageParams p) {
   __shared__ uint32_t tabs[BF_MF_WG_WAVES][BF_MF_TABCAP + BF_MF_TABPAD];
 #if BF_MF_DMA
@@ -503,6 +754,7 @@ __global__ __launch_bounds__(64 * BF_MF_WG_WAVES) __attribute__((amdgpu_waves_pe
   bfStageBodyC128Mfma<4, BF_MFMA_WAVES_PER_SIMD, false, false>(p, tabs, nullptr);
 #endif
 }
+#endif
 __global__ __launch_bounds__(64 * BF_MF_WG_WAVES) __attribute__((amdgpu_waves_per_eu(3, 3))) void bfStageKernelC128Mfma2Exact(StageParams p) {
   __shared__ uint32_t tabs[BF_MF_WG_WAVES][BF_MF_TABCAP + BF_MF_TABPAD];
   bfStageBodyC128Mfma<2, 3, false, false>(p, tabs, nullptr);

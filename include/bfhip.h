@@ -419,6 +419,10 @@ typedef struct BfhipStageView {
   uint64_t numItems, numPieces, numReduce;
   const void *items;      /* BfDevItem[numItems]  (16 bytes each) */
   const void *pieces;     /* BfDevPiece[numPieces] (24 bytes each) */
+  /* filled when structSize covers them: forward complex128 stages -- runs of up to 4 list neighbours that read the same input rows
+   * (one workgroup of the 64-RHS kernel each: its wavefronts fetch every X tile once); bundleBegin[numBundles + 1] */
+  uint64_t numBundles;
+  const uint32_t *bundleBegin;
 } BfhipStageView;
 typedef struct BfhipReduceView {
   uint32_t structSize, destIsY;

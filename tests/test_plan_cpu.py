@@ -239,6 +239,51 @@ def test_row_sharding_union_equals_full(helm2_cases):
     assert rel(plan_emulator.run_plan(op, x), want) < 1e-13
 
 
+def test_rhs_block_operators_keep_items_with_equal_inputs_together(helm2_cases):
+    """Operators compiled for blocks of right-hand sides (complex128): the row chunks of a group and the sibling groups of a radix-4
+    stage (reference src/fac_helm2.c:277-318) read the same input rows; the planner keeps them together in the item list (items of
+    <= 32 rows), and the stage view's bundle table partitions the list into workgroups of <= 4 neighbours -- shared ones (bit 31
+    clear): exactly four items with the same pieces' input rows, <= 32 rows and the same number of 16-row slabs; mixed ones: the
+    rest.  The plan still computes A x (emulator), and most of a butterfly stage's work sits in runs of >= 2 equal neighbours."""
+    n, k = 4096, 256
+    desc, tp, vals = helm2_cases(n, k)
+    x = hb.complex_randn(n, 3)
+    op = HipOperator.from_desc(desc, vals, flags=_capi.FLAG_PLAN_ONLY, max_rhs=64)
+    assert rel(plan_emulator.run_plan(op, x), bfref.mat_mul(bfref.from_desc(desc, vals), x)) < 1e-13
+    lib = _capi.load()
+    info = _capi.BfhipPlanInfo(); info.structSize = C.sizeof(info)
+    _capi.check(lib.bfhipPlanGetInfo(op.handle, C.byref(info)))
+    shared_items = total_items = 0
+    for s in range(int(info.numStages)):
+        sv = _capi.BfhipStageView(); sv.structSize = C.sizeof(sv)
+        _capi.check(lib.bfhipPlanGetStage(op.handle, s, C.byref(sv)))
+        items = np.frombuffer((C.c_char * (int(sv.numItems) * 16)).from_address(sv.items), dtype=_capi.ITEM_DTYPE)
+        pieces = np.frombuffer((C.c_char * (int(sv.numPieces) * 24)).from_address(sv.pieces), dtype=_capi.PIECE_DTYPE)
+        bb = np.frombuffer((C.c_char * ((int(sv.numBundles) + 1) * 4)).from_address(sv.bundleBegin), dtype=np.uint32)
+        first = (bb & 0x7FFFFFFF).astype(np.int64)
+        assert first[0] == 0 and first[-1] == len(items) and (np.diff(first) >= 1).all() and (np.diff(first) <= 4).all()
+        mr = items["mrFlags"] & 0xFFFF
+        assert (mr[items["numPieces"] > 0] <= 32).all()
+
+        def key(i):
+            p = pieces[items["pieceBegin"][i]:items["pieceBegin"][i] + items["numPieces"][i]]
+            return (p["inOff"].tobytes(), p["ncols"].tobytes(), (p["flags"] & 3).tobytes())
+
+        for b in range(len(bb) - 1):
+            mem = range(first[b], first[b + 1])
+            if bb[b] >> 31:
+                continue
+            assert len(mem) == 4 and len({key(i) for i in mem}) == 1 and len({bool(mr[i] > 16) for i in mem}) == 1 and all(0 < mr[i] <= 32 for i in mem)
+            shared_items += 4
+        total_items += int((items["numPieces"] > 0).sum())
+        # equal inputs are neighbours: every key occupies ONE contiguous run of the list per cost bucket at most a few times
+        keys = [key(i) for i in range(len(items)) if items["numPieces"][i]]
+        runs = 1 + sum(keys[i] != keys[i - 1] for i in range(1, len(keys)))
+        assert runs <= 3 * len(set(keys)), (s, runs, len(set(keys)))
+    assert shared_items >= 0.1 * total_items, (shared_items, total_items)
+    op.close()
+
+
 # ---- error behaviour (mirrors the reference's BfError codes) ---------------
 @pytest.mark.parametrize("seed", range(8))
 def test_row_ranges_of_random_nested_graphs(seed):

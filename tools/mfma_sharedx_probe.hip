@@ -24,83 +24,22 @@
 
 #define PROBE_COLS 1792u
 #define PROBE_PAD 48u
-#define SX_SLOT 4096u
 
-// one k-step of the shared loop: fragments a[SET] (requested a k-step ago) and x[] (read from the ring during the previous k-step)
-template <int SET>
-__device__ __forceinline__ void sxStep(bf_d4 (&acc)[3][2][4], BfFrag (&a)[2][2], BfFrag (&x)[4], BfMfSeg const &sg, uint32_t &soffA, uint32_t voffXnext2,
-                                       uint32_t slotNext, uint32_t slotFree, uint32_t laneLds, uint32_t w) {
-  // everything this wavefront asked for has arrived: the leaf fragments of this k-step, its tile of the NEXT k-step's X (LDS-DMA),
-  // the X fragments of this k-step (ds_read)
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(a[SET][0].u), "+v"(a[SET][1].u), "+v"(x[0].u), "+v"(x[1].u), "+v"(x[2].u), "+v"(x[3].u));
-  // ... and everybody else's: the next k-step's slot is complete, nobody still reads the slot before this one
-  asm volatile("s_barrier" ::: "memory");
-  soffA += sg.stepA;
-  bfMfmaRequestA<2, SET ^ 1>(a, sg, soffA);
-  bfDmaLoad<0>(slotFree + 1024u * w, voffXnext2, sg.rx, bfSgprConst<0>());
-  uint32_t const vaddr = laneLds + slotNext;
-  double as[2];
-  as[0] = a[SET][0].d[0] + a[SET][0].d[1];
-  as[1] = a[SET][1].d[0] + a[SET][1].d[1];
-  __builtin_amdgcn_sched_barrier(0);
-#define SX_TILE(T) do { \
-    double const xs = x[T].d[0] + x[T].d[1]; \
-    _Pragma("unroll") for (int m = 0; m < 2; ++m) { \
-      acc[0][m][T] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[SET][m].d[0], x[T].d[0], acc[0][m][T], 0, 0, 0); \
-      acc[1][m][T] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[SET][m].d[1], x[T].d[1], acc[1][m][T], 0, 0, 0); \
-      acc[2][m][T] = __builtin_amdgcn_mfma_f64_16x16x4f64(as[m], xs, acc[2][m][T], 0, 0, 0); \
-    } \
-    __builtin_amdgcn_sched_barrier(0); \
-    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(x[T].u) : "v"(vaddr), "n"(1024 * T)); \
-    __builtin_amdgcn_sched_barrier(0); \
-  } while (0)
-  SX_TILE(0); SX_TILE(1); SX_TILE(2); SX_TILE(3);
-#undef SX_TILE
-}
-
-__device__ __forceinline__ void sxSegment(bf_d4 (&acc)[3][2][4], BfMfSeg const &sg, uint32_t const *tab, uint32_t lk, uint32_t ring, uint32_t lane, uint32_t w) {
-  BfFrag a[2][2], x[4];
-  uint32_t const cXw = sg.cX + 256u * w;          // this wavefront's tile of a k-step's X rows
-  uint32_t const laneLds = lane * 16u;
-  uint32_t ti = lk, soffA = 0;
-  uint32_t s0 = ring, s1 = ring + SX_SLOT, s2 = ring + 2u * SX_SLOT;      // slots of k-steps ks, ks + 1, ks + 2 (wave-uniform)
-  bfDmaLoad<0>(s0 + 1024u * w, tab[ti] + cXw, sg.rx, bfSgprConst<0>());
-  bfDmaLoad<0>(s1 + 1024u * w, tab[ti + 4] + cXw, sg.rx, bfSgprConst<0>());
-  bfMfmaRequestA<2, 0>(a, sg, soffA);
-  uint32_t t2 = tab[ti + 8], t3 = tab[ti + 12];
-  ti += 16;
-  asm volatile("s_waitcnt vmcnt(0)" : "+v"(a[0][0].u), "+v"(a[0][1].u));
-  asm volatile("s_barrier" ::: "memory");
-  {
-    uint32_t const vaddr = laneLds + s0;
-    asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:1024\n\tds_read_b128 %2, %4 offset:2048\n\tds_read_b128 %3, %4 offset:3072"
-                 : "=&v"(x[0].u), "=&v"(x[1].u), "=&v"(x[2].u), "=&v"(x[3].u) : "v"(vaddr));
-  }
-  for (uint32_t ks = 0; ks < sg.ksteps; ks += 2) {
-    uint32_t const v2 = t2 + cXw, v3 = t3 + cXw;
-    t2 = tab[ti];
-    t3 = tab[ti + 4];
-    ti += 8;
-    sxStep<0>(acc, a, x, sg, soffA, v2, s1, s2, laneLds, w);
-    sxStep<1>(acc, a, x, sg, soffA, v3, s2, s0, laneLds, w);
-    uint32_t const o0 = s0, o1 = s1;
-    s0 = s2; s1 = o0; s2 = o1;                       // two k-steps on: (s0, s1, s2) <- (s2, s0, s1)
-  }
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(a[0][0].u), "+v"(a[0][1].u), "+v"(a[1][0].u), "+v"(a[1][1].u), "+v"(x[0].u), "+v"(x[1].u), "+v"(x[2].u), "+v"(x[3].u));
-  asm volatile("s_barrier" ::: "memory");            // the ring is rewritten by the next segment
-}
-
-template <int WPS>
+template <int WPS, int MS>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPS, WPS))) void probeSharedX(double *out, char const *A, char const *X, uint64_t aStride, uint32_t aBytes,
-                                                                                                 uint32_t xRows, uint32_t reps, uint32_t cols, uint32_t aWaves) {
+                                                                                                 uint32_t xRows, uint32_t reps, uint32_t cols, uint32_t aWaves, uint32_t cnt) {
   __shared__ uint32_t tab[PROBE_COLS + PROBE_PAD];
-  __shared__ __attribute__((aligned(16))) char ringMem[3 * SX_SLOT];
+  __shared__ __attribute__((aligned(16))) char ringMem[BF_MF_SX_RING];
   uint32_t const lane = threadIdx.x & 63u, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   uint32_t const li = lane & 15, lk = lane >> 4;
   uint32_t const wave = (blockIdx.x * 4u + w) % aWaves;
   uint32_t const row0 = (blockIdx.x * 2654435761u) % xRows;           // rows private to the workgroup
   for (uint32_t j = threadIdx.x; j < cols + PROBE_PAD; j += 256) tab[j] = j < cols ? ((row0 + j) % xRows) * 1024u : (row0 % xRows) * 1024u;
   __syncthreads();
+  if (w >= cnt) return;                  // a bundle of fewer than four: the barriers wait for the surviving wavefronts only
+  uint32_t mine = 0;
+  for (uint32_t t = 0; t < 4u; ++t) if (t % cnt == w) mine |= 1u << t;
+  mine = __builtin_amdgcn_readfirstlane(mine);
   bf_d4 acc[3][2][4];
 #pragma unroll
   for (int g = 0; g < 3; ++g)
@@ -108,20 +47,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPS, WPS)))
     for (int m = 0; m < 2; ++m)
 #pragma unroll
       for (int t = 0; t < 4; ++t) acc[g][m][t] = (bf_d4){0, 0, 0, 0};
+  uint32_t const mr = 16u * MS;
   BfMfSeg sg;
-  sg.stepA = 4u * 32u * 16u;
+  sg.stepA = 4u * mr * 16u;
   sg.ksteps = (cols + 3u) / 4u;
   sg.ra = bfMakeRsrc(A + (uint64_t)wave * aStride, aBytes);
   sg.rx = bfMakeRsrc(X, xRows * 1024u);
-  sg.voffA = (lk * 32u + li) * 16u;
+  sg.voffA = (lk * mr + li) * 16u;
   sg.cX = li * 16u;
   uint32_t const ring = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)ringMem);
-  for (uint32_t r = 0; r < reps; ++r) sxSegment(acc, sg, tab, lk, ring, lane, w);
+  for (uint32_t r = 0; r < reps; ++r) bfSxSegment<MS, true>(acc, sg, tab, lk, ring, lane, mine);      // the product's loop (bfhip_stage_mfma.h)
   double sum = 0;
 #pragma unroll
   for (int g = 0; g < 3; ++g)
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+    for (int m = 0; m < MS; ++m)
 #pragma unroll
       for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -130,7 +70,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPS, WPS)))
 }
 
 // the product's register loop, X rows shared by `xGroup` list neighbours (one-wavefront workgroups, no pacing)
-template <int WPS>
+template <int WPS, int MS>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPS, WPS))) void probeRegister(double *out, char const *A, char const *X, uint64_t aStride, uint32_t aBytes,
                                                                                                  uint32_t xRows, uint32_t reps, uint32_t cols, uint32_t aWaves, uint32_t xGroup) {
   __shared__ uint32_t tab[PROBE_COLS + PROBE_PAD];
@@ -147,19 +87,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPS, WPS))) 
     for (int m = 0; m < 2; ++m)
 #pragma unroll
       for (int t = 0; t < 4; ++t) acc[g][m][t] = (bf_d4){0, 0, 0, 0};
+  uint32_t const mr = 16u * MS;
   BfMfSeg sg;
-  sg.stepA = 4u * 32u * 16u;
+  sg.stepA = 4u * mr * 16u;
   sg.ksteps = (cols + 3u) / 4u;
   sg.ra = bfMakeRsrc(A + (uint64_t)wave * aStride, aBytes);
   sg.rx = bfMakeRsrc(X, xRows * 1024u);
-  sg.voffA = (lk * 32u + li) * 16u;
+  sg.voffA = (lk * mr + li) * 16u;
   sg.cX = li * 16u;
-  for (uint32_t r = 0; r < reps; ++r) bfMfmaSegment<4, 2>(acc, sg, tab, lk);
+  for (uint32_t r = 0; r < reps; ++r) bfMfmaSegment<4, MS>(acc, sg, tab, lk);
   double sum = 0;
 #pragma unroll
   for (int g = 0; g < 3; ++g)
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+    for (int m = 0; m < MS; ++m)
 #pragma unroll
       for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -193,37 +134,44 @@ int main(int argc, char **argv) {
   printf("{\n");
   // the two loops must agree bit for bit: same rows (xGroup = 4 <-> one workgroup of 4), same leaf windows, ragged column count
   int bad = 0;
-  for (uint32_t cols : {1792u, 1787u, 61u, 5u}) {
-    size_t const nOut = (size_t)64 * 64;
-    std::vector<double> h0(nOut), h1(nOut);
-    uint32_t const ab = 32u * cols * 16u;
-    probeRegister<2><<<64, 64>>>(out, A, X1g, aBytes, ab, 1048576, 2, cols, 2048, 4);
-    CHECK(hipDeviceSynchronize());
-    CHECK(hipMemcpy(h0.data(), out, nOut * 8, hipMemcpyDeviceToHost));
-    probeSharedX<2><<<16, 256>>>(out, A, X1g, aBytes, ab, 1048576, 2, cols, 2048);
-    CHECK(hipDeviceSynchronize());
-    CHECK(hipMemcpy(h1.data(), out, nOut * 8, hipMemcpyDeviceToHost));
-    size_t diff = 0;
-    for (size_t i = 0; i < nOut; ++i) diff += memcmp(&h0[i], &h1[i], 8) != 0;
-    printf("\"compare_cols%u\": {\"values\": %zu, \"different\": %zu},\n", cols, nOut, diff);
-    bad |= diff != 0;
-  }
+  // (a bundle of cnt < 4: the register loop's wavefronts 4 b + w, w >= cnt, have no counterpart and are not compared)
+#define COMPARE(MSV) \
+  for (uint32_t cnt : {4u, 3u, 2u}) \
+    for (uint32_t cols : {1792u, 1787u, 61u, 5u}) { \
+      size_t const nOut = (size_t)64 * 64; \
+      std::vector<double> h0(nOut), h1(nOut, 0.0); \
+      uint32_t const ab = 16u * MSV * cols * 16u; \
+      probeRegister<2, MSV><<<64, 64>>>(out, A, X1g, aBytes, ab, 1048576, 2, cols, 2048, 4); \
+      CHECK(hipDeviceSynchronize()); \
+      CHECK(hipMemcpy(h0.data(), out, nOut * 8, hipMemcpyDeviceToHost)); \
+      CHECK(hipMemset(out, 0, nOut * 8)); \
+      probeSharedX<2, MSV><<<16, 256>>>(out, A, X1g, aBytes, ab, 1048576, 2, cols, 2048, cnt); \
+      CHECK(hipDeviceSynchronize()); \
+      CHECK(hipMemcpy(h1.data(), out, nOut * 8, hipMemcpyDeviceToHost)); \
+      size_t diff = 0; \
+      for (size_t i = 0; i < nOut; ++i) if ((i / 64) % 4 < cnt) diff += memcmp(&h0[i], &h1[i], 8) != 0; \
+      printf("\"compare_ms%d_cnt%u_cols%u\": {\"different\": %zu},\n", MSV, cnt, cols, diff); \
+      bad |= diff != 0; \
+    }
+  COMPARE(2)
+  COMPARE(1)
+#undef COMPARE
   hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
   float ms;
   int const waves = 256 * 4 * 2;
   for (uint32_t xg : {1u, 4u}) {
-    probeRegister<2><<<waves, 64>>>(out, A, X1g, aBytes, aBytes, 1048576, 8, PROBE_COLS, 2048, xg);
+    probeRegister<2, 2><<<waves, 64>>>(out, A, X1g, aBytes, aBytes, 1048576, 8, PROBE_COLS, 2048, xg);
     CHECK(hipDeviceSynchronize());
     CHECK(hipEventRecord(e0));
-    probeRegister<2><<<waves, 64>>>(out, A, X1g, aBytes, aBytes, 1048576, reps, PROBE_COLS, 2048, xg);
+    probeRegister<2, 2><<<waves, 64>>>(out, A, X1g, aBytes, aBytes, 1048576, reps, PROBE_COLS, 2048, xg);
     CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
     CHECK(hipEventElapsedTime(&ms, e0, e1));
     report(xg == 1 ? "register_loop_x_private_to_a_wavefront_1gb" : "register_loop_x_shared_by_4_neighbours_1gb", ms, waves, reps);
   }
-  probeSharedX<2><<<waves / 4, 256>>>(out, A, X1g, aBytes, aBytes, 1048576, 8, PROBE_COLS, 2048);
+  probeSharedX<2, 2><<<waves / 4, 256>>>(out, A, X1g, aBytes, aBytes, 1048576, 8, PROBE_COLS, 2048, 4);
   CHECK(hipDeviceSynchronize());
   CHECK(hipEventRecord(e0));
-  probeSharedX<2><<<waves / 4, 256>>>(out, A, X1g, aBytes, aBytes, 1048576, reps, PROBE_COLS, 2048);
+  probeSharedX<2, 2><<<waves / 4, 256>>>(out, A, X1g, aBytes, aBytes, 1048576, reps, PROBE_COLS, 2048, 4);
   CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
   CHECK(hipEventElapsedTime(&ms, e0, e1));
   report("shared_x_loop_4_wavefronts_per_workgroup_1gb", ms, waves, reps);
