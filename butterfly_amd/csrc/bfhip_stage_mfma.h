@@ -449,10 +449,11 @@ __device__ __forceinline__ void bfMfmaDispatch(uint32_t nt, StageParams const &p
 // (tools/mfma_sharedx_probe.hip compares them; the GPU suite passes with either kernel).
 // What it does (N = 262144, 64 RHS, counters over the shared bundles alone, 83 - 93 % of a stage's work): HBM traffic 1.08x the
 // algorithmic bytes instead of 1.4x, clock +6 % -- and the matrix pipe busy 0.80 of the cycles instead of 0.87: four wavefronts
-// that wait for each other at every k-step, at every segment's table (written by wavefront 0) and at every segment's first requests.
+// that wait for each other at every k-step and at every segment's first requests (and, in the first version, for the ONE table that
+// wavefront 0 wrote: every wavefront writes its own copy now, 1 % of the apply).
 // On the bare machine (the probe: no items, no tables) the loop is 9 - 17 % faster than the register loop; in the kernel the shared
-// bundles are 2 - 5 % faster per unit of work, the mixed ones 2 % slower than one-wavefront workgroups, the whole apply 31.2 - 31.7 ms
-// against 30.3 - 30.6 for the one-wavefront kernel on the same plan, same box.  DESIGN.md section 9.
+// bundles are 2 - 5 % faster per unit of work, the mixed ones 2 % slower than one-wavefront workgroups, the whole apply 30.65 - 30.88 ms
+// against 30.13 - 30.22 for the one-wavefront kernel, same box.  DESIGN.md section 9.
 #define BF_MF_SX_SLOT 4096u
 #define BF_MF_SX_RING (3u * BF_MF_SX_SLOT)
 #ifndef BF_MF_BUNDLES
@@ -546,8 +547,9 @@ __device__ __forceinline__ void bfSxSegment(bf_d4 (&acc)[3][2][4], BfMfSeg const
   asm volatile("s_barrier" ::: "memory");
 }
 
-// One pass of one wavefront of a bundle: rows [0, mr <= 16 MS) x RHS [q0, q0 + 64) of ITS item; the segment table (the same for every
-// wavefront of the bundle) is written by wavefront 0 into the workgroup's one table.
+// One pass of one wavefront of a bundle: rows [0, mr <= 16 MS) x RHS [q0, q0 + 64) of ITS item.  Every wavefront writes its own copy
+// of the segment table (the same rows for all of them): with ONE table, written by wavefront 0, the other three waited for it at
+// every segment.
 template <int MS, bool GAUSS>
 __device__ __forceinline__ void bfMfmaPassBundle(StageParams const &p, BfDevItem const &it, uint32_t mr, uint32_t q0, uint32_t *tab, int lane, uint32_t ring, uint32_t wave, uint32_t mine) {
   uint32_t const nrhs = p.nrhs;
@@ -565,7 +567,7 @@ __device__ __forceinline__ void bfMfmaPassBundle(StageParams const &p, BfDevItem
   uint32_t pi = 0;
   while (pi < np) {
     // every wavefront walks ITS item's descriptors (same input rows and widths for all of them, its own leaf offsets) and finds the
-    // same segment; wavefront 0 writes the table
+    // same segment
     uint32_t cols = 0, minRow = 0, maxRow = 0, inX = 0;
     uint64_t aOff = 0, expect = 0;
     bool started = false;
@@ -592,19 +594,16 @@ __device__ __forceinline__ void bfMfmaPassBundle(StageParams const &p, BfDevItem
       }
       minRow = lo;
       maxRow = hi;
-      if (wave == 0) for (uint32_t j = (uint32_t)lane; j < pc.ncols; j += 64u) tab[cols + j] = pc.inOff + j;
+      for (uint32_t j = (uint32_t)lane; j < pc.ncols; j += 64u) tab[cols + j] = pc.inOff + j;
       cols += pc.ncols;
       expect = pc.dataOff + (uint64_t)mr * pc.ncols;
       ++pi;
     }
     if (!cols) break;                      // identity pieces only (the same for every wavefront of the bundle)
-    if (wave == 0) {
-      if ((uint32_t)lane < BF_MF_TABPAD) tab[cols + lane] = minRow;
-      waveSync();
-      for (uint32_t j = (uint32_t)lane; j < cols + BF_MF_TABPAD; j += 64u) tab[j] = (tab[j] - minRow) * (nrhs * 16u);
-      waveSync();
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // the table is there for everybody
+    if ((uint32_t)lane < BF_MF_TABPAD) tab[cols + lane] = minRow;
+    waveSync();
+    for (uint32_t j = (uint32_t)lane; j < cols + BF_MF_TABPAD; j += 64u) tab[j] = (tab[j] - minRow) * (nrhs * 16u);
+    waveSync();
     BfMfSeg sg;
     sg.stepA = 4u * mr * 16u;
     sg.ksteps = (cols + 3u) / 4u;
@@ -646,7 +645,7 @@ __device__ __forceinline__ void bfStageBodyC128MfmaBundles(StageParams const &p,
   uint32_t mine = 0;
   for (uint32_t t = 0; t < 4u; ++t) if (t % cnt == wave) mine |= 1u << t;
   mine = __builtin_amdgcn_readfirstlane(mine);
-  uint32_t *tab = tabs[mixed ? wave : 0u];
+  uint32_t *tab = tabs[wave];
   for (uint32_t q0 = 0; q0 < nrhs; q0 += 64) {
     if (!mixed) {                          // (bfPlanBundles: <= 32 rows each, the same number of slabs)
       // (the last, partial 64-RHS block of a wider right-hand side runs all four tiles: the columns past nrhs are whatever follows
