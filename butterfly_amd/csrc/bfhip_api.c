@@ -1583,6 +1583,50 @@ static BfAbiMat *shimMul(BfAbiMat const *lhs, BfAbiMat const *rhs) {
   return shimMulImpl(rhs, (BfhipMat const *)lhs, ((BfhipMat const *)lhs)->transposed);
 }
 
+/* bfMatRmul(A_hip, X) = X A (slot 44, src/mat.c:195-197; bfMatProductRmul walks the factors in order, src/mat_product.c:282-310, down
+ * to bfMatDenseComplexRmul's one zgemm, src/mat_dense_complex.c:1075-1133 -- a dense complex `otherMat` only, :1125-1133).
+ * X A = (A^T X^T)^T: the adjoint plan applied to the rows of X as right-hand sides.  X^T is gathered into a packed copy (any row /
+ * column stride of X), the result is scattered into a matrix allocated through X's EmptyLike.  After bfMatTranspose the object
+ * stands for A^H (shimMulImpl): X A^H = conj(conj(X) A^T) = conj((A conj(X)^T)^T), the FORWARD plan between two conjugations. */
+static BfAbiMat *shimRmul(BfAbiMat const *lhs, BfAbiMat const *other) {
+  BfhipMat const *self = (BfhipMat const *)lhs;
+  BfhipOperator *op = self ? self->op : NULL;
+  if (!op || !other || !other->vtbl) SHIM_FAIL(BFABI_ERROR_INVALID_ARGUMENTS, "NULL operand");
+  int const conj = self->transposed, transpose = !self->transposed;          /* which plan runs */
+  if (transpose && !op->hasTplan) SHIM_FAIL(BFABI_ERROR_NOT_IMPLEMENTED, "Rmul needs an operator compiled with BFHIP_FLAG_ADJOINT");
+  BfAbiGetTypeFn getType = (BfAbiGetTypeFn)other->vtbl->slot[BFABI_SLOT_GetType];
+  if (!getType || getType(other) != BFABI_TYPE_MAT_DENSE_COMPLEX || op->srcDtype != BFHIP_C128)
+    SHIM_FAIL(BFABI_ERROR_NOT_IMPLEMENTED, "Rmul needs a complex operator and a BfMatDenseComplex left operand");
+  if (other->props & (BFABI_MAT_PROPS_TRANS | BFABI_MAT_PROPS_CONJ)) SHIM_FAIL(BFABI_ERROR_NOT_IMPLEMENTED, "transposed left operand");
+  /* rows / columns of what the object stands for */
+  uint64_t const rows = self->transposed ? shimOpCols(self) : shimOpRows(self), cols = self->transposed ? shimOpRows(self) : shimOpCols(self);
+  size_t const m = other->numRows, k = other->numCols;
+  if (k != rows) SHIM_FAIL(BFABI_ERROR_INCOMPATIBLE_SHAPES, "operator has %llu rows, left operand %llu columns", (unsigned long long)rows, (unsigned long long)k);
+  BfAbiLikeFn emptyLike = (BfAbiLikeFn)other->vtbl->slot[BFABI_SLOT_EmptyLike];
+  if (!emptyLike) SHIM_FAIL(BFABI_ERROR_INVALID_ARGUMENTS, "left operand has no EmptyLike");
+  BfAbiMatDenseComplex const *x = (BfAbiMatDenseComplex const *)other;
+  double *xt = malloc((k && m ? k * m : 1) * 16), *zt = malloc((cols && m ? cols * m : 1) * 16);
+  if (!xt || !zt) { free(xt); free(zt); SHIM_FAIL(BFABI_ERROR_MEMORY_ERROR, "host OOM"); }
+  for (size_t q = 0; q < m; ++q)
+    for (size_t i = 0; i < k; ++i) {
+      double const *e = (double const *)((char const *)x->data + (q * x->rowStride + i * x->colStride) * 16);
+      xt[2 * (i * m + q)] = e[0]; xt[2 * (i * m + q) + 1] = conj ? -e[1] : e[1];
+    }
+  int rc = shimApplyHost(self, transpose, xt, m, m, zt, m);          /* (k x m) -> (cols x m) */
+  free(xt);
+  if (rc) { free(zt); shimRaise(rc); return NULL; }
+  BfAbiMat *res = emptyLike(other, m, cols);
+  if (!res) { free(zt); SHIM_FAIL(BFABI_ERROR_MEMORY_ERROR, "EmptyLike failed"); }
+  BfAbiMatDenseComplex *y = (BfAbiMatDenseComplex *)res;
+  for (size_t q = 0; q < m; ++q)
+    for (size_t j = 0; j < cols; ++j) {
+      double *d = (double *)((char *)y->data + (q * y->rowStride + j * y->colStride) * 16);
+      d[0] = zt[2 * (j * m + q)]; d[1] = conj ? -zt[2 * (j * m + q) + 1] : zt[2 * (j * m + q) + 1];
+    }
+  free(zt);
+  return res;
+}
+
 /* bfMatTranspose (slot 63, src/mat.c:271-273): in place, as bfMatProductTranspose reverses and transposes its factors
  * (src/mat_product.c:409-420).  The adjoint plan over the same packed leaves exists already (BFHIP_FLAG_ADJOINT), so the
  * object only changes which of its two plans Mul / MulVec / RmulVec run and what GetNumRows / GetNumCols answer; twice
@@ -1645,6 +1689,7 @@ static BfAbiMatVtable ShimVtable = {.slot = {
   [BFABI_SLOT_GetNumRows] = (void *)shimGetNumRows,
   [BFABI_SLOT_GetNumCols] = (void *)shimGetNumCols,
   [BFABI_SLOT_Mul] = (void *)shimMul,
+  [BFABI_SLOT_Rmul] = (void *)shimRmul,
   [BFABI_SLOT_MulVec] = (void *)shimMulVec,
   [BFABI_SLOT_Transpose] = (void *)shimTranspose,
 }};

@@ -457,14 +457,17 @@ void bfhipFree(BfhipOperator **op);
 
 /* ---- reference-vtable shim ----------------------------------------------- */
 
-/* A `BfMat *` whose vtable implements Mul, MulVec, RmulVec, Transpose, GetView, GetNumRows,
+/* A `BfMat *` whose vtable implements Mul, Rmul, MulVec, RmulVec, Transpose, GetView, GetNumRows,
  * GetNumCols, GetType (-> BF_TYPE_MAT_FUNC), NumBytes and Delete on top of
  * `op`, so that unmodified reference code (bfSolveGMRES src/linalg.c:125,155;
  * cov_matvec examples/covariance/lbo_cov.c:48-60; an enclosing BfMatBlockDense,
  * src/mat_block_dense.c:541-563) can call bfMatMul / bfMatMulVec / bfMatRmulVec
  * on it.  Mul results are allocated through the RHS's own vtable (`EmptyLike`,
  * slot 8) so that the reference's bfMatDelete frees them
- * (mat_dense_complex.c:2164-2187); MulVec / RmulVec results are malloc'd
+ * (mat_dense_complex.c:2164-2187); Rmul (slot 44: bfMatRmul(A, X) = X A for a
+ * BfMatDenseComplex X, src/mat.c:195-197, src/mat_product.c:282-310,
+ * src/mat_dense_complex.c:1075-1133) applies the adjoint plan to the rows of X
+ * (BFHIP_FLAG_ADJOINT) and allocates X A the same way; MulVec / RmulVec results are malloc'd
  * BfVecReal of the operator's row / column count carrying the argument's
  * vtable (rectangular operators are fine).  Transpose (slot 63, bfMatTranspose,
  * src/mat.c:271-273) works in place like bfMatProductTranspose

@@ -87,6 +87,13 @@ BfVec *bfMatMulVec(BfMat const *lhs, BfVec const *rhs) {
 BfVec *bfMatRmulVec(BfMat const *lhs, BfVec const *rhs) {
   return SLOT(lhs, BFABI_SLOT_RmulVec, BfAbiMulVecFn)(lhs, rhs);
 }
+/* src/mat.c:195-197: bfMatRmul(mat, otherMat) = otherMat * mat.  (A type without the slot -- every block type: the reference's own
+ * chain ends in a NULL call at BlockCoo / BlockDiag -- is an error here.) */
+BfMat *bfMatRmul(BfMat const *mat, BfMat const *otherMat) {
+  BfAbiMulFn f = SLOT(mat, BFABI_SLOT_Rmul, BfAbiMulFn);
+  if (!f) { setError(BFABI_ERROR_NOT_IMPLEMENTED); return NULL; }
+  return f(mat, otherMat);
+}
 void bfMatDelete(BfMat **mat) {
   if (mat && *mat) SLOT(*mat, BFABI_SLOT_Delete, BfAbiDeleteFn)(mat);
 }
@@ -375,6 +382,25 @@ static BfMat *denseComplexMul(BfMat const *op1, BfMat const *op2) {
   }
   return &c->super;
 }
+/* :1075-1133 Rmul: result (m x n) = other (m x k) * this (k x n), one zgemm; a dense complex `other` only (:1125-1133).  Flagged
+ * operands are not on this path; refused. */
+static BfMat *denseComplexRmul(BfMat const *mat, BfMat const *other) {
+  if (bfMatGetType(other) != BFABI_TYPE_MAT_DENSE_COMPLEX) { setError(BFABI_ERROR_NOT_IMPLEMENTED); return NULL; }
+  if ((mat->props | other->props) & (BFABI_MAT_PROPS_TRANS | BFABI_MAT_PROPS_CONJ)) { setError(BFABI_ERROR_NOT_IMPLEMENTED); return NULL; }
+  size_t const m = bfMatGetNumRows(other), n = bfMatGetNumCols(mat), k = bfMatGetNumCols(other);
+  if (k != bfMatGetNumRows(mat)) { setError(BFABI_ERROR_INCOMPATIBLE_SHAPES); return NULL; }
+  if (!(m > 0 && n > 0 && k > 0)) { setError(BFABI_ERROR_INVALID_ARGUMENTS); return NULL; }
+  BfAbiMatDenseComplex const *a = (BfAbiMatDenseComplex const *)other, *b = (BfAbiMatDenseComplex const *)mat;
+  BfAbiMatDenseComplex *c = denseComplexNewInit(m, n, 0);
+  ++counters.gemmCalls;
+  counters.macs += (uint64_t)m * n * k;
+  if (blas_zgemm) {
+    double alpha[2] = {1, 0}, beta[2] = {0, 0};
+    blas_zgemm(101 /*RowMajor*/, 111, 111, (int)m, (int)n, (int)k, alpha, a->data, (int)a->rowStride, b->data, (int)b->rowStride, beta, c->data, (int)c->rowStride);
+  } else
+    zgemm_builtin(m, n, k, (cplx const *)a->data, a->rowStride, (cplx const *)b->data, b->rowStride, (cplx *)c->data, c->rowStride);
+  return &c->super;
+}
 /* :1475-1478 */
 static void denseComplexTranspose(BfMat *mat) { mat->props ^= (BFABI_MAT_PROPS_TRANS | BFABI_MAT_PROPS_CONJ); }
 
@@ -391,6 +417,7 @@ static BfAbiMatVtable MatDenseComplexVtable = {.slot = {
   [BFABI_SLOT_SetRowRange] = (void *)denseComplexSetRowRange,
   [BFABI_SLOT_AddInplace] = (void *)denseComplexAddInplace,
   [BFABI_SLOT_Mul] = (void *)denseComplexMul,
+  [BFABI_SLOT_Rmul] = (void *)denseComplexRmul,
   [BFABI_SLOT_Transpose] = (void *)denseComplexTranspose,
 }};
 
@@ -1007,6 +1034,20 @@ static BfMat *productMul(BfMat const *matProduct, BfMat const *otherMat) {
   }
   return result;
 }
+/* :282-310 Rmul: mat * F0 * F1 * ... * F_{L-1}, factors in order */
+static BfMat *productRmul(BfMat const *matProduct, BfMat const *mat) {
+  if (bfMatGetNumCols(mat) != bfMatGetNumRows(matProduct)) { setError(BFABI_ERROR_INVALID_ARGUMENTS); return NULL; }
+  BfMat *prev = bfMatRmul(productFactor(matProduct, 0), mat);
+  BfMat *result = prev;
+  if (currentError) { bfMatDelete(&prev); return NULL; }
+  for (size_t i = 1; i < productNumFactors(matProduct); ++i) {
+    result = bfMatRmul(productFactor(matProduct, i), prev);
+    bfMatDelete(&prev);
+    if (currentError) { bfMatDelete(&result); return NULL; }
+    prev = result;
+  }
+  return result;
+}
 /* :247-280 */
 static BfVec *productMulVec(BfMat const *matProduct, BfVec const *vec) {
   size_t numFactors = productNumFactors(matProduct);
@@ -1056,6 +1097,7 @@ static BfAbiMatVtable MatProductVtable = {.slot = {
   [BFABI_SLOT_GetNumRows] = (void *)productGetNumRows,
   [BFABI_SLOT_GetNumCols] = (void *)productGetNumCols,
   [BFABI_SLOT_Mul] = (void *)productMul,
+  [BFABI_SLOT_Rmul] = (void *)productRmul,
   [BFABI_SLOT_MulVec] = (void *)productMulVec,
 }};
 BfMat *bfMatProductNewFromFactors(size_t numFactors, BfMat **factors) {

@@ -40,6 +40,7 @@ def load():
     lib.bfMatMul.argtypes = [vp, vp]; lib.bfMatMul.restype = vp
     lib.bfMatMulVec.argtypes = [vp, vp]; lib.bfMatMulVec.restype = vp
     lib.bfMatRmulVec.argtypes = [vp, vp]; lib.bfMatRmulVec.restype = vp
+    lib.bfMatRmul.argtypes = [vp, vp]; lib.bfMatRmul.restype = vp
     lib.bfMatDelete.argtypes = [C.POINTER(vp)]; lib.bfMatDelete.restype = None
     lib.bfMatTranspose.argtypes = [vp]; lib.bfMatTranspose.restype = None
     lib.bfrefMatFromDescTyped.argtypes = [vp, C.c_uint64, C.c_uint64]; lib.bfrefMatFromDescTyped.restype = vp
@@ -210,6 +211,20 @@ def mat_mul(a: Mat, x: np.ndarray) -> np.ndarray:
     Y = Mat(r)
     out = Y.to_numpy()
     return out[:, 0] if np.ndim(x) == 1 else out
+
+
+def mat_rmul(a: Mat, x: np.ndarray) -> np.ndarray:
+    """Z = bfMatRmul(A, X) = X A with X an m x numRows(A) complex128 array (src/mat.c:195-197; Product and DenseComplex fill
+    the slot, src/mat_product.c:282-310, src/mat_dense_complex.c:1075-1133; the block types do not)."""
+    lib = load()
+    X = dense_complex(x)
+    lib.bfClearError()
+    r = lib.bfMatRmul(a.ptr, X.ptr)
+    if not r:
+        err = lib.bfGetError()
+        lib.bfClearError()
+        raise RuntimeError(f"oracle bfMatRmul returned NULL (BfError {err})")
+    return Mat(r).to_numpy()
 
 
 def mat_mul_vec(a: Mat, x: np.ndarray) -> np.ndarray:

@@ -67,6 +67,57 @@ def test_dropin_vtable_shim(helm2_cases):
     op.close()
 
 
+def test_rmul_slot_of_the_shim(helm2_cases):
+    """bfMatRmul(A_hip, X) = X A through the oracle's own dispatch (src/mat.c:195-197): the adjoint plan applied to the rows of X;
+    as the last factor of an oracle Product (bfMatProductRmul walks the factors in order, src/mat_product.c:282-310); after
+    bfMatTranspose the object stands for A^H, as the reference's transposed complex leaves do; a left operand of the wrong
+    width and an operator without an adjoint plan raise the reference's error state and return NULL."""
+    from butterfly_amd import _capi
+    from butterfly_amd.operator import HipOperator
+    from oracle import bfref
+    n, k = 2048, 128
+    desc, tp, vals = helm2_cases(n, k)
+    A = bfref.from_desc(desc, vals)
+    dense = bfref.mat_mul(A, np.eye(n, dtype=complex))
+    op = HipOperator.from_bfmat(A.ptr.value, flags=_capi.FLAG_ADJOINT)
+    a_hip = op.as_bfmat()
+    h = _handle(a_hip, (n, n))
+    rng = np.random.default_rng(44)
+    c = lambda m, q: rng.standard_normal((m, q)) + 1j * rng.standard_normal((m, q))
+    for m in (1, 5):
+        x = c(m, n)
+        z = bfref.mat_rmul(h, x)
+        assert z.shape == (m, n) and rel(z, x @ dense) <= 1e-11
+    # X F0 A_hip: the shim as the last factor of a reference product
+    f0 = c(37, n) / np.sqrt(n)
+    x = c(4, 37)
+    first = bfref.mat_rmul(bfref.dense_complex(f0), x)                     # X F0
+    assert rel(bfref.mat_rmul(h, first), x @ f0 @ dense) <= 1e-11
+    # wrong width
+    lib = bfref.load()
+    lib.bfClearError()
+    with pytest.raises(RuntimeError):
+        bfref.mat_rmul(h, c(2, n - 1))
+    # transposed object: X A^H
+    bfref.mat_transpose(h)
+    x = c(3, n)
+    assert rel(bfref.mat_rmul(h, x), x @ dense.conj().T) <= 1e-11
+    bfref.mat_transpose(h)
+    assert rel(bfref.mat_rmul(h, x), x @ dense) <= 1e-11
+    p = C.c_void_p(a_hip)
+    lib.bfMatDelete(C.byref(p))
+    op.close()
+    # without an adjoint plan: NOT_IMPLEMENTED, NULL
+    op = HipOperator.from_bfmat(A.ptr.value)
+    a_hip = op.as_bfmat()
+    lib.bfClearError()
+    with pytest.raises(RuntimeError):
+        bfref.mat_rmul(_handle(a_hip, (n, n)), c(2, n))
+    p = C.c_void_p(a_hip)
+    lib.bfMatDelete(C.byref(p))
+    op.close()
+
+
 def test_shim_takes_a_column_strided_right_hand_side(helm2_cases):
     """A BfMatDenseComplex whose colStride is not 1 (every other column of a wider matrix: what a column-range view of
     the reference looks like, src/mat_dense_complex.c:648-672) through the shim's Mul slot: gathered, applied, and

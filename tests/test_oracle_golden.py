@@ -135,6 +135,25 @@ def test_oracle_block_types_against_numpy():
     assert prod.num_bytes() == 16 * (sum(v.size for v in g) + e.size + f.size)
 
 
+def test_oracle_rmul_walks_a_product_of_dense_factors_in_order():
+    """bfMatRmul(P, X) = X F0 F1 F2 (src/mat_product.c:282-310 down to bfMatDenseComplexRmul's one zgemm,
+    src/mat_dense_complex.c:1075-1133); a mismatched left operand and a factor type without the slot (every block type: the
+    reference's own chain is a NULL call there) are errors."""
+    rng = np.random.default_rng(17)
+    c = lambda m, n: rng.standard_normal((m, n)) + 1j * rng.standard_normal((m, n))
+    f = [c(9, 6), c(6, 11), c(11, 4)]
+    prod = bfref.product([bfref.dense_complex(v) for v in f])
+    x = c(5, 9)
+    assert rel(bfref.mat_rmul(prod, x), x @ f[0] @ f[1] @ f[2]) < 1e-14
+    y = c(3, 6)
+    assert rel(bfref.mat_rmul(bfref.dense_complex(f[1]), y), y @ f[1]) < 1e-14
+    with pytest.raises(RuntimeError):
+        bfref.mat_rmul(prod, c(5, 8))
+    diag = bfref.block_diag([bfref.dense_complex(c(4, 4)), bfref.dense_complex(c(5, 5))])
+    with pytest.raises(RuntimeError):
+        bfref.mat_rmul(bfref.product([diag]), c(2, 9))
+
+
 @pytest.mark.parametrize("seed", range(6))
 def test_oracle_transpose_is_the_conjugate_transpose_for_complex_leaves(seed):
     """bfMatTranspose through the restated slots (Product :409-420, BlockDiag mat_block_diag.c:603-624, BlockDense
