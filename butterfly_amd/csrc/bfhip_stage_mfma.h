@@ -453,7 +453,8 @@ __device__ __forceinline__ void bfMfmaDispatch(uint32_t nt, StageParams const &p
 // wavefront 0 wrote: every wavefront writes its own copy now, 1 % of the apply).
 // On the bare machine (the probe: no items, no tables) the loop is 9 - 17 % faster than the register loop; in the kernel the shared
 // bundles are 2 - 5 % faster per unit of work, the mixed ones 2 % slower than one-wavefront workgroups, the whole apply 30.65 - 30.88 ms
-// against 30.13 - 30.22 for the one-wavefront kernel, same box.  DESIGN.md section 9.
+// against 30.13 - 30.22 for the one-wavefront kernel, same box.  Not the barrier itself (without it, wrong results: the same time) and
+// not the order of the bundles (shuffled inside their cost buckets: the same time).  DESIGN.md section 9.
 #define BF_MF_SX_SLOT 4096u
 #define BF_MF_SX_RING (3u * BF_MF_SX_SLOT)
 #ifndef BF_MF_BUNDLES
