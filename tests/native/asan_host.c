@@ -37,6 +37,16 @@ static int drive(double const *pts, uint64_t n, double const *tgt, uint64_t m, d
         v.structSize = sizeof v;
         CHECK(bfhipPlanGetStage(op, s, &v));
         items += v.numItems;
+        /* the bundle table of forward complex stages: a partition of the item list into runs of <= 4 */
+        if (v.bundleBegin) {
+          uint32_t prev = 0;
+          for (uint64_t b_ = 0; b_ <= v.numBundles; ++b_) {
+            uint32_t const f = v.bundleBegin[b_] & 0x7fffffffu;
+            if ((b_ == 0 && f != 0) || (b_ > 0 && (f <= prev || f - prev > 4)) || f > v.numItems) return 7;
+            prev = f;
+          }
+          if (prev != v.numItems) return 7;
+        }
         for (uint64_t r = 0; r < v.numReduce; ++r) {
           BfhipReduceView rv;
           memset(&rv, 0, sizeof rv);
