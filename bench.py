@@ -919,7 +919,7 @@ def main():
         }
         if multi:
             out["multi_gpu"] = multi
-        if args.adjoint and world == 1:
+        if args.adjoint and world == 1 and args.emulate_world <= 1:      # (an emulated shard's adjoint partial is timed with the shards, below)
             xt = torch.from_numpy(rng.standard_normal((local_rows,) + shape[1:]) if real else x_host).to(dev).to(tdtype)
             for _ in range(2):
                 yt = op.apply_transpose_device(xt)
@@ -1038,10 +1038,25 @@ def main():
                 o.apply_device(x, yb)
             torch.cuda.synchronize()
             times.append({"rank": r, "leaf_gb": o.stats()["leafBytes"] / 1e9, "ms_per_apply": (time.perf_counter() - t1) / args.steps * 1e3})
+            if args.adjoint:
+                # the rank's part of the sharded adjoint step: A_r^T on its rows of v (shared leaves), before the one all-reduce
+                vr = torch.randn((rows,) + shape[1:], dtype=tdtype, device=dev)
+                zb = torch.empty(shape, dtype=tdtype, device=dev)
+                for _ in range(2):
+                    o.apply_transpose_device(vr, zb)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(args.steps):
+                    o.apply_transpose_device(vr, zb)
+                torch.cuda.synchronize()
+                times[-1]["adjoint_ms_per_apply"] = (time.perf_counter() - t1) / args.steps * 1e3
+                del vr, zb
             o.close()
             del yb
         out["emulated_shard"]["all_ranks"] = times
         out["emulated_shard"]["slowest_ms"] = max(t["ms_per_apply"] for t in times)
+        if all("adjoint_ms_per_apply" in t for t in times):
+            out["emulated_shard"]["adjoint_slowest_ms"] = max(t["adjoint_ms_per_apply"] for t in times)
         op = None
 
     # BASELINE configs[2] rides along on the default line: the same operand applied to 64 right-hand sides

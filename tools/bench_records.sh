@@ -24,6 +24,8 @@ if [ "$PART" = all ] || [ "$PART" = shards ]; then
 # every rank's shard of a 2 / 4 / 8-GPU job, one after another on this GPU (the slowest bounds the job)
 for w in 2 4 8; do run ${TAG}_bench_n262144_shards${w}_emulated $B --emulate-world $w --emulate-rank -1 --steps 20 --no-cpu-baseline --no-extra; done
 for m in rows rowsum blocks; do run ${TAG}_bench_n262144_shards8_${m}_emulated $B --emulate-world 8 --emulate-rank -1 --steps 20 --shard $m --no-cpu-baseline --no-extra; done
+# ... and every rank's part of the sharded ADJOINT step (A_r^T on its rows of v, shared leaves), before the one all-reduce
+for m in rows rowsum; do run ${TAG}_bench_n262144_shards8_${m}_adjoint_emulated $B --emulate-world 8 --emulate-rank -1 --steps 20 --shard $m --adjoint --no-cpu-baseline --no-extra; done
 run ${TAG}_bench_n1048576_shards8_emulated    $B --npoints 1048576 --emulate-world 8 --emulate-rank -1 --steps 10 --no-cpu-baseline --no-extra
 fi
 if [ "$PART" = all ] || [ "$PART" = streamer ]; then
