@@ -440,8 +440,9 @@ __device__ __forceinline__ void bfMfmaDispatch(uint32_t nt, StageParams const &p
 // stage (reference src/fac_helm2.c:277-318) multiply different leaf rows by the same rows of the input; the planner keeps them
 // together in the list and bfPlanBundles marks runs of four with equal inputs, <= 32 rows and the same number of slabs (SHARED
 // bundles: ONE pass each, the same number of k-steps); everything else goes four unrelated items to a workgroup (MIXED bundles, the
-// one-wavefront passes above -- a workgroup must keep all four SIMDs busy: workgroups whose other wavefronts had exited ran at a fifth
-// of the rate).  In a shared bundle every wavefront streams its own leaf fragments into registers exactly as bfMfmaSegment does; the
+// one-wavefront passes above -- a workgroup must keep its four wavefronts alive: a new workgroup needs a free slot on EVERY SIMD
+// (tools/wave_placement_probe.hip: its four wavefronts always land on four different SIMDs), so survivors of workgroups whose other
+// wavefronts had exited block the CU as soon as one SIMD holds two of them -- such workgroups ran at a fifth of the rate).  In a shared bundle every wavefront streams its own leaf fragments into registers exactly as bfMfmaSegment does; the
 // four X tiles of a k-step are fetched ONCE per workgroup -- wavefront w brings tile w as an LDS-DMA, two k-steps ahead, into a ring of
 // three 4 KiB slots -- and every wavefront reads them with ds_read_b128 right after the MFMAs that used the previous k-step's copy.
 // One workgroup barrier per k-step: behind it the next k-step's slot is complete and nobody still reads the slot before the current
@@ -619,8 +620,8 @@ __device__ __forceinline__ void bfMfmaPassBundle(StageParams const &p, BfDevItem
 }
 
 // The 64-RHS kernel's body: workgroup = bundle of four items.  SHARED bundles run the loop above; MIXED ones (items that found nobody
-// to share with, taller ones, zero fills) the one-wavefront passes, four unrelated items side by side -- a workgroup always fills
-// all four SIMDs (measured: workgroups that kept one live wavefront ran at a fifth of the rate, their survivors crowd one SIMD).
+// to share with, taller ones, zero fills) the one-wavefront passes, four unrelated items side by side -- a workgroup always keeps
+// four live wavefronts (measured: workgroups that kept one ran at a fifth of the rate; see the note on bundles above).
 template <bool GAUSS>
 __device__ __forceinline__ void bfStageBodyC128MfmaBundles(StageParams const &p, uint32_t (*tabs)[BF_MF_TABCAP + BF_MF_TABPAD], char *ringMem) {
   int const lane = threadIdx.x & 63;
