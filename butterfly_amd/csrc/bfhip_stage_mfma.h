@@ -53,6 +53,9 @@
 #ifndef BF_MFMA_MIN_RHS
 #define BF_MFMA_MIN_RHS 2
 #endif
+#ifndef BF_MF_QUARTER
+#define BF_MF_QUARTER 1            /* the 64-RHS kernel runs the ragged last slab of an item on v_mfma_f64_4x4x4 (A/B builds: 0) */
+#endif
 // (Round 5, measured and removed: with BF_MF_WG_WAVES = 2 / 4 / 8 an s_barrier every pair of k-steps, so that list neighbours -- which
 // walk the same X rows -- pace each other and their X requests reach the L2 together: 31.38 / 31.67 / 34.07 ms against 30.91 with
 // one-wavefront workgroups; 4 wavefronts without the barrier 31.51.  DESIGN.md section 9.)
@@ -190,6 +193,129 @@ __device__ __forceinline__ void bfMfmaSegment(bf_d4 (&acc)[3][2][4], BfMfSeg con
   // the requests of the k-steps past the end (zeros from the range check / a padded table row) must land before the
   // registers are used again
   asm volatile("s_waitcnt vmcnt(0)" : "+v"(a[0][0].u), "+v"(a[0][MS > 1 ? 1 : 0].u), "+v"(x[0].u), "+v"(x[NT > 1 ? 1 : 0].u), "+v"(x[NT > 2 ? 2 : 0].u), "+v"(x[NT > 3 ? 3 : 0].u));
+}
+
+// ---- the ragged last slab of a pass on v_mfma_f64_4x4x4 (round 5) ----------------------------------------------------------------------
+// Row groups are ranks of (target, source) pairs -- 17 - 24 rows are common -- and an item's last 16-row slab is mostly padding (N =
+// 262144: 4.4 % of all MFMA time, N = 65536: 10 %).  v_mfma_f64_4x4x4 computes four independent 4 x 4 x 4 blocks in a quarter of the
+// big instruction's time (tools/mfma_4x4x4_probe.hip: A[i][k] in lane 16 k + 4 b + i, B[k][j] in lane 16 k + 4 b + j, D[i][j] in lane
+// 16 i + 4 b + j for block b; 0.88 of the big instruction's flop rate).  Its B operand is the 16 x 16 x 4 X FRAGMENT AS IT STANDS -- block
+// b = right-hand sides 4 b ... 4 b + 3 -- and the SAME four leaf rows go to every block: a quarter fragment is one more leaf load whose
+// lanes take row (lane & 3) instead of row (lane & 15).  A tail of t = 1 ... 12 rows runs as ceil(t / 4) quarter slabs (QT), next to MS = 0
+// or 1 full slabs; 13 ... 16 rows stay a full slab.  Accumulators: one double per lane, tile and product.  Same waits as bfMfmaSegment
+// with MS + QT leaf requests per k-step.  (The sums of a 4 x 4 x 4 block and of a 16 x 16 x 4 tile may round differently: results are not
+// bit-identical to the all-full-slab kernel, equally accurate.)
+template <int MS, int QT, int SET>
+__device__ __forceinline__ void bfMfmaRequestAQ(BfFrag (&a)[2], BfFrag (&aq)[2][3], BfMfSeg const &sg, uint32_t voffAq, uint32_t soffA) {
+  if (MS > 0) bfFragLoad<1, 0>(a[SET], sg.voffA, sg.ra, soffA);
+  bfFragLoad<1, 256 * MS>(aq[SET][0], voffAq, sg.ra, soffA);
+  if (QT > 1) bfFragLoad<1, 256 * MS + 64>(aq[SET][1], voffAq, sg.ra, soffA);
+  if (QT > 2) bfFragLoad<1, 256 * MS + 128>(aq[SET][2], voffAq, sg.ra, soffA);
+}
+template <int MS, int QT, int SET, int T>
+__device__ __forceinline__ void bfMfmaTileQ(bf_d4 (&acc)[3][4], double (&accq)[3][3][4], BfFrag (&a)[2], BfFrag (&aq)[2][3], BfFrag (&x)[4], double &as, double (&asq)[3],
+                                            BfMfSeg const &sg, uint32_t voffXnext) {
+  constexpr int pending = 4 - 1 + MS + QT;
+  if (T == 0) {      // this k-step's leaf fragments and tile 0 (never the same variable twice in one statement)
+    if (MS > 0 && QT == 1) asm volatile("s_waitcnt vmcnt(%3)" : "+v"(a[SET].u), "+v"(aq[SET][0].u), "+v"(x[0].u) : "n"(pending));
+    else if (MS > 0 && QT == 2) asm volatile("s_waitcnt vmcnt(%4)" : "+v"(a[SET].u), "+v"(aq[SET][0].u), "+v"(aq[SET][1].u), "+v"(x[0].u) : "n"(pending));
+    else if (MS > 0) asm volatile("s_waitcnt vmcnt(%5)" : "+v"(a[SET].u), "+v"(aq[SET][0].u), "+v"(aq[SET][1].u), "+v"(aq[SET][2].u), "+v"(x[0].u) : "n"(pending));
+    else if (QT == 1) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(aq[SET][0].u), "+v"(x[0].u) : "n"(pending));
+    else if (QT == 2) asm volatile("s_waitcnt vmcnt(%3)" : "+v"(aq[SET][0].u), "+v"(aq[SET][1].u), "+v"(x[0].u) : "n"(pending));
+    else asm volatile("s_waitcnt vmcnt(%4)" : "+v"(aq[SET][0].u), "+v"(aq[SET][1].u), "+v"(aq[SET][2].u), "+v"(x[0].u) : "n"(pending));
+    if (MS > 0) as = a[SET].d[0] + a[SET].d[1];
+#pragma unroll
+    for (int q = 0; q < QT; ++q) asq[q] = aq[SET][q].d[0] + aq[SET][q].d[1];
+  } else asm volatile("s_waitcnt vmcnt(%1)" : "+v"(x[T].u) : "n"(pending));
+  double const xs = x[T].d[0] + x[T].d[1];
+  if (MS > 0) {
+    acc[0][T] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[SET].d[0], x[T].d[0], acc[0][T], 0, 0, 0);
+    acc[1][T] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[SET].d[1], x[T].d[1], acc[1][T], 0, 0, 0);
+    acc[2][T] = __builtin_amdgcn_mfma_f64_16x16x4f64(as, xs, acc[2][T], 0, 0, 0);
+  }
+#pragma unroll
+  for (int q = 0; q < QT; ++q) {
+    accq[0][q][T] = __builtin_amdgcn_mfma_f64_4x4x4f64(aq[SET][q].d[0], x[T].d[0], accq[0][q][T], 0, 0, 0);
+    accq[1][q][T] = __builtin_amdgcn_mfma_f64_4x4x4f64(aq[SET][q].d[1], x[T].d[1], accq[1][q][T], 0, 0, 0);
+    accq[2][q][T] = __builtin_amdgcn_mfma_f64_4x4x4f64(asq[q], xs, accq[2][q][T], 0, 0, 0);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  bfMfmaRequestX<T>(x, sg, voffXnext);
+  __builtin_amdgcn_sched_barrier(0);
+}
+// the k-loop of one segment: MS (0 or 1) full slabs + QT (1 ... 3) quarter slabs x 4 tiles, Gauss's three multiplications
+template <int MS, int QT>
+__device__ __forceinline__ void bfMfmaSegmentQ(bf_d4 (&acc)[3][4], double (&accq)[3][3][4], BfMfSeg const &sg, uint32_t voffAq, uint32_t const *tab, uint32_t lk) {
+  BfFrag a[2], aq[2][3], x[4];
+  double as = 0, asq[3];
+  uint32_t ti = lk;
+  uint32_t soffA = 0;
+  {
+    uint32_t const v0 = tab[ti] + sg.cX;
+    bfMfmaRequestAQ<MS, QT, 0>(a, aq, sg, voffAq, soffA);
+    bfMfmaRequestX<0>(x, sg, v0);
+    bfMfmaRequestX<1>(x, sg, v0);
+    bfMfmaRequestX<2>(x, sg, v0);
+    bfMfmaRequestX<3>(x, sg, v0);
+  }
+  uint32_t t1 = tab[ti + 4], t2 = tab[ti + 8];      // read an iteration ahead of their use
+  ti += 12;
+  for (uint32_t ks = 0; ks < sg.ksteps; ks += 2) {
+    uint32_t const v1 = t1 + sg.cX, v2 = t2 + sg.cX;
+    t1 = tab[ti];                                    // the table is padded past the last k-step (BF_MF_TABPAD)
+    t2 = tab[ti + 4];
+    ti += 8;
+    soffA += sg.stepA;
+    __builtin_amdgcn_sched_barrier(0);
+    bfMfmaRequestAQ<MS, QT, 1>(a, aq, sg, voffAq, soffA);
+    __builtin_amdgcn_sched_barrier(0);
+    bfMfmaTileQ<MS, QT, 0, 0>(acc, accq, a, aq, x, as, asq, sg, v1);
+    bfMfmaTileQ<MS, QT, 0, 1>(acc, accq, a, aq, x, as, asq, sg, v1);
+    bfMfmaTileQ<MS, QT, 0, 2>(acc, accq, a, aq, x, as, asq, sg, v1);
+    bfMfmaTileQ<MS, QT, 0, 3>(acc, accq, a, aq, x, as, asq, sg, v1);
+    soffA += sg.stepA;
+    bfMfmaRequestAQ<MS, QT, 0>(a, aq, sg, voffAq, soffA);
+    __builtin_amdgcn_sched_barrier(0);
+    bfMfmaTileQ<MS, QT, 1, 0>(acc, accq, a, aq, x, as, asq, sg, v2);
+    bfMfmaTileQ<MS, QT, 1, 1>(acc, accq, a, aq, x, as, asq, sg, v2);
+    bfMfmaTileQ<MS, QT, 1, 2>(acc, accq, a, aq, x, as, asq, sg, v2);
+    bfMfmaTileQ<MS, QT, 1, 3>(acc, accq, a, aq, x, as, asq, sg, v2);
+  }
+  // the requests of the k-steps past the end (set 0 of the leaf fragments, every X tile) must land before the registers are used again
+  if (MS > 0) asm volatile("s_waitcnt vmcnt(0)" : "+v"(a[0].u) :: "memory");
+  if (QT == 1) asm volatile("s_waitcnt vmcnt(0)" : "+v"(aq[0][0].u), "+v"(x[0].u), "+v"(x[1].u), "+v"(x[2].u), "+v"(x[3].u));
+  else if (QT == 2) asm volatile("s_waitcnt vmcnt(0)" : "+v"(aq[0][0].u), "+v"(aq[0][1].u), "+v"(x[0].u), "+v"(x[1].u), "+v"(x[2].u), "+v"(x[3].u));
+  else asm volatile("s_waitcnt vmcnt(0)" : "+v"(aq[0][0].u), "+v"(aq[0][1].u), "+v"(aq[0][2].u), "+v"(x[0].u), "+v"(x[1].u), "+v"(x[2].u), "+v"(x[3].u));
+}
+// the rows of the quarter slabs out of their accumulators: lane (i = lane >> 4, j = lane & 15) holds D[i][j] of every quarter and tile
+template <int MS, int QT>
+__device__ __forceinline__ void bfMfmaStoreQ(StageParams const &p, BfDevItem const &it, uint32_t mr, uint32_t s0, uint32_t q0, double (&accq)[3][3][4], bool hasIdentity, int lane) {
+  uint32_t const nrhs = p.nrhs, np = it.numPieces;
+  double2 *out = (it.mrFlags & BF_ITEM_OUT_Y) ? (double2 *)p.y : (double2 *)p.temp;
+  uint32_t const qmax = nrhs - 1 - q0;
+  uint32_t lane2 = (uint32_t)lane;
+  asm volatile("" : "+v"(lane2));
+  uint32_t const li2 = lane2 & 15u, lk2 = lane2 >> 4;
+#pragma unroll
+  for (int q = 0; q < QT; ++q)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      uint32_t const row = s0 + 16u * MS + 4u * q + lk2;
+      if (row < mr && 16u * t + li2 <= qmax) {
+        double re = accq[0][q][t] - accq[1][q][t];
+        double im = accq[2][q][t] - accq[0][q][t] - accq[1][q][t];
+        if (hasIdentity) {
+          for (uint32_t k = 0; k < np; ++k) {
+            BfDevPiece const pc = p.pieces[it.pieceBegin + k];
+            if (!(pc.flags & BF_PIECE_IDENTITY)) continue;
+            double2 const *xin = (pc.flags & BF_PIECE_IN_X) ? (double2 const *)p.x : (double2 const *)p.temp;
+            double2 xv = xin[((uint64_t)pc.inOff + row) * nrhs + q0 + 16 * t + li2];
+            re += xv.x; im += xv.y;
+          }
+        }
+        out[((uint64_t)it.outOff + row) * nrhs + q0 + 16 * t + li2] = make_double2(re, im);
+      }
+    }
 }
 
 // ---- the same k-loop with its fragments prefetched through LDS (round 5: built, measured, NOT the product's loop: BF_MF_DMA) --------
@@ -354,17 +480,31 @@ __device__ __forceinline__ void bfMfmaStore(StageParams const &p, BfDevItem cons
 
 // One pass = rows [s0, s0 + 16 MS) x RHS [q0, q0 + 16 NT) of one item, over all its segments.
 // (DMA: the k-loop with its fragments prefetched through the wavefront's LDS ring -- the 4-tile kernel; `ring` = its LDS byte address)
-template <int NT, int MS, bool DMA, bool GAUSS>
+// (QT > 0: MS = 0 or 1 full slabs and QT quarter slabs on v_mfma_f64_4x4x4, four tiles, Gauss -- bfMfmaSegmentQ)
+template <int NT, int MS, bool DMA, bool GAUSS, int QT = 0>
 __device__ __forceinline__ void bfMfmaPass(StageParams const &p, BfDevItem const &it, uint32_t mr, uint32_t s0, uint32_t q0, uint32_t *tab, int lane, uint32_t ring) {
+  static_assert(QT == 0 || (NT == 4 && MS <= 1 && GAUSS && !DMA), "quarter slabs: the 4-tile Gauss register loop");
   uint32_t const nrhs = p.nrhs;
   uint32_t const li = lane & 15, lk = lane >> 4;
   bf_d4 acc[3][2][4];            // T1 = sum Ar Xr, T2 = sum Ai Xi, T3 = sum (Ar + Ai)(Xr + Xi)
+  bf_d4 accs[3][4];              // QT > 0: the one full slab
+  double accq[3][3][4];          // QT > 0: the quarter slabs
 #pragma unroll
   for (int g = 0; g < 3; ++g)
 #pragma unroll
     for (int m = 0; m < MS; ++m)
 #pragma unroll
       for (int t = 0; t < NT; ++t) acc[g][m][t] = (bf_d4){0, 0, 0, 0};
+  if (QT > 0) {
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        accs[g][t] = (bf_d4){0, 0, 0, 0};
+#pragma unroll
+        for (int q = 0; q < 3; ++q) accq[g][q][t] = 0.0;
+      }
+  }
   bool hasIdentity = false;
   uint32_t const np = it.numPieces;
   uint32_t const spanRows = BF_MF_SPAN_BYTES / (nrhs * 16u);
@@ -420,9 +560,19 @@ __device__ __forceinline__ void bfMfmaPass(StageParams const &p, BfDevItem const
     sg.rx = bfMakeRsrc(xin + ((uint64_t)minRow * nrhs + q0) * 16u, ((maxRow - minRow) * nrhs + (nrhs - q0)) * 16u);
     sg.voffA = (lk * mr + s0 + li) * 16u;          // rows past the item's end alias the next column: rows of the product that are never stored
     sg.cX = li * 16u;
-    if (DMA) bfMfmaSegmentDma<NT, MS, GAUSS>(acc, sg, tab, lk, ring, ring + (uint32_t)lane * 16u);
+    if constexpr (QT > 0) bfMfmaSegmentQ<MS, QT>(accs, accq, sg, (lk * mr + s0 + (li & 3u)) * 16u, tab, lk);      // a quarter fragment: row (lane & 3) of its four
+    else if (DMA) bfMfmaSegmentDma<NT, MS, GAUSS>(acc, sg, tab, lk, ring, ring + (uint32_t)lane * 16u);
     else bfMfmaSegment<NT, MS, GAUSS>(acc, sg, tab, lk);
     waveSync();                                      // the table is rewritten by the next segment
+  }
+  if constexpr (QT > 0) {
+    bfMfmaStoreQ<MS, QT>(p, it, mr, s0, q0, accq, hasIdentity, lane);
+    if (MS > 0) {
+#pragma unroll
+      for (int g = 0; g < 3; ++g)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[g][0][t] = accs[g][t];
+    }
   }
   bfMfmaStore<NT, MS, GAUSS>(p, it, mr, s0, q0, acc, hasIdentity, lane);
 }
@@ -696,7 +846,24 @@ __device__ __forceinline__ void bfStageBodyC128Mfma(StageParams const &p, uint32
     uint32_t const nt = (nrhs - q0 >= 64) ? 4u : (nrhs - q0 + 15u) / 16u;
     uint32_t s0 = 0;
     while (s0 < mr) {
-      if (mr - s0 > 16) { bfMfmaDispatch<2, MAXNT, DMA, GAUSS>(nt, p, it, mr, s0, q0, tab, lane, ring); s0 += 32; }
+      uint32_t const left = mr - s0;
+      if (BF_MF_QUARTER && MAXNT == 4 && GAUSS && !DMA && nt == 4 && left < 32 && (left & 15u) && (left & 15u) <= 12u) {
+        // the last pass of the item ends in 1 ... 12 rows: quarter slabs (v_mfma_f64_4x4x4) instead of a mostly padded full one
+        if constexpr (MAXNT == 4 && GAUSS && !DMA) {
+          uint32_t const qt = ((left & 15u) + 3u) / 4u;
+          if (left > 16) {
+            if (qt == 1) bfMfmaPass<4, 1, false, true, 1>(p, it, mr, s0, q0, tab, lane, ring);
+            else if (qt == 2) bfMfmaPass<4, 1, false, true, 2>(p, it, mr, s0, q0, tab, lane, ring);
+            else bfMfmaPass<4, 1, false, true, 3>(p, it, mr, s0, q0, tab, lane, ring);
+          } else {
+            if (qt == 1) bfMfmaPass<4, 0, false, true, 1>(p, it, mr, s0, q0, tab, lane, ring);
+            else if (qt == 2) bfMfmaPass<4, 0, false, true, 2>(p, it, mr, s0, q0, tab, lane, ring);
+            else bfMfmaPass<4, 0, false, true, 3>(p, it, mr, s0, q0, tab, lane, ring);
+          }
+        }
+        s0 = mr;
+      }
+      else if (left > 16) { bfMfmaDispatch<2, MAXNT, DMA, GAUSS>(nt, p, it, mr, s0, q0, tab, lane, ring); s0 += 32; }
       else { bfMfmaDispatch<1, MAXNT, DMA, GAUSS>(nt, p, it, mr, s0, q0, tab, lane, ring); s0 += 16; }
     }
   }
