@@ -22,6 +22,9 @@
 //     tools/mfma_probe.hip), two accumulators per tile: componentwise what cblas_zgemm's own recurrence gives
 //     (src/mat_dense_complex.c:1704-1765), a third more matrix-pipe work.
 //
+// The ragged last slab of an item (1 - 12 of its 16 rows real) runs as QUARTER slabs on v_mfma_f64_4x4x4 in the 64-RHS kernel
+// (bfMfmaSegmentQ below): the X fragment is that instruction's B operand as it stands.
+//
 // What the inner loops are made of, and why (tools/mfma_probe.hip, tools/mfma_loop_probe.hip, profiles/r4_mfma_probe.json):
 //   * ONE wavefront cannot keep the FP64 matrix pipe busy (0.75 of peak with 16 independent accumulators), two or more
 //     can (0.99): every cycle a wavefront spends on anything else costs a quarter of the pipe, so the loop holds no

@@ -372,6 +372,38 @@ def test_rhs_block_kernel_segments(nrhs):
         op.close()
 
 
+def test_rhs_block_kernel_row_tails_of_every_height():
+    """The 64-RHS kernel runs the ragged last slab of an item as quarter slabs on v_mfma_f64_4x4x4 (tails of 1 - 12 rows; 13 - 16 stay
+    a full slab): row groups of every height from 1 to 37, two column widths (one a ragged k-step), 64 and 70 right-hand sides (the
+    partial second block runs the full-slab passes), against numpy; and componentwise for real data stored as complex (Gauss's
+    error bound does not depend on which instruction formed the products)."""
+    from butterfly_amd import helm2_structure as hs
+    from butterfly_amd.operator import HipOperator
+    rng = np.random.default_rng(4711)
+    for ncols in (40, 61):
+        d = hs.Desc(dtype=0)
+        vals, blocks, r0 = {}, [], 0
+        heights = list(range(1, 38))
+        for i, m in enumerate(heights):
+            leaf = d.add(hs.NODE_DENSE, m, ncols)
+            vals[leaf] = (rng.standard_normal((m, ncols)) + 1j * rng.standard_normal((m, ncols))) / np.sqrt(ncols)
+            blocks.append((leaf, r0, i * ncols))
+            r0 += m
+        d.root = d.add(hs.NODE_BLOCK, r0, len(heights) * ncols, blocks, hs.BF_TYPE_BLOCK_DIAG)
+        dense = np.zeros((r0, len(heights) * ncols), dtype=complex)
+        for leaf, rr, cc in blocks:
+            dense[rr:rr + vals[leaf].shape[0], cc:cc + ncols] = vals[leaf]
+        for nrhs in (64, 70):
+            x = rng.standard_normal((dense.shape[1], nrhs)) + 1j * rng.standard_normal((dense.shape[1], nrhs))
+            op = HipOperator.from_desc(d, vals, max_rhs=nrhs)
+            y = op.apply_host(x)
+            want = dense @ x
+            assert rel(y, want) <= TOL
+            # row by row: no tail row is dropped or duplicated
+            assert np.max(np.abs(y - want) / (np.abs(dense) @ np.abs(x) + 1e-300)) <= 1e-14
+            op.close()
+
+
 def test_row_sharded_operators_on_gpu(helm2_cases):
     from butterfly_amd import helm2_structure as hs
     from butterfly_amd.operator import HipOperator
