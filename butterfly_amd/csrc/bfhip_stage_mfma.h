@@ -477,8 +477,8 @@ __device__ __forceinline__ void bfMfmaStore(StageParams const &p, BfDevItem cons
           out[((uint64_t)it.outOff + row) * nrhs + q0 + 16 * t + li2] = make_double2(re, im);
         }
       }
-  // stores and fragment requests share vmcnt: nothing of this pass may be pending when the next one counts
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  // (stores and fragment requests share vmcnt: the NEXT pass of the wavefront, if there is one, waits for these stores before it
+  //  requests anything -- bfMfmaPass; the last pass ends with its stores in flight and frees its slot that much earlier)
 }
 
 // One pass = rows [s0, s0 + 16 MS) x RHS [q0, q0 + 16 NT) of one item, over all its segments.
@@ -487,6 +487,7 @@ __device__ __forceinline__ void bfMfmaStore(StageParams const &p, BfDevItem cons
 template <int NT, int MS, bool DMA, bool GAUSS, int QT = 0>
 __device__ __forceinline__ void bfMfmaPass(StageParams const &p, BfDevItem const &it, uint32_t mr, uint32_t s0, uint32_t q0, uint32_t *tab, int lane, uint32_t ring) {
   static_assert(QT == 0 || (NT == 4 && MS <= 1 && GAUSS && !DMA), "quarter slabs: the 4-tile Gauss register loop");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the stores of the wavefront's previous pass: nothing may be pending when the k-loop counts
   uint32_t const nrhs = p.nrhs;
   uint32_t const li = lane & 15, lk = lane >> 4;
   bf_d4 acc[3][2][4];            // T1 = sum Ar Xr, T2 = sum Ai Xi, T3 = sum (Ar + Ai)(Xr + Xi)
@@ -707,6 +708,7 @@ __device__ __forceinline__ void bfSxSegment(bf_d4 (&acc)[3][2][4], BfMfSeg const
 // every segment.
 template <int MS, bool GAUSS>
 __device__ __forceinline__ void bfMfmaPassBundle(StageParams const &p, BfDevItem const &it, uint32_t mr, uint32_t q0, uint32_t *tab, int lane, uint32_t ring, uint32_t wave, uint32_t mine) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the stores of the previous pass
   uint32_t const nrhs = p.nrhs;
   uint32_t const li = lane & 15, lk = lane >> 4;
   bf_d4 acc[3][2][4];
