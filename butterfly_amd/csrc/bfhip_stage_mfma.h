@@ -792,9 +792,6 @@ __device__ __forceinline__ void bfStageBodyC128MfmaBundles(StageParams const &p,
   uint32_t const cnt = (__builtin_amdgcn_readfirstlane(p.bundles[wg + 1]) & 0x7fffffffu) - first;
   bool const mixed = (entry >> 31) != 0;   // four unrelated items: one-wavefront passes, every wavefront its own table
   if (wave >= cnt) return;                 // (the last bundle of a list; a barrier waits for the surviving wavefronts of a workgroup only)
-#ifdef BF_MF_ONLY_CNT                      /* timing experiments: only the bundles of this many items run (wrong results) */
-  if (cnt != BF_MF_ONLY_CNT) return;
-#endif
   BfDevItem const it = p.items[first + wave];
   uint32_t const mr = it.mrFlags & 0xffffu;
   uint32_t const nrhs = p.nrhs;
