@@ -40,7 +40,9 @@ def test_default_contract_keys():
 def test_rhs_block_reports_mfma_roofline():
     d = run_bench("--nrhs", "64", "--no-cpu-baseline")
     r = d["roofline"]
-    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 78.6 and 0 < r["frac"] < 1
+    # (algorithmic flops over the peak: Gauss's three multiplications put the ceiling of this fraction at 4 / 3; the full-size
+    #  operand reaches 0.97 - 1.02, this small one a fraction of that)
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 78.6 and 0 < r["frac"] < 4 / 3
 
 
 def test_bench_starts_its_own_ranks(monkeypatch):
