@@ -813,7 +813,7 @@ def main():
                         "kernel_ms_per_apply": kern_ms / max(launches.max(), 1),
                         "executed_mfma_flops_per_apply": 6.0 * args.nrhs * st["leafElems"],
                         "note": "algorithmic flops = 8 nrhs sum(m n) (SURVEY 8(d)); the kernel forms each complex product with Gauss's 3 real "
-                                "multiplications: 6 nrhs sum(m n) MFMA flops issued (+ tile padding)",
+                                "multiplications: 6 nrhs sum(m n) MFMA flops issued (+ tile padding) -- the ceiling of `frac` is 4/3, values above 1 are not an error",
                         "event_sampling": f"HIP events around every launch of 1 apply in {ev_every} of the timed region"}
         else:
             roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -1096,7 +1096,8 @@ def main():
                                           "algorithmic_flops_per_apply": flops,
                                           "executed_mfma_flops_per_apply": 6.0 * nr * o64.stats()["leafElems"],
                                           "note": "algorithmic flops = 8 nrhs sum(m n) (4 real multiply-adds per complex one, SURVEY 8(d)); the kernel forms each "
-                                                  "complex product with Gauss's 3 real multiplications, i.e. issues 6 nrhs sum(m n) MFMA flops (+ tile padding)"}}
+                                                  "complex product with Gauss's 3 real multiplications, i.e. issues 6 nrhs sum(m n) MFMA flops (+ tile padding): "
+                                                  "the ceiling of this fraction is 4/3, values above 1 are not an error"}}
             try:        # the matrix pipe's share of the cycles and the clock the chip sustained under this kernel (committed --pmc pass)
                 pm, pm_round = load_pmc_summary()
                 clk = pm["mfma_sustained_clock"]
